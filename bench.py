@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Benchmark of the BESS hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode score|train]
+
+Metric (BASELINE.json): positive+negative triples scored per second, and the
+achieved HBM GB/s of the dominant (gather + score) kernel against the roofline.
+
+Workload at N = 1 (BASELINE.json configs[1], "C2"): ogbl-biokg-shaped ComplEx,
+embedding_size 256 (W = Wr = 512, fp32, 2 KiB rows), 93,773 entities,
+51 relations, n_shard = 1; one step = one micro-batch of S = 4096 positive
+triples, each scored against its own K = 256 negative tails (per-triple
+negatives: the HBM-bound regime, one gathered row per scored triple) through
+`EmbeddingMovingBessKGE`, with the log-sigmoid loss: K1 gather (fused), K2-K6
+scoring, K8 loss.  `--mode train` adds backward + sparse SGD (K9/K10).
+Synthetic indices (uniform), default-initialised tables; the index tensors of a
+pool of distinct micro-batches are resident in HBM before the timed region.
+
+N > 1 (one process per GPU, torch.distributed / RCCL): weak scaling - every GPU
+holds a 93,773-row shard and scores S = 4096 positives against 256 negatives
+spread over the N shards (K = 256 / N per shard pair) with
+`ScoreMovingBessKGE` (queries all-gathered, scores returned by all-to-all: the
+scheme the reference recommends for per-triple negatives, docs/source/bess.rst).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(REPO, "bess-kge_amd"), REPO):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+N_ENTITY_PER_SHARD = 93_773
+N_REL = 51
+D = 256  # complex embedding size -> W = 512
+S = 4096
+K_TOTAL = 256
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def build(n_shard: int, rank: int, dev: torch.device, mode: str):
+    import besskge  # noqa: F401
+    from besskge import runtime
+    from besskge.bess import EmbeddingMovingBessKGE, ScoreMovingBessKGE
+    from besskge.collectives import DistributedGroup, SingleProcessGroup
+    from besskge.embedding import init_KGE_normal, initialize_entity_embedding
+    from besskge.loss import LogSigmoidLoss
+    from besskge.negative_sampler import RandomShardedNegativeSampler
+    from besskge.scoring import ComplEx
+    from besskge.sharding import Sharding
+
+    n_entity = N_ENTITY_PER_SHARD * n_shard
+    sharding = Sharding.create(n_entity, n_shard, seed=1234)
+    torch.manual_seed(rank)
+    # only this rank's slice is allocated, directly on the device
+    table = initialize_entity_embedding(sharding, [init_KGE_normal], [2 * D], device=dev, shards=[rank])
+    placeholder = torch.zeros(n_shard, sharding.max_entity_per_shard, 0)
+    fn = ComplEx.__new__(ComplEx)
+    torch.nn.Module.__init__(fn)
+    fn.negative_sample_sharing = False
+    fn.sharding = sharding
+    fn.embedding_size = D
+    fn.entity_embedding = table
+    torch.manual_seed(1)
+    fn.relation_embedding = torch.nn.Parameter(init_KGE_normal(torch.empty(N_REL, 2 * D, device=dev)))
+    del placeholder
+    k_pair = K_TOTAL // n_shard
+    ns = RandomShardedNegativeSampler(k_pair, sharding, 1234, "t", local_sampling=False, flat_negative_format=False)
+    loss = LogSigmoidLoss(margin=12.0, negative_adversarial_sampling=True)
+    cls = EmbeddingMovingBessKGE if n_shard == 1 else ScoreMovingBessKGE
+    model = cls(negative_sampler=ns, score_fn=fn, loss_fn=loss)
+    group = SingleProcessGroup(1) if n_shard == 1 else DistributedGroup()
+    model.entity_embedding = fn.entity_embedding
+    for p in (fn.entity_embedding, fn.relation_embedding):
+        p.requires_grad_(False)
+    model.attach(group, {rank: 0})
+    return model, sharding, k_pair
+
+
+def make_batches(n_shard: int, rank: int, sharding, k_pair: int, pool: int, dev: torch.device):
+    """Index tensors of `pool` micro-batches for this rank, resident on the device.
+    Layout of one replica's inputs (reference bess.py:142-156)."""
+    rng = np.random.default_rng(1000 + rank)
+    ppp = S // n_shard
+    counts = sharding.shard_counts
+    out = []
+    for _ in range(pool):
+        b = dict(
+            head=rng.integers(counts[rank], size=(1, n_shard, ppp)),
+            relation=rng.integers(N_REL, size=(1, n_shard, ppp)),
+            tail=rng.integers(counts[rank], size=(1, n_shard, ppp)),
+            negative=rng.integers(counts[rank], size=(1, n_shard, S, k_pair)),
+        )
+        out.append({k: torch.from_numpy(v.astype(np.int32)).to(dev) for k, v in b.items()})
+    return out
+
+
+def cpu_baseline(seconds: float = 12.0):
+    """The oracle (CPU restatement of the reference's torch path) on this box's
+    host cores, on a bounded sample of the same workload: S_cpu triples x
+    K_TOTAL per-triple negatives, ComplEx d=256, table of 93,773 rows."""
+    from oracle import kge
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gen = torch.Generator().manual_seed(0)
+    W = 2 * D
+    table = (torch.randn(1, N_ENTITY_PER_SHARD, W, generator=gen) / W)
+    rel = torch.randn(N_REL, W, generator=gen) / W
+    s_cpu = 256
+    spec = kge.StepSpec("ComplEx", 0, False, "t", False)
+    rng = np.random.default_rng(0)
+    batch = dict(
+        head=torch.from_numpy(rng.integers(N_ENTITY_PER_SHARD, size=(1, 1, s_cpu))),
+        relation=torch.from_numpy(rng.integers(N_REL, size=(1, 1, s_cpu))),
+        tail=torch.from_numpy(rng.integers(N_ENTITY_PER_SHARD, size=(1, 1, s_cpu))),
+        negative=torch.from_numpy(rng.integers(N_ENTITY_PER_SHARD, size=(1, 1, s_cpu, K_TOTAL))),
+    )
+    loss = dict(kind="logsigmoid", margin=12.0, adversarial=True, adversarial_scale=1.0)
+    with torch.no_grad():
+        kge.bess_step(spec, "EmbeddingMoving", table, rel, batch, loss)  # warm-up
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < seconds:
+            kge.bess_step(spec, "EmbeddingMoving", table, rel, batch, loss)
+            reps += 1
+        dt = time.perf_counter() - t0
+    return dict(
+        value=reps * s_cpu * (1 + K_TOTAL) / dt,
+        unit="triples/s",
+        cores=cores,
+        kind="port",
+        sample=f"{reps} passes of {s_cpu} triples x {K_TOTAL} per-triple negatives (forward: gather+score+loss), "
+               f"torch CPU fp32, {cores} threads, {dt:.1f} s",
+    )
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", choices=["score", "train"], default="score")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    if args.mode == "train" and world > 1:
+        raise SystemExit("--mode train is single-GPU (EmbeddingMoving) in this round")
+
+    from besskge import _native as nat
+
+    model, sharding, k_pair = build(world, rank, dev, args.mode)
+    batches = make_batches(world, rank, sharding, k_pair, pool=8, dev=dev)
+    lr = 1e-3
+
+    def step(i: int) -> None:
+        b = batches[i % len(batches)]
+        if args.mode == "train":
+            model.train_step_replicas([b], lr)
+        else:
+            with torch.no_grad():
+                model.forward_replicas([b])
+
+    def fence() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    timed = ["bess_neg_score_pertriple_fwd", "bess_neg_score_pertriple_bwd", "bess_sparse_sgd"]
+    nat.start_kernel_timing(timed)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = nat.stop_kernel_timing()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_neg = K_TOTAL  # negatives per positive, over all shards
+    scored_per_step = world * S * (1 + n_neg)
+    value = scored_per_step * args.steps / elapsed
+
+    # roofline of the dominant kernel (K5 forward): algorithmic bytes per launch
+    W, sz = 2 * D, 4
+    rows = S * world * k_pair if world > 1 else S * k_pair  # rows gathered per launch on this GPU
+    nq = S * world if world > 1 else S
+    algo_bytes = rows * (W * sz + 4 + 4) + nq * W * 4
+    fwd = kernel_ms.get("bess_neg_score_pertriple_fwd", [])
+    avg_ms = float(np.mean(fwd)) if fwd else float("nan")
+    achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if fwd else float("nan")
+    traffic = None
+    pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("neg_score_pertriple_fwd_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        line = {
+            "metric": "positive+negative triples scored/sec",
+            "value": value,
+            "unit": "triples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "ogbl-biokg-shaped ComplEx d=256 fp32 (W=512), 93,773 entities per shard, "
+                            f"n_shard={world}, S=4096 positives x 256 per-triple negatives per GPU per step, "
+                            f"{'EmbeddingMoving' if world == 1 else 'ScoreMoving'}, mode={args.mode} "
+                            "(gather+score+loss" + ("+backward+sparse SGD)" if args.mode == "train" else ")"),
+                "n_shard": world,
+                "shard_bs": S,
+                "negatives_per_triple": n_neg,
+                "mode": args.mode,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_neg_pertriple_fwd (bess_neg_score_pertriple_fwd)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "avg_launch_ms": avg_ms,
+                "launches_timed": len(fwd),
+            },
+        }
+        extra = {k: float(np.mean(v)) for k, v in kernel_ms.items() if v}
+        line["kernel_avg_ms"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

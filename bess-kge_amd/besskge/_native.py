@@ -1,0 +1,540 @@
+"""ctypes binding of `libbesskge_hip.so` (C ABI: include/besskge_hip.h).
+
+This is the only place the Python side touches the native library.  Tensors
+are validated here (device, dtype, contiguity, shapes) so that a kernel never
+sees operand shapes its grid does not assume; then raw device pointers and
+PyTorch's current HIP stream are handed over.  PyTorch is used for device
+memory and streams only.
+
+There is deliberately no CPU fallback: every wrapper raises if a tensor is not
+on a CUDA/HIP device or if the library is missing.
+"""
+
+import ctypes
+import pathlib
+from typing import Any, Optional, Sequence, Tuple
+
+import torch
+
+LIB_NAME = "libbesskge_hip.so"
+ABI_VERSION = 1
+
+TRANSE, ROTATE, DISTMULT, COMPLEX = 0, 1, 2, 3
+F32, F16 = 0, 1
+CORRUPT_HEAD, CORRUPT_TAIL = 0, 1
+LOSS_LOGSIGMOID, LOSS_MARGIN, LOSS_SSCE = 0, 1, 2
+BAD_NEGATIVE_SCORE = -50000.0
+
+_c_i32p = ctypes.POINTER(ctypes.c_int32)
+_c_f32p = ctypes.POINTER(ctypes.c_float)
+_c_u8p = ctypes.POINTER(ctypes.c_uint8)
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+_f32 = ctypes.c_float
+
+
+class ModelDesc(ctypes.Structure):
+    """struct bess_model_desc"""
+
+    _fields_ = [
+        ("scorer", _i32),
+        ("norm_p", _i32),
+        ("dtype", _i32),
+        ("width", _i32),
+        ("rel_width", _i32),
+        ("reserved", _i32 * 3),
+    ]
+
+
+class LossDesc(ctypes.Structure):
+    """struct bess_loss_desc"""
+
+    _fields_ = [
+        ("kind", _i32),
+        ("adversarial", _i32),
+        ("margin", _f32),
+        ("adversarial_scale", _f32),
+        ("loss_scale", _f32),
+        ("ssce_shift", _f32),
+        ("reserved", _i32 * 2),
+    ]
+
+
+_MD = ctypes.POINTER(ModelDesc)
+_LD = ctypes.POINTER(LossDesc)
+
+# name -> argtypes; every function returns int
+SIGNATURES = {
+    "bess_version": [],
+    "bess_last_error": [ctypes.c_char_p, ctypes.c_size_t],
+    "bess_gather_rows": [_i32, _i32, _vp, _vp, _i64, _vp, _vp],
+    "bess_score_triple_fwd": [_MD, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    "bess_score_triple_bwd": [_MD, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
+    "bess_query_fwd": [_MD, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    "bess_query_bwd": [_MD, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "bess_neg_score_pertriple_fwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
+    "bess_neg_score_pertriple_bwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
+    "bess_neg_score_shared_fwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
+    "bess_neg_score_shared_bwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
+    "bess_mask_scores": [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _vp],
+    "bess_loss_fwd_bwd": [_LD, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
+    "bess_scatter_add_rows": [_vp, _i32, _vp, _vp, _i64, _f32, _vp],
+    "bess_sparse_sgd": [_i32, _i32, _vp, _vp, _vp, _i64, _f32, _vp],
+    "bess_dense_sgd": [_i32, _vp, _vp, _i64, _f32, _vp],
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+# Optional per-launch timing of selected entry points with HIP events recorded
+# on the stream the kernel is launched on (bench.py's roofline leg).
+_timing: Optional[list] = None
+_timed_names: Tuple[str, ...] = ()
+
+
+def start_kernel_timing(names: Sequence[str]) -> None:
+    """Record a HIP event pair around every call of the named entry points."""
+    global _timing, _timed_names
+    _timing, _timed_names = [], tuple(names)
+
+
+def stop_kernel_timing() -> dict:
+    """{entry point: [milliseconds per launch]} since start_kernel_timing()."""
+    global _timing
+    rec, _timing = _timing or [], None
+    torch.cuda.synchronize()
+    out: dict = {}
+    for name, a, b in rec:
+        out.setdefault(name, []).append(a.elapsed_time(b))
+    return out
+
+
+class _Timed:
+    def __init__(self, name: str, dev: torch.device) -> None:
+        self.on = _timing is not None and name in _timed_names
+        self.name, self.dev = name, dev
+
+    def __enter__(self) -> None:
+        if self.on:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream(self.dev))
+
+    def __exit__(self, *exc: Any) -> None:
+        if self.on:
+            self.b.record(torch.cuda.current_stream(self.dev))
+            _timing.append((self.name, self.a, self.b))  # type: ignore
+
+
+def library_path() -> pathlib.Path:
+    """In-tree location of the shared library (built by `__graft_entry__.build`)."""
+    return pathlib.Path(__file__).parent.absolute() / LIB_NAME
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the HIP library; ImportError if it is missing or ABI-incompatible.
+
+    Same role and failure mode as the reference's `load_custom_ops_so`
+    (reference `besskge/__init__.py:10-37`).
+    """
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not path.exists():
+        raise ImportError(
+            f"Cannot find the HIP extension library {LIB_NAME} - tried {[str(path)]}."
+            " Build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (or `make -C bess-kge_amd/csrc`)."
+        )
+    lib = ctypes.CDLL(str(path))
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"{path} does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    if lib.bess_version() != ABI_VERSION:
+        raise ImportError(
+            f"{path}: ABI version {lib.bess_version()} != expected {ABI_VERSION}"
+        )
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        buf = ctypes.create_string_buffer(512)
+        load().bess_last_error(buf, 512)
+        kind = "invalid argument" if rc < 0 else f"hipError {rc}"
+        raise RuntimeError(f"besskge native call {what} failed ({kind}): {buf.value.decode()}")
+
+
+# --------------------------------------------------------------------------- #
+# tensor checks
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float16:
+        return F16
+    raise TypeError(f"embedding tables must be float32 or float16, got {t.dtype}")
+
+
+def _dev(t: torch.Tensor, name: str) -> torch.device:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"besskge: `{name}` is on {t.device}; the BESS hot path runs on"
+            " HIP devices only (there is no CPU fallback)"
+        )
+    return t.device
+
+
+def _same_device(ts: Sequence[Tuple[str, Optional[torch.Tensor]]]) -> torch.device:
+    dev = None
+    for name, t in ts:
+        if t is None:
+            continue
+        d = _dev(t, name)
+        if dev is None:
+            dev = d
+        elif d != dev:
+            raise RuntimeError(f"besskge: `{name}` is on {d}, expected {dev}")
+    assert dev is not None
+    return dev
+
+
+def _rows(base: torch.Tensor, name: str, width: int) -> None:
+    if base.dim() != 2 or base.shape[1] != width or not base.is_contiguous():
+        raise ValueError(
+            f"`{name}` must be a contiguous [rows, {width}] tensor, got"
+            f" shape {tuple(base.shape)} stride {base.stride()}"
+        )
+
+
+def _idx(idx: Optional[torch.Tensor], name: str, n: Optional[int] = None) -> int:
+    if idx is None:
+        return 0
+    if idx.dtype != torch.int32 or idx.dim() != 1 or not idx.is_contiguous():
+        raise ValueError(
+            f"`{name}` must be a contiguous 1-D int32 tensor, got {idx.dtype} {tuple(idx.shape)}"
+        )
+    if n is not None and idx.numel() != n:
+        raise ValueError(f"`{name}` has {idx.numel()} entries, expected {n}")
+    return idx.data_ptr()
+
+
+def _f32(t: torch.Tensor, name: str) -> None:
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"`{name}` must be contiguous float32, got {t.dtype}")
+
+
+def _row_count(base: torch.Tensor, idx: Optional[torch.Tensor]) -> int:
+    return int(idx.numel()) if idx is not None else int(base.shape[0])
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class RowSource:
+    """`rows[i] = base[idx[i]]` (idx None: identity).  `base` is a contiguous
+    [*, W] table-dtype tensor: a shard, a receive buffer or plain embeddings."""
+
+    __slots__ = ("base", "idx")
+
+    def __init__(self, base: torch.Tensor, idx: Optional[torch.Tensor] = None) -> None:
+        self.base = base
+        self.idx = idx
+
+    def __len__(self) -> int:
+        return _row_count(self.base, self.idx)
+
+
+def make_desc(scorer: int, norm_p: int, table: torch.Tensor, rel_width: int) -> ModelDesc:
+    d = ModelDesc()
+    d.scorer = scorer
+    d.norm_p = norm_p
+    d.dtype = _dtype_code(table)
+    d.width = int(table.shape[-1])
+    d.rel_width = rel_width
+    return d
+
+
+# --------------------------------------------------------------------------- #
+# wrappers (one per C entry point)
+def gather_rows(table: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    dev = _same_device([("table", table), ("idx", idx), ("out", out)])
+    W = int(table.shape[1])
+    _rows(table, "table", W)
+    n = idx.numel()
+    ip = _idx(idx, "idx")
+    if out is None:
+        out = torch.empty((n, W), dtype=table.dtype, device=dev)
+    else:
+        _rows(out, "out", W)
+        if out.shape[0] != n or out.dtype != table.dtype:
+            raise ValueError("gather_rows: `out` does not match idx / table dtype")
+    with torch.cuda.device(dev), _Timed("bess_gather_rows", dev):
+        rc = load().bess_gather_rows(_dtype_code(table), W, table.data_ptr(), ip, n, out.data_ptr(), _stream(dev))
+    _check(rc, "bess_gather_rows")
+    return out
+
+
+def _triple_operands(d: ModelDesc, head: RowSource, tail: RowSource, rel_table: torch.Tensor, rel_idx: torch.Tensor):
+    dev = _same_device(
+        [("head", head.base), ("head_idx", head.idx), ("tail", tail.base), ("tail_idx", tail.idx),
+         ("relation_embedding", rel_table), ("relation", rel_idx)]
+    )
+    _rows(head.base, "head rows", d.width)
+    _rows(tail.base, "tail rows", d.width)
+    _rows(rel_table, "relation_embedding", d.rel_width)
+    for t, nm in ((head.base, "head rows"), (tail.base, "tail rows"), (rel_table, "relation_embedding")):
+        if _dtype_code(t) != d.dtype:
+            raise TypeError(f"`{nm}` dtype {t.dtype} does not match the model descriptor")
+    n = len(head)
+    if len(tail) != n:
+        raise ValueError(f"{n} head rows but {len(tail)} tail rows")
+    _idx(rel_idx, "relation", n)
+    return dev, n
+
+
+def score_triple_fwd(d: ModelDesc, head: RowSource, tail: RowSource, rel_table: torch.Tensor,
+                     rel_idx: torch.Tensor) -> torch.Tensor:
+    dev, n = _triple_operands(d, head, tail, rel_table, rel_idx)
+    out = torch.empty((n,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().bess_score_triple_fwd(
+            ctypes.byref(d), head.base.data_ptr(), _idx(head.idx, "head_idx"), tail.base.data_ptr(),
+            _idx(tail.idx, "tail_idx"), rel_table.data_ptr(), rel_idx.data_ptr(), n, out.data_ptr(), _stream(dev))
+    _check(rc, "bess_score_triple_fwd")
+    return out
+
+
+def score_triple_bwd(d: ModelDesc, head: RowSource, tail: RowSource, rel_table: torch.Tensor,
+                     rel_idx: torch.Tensor, d_out: torch.Tensor, d_rel_table: torch.Tensor
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Returns (d_head [n, W], d_tail [n, W]); accumulates into d_rel_table."""
+    dev, n = _triple_operands(d, head, tail, rel_table, rel_idx)
+    _same_device([("d_out", d_out), ("d_rel_table", d_rel_table), ("x", head.base)])
+    _f32(d_out, "d_out")
+    _f32(d_rel_table, "d_rel_table")
+    if d_out.numel() != n or tuple(d_rel_table.shape) != tuple(rel_table.shape):
+        raise ValueError("score_triple_bwd: gradient shapes do not match")
+    dh = torch.empty((n, d.width), dtype=torch.float32, device=dev)
+    dt = torch.empty((n, d.width), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().bess_score_triple_bwd(
+            ctypes.byref(d), head.base.data_ptr(), _idx(head.idx, "head_idx"), tail.base.data_ptr(),
+            _idx(tail.idx, "tail_idx"), rel_table.data_ptr(), rel_idx.data_ptr(), n, d_out.data_ptr(),
+            dh.data_ptr(), dt.data_ptr(), d_rel_table.data_ptr(), _stream(dev))
+    _check(rc, "bess_score_triple_bwd")
+    return dh, dt
+
+
+def _query_operands(d: ModelDesc, ent: RowSource, rel_table: torch.Tensor, rel_idx: torch.Tensor):
+    dev = _same_device([("entity rows", ent.base), ("entity idx", ent.idx),
+                        ("relation_embedding", rel_table), ("relation", rel_idx)])
+    _rows(ent.base, "entity rows", d.width)
+    _rows(rel_table, "relation_embedding", d.rel_width)
+    if _dtype_code(ent.base) != d.dtype or _dtype_code(rel_table) != d.dtype:
+        raise TypeError("query: operand dtype does not match the model descriptor")
+    n = len(ent)
+    _idx(rel_idx, "relation", n)
+    return dev, n
+
+
+def query_fwd(d: ModelDesc, side: int, ent: RowSource, rel_table: torch.Tensor, rel_idx: torch.Tensor) -> torch.Tensor:
+    dev, n = _query_operands(d, ent, rel_table, rel_idx)
+    q = torch.empty((n, d.width), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().bess_query_fwd(ctypes.byref(d), side, ent.base.data_ptr(), _idx(ent.idx, "entity idx"),
+                                   rel_table.data_ptr(), rel_idx.data_ptr(), n, q.data_ptr(), _stream(dev))
+    _check(rc, "bess_query_fwd")
+    return q
+
+
+def query_bwd(d: ModelDesc, side: int, ent: RowSource, rel_table: torch.Tensor, rel_idx: torch.Tensor,
+              d_query: torch.Tensor, d_rel_table: torch.Tensor) -> torch.Tensor:
+    """Returns d_ent [n, W]; accumulates into d_rel_table."""
+    dev, n = _query_operands(d, ent, rel_table, rel_idx)
+    _same_device([("d_query", d_query), ("d_rel_table", d_rel_table), ("x", ent.base)])
+    _f32(d_query, "d_query")
+    _f32(d_rel_table, "d_rel_table")
+    if tuple(d_query.shape) != (n, d.width) or tuple(d_rel_table.shape) != tuple(rel_table.shape):
+        raise ValueError("query_bwd: gradient shapes do not match")
+    dx = torch.empty((n, d.width), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().bess_query_bwd(ctypes.byref(d), side, ent.base.data_ptr(), _idx(ent.idx, "entity idx"),
+                                   rel_table.data_ptr(), rel_idx.data_ptr(), n, d_query.data_ptr(),
+                                   dx.data_ptr(), d_rel_table.data_ptr(), _stream(dev))
+    _check(rc, "bess_query_bwd")
+    return dx
+
+
+def _neg_operands(d: ModelDesc, query: torch.Tensor, neg: RowSource, n_idx: int):
+    dev = _same_device([("query", query), ("negative rows", neg.base), ("negative idx", neg.idx)])
+    _f32(query, "query")
+    if query.dim() != 2 or query.shape[1] != d.width:
+        raise ValueError(f"`query` must be [n_query, {d.width}], got {tuple(query.shape)}")
+    _rows(neg.base, "negative rows", d.width)
+    if _dtype_code(neg.base) != d.dtype:
+        raise TypeError("negative rows dtype does not match the model descriptor")
+    if len(neg) != n_idx:
+        raise ValueError(f"expected {n_idx} negative rows, got {len(neg)}")
+    return dev
+
+
+def _neg_idx_ptr(neg: RowSource, dev: torch.device) -> Tuple[int, Optional[torch.Tensor]]:
+    """The per-triple kernel needs an explicit index array."""
+    if neg.idx is not None:
+        return _idx(neg.idx, "negative idx"), None
+    ar = torch.arange(neg.base.shape[0], dtype=torch.int32, device=dev)
+    return ar.data_ptr(), ar
+
+
+def neg_score_pertriple_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n_neg: int,
+                            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    nq = int(query.shape[0])
+    dev = _neg_operands(d, query, neg, nq * n_neg)
+    if out is None:
+        out = torch.empty((nq, n_neg), dtype=torch.float32, device=dev)
+    _f32(out, "out")
+    if tuple(out.shape) != (nq, n_neg):
+        raise ValueError("neg_score_pertriple_fwd: bad `out` shape")
+    ip, keep = _neg_idx_ptr(neg, dev)
+    with torch.cuda.device(dev), _Timed("bess_neg_score_pertriple_fwd", dev):
+        rc = load().bess_neg_score_pertriple_fwd(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(), ip,
+                                                 n_neg, out.data_ptr(), n_neg, _stream(dev))
+    _check(rc, "bess_neg_score_pertriple_fwd")
+    del keep
+    return out
+
+
+def neg_score_pertriple_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n_neg: int,
+                            d_out: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Returns (d_query [nq, W], d_neg [nq*n_neg, W])."""
+    nq = int(query.shape[0])
+    dev = _neg_operands(d, query, neg, nq * n_neg)
+    _same_device([("d_out", d_out), ("query", query)])
+    _f32(d_out, "d_out")
+    if tuple(d_out.shape) != (nq, n_neg):
+        raise ValueError("neg_score_pertriple_bwd: bad `d_out` shape")
+    dq = torch.empty((nq, d.width), dtype=torch.float32, device=dev)
+    dn = torch.empty((nq * n_neg, d.width), dtype=torch.float32, device=dev)
+    ip, keep = _neg_idx_ptr(neg, dev)
+    with torch.cuda.device(dev), _Timed("bess_neg_score_pertriple_bwd", dev):
+        rc = load().bess_neg_score_pertriple_bwd(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(), ip,
+                                                 n_neg, d_out.data_ptr(), n_neg, dq.data_ptr(), dn.data_ptr(),
+                                                 _stream(dev))
+    _check(rc, "bess_neg_score_pertriple_bwd")
+    del keep
+    return dq, dn
+
+
+def neg_score_shared_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource) -> torch.Tensor:
+    nq, n_neg = int(query.shape[0]), len(neg)
+    dev = _neg_operands(d, query, neg, n_neg)
+    out = torch.empty((nq, n_neg), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _Timed("bess_neg_score_shared_fwd", dev):
+        rc = load().bess_neg_score_shared_fwd(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
+                                              _idx(neg.idx, "negative idx"), n_neg, out.data_ptr(), n_neg,
+                                              _stream(dev))
+    _check(rc, "bess_neg_score_shared_fwd")
+    return out
+
+
+def neg_score_shared_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, out: torch.Tensor,
+                         d_out: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Returns (d_query [nq, W], d_neg [n_neg, W])."""
+    nq, n_neg = int(query.shape[0]), len(neg)
+    dev = _neg_operands(d, query, neg, n_neg)
+    _same_device([("d_out", d_out), ("out", out), ("query", query)])
+    _f32(d_out, "d_out")
+    _f32(out, "out")
+    if tuple(d_out.shape) != (nq, n_neg) or tuple(out.shape) != (nq, n_neg):
+        raise ValueError("neg_score_shared_bwd: bad score shapes")
+    dq = torch.empty((nq, d.width), dtype=torch.float32, device=dev)
+    dn = torch.empty((n_neg, d.width), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _Timed("bess_neg_score_shared_bwd", dev):
+        rc = load().bess_neg_score_shared_bwd(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
+                                              _idx(neg.idx, "negative idx"), n_neg, out.data_ptr(), n_neg,
+                                              d_out.data_ptr(), n_neg, dq.data_ptr(), dn.data_ptr(), _stream(dev))
+    _check(rc, "bess_neg_score_shared_bwd")
+    return dq, dn
+
+
+def mask_scores(neg: torch.Tensor, diag_step: int, ht: bool, ppp: int, mask: Optional[torch.Tensor]) -> None:
+    """In place K7 (see include/besskge_hip.h)."""
+    dev = _same_device([("negative_score", neg), ("negative_mask", mask)])
+    _f32(neg, "negative_score")
+    if neg.dim() != 2:
+        raise ValueError("negative_score must be 2-D")
+    S, N = int(neg.shape[0]), int(neg.shape[1])
+    mp, mrows, mcols = 0, 0, 0
+    if mask is not None:
+        if mask.dtype != torch.bool or mask.dim() != 2 or not mask.is_contiguous():
+            raise ValueError("negative_mask must be a contiguous 2-D bool tensor")
+        mp, mrows, mcols = mask.data_ptr(), int(mask.shape[0]), int(mask.shape[1])
+    with torch.cuda.device(dev):
+        rc = load().bess_mask_scores(neg.data_ptr(), S, N, N, diag_step, int(ht), ppp, mp, mrows, mcols, _stream(dev))
+    _check(rc, "bess_mask_scores")
+
+
+def loss_fwd_bwd(l: LossDesc, pos: torch.Tensor, neg: torch.Tensor, weight: torch.Tensor, want_grad: bool
+                 ) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """Returns (loss [] f32, d_pos [S] | None, d_neg [S, N] | None)."""
+    dev = _same_device([("positive_score", pos), ("negative_score", neg), ("triple_weight", weight)])
+    for t, nm in ((pos, "positive_score"), (neg, "negative_score"), (weight, "triple_weight")):
+        _f32(t, nm)
+    S, N = int(neg.shape[0]), int(neg.shape[1])
+    if pos.numel() != S or weight.numel() not in (1, S):
+        raise ValueError("loss: shapes of positive_score / triple_weight do not match negative_score")
+    row_loss = torch.empty((S,), dtype=torch.float32, device=dev)
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    dp = torch.empty((S,), dtype=torch.float32, device=dev) if want_grad else None
+    dn = torch.empty((S, N), dtype=torch.float32, device=dev) if want_grad else None
+    with torch.cuda.device(dev):
+        rc = load().bess_loss_fwd_bwd(ctypes.byref(l), pos.data_ptr(), neg.data_ptr(), S, N, N, weight.data_ptr(),
+                                      weight.numel(), row_loss.data_ptr(), loss.data_ptr(),
+                                      dp.data_ptr() if want_grad else 0, dn.data_ptr() if want_grad else 0, N,
+                                      _stream(dev))
+    _check(rc, "bess_loss_fwd_bwd")
+    return loss.reshape(()), dp, dn
+
+
+def scatter_add_rows(dst: torch.Tensor, idx: torch.Tensor, src: torch.Tensor, scale: float = 1.0) -> None:
+    dev = _same_device([("dst", dst), ("idx", idx), ("src", src)])
+    _f32(dst, "dst")
+    _f32(src, "src")
+    W = int(dst.shape[1])
+    _rows(dst, "dst", W)
+    _rows(src, "src", W)
+    n = int(src.shape[0])
+    ip = _idx(idx, "idx", n)
+    with torch.cuda.device(dev):
+        rc = load().bess_scatter_add_rows(dst.data_ptr(), W, ip, src.data_ptr(), n, scale, _stream(dev))
+    _check(rc, "bess_scatter_add_rows")
+
+
+def sparse_sgd(table: torch.Tensor, idx: torch.Tensor, grad: torch.Tensor, lr: float) -> None:
+    dev = _same_device([("table", table), ("idx", idx), ("grad", grad)])
+    W = int(table.shape[1])
+    _rows(table, "table", W)
+    _f32(grad, "grad")
+    _rows(grad, "grad", W)
+    n = int(grad.shape[0])
+    ip = _idx(idx, "idx", n)
+    with torch.cuda.device(dev), _Timed("bess_sparse_sgd", dev):
+        rc = load().bess_sparse_sgd(_dtype_code(table), W, table.data_ptr(), ip, grad.data_ptr(), n, lr, _stream(dev))
+    _check(rc, "bess_sparse_sgd")
+
+
+def dense_sgd(table: torch.Tensor, grad: torch.Tensor, lr: float) -> None:
+    dev = _same_device([("table", table), ("grad", grad)])
+    _f32(grad, "grad")
+    if not table.is_contiguous() or table.numel() != grad.numel():
+        raise ValueError("dense_sgd: table / grad mismatch")
+    with torch.cuda.device(dev):
+        rc = load().bess_dense_sgd(_dtype_code(table), table.data_ptr(), grad.data_ptr(), table.numel(), lr, _stream(dev))
+    _check(rc, "bess_dense_sgd")

@@ -1,0 +1,689 @@
+"""BESS distribution schemes on MI355X: gather -> exchange -> score -> loss.
+
+Host-side mirror of the reference interface (`besskge/bess.py:34-603`):
+`BessKGE`, `EmbeddingMovingBessKGE`, `ScoreMovingBessKGE`,
+`BAD_NEGATIVE_SCORE`, with the same constructor and
+`forward(head, relation, tail, negative, triple_mask, triple_weight,
+negative_mask) -> dict` contract (every tensor carries a leading replica dim of
+1, reference `bess.py:142-176`).
+
+How one replica's step maps to the device:
+
+  K1  rows leaving the shard are packed by `bess_gather_rows` into the send
+      buffer `[n_shard, ppp + B*K, W]`; rows that stay (heads, and everything
+      when n_shard == 1) are *not* copied - kernels read them from the shard
+      through an index ("row source").
+  C1  one balanced all-to-all of that buffer (`ReplicaGroup.all_to_all`; RCCL).
+  K2-K6  positive score, query transform, negative scores: kernels read tails /
+      negatives from the receive buffer through static index maps, so the
+      reference's reshape/transpose/concat of embeddings (`bess.py:356-466`)
+      becomes index arithmetic on a few KiB of int32.
+  K7  mask / augment kill (in place).   K8  fused loss (+ score gradients).
+
+Training (`BessKGE.train_step`, EmbeddingMoving): backward kernels produce the
+gradient of every *gathered row*; rows that came through the all-to-all travel
+back through one more all-to-all (C8) and are applied to the owning shard with
+a sparse atomic SGD update (K9+K10).  The shard gradient is never dense and
+never all-reduced; only the replicated relation table is (C9).
+"""
+
+from abc import ABC, abstractmethod
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import torch
+
+from besskge import _native as nat
+from besskge._native import RowSource
+from besskge.collectives import ReplicaGroup, SingleProcessGroup
+from besskge.loss import BaseLossFunction, SampledSoftmaxCrossEntropyLoss
+from besskge.negative_sampler import (
+    ShardedNegativeSampler,
+    TripleBasedShardedNegativeSampler,
+)
+from besskge.scoring import BaseScoreFunction
+
+BAD_NEGATIVE_SCORE = -50000.0
+
+_Batch = Dict[str, torch.Tensor]
+
+
+def _i32(x: torch.Tensor) -> torch.Tensor:
+    x = x if x.dtype == torch.int32 else x.to(torch.int32)
+    return x.contiguous()
+
+
+class _NegGroup:
+    """One (queries, corrupted side, candidate rows) scoring problem."""
+
+    def __init__(self, side: int, sel: Optional[torch.Tensor], ent: RowSource, rel_idx: torch.Tensor,
+                 neg: RowSource, shared: bool, n_per_query: int) -> None:
+        self.side = side          # nat.CORRUPT_HEAD | nat.CORRUPT_TAIL
+        self.sel = sel            # triple slots scored by this group (None = all)
+        self.ent = ent            # the entity kept in the query (tail | head rows)
+        self.rel_idx = rel_idx    # relation ids of the group's triples
+        self.neg = neg            # candidate rows (shared list, or [Q * n_per_query])
+        self.shared = shared
+        self.n_per_query = n_per_query
+        # filled by forward, consumed by backward
+        self.query: Optional[torch.Tensor] = None
+        self.out: Optional[torch.Tensor] = None
+
+
+class _ReplicaStep:
+    """Per-replica state of one micro-batch (forward products + backward ctx)."""
+
+    def __init__(self) -> None:
+        self.table: torch.Tensor = None  # type: ignore  # local shard [M, W]
+        self.head_idx: torch.Tensor = None  # type: ignore  # [S] rows of the shard
+        self.rel_idx: torch.Tensor = None  # type: ignore  # [S]
+        self.tail: RowSource = None  # type: ignore  # tails of my triples
+        self.groups: List[_NegGroup] = []
+        self.send_idx: Optional[torch.Tensor] = None  # rows packed for the exchange
+        self.recv: Optional[torch.Tensor] = None  # [n*L (+ext), W]
+        self.recv_rows: int = 0  # n*L: rows that came through the all-to-all
+        self.ext_src: Optional[RowSource] = None  # provenance of the rows appended to recv
+        self.n: int = 1
+        self.ppp: int = 0
+        self.neg_shape: Tuple[int, ...] = ()  # (n, B, K) of the negative index tensor
+        self.local_neg: torch.Tensor = None  # type: ignore
+        self.local_tail: torch.Tensor = None  # type: ignore
+        self.positive_score: torch.Tensor = None  # type: ignore
+        self.negative_score: torch.Tensor = None  # type: ignore
+
+
+class BessKGE(torch.nn.Module, ABC):
+    """Base class of the distributed KGE step (see module docstring)."""
+
+    def __init__(
+        self,
+        negative_sampler: ShardedNegativeSampler,
+        score_fn: BaseScoreFunction,
+        loss_fn: Optional[BaseLossFunction] = None,
+        evaluation: Optional[Any] = None,
+        return_scores: bool = False,
+        augment_negative: bool = False,
+    ) -> None:
+        """
+        :param negative_sampler: sampler of corrupting entities (only its
+            `flat_negative_format`, `local_sampling`, `corruption_scheme`
+            attributes are read here).
+        :param score_fn: scoring function (owns the embedding tables).
+        :param loss_fn: loss, required for training.
+        :param evaluation: object with `ranks_from_scores(pos, neg)`,
+            `stacked_metrics_from_ranks(ranks, mask)` and `return_ranks`.
+        :param return_scores: return positive / negative scores.
+        :param augment_negative: also use the other positives of the
+            micro-batch as negatives (needs negative sample sharing).
+        """
+        super().__init__()
+        self.sharding = score_fn.sharding
+        self.negative_sampler = negative_sampler
+        self.score_fn = score_fn
+        self.loss_fn = loss_fn
+        self.evaluation = evaluation
+        self.return_scores = return_scores
+        self.augment_negative = augment_negative
+        if not (loss_fn or evaluation or return_scores):
+            raise ValueError(
+                "Nothing to return. At least one of loss_fn,"
+                " evaluation or return_scores needs to be != None"
+            )
+        if self.augment_negative:
+            assert (
+                score_fn.negative_sample_sharing
+            ), "Negative augmentation requires negative sample sharing"
+            assert not isinstance(
+                self, ScoreMovingBessKGE
+            ), "ScoreMovingBessKGE does not support negative augmentation"
+        if negative_sampler.flat_negative_format:
+            assert (
+                score_fn.negative_sample_sharing
+            ), "Using flat negative format requires negative sample sharing"
+        elif score_fn.negative_sample_sharing and isinstance(
+            self.negative_sampler, TripleBasedShardedNegativeSampler
+        ):
+            raise ValueError(
+                "Negative sample sharing cannot be used"
+                " with non-flat triple-specific negatives"
+            )
+        self.entity_embedding = self.score_fn.entity_embedding
+        self.entity_embedding_size: int = self.score_fn.entity_embedding.shape[-1]
+        #: replica group; None = a private SingleProcessGroup(n_shard) on first use
+        self.replica_group: Optional[ReplicaGroup] = None
+        #: position of each hosted shard inside `entity_embedding` (dim 0)
+        self._shard_slot: Optional[Dict[int, int]] = None
+        self._map_cache: Dict[Any, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ setup
+    @property
+    def n_embedding_parameters(self) -> int:
+        """Trainable parameters in the embedding tables."""
+        return self.score_fn.entity_embedding.numel() + self.score_fn.relation_embedding.numel()
+
+    def attach(self, group: ReplicaGroup, shard_slot: Optional[Dict[int, int]] = None) -> None:
+        """Bind the module to a replica group.
+
+        :param shard_slot: {shard id: index along dim 0 of `entity_embedding`}
+            for the shards hosted here; default: the table holds all shards.
+        """
+        if group.n_shard != self.sharding.n_shard:
+            raise ValueError(f"group has {group.n_shard} replicas, sharding {self.sharding.n_shard}")
+        self.replica_group = group
+        self._shard_slot = shard_slot
+
+    def _group(self) -> ReplicaGroup:
+        if self.replica_group is None:
+            self.replica_group = SingleProcessGroup(self.sharding.n_shard)
+        return self.replica_group
+
+    def _local_table(self, shard: int) -> torch.Tensor:
+        emb = self.score_fn.entity_embedding
+        slot = shard if self._shard_slot is None else self._shard_slot[shard]
+        if emb.dim() != 3 or slot >= emb.shape[0]:
+            raise RuntimeError(
+                f"entity_embedding {tuple(emb.shape)} does not hold shard {shard};"
+                " use besskge.runtime to place the shards"
+            )
+        return emb.data[slot]
+
+    def _static_map(self, key: Any, build: Any, device: torch.device) -> torch.Tensor:
+        k = (key, device)
+        if k not in self._map_cache:
+            self._map_cache[k] = build().to(device=device, dtype=torch.int32).contiguous()
+        return self._map_cache[k]
+
+    # ---------------------------------------------------------------- forward
+    def forward(
+        self,
+        head: torch.Tensor,
+        relation: torch.Tensor,
+        tail: torch.Tensor,
+        negative: torch.Tensor,
+        triple_mask: Optional[torch.Tensor] = None,
+        triple_weight: Optional[torch.Tensor] = None,
+        negative_mask: Optional[torch.Tensor] = None,
+    ) -> Dict[str, Any]:
+        """One micro-batch of one replica (this process must host exactly one).
+
+        :param head: (1, n_shard, positive_per_partition) head rows.
+        :param relation: (1, n_shard, positive_per_partition) relation ids.
+        :param tail: (1, n_shard, positive_per_partition) tail rows.
+        :param negative: (1, n_shard, B, padded_negative) negative rows,
+            B = 1, 2 or n_shard * positive_per_partition.
+        :param triple_mask: (1, n_shard, positive_per_partition) triples that
+            count for the metrics.
+        :param triple_weight: (1, n_shard * positive_per_partition) or (1,).
+        :param negative_mask: (1, B, n_shard, padded_negative) real (non
+            padding) negatives.
+        :return: dict with `loss`, `positive_score`, `negative_score`,
+            `ranks`, `metrics` as configured.
+        """
+        batch = dict(head=head, relation=relation, tail=tail, negative=negative)
+        for k, v in (("triple_mask", triple_mask), ("triple_weight", triple_weight),
+                     ("negative_mask", negative_mask)):
+            if v is not None:
+                batch[k] = v
+        if len(self._group().local_shards) != 1:
+            raise RuntimeError(
+                "forward() steps a single replica; this process hosts"
+                f" {len(self._group().local_shards)} - use forward_replicas()"
+            )
+        return self.forward_replicas([batch])[0]
+
+    def forward_replicas(self, batches: List[_Batch]) -> List[Dict[str, Any]]:
+        """Lock-step forward of all replicas hosted by this process."""
+        steps = self._score_replicas(batches)
+        return [self._finish(st, b, want_grad=False)[0] for st, b in zip(steps, batches)]
+
+    def _score_replicas(self, batches: List[_Batch]) -> List[_ReplicaStep]:
+        group = self._group()
+        if len(batches) != len(group.local_shards):
+            raise ValueError(f"{len(batches)} batches for {len(group.local_shards)} local replicas")
+        squeezed = []
+        for b in batches:
+            for k in ("head", "relation", "tail", "negative"):
+                if b[k].shape[0] != 1:
+                    raise ValueError(f"`{k}` must have a leading replica dim of 1, got {tuple(b[k].shape)}")
+            squeezed.append({k: _i32(b[k].squeeze(0)) for k in ("head", "relation", "tail", "negative")})
+        return self.score_batch_replicas(squeezed)
+
+    def score_batch(
+        self, head: torch.Tensor, relation: torch.Tensor, tail: torch.Tensor, negative: torch.Tensor
+    ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Positive [S] and negative [S, n_negative] scores of one replica's
+        micro-batch (inputs without the leading replica dim)."""
+        if len(self._group().local_shards) != 1:
+            raise RuntimeError("score_batch() steps a single replica; use score_batch_replicas()")
+        st = self.score_batch_replicas(
+            [dict(head=_i32(head), relation=_i32(relation), tail=_i32(tail), negative=_i32(negative))]
+        )[0]
+        return st.positive_score, st.negative_score
+
+    @abstractmethod
+    def score_batch_replicas(self, batches: List[_Batch]) -> List[_ReplicaStep]:
+        """Scores of every local replica's micro-batch (lock-step)."""
+        raise NotImplementedError
+
+    # -------------------------------------------------- mask / loss / metrics
+    def _finish(self, st: _ReplicaStep, batch: _Batch, want_grad: bool
+                ) -> Tuple[Dict[str, Any], Optional[torch.Tensor], Optional[torch.Tensor]]:
+        pos, neg = st.positive_score, st.negative_score
+        dev = pos.device
+        ns = self.negative_sampler
+        n, ppp = st.n, st.ppp
+        flat_ht = ns.flat_negative_format and ns.corruption_scheme == "ht"
+
+        negative_mask = batch.get("negative_mask")
+        mask2d = None
+        if negative_mask is not None:
+            # (1, B', n_shard, L) -> [B', n_shard * L]   (bess.py:182-199)
+            mask2d = negative_mask.squeeze(0).flatten(start_dim=-2).to(device=dev, dtype=torch.bool).contiguous()
+            if mask2d.shape[0] not in (1, 2, pos.shape[0]):
+                raise ValueError(f"negative_mask has {mask2d.shape[0]} rows")
+            if mask2d.shape[0] == 2 and not flat_ht:
+                raise ValueError("a 2-row negative_mask needs flat 'ht' negatives")
+        if self.augment_negative:
+            # true head/tail sits at column step * (position of the triple among the queries)
+            step = 1 if ns.flat_negative_format else 1 + n * int(batch["negative"].shape[-1])
+            nat.mask_scores(neg, step, ns.corruption_scheme == "ht", ppp, mask2d)
+        elif mask2d is not None:
+            nat.mask_scores(neg, 0, False, ppp if flat_ht else 0, mask2d)
+
+        out: Dict[str, Any] = dict()
+        ret_neg = neg
+        d_pos = d_neg = None
+        if self.loss_fn:
+            w = batch.get("triple_weight")
+            if w is None:
+                w = torch.ones(1, dtype=torch.float32, device=dev)
+            w = w.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+            ld = self.loss_fn.kernel_desc(int(neg.shape[1]))
+            loss, d_pos, d_neg = nat.loss_fwd_bwd(ld, pos, neg, w, want_grad)
+            out["loss"] = loss
+            if isinstance(self.loss_fn, SampledSoftmaxCrossEntropyLoss) and self.return_scores \
+                    and self.score_fn.relation_embedding.dtype == torch.float32:
+                # the reference shifts fp32 negative scores in place before the
+                # cross entropy (loss.py:233-237) and returns that same tensor
+                ret_neg = neg + ld.ssce_shift
+        if self.return_scores:
+            dt = self.score_fn.relation_embedding.dtype
+            out.update(positive_score=pos.to(dt), negative_score=ret_neg.to(dt))
+        if self.evaluation:
+            tm = batch.get("triple_mask")
+            if tm is not None:
+                tm = tm.flatten().to(dev)
+            with torch.no_grad():
+                ranks = self.evaluation.ranks_from_scores(pos, neg)
+                if self.evaluation.return_ranks:
+                    out["ranks"] = ranks
+                out["metrics"] = self.evaluation.stacked_metrics_from_ranks(ranks, tm)
+        return out, d_pos, d_neg
+
+    # ------------------------------------------------------ group execution
+    def _run_groups(self, st: _ReplicaStep, desc: nat.ModelDesc) -> List[torch.Tensor]:
+        rel = self.score_fn.relation_embedding.data
+        outs = []
+        for g in st.groups:
+            g.query = nat.query_fwd(desc, g.side, g.ent, rel, g.rel_idx)
+            if g.shared:
+                g.out = nat.neg_score_shared_fwd(desc, g.query, g.neg)
+            else:
+                g.out = nat.neg_score_pertriple_fwd(desc, g.query, g.neg, g.n_per_query)
+            outs.append(g.out)
+        return outs
+
+
+class EmbeddingMovingBessKGE(BessKGE):
+    """Negatives are scored where the positive triple is (head shard): the
+    embeddings of tails and negatives move, with a single all-to-all.
+
+    Each triple is scored against `n_negative * n_shard` entities without
+    negative sample sharing, `n_negative * n_shard * B` with it ("h"/"t"), or
+    `n_negative * n_shard * (B > 2 ? B // 2 : 1)` for "ht"
+    (reference `bess.py:308-468`).
+    """
+
+    def score_batch_replicas(self, batches: List[_Batch]) -> List[_ReplicaStep]:
+        group = self._group()
+        n = group.n_shard
+        ns = self.negative_sampler
+        fn = self.score_fn
+        W = self.entity_embedding_size
+        steps: List[_ReplicaStep] = []
+        sends: List[torch.Tensor] = []
+        exchange_negatives = n > 1 and not ns.local_sampling
+        for shard, b in zip(group.local_shards, batches):
+            st = _ReplicaStep()
+            st.table = self._local_table(shard)
+            dev = st.table.device
+            head, rel, tail, neg = (b[k].to(dev) for k in ("head", "relation", "tail", "negative"))
+            if head.shape[0] != n or neg.shape[0] != n:
+                raise ValueError(f"batch is laid out for {head.shape[0]} shards, group has {n}")
+            st.n, st.ppp = n, int(head.shape[1])
+            st.head_idx = head.reshape(-1)
+            st.rel_idx = rel.reshape(-1)
+            st.neg_shape = tuple(neg.shape)
+            if n > 1:
+                # K1: pack what leaves the shard, block j -> replica j
+                parts = [tail] + ([neg.flatten(start_dim=1)] if exchange_negatives else [])
+                st.send_idx = torch.cat(parts, dim=1).contiguous()  # [n, L]
+                sends.append(nat.gather_rows(st.table, st.send_idx.reshape(-1)).reshape(n, -1, W))
+            st.local_neg = neg  # type: ignore
+            st.local_tail = tail  # type: ignore
+            steps.append(st)
+        if n > 1:
+            recvs = group.all_to_all(sends)  # C1
+            for st, y in zip(steps, recvs):
+                st.recv = y.reshape(-1, W)
+                st.recv_rows = st.recv.shape[0]
+
+        desc = fn.kernel_desc()
+        rel_table = fn.relation_embedding.data
+        for st in steps:
+            self._build_groups(st, exchange_negatives)
+            st.positive_score = nat.score_triple_fwd(
+                desc, RowSource(st.table, st.head_idx), st.tail, rel_table, st.rel_idx
+            )
+            outs = self._run_groups(st, desc)
+            if len(outs) == 1:
+                st.negative_score = outs[0]
+            else:
+                # "ht": first half of every block corrupts heads, second half tails
+                n_, cut = st.n, st.ppp // 2
+                st.negative_score = torch.cat(
+                    [outs[0].reshape(n_, cut, -1), outs[1].reshape(n_, st.ppp - cut, -1)], dim=1
+                ).flatten(end_dim=1).contiguous()
+        return steps
+
+    # ------------------------------------------------------------------
+    def _build_groups(self, st: _ReplicaStep, exchange_negatives: bool) -> None:
+        """Translate the reference's embedding reshapes (bess.py:356-466) into
+        index lists over (shard | receive buffer)."""
+        ns = self.negative_sampler
+        fn = self.score_fn
+        n, ppp = st.n, st.ppp
+        S = n * ppp
+        _, B, K = st.neg_shape  # type: ignore
+        dev = st.table.device
+        sharing = bool(fn.negative_sample_sharing)
+
+        # --- where do tails and negatives live?
+        if n == 1:
+            tail_src = RowSource(st.table, st.local_tail.reshape(-1))  # type: ignore
+            neg_base = st.table
+            neg_idx2d = st.local_neg[0]  # type: ignore  # [B, K]
+        else:
+            L = ppp + (B * K if exchange_negatives else 0)
+            tail_map = self._static_map(
+                ("tail", n, ppp, L),
+                lambda: (torch.arange(n)[:, None] * L + torch.arange(ppp)[None, :]).reshape(-1), dev)
+            tail_src = RowSource(st.recv, tail_map)
+            if exchange_negatives:
+                neg_base = st.recv
+                # recv block j = [tails(ppp) | negatives(B, K)]; wanted order [B, n*K]
+                neg_idx2d = self._static_map(
+                    ("neg", n, ppp, B, K),
+                    lambda: (torch.arange(n)[None, :, None] * L + ppp
+                             + torch.arange(B)[:, None, None] * K + torch.arange(K)[None, None, :]
+                             ).reshape(B, n * K), dev)
+            else:
+                neg_base = st.table
+                neg_idx2d = st.local_neg.transpose(0, 1).reshape(B, n * K).contiguous()  # type: ignore
+        st.tail = tail_src
+        head_src = RowSource(st.table, st.head_idx)
+        nK = int(neg_idx2d.shape[1])
+        scheme = ns.corruption_scheme
+
+        # Augmentation concatenates the positives of the corrupted side with the
+        # negatives (bess.py:369-393, 430-448): both must be addressable in one
+        # row space.  Tails and exchanged negatives share the receive buffer;
+        # heads live in the shard, so a copy of the S head rows is appended to
+        # the receive buffer when heads are corrupted on several shards.
+        pos_of = {nat.CORRUPT_HEAD: head_src, nat.CORRUPT_TAIL: tail_src}
+        if self.augment_negative and n > 1:
+            if neg_base is st.recv and scheme in ("h", "ht"):
+                st.recv = torch.cat([st.recv, nat.gather_rows(st.table, st.head_idx)], dim=0)
+                st.ext_src = head_src
+                neg_base = st.recv
+                tail_src = st.tail = RowSource(st.recv, tail_src.idx)
+                ext_idx = st.recv_rows + torch.arange(S, dtype=torch.int32, device=dev)
+                pos_of[nat.CORRUPT_HEAD] = RowSource(st.recv, ext_idx)
+                pos_of[nat.CORRUPT_TAIL] = tail_src
+            elif neg_base is st.table and scheme in ("t", "ht"):
+                raise NotImplementedError(
+                    "augment_negative with local_sampling on several shards"
+                    " (tails received, negatives local) is not supported"
+                )
+
+        def make(side: int, sel: Optional[torch.Tensor], rows2d: torch.Tensor) -> _NegGroup:
+            """rows2d: [Bg, nK] candidate rows for this group's queries."""
+            ent_src = tail_src if side == nat.CORRUPT_HEAD else head_src
+            pos_src = pos_of[side]  # the corrupted side
+            rel = st.rel_idx
+            if sel is not None:
+                ent_src = RowSource(ent_src.base, ent_src.idx[sel])
+                pos_src = RowSource(pos_src.base, pos_src.idx[sel])
+                rel = rel[sel].contiguous()
+            Q = len(ent_src)
+            Bg = int(rows2d.shape[0])
+            base = neg_base
+            if self.augment_negative:
+                # positives of the group become extra candidates (bess.py:369-393, 430-448)
+                assert pos_src.base is base
+                rows2d = torch.cat([pos_src.idx.reshape(Bg, -1), rows2d], dim=1)
+            if sharing or Bg == 1:
+                lst = rows2d.reshape(-1).contiguous()
+                return _NegGroup(side, sel, ent_src, rel, RowSource(base, lst), True, int(lst.numel()))
+            if Bg != Q:
+                raise ValueError(f"per-triple negatives: {Bg} candidate lists for {Q} queries")
+            return _NegGroup(side, sel, ent_src, rel, RowSource(base, rows2d.reshape(-1).contiguous()),
+                             False, int(rows2d.shape[1]))
+
+        if scheme == "h":
+            st.groups = [make(nat.CORRUPT_HEAD, None, neg_idx2d)]
+        elif scheme == "t":
+            st.groups = [make(nat.CORRUPT_TAIL, None, neg_idx2d)]
+        elif scheme == "ht":
+            cut = ppp // 2
+            slot = torch.arange(S, device=dev).reshape(n, ppp)
+            sel_h = slot[:, :cut].reshape(-1)
+            sel_t = slot[:, cut:].reshape(-1)
+            if ns.flat_negative_format:
+                rows_h, rows_t = neg_idx2d[0:1], neg_idx2d[1:2]
+            else:
+                per = neg_idx2d.reshape(n, ppp, nK)
+                rows_h = per[:, :cut].reshape(-1, nK)
+                rows_t = per[:, cut:].reshape(-1, nK)
+            st.groups = [make(nat.CORRUPT_HEAD, sel_h, rows_h), make(nat.CORRUPT_TAIL, sel_t, rows_t)]
+        else:
+            raise ValueError(f"corruption scheme {scheme!r} not supported")
+
+    # ---------------------------------------------------------------- training
+    def train_step_replicas(self, batches: List[_Batch], lr: float) -> List[Dict[str, Any]]:
+        """Forward + backward + sparse SGD update of every local replica.
+
+        Backward of the reference's autograd graph (`bess.py:322-468`) written
+        out: K8' -> K4'/K5' -> K6' -> K3' give the gradient of every gathered
+        row; rows received through the all-to-all are returned to their owner
+        by a second all-to-all (C8); K9+K10 apply them to the shard sparsely.
+        """
+        if self.loss_fn is None:
+            raise RuntimeError("train_step needs a loss function")
+        group = self._group()
+        fn = self.score_fn
+        n = group.n_shard
+        W = self.entity_embedding_size
+        steps = self._score_replicas(batches)
+        desc = fn.kernel_desc()
+        rel_table = fn.relation_embedding.data
+        results = []
+        d_rel = torch.zeros(rel_table.shape, dtype=torch.float32, device=rel_table.device)
+        back: List[torch.Tensor] = []
+        local_updates: List[List[Tuple[torch.Tensor, torch.Tensor]]] = []
+        for st, b in zip(steps, batches):
+            out, d_pos, d_neg = self._finish(st, b, want_grad=True)
+            results.append(out)
+            dev = st.table.device
+            upd: List[Tuple[torch.Tensor, torch.Tensor]] = []  # (rows of my shard, gradient rows)
+            d_recv = None
+            if n > 1:
+                d_recv = torch.zeros((st.recv.shape[0], W), dtype=torch.float32, device=dev)
+
+            def sink(src: RowSource, g: torch.Tensor) -> None:
+                if src.base is st.table:
+                    upd.append((src.idx, g))
+                elif src.base is st.recv:
+                    nat.scatter_add_rows(d_recv, src.idx, g)
+                else:  # pragma: no cover
+                    raise RuntimeError("gradient for an unknown row space")
+
+            # K3': positive scores
+            dh, dt = nat.score_triple_bwd(desc, RowSource(st.table, st.head_idx), st.tail, rel_table,
+                                          st.rel_idx, d_pos, d_rel)
+            sink(RowSource(st.table, st.head_idx), dh)
+            sink(st.tail, dt)
+            # K4'/K5' + K6': negative scores
+            if len(st.groups) == 1:
+                d_outs = [d_neg]
+            else:
+                cut = st.ppp // 2
+                dn3 = d_neg.reshape(st.n, st.ppp, -1)
+                d_outs = [dn3[:, :cut].reshape(-1, dn3.shape[-1]).contiguous(),
+                          dn3[:, cut:].reshape(-1, dn3.shape[-1]).contiguous()]
+            for g, go in zip(st.groups, d_outs):
+                if g.shared:
+                    dq, dn = nat.neg_score_shared_bwd(desc, g.query, g.neg, g.out, go)
+                else:
+                    dq, dn = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go)
+                sink(g.neg, dn)
+                dx = nat.query_bwd(desc, g.side, g.ent, rel_table, g.rel_idx, dq, d_rel)
+                sink(g.ent, dx)
+            if n > 1:
+                if st.ext_src is not None:  # rows appended for augmentation -> their origin
+                    sink(st.ext_src, d_recv[st.recv_rows:].contiguous())
+                back.append(d_recv[: st.recv_rows].reshape(n, -1, W))
+            local_updates.append(upd)
+        if n > 1:
+            returned = group.all_to_all(back)  # C8
+            for st, upd, g in zip(steps, local_updates, returned):
+                upd.append((st.send_idx.reshape(-1), g.reshape(-1, W)))
+        # K9 + K10: sparse SGD on the shard (gradients were all computed from
+        # the pre-update tables above)
+        for st, upd in zip(steps, local_updates):
+            for idx, g in upd:
+                nat.sparse_sgd(st.table, idx.contiguous(), g.contiguous(), lr)
+        # C9: replicated relation table
+        # (single process: d_rel already holds the sum over the local replicas)
+        (d_rel,) = group.all_reduce_sum([d_rel]) if len(group.local_shards) == 1 else (d_rel,)
+        nat.dense_sgd(rel_table, d_rel, lr)
+        return results
+
+    def train_step(self, lr: float, **batch: torch.Tensor) -> Dict[str, Any]:
+        """Single-replica convenience wrapper of :meth:`train_step_replicas`."""
+        return self.train_step_replicas([batch], lr)[0]
+
+
+class ScoreMovingBessKGE(BessKGE):
+    """Negatives are scored on the shard that stores them: queries are
+    all-gathered, scores (not embeddings) are sent back with an all-to-all.
+    No local sampling, no negative augmentation (reference `bess.py:471-603`).
+    With negative sample sharing every query sees `n_shard` times the
+    negatives documented for :class:`EmbeddingMovingBessKGE`.
+    """
+
+    def score_batch_replicas(self, batches: List[_Batch]) -> List[_ReplicaStep]:
+        group = self._group()
+        n = group.n_shard
+        ns = self.negative_sampler
+        fn = self.score_fn
+        W = self.entity_embedding_size
+        desc = fn.kernel_desc()
+        rel_table = fn.relation_embedding.data
+        sharing = bool(fn.negative_sample_sharing)
+        scheme = ns.corruption_scheme
+        steps: List[_ReplicaStep] = []
+        tails_out, heads_q, tails_q, rels = [], [], [], []
+        for shard, b in zip(group.local_shards, batches):
+            st = _ReplicaStep()
+            st.table = self._local_table(shard)
+            dev = st.table.device
+            head, rel, tail, neg = (b[k].to(dev) for k in ("head", "relation", "tail", "negative"))
+            st.n, st.ppp = n, int(head.shape[1])
+            cut = st.ppp // 2
+            st.head_idx, st.rel_idx = head.reshape(-1), rel.reshape(-1)
+            if isinstance(ns, TripleBasedShardedNegativeSampler) and ns.flat_negative_format:
+                neg = neg[0:1]  # replicated along dim 0; one copy is enough (bess.py:511-517)
+            st.local_neg = neg  # type: ignore
+            # rows of my shard that other replicas need
+            tail_rows = nat.gather_rows(st.table, tail.reshape(-1)).reshape(n, st.ppp, W)
+            tails_out.append(tail_rows)
+            if scheme == "h":
+                tails_q.append(tail_rows)
+            elif scheme == "t":
+                heads_q.append(nat.gather_rows(st.table, st.head_idx).reshape(n, st.ppp, W))
+            else:
+                tails_q.append(tail_rows[:, :cut].contiguous())
+                heads_q.append(nat.gather_rows(st.table, head[:, cut:].reshape(-1)).reshape(n, st.ppp - cut, W))
+            rels.append(rel)
+            steps.append(st)
+        rel_all = group.all_gather(rels)  # C2  [n(j), n, ppp]
+        tq_all = group.all_gather(tails_q) if tails_q else None  # C3  [n(t), n(j), ., W]
+        hq_all = group.all_gather(heads_q) if heads_q else None  # C3  [n(j), n(t), ., W]
+
+        scores_out = []
+        for r, st in enumerate(steps):
+            dev = st.table.device
+            ppp, cut = st.ppp, st.ppp // 2
+            neg = st.local_neg  # type: ignore  # [n | 1, B, K]
+            nB, B, K = (int(x) for x in neg.shape)
+            relr = rel_all[r]
+
+            def queries(side: int, ent_all: torch.Tensor, transpose: bool, rel_sel: torch.Tensor) -> torch.Tensor:
+                """Query matrix [n * Sg, W] in (processing replica, block, triple) order."""
+                Sg = int(ent_all.shape[2])
+                rows = ent_all.reshape(-1, W)
+                idx = None
+                if transpose:  # gathered as [t, j, p] but wanted as [j, t, p]
+                    idx = self._static_map(
+                        ("smT", n, Sg),
+                        lambda: torch.arange(n * n * Sg).reshape(n, n, Sg).transpose(0, 1).reshape(-1), dev)
+                return nat.query_fwd(desc, side, RowSource(rows, idx), rel_table, rel_sel.reshape(-1).contiguous())
+
+            def score(q: torch.Tensor, rows2d: torch.Tensor) -> torch.Tensor:
+                """rows2d [Bg, K] rows of my shard."""
+                if sharing or rows2d.shape[0] == 1:
+                    return nat.neg_score_shared_fwd(desc, q, RowSource(st.table, rows2d.reshape(-1).contiguous()))
+                if rows2d.shape[0] != q.shape[0]:
+                    raise ValueError("per-triple negatives do not match the gathered queries")
+                return nat.neg_score_pertriple_fwd(desc, q, RowSource(st.table, rows2d.reshape(-1).contiguous()),
+                                                   int(rows2d.shape[1]))
+
+            if scheme == "h":
+                q = queries(nat.CORRUPT_HEAD, tq_all[r], True, relr)
+                sc = score(q, neg.reshape(nB * B, K))
+            elif scheme == "t":
+                q = queries(nat.CORRUPT_TAIL, hq_all[r], False, relr)
+                sc = score(q, neg.reshape(nB * B, K))
+            else:
+                qh = queries(nat.CORRUPT_HEAD, tq_all[r], True, relr[:, :, :cut])
+                qt = queries(nat.CORRUPT_TAIL, hq_all[r], False, relr[:, :, cut:])
+                if ns.flat_negative_format:
+                    rows_h, rows_t = neg[:, 0], neg[:, 1]  # [n | 1, K]
+                else:
+                    per = neg.reshape(n, n, ppp, K)
+                    rows_h = per[:, :, :cut].reshape(-1, K)
+                    rows_t = per[:, :, cut:].reshape(-1, K)
+                sh = score(qh, rows_h)
+                stl = score(qt, rows_t)
+                sc = torch.cat([sh.reshape(n, n, cut, -1), stl.reshape(n, n, ppp - cut, -1)], dim=2).reshape(
+                    n * n * ppp, -1)
+            scores_out.append(sc.reshape(n, n * ppp, -1).contiguous())
+        scores_back = group.all_to_all(scores_out)  # C4  [n(src), S, Nl]
+        tails_in = group.all_to_all(tails_out)  # C5  [n, ppp, W]
+        for st, sb, tl in zip(steps, scores_back, tails_in):
+            st.negative_score = sb.transpose(0, 1).flatten(start_dim=1).contiguous()
+            st.recv = tl.reshape(-1, W)
+            st.tail = RowSource(st.recv, None)
+            st.positive_score = nat.score_triple_fwd(
+                desc, RowSource(st.table, st.head_idx), st.tail, rel_table, st.rel_idx)
+        return steps

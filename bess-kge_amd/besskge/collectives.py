@@ -1,0 +1,116 @@
+"""Replica groups: who holds which shard, and the two BESS collectives.
+
+The reference runs one PopTorch replica per shard and uses exactly two
+collectives from poptorch_experimental_addons (reference `bess.py:14-19`):
+`all_to_all_single_cross_replica` (equal splits along dim 0: block j goes to
+replica j, result block j came from replica j) and `all_gather_cross_replica`
+(stack in rank order).  Here:
+
+* :class:`DistributedGroup` - the production layout: one process per GPU,
+  rank == shard, `torch.distributed` (backend "nccl" = RCCL over xGMI; "gloo"
+  for CPU-side tests of the routing).
+* :class:`SingleProcessGroup` - all `n_shard` replicas live in this process on
+  one device and are stepped in lock-step (the role PopTorch's IPUModel plays
+  in the reference's tests, `tests/test_bess.py:123-127`); the collectives are
+  device-side block transposes.
+
+Both operate on *lists* with one tensor per local replica, so the model code is
+written once.  The entity-shard gradient is never all-reduced (the reference
+removes that all-reduce with a PopART pattern,
+`custom_ops/remove_all_reduce_pattern.cpp:15-47`); only replicated parameters
+(relation table) go through :meth:`all_reduce_sum`.
+"""
+
+from abc import ABC, abstractmethod
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class ReplicaGroup(ABC):
+    """Set of BESS replicas hosted by this process."""
+
+    #: total number of shards / replicas
+    n_shard: int
+    #: shard ids hosted here, in execution order
+    local_shards: List[int]
+
+    @abstractmethod
+    def all_to_all(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        """xs[r] is [n_shard, ...]; out[r][j] = (replica j's x)[shard of r]."""
+
+    @abstractmethod
+    def all_gather(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        """out[r] = stack over all replicas j of (replica j's x): [n_shard, ...]."""
+
+    @abstractmethod
+    def all_reduce_sum(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        """Sum over all replicas (replicated parameters' gradients)."""
+
+    def barrier(self) -> None:
+        """Synchronise all replicas (no-op when they share a process)."""
+
+
+class SingleProcessGroup(ReplicaGroup):
+    """All replicas in one process, executed in lock-step."""
+
+    def __init__(self, n_shard: int) -> None:
+        self.n_shard = n_shard
+        self.local_shards = list(range(n_shard))
+
+    def all_to_all(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        assert len(xs) == self.n_shard
+        if self.n_shard == 1:
+            return [xs[0]]
+        # stacked[j, r] = block r of replica j  ->  out[r][j]
+        stacked = torch.stack(xs, dim=0)
+        swapped = stacked.transpose(0, 1).contiguous()
+        return [swapped[r] for r in range(self.n_shard)]
+
+    def all_gather(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        assert len(xs) == self.n_shard
+        stacked = torch.stack(xs, dim=0)
+        return [stacked for _ in range(self.n_shard)]
+
+    def all_reduce_sum(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        total = xs[0].clone()
+        for x in xs[1:]:
+            total += x
+        return [total for _ in xs]
+
+
+class DistributedGroup(ReplicaGroup):
+    """One replica per process; rank r of `process_group` holds shard r."""
+
+    def __init__(self, process_group: Optional[dist.ProcessGroup] = None) -> None:
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.pg = process_group
+        self.n_shard = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        self.local_shards = [self.rank]
+
+    def all_to_all(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        (x,) = xs
+        if x.shape[0] != self.n_shard:
+            raise ValueError(f"all_to_all: leading dim {x.shape[0]} != n_shard {self.n_shard}")
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        dist.all_to_all_single(out, x, group=self.pg)
+        return [out]
+
+    def all_gather(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        (x,) = xs
+        x = x.contiguous()
+        out = torch.empty((self.n_shard, *x.shape), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=self.pg)
+        return [out]
+
+    def all_reduce_sum(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        (x,) = xs
+        dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.pg)
+        return [x]
+
+    def barrier(self) -> None:
+        dist.barrier(group=self.pg)

@@ -1,0 +1,155 @@
+"""Thin runner that replaces the PopTorch runtime of the reference.
+
+The reference hands its module to `poptorch.inferenceModel / trainingModel`,
+which (a) place slice `r` of `entity_embedding` on replica `r`
+(`replicaGrouping(NoGrouping, 0, OnePerGroup)`, reference
+`tests/test_bess.py:146-150`), (b) split every input along dim 0 over
+`device_iterations x replicas` and (c) concatenate the replicas' outputs
+(reference `tests/test_bess.py:122-135,181-196`).  This module does the same
+three things for HIP devices:
+
+    runner = besskge.runtime.inference_model(model)            # all shards, 1 process
+    runner = besskge.runtime.inference_model(model, group=DistributedGroup())
+    res = runner(**{k: v.flatten(end_dim=1) for k, v in batch.items()})
+
+so a notebook's `poptorch.X` lines become `besskge.runtime.X`.
+"""
+
+import dataclasses
+from typing import Any, Dict, List, Optional
+
+import torch
+
+from besskge.bess import BessKGE, EmbeddingMovingBessKGE
+from besskge.collectives import DistributedGroup, ReplicaGroup, SingleProcessGroup
+
+_BATCH_KEYS = ("head", "relation", "tail", "negative", "triple_mask", "triple_weight", "negative_mask")
+
+
+@dataclasses.dataclass
+class Options:
+    """The subset of `poptorch.Options` the BESS notebooks use."""
+
+    #: micro-batches consumed per call (poptorch `deviceIterations`)
+    device_iterations: int = 1
+    #: "all": outputs of every micro-batch; "final": only the last one
+    output_mode: str = "all"
+    #: distributed runs: all-gather outputs so every rank sees all replicas
+    gather_outputs: bool = False
+
+    def deviceIterations(self, n: int) -> "Options":  # noqa: N802 - poptorch spelling
+        self.device_iterations = n
+        return self
+
+
+@dataclasses.dataclass
+class SGD:
+    """Plain SGD; applied sparsely to the rows a step touched."""
+
+    lr: float = 0.01
+    #: how replicated-parameter gradients are combined over replicas ("sum" is
+    #: d(sum of replica losses); PopTorch's choice is not visible in the
+    #: reference repo -> parity unpinned)
+    replica_reduction: str = "sum"
+
+
+def place_shards(model: BessKGE, group: ReplicaGroup, device: torch.device,
+                 dtype: Optional[torch.dtype] = None) -> None:
+    """Move the hosted shard(s) and the relation table to `device`."""
+    fn = model.score_fn
+    emb = fn.entity_embedding.data
+    n = model.sharding.n_shard
+    if emb.dim() != 3:
+        raise ValueError("entity_embedding must be [n_shard, max_entity_per_shard, W]")
+    if emb.shape[0] == n and len(group.local_shards) != n:
+        emb = emb[group.local_shards]  # keep only what this process hosts
+    elif emb.shape[0] != len(group.local_shards):
+        raise ValueError(
+            f"entity_embedding holds {emb.shape[0]} shards, process hosts {len(group.local_shards)}"
+        )
+    dt = dtype or emb.dtype
+    fn.entity_embedding = torch.nn.Parameter(emb.to(device=device, dtype=dt).contiguous(), requires_grad=False)
+    fn.relation_embedding = torch.nn.Parameter(
+        fn.relation_embedding.data.to(device=device, dtype=dt).contiguous(), requires_grad=False)
+    model.entity_embedding = fn.entity_embedding
+    model.attach(group, {s: i for i, s in enumerate(group.local_shards)})
+
+
+class Runner:
+    """Callable that steps a :class:`BessKGE` module like a PopTorch model."""
+
+    def __init__(self, model: BessKGE, options: Optional[Options], group: Optional[ReplicaGroup],
+                 device: Optional[torch.device], optimizer: Optional[SGD],
+                 dtype: Optional[torch.dtype] = None) -> None:
+        self.model = model
+        self.options = options or Options()
+        n = model.sharding.n_shard
+        if group is None:
+            group = SingleProcessGroup(n)
+        self.group = group
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = device
+        self.optimizer = optimizer
+        if optimizer is not None and not isinstance(model, EmbeddingMovingBessKGE):
+            raise NotImplementedError("training is implemented for EmbeddingMovingBessKGE")
+        place_shards(model, group, device, dtype)
+
+    def _split(self, batch: Dict[str, torch.Tensor], it: int) -> List[Dict[str, torch.Tensor]]:
+        n = self.group.n_shard
+        out = []
+        for shard in self.group.local_shards:
+            row = it * n + shard
+            out.append({k: v[row: row + 1].to(self.device, non_blocking=True) for k, v in batch.items()})
+        return out
+
+    def __call__(self, **batch: torch.Tensor) -> Dict[str, torch.Tensor]:
+        n = self.group.n_shard
+        unknown = set(batch) - set(_BATCH_KEYS)
+        if unknown:
+            raise TypeError(f"unexpected inputs {sorted(unknown)}")
+        rows = batch["head"].shape[0]
+        iters = self.options.device_iterations
+        if rows != iters * n:
+            raise ValueError(
+                f"inputs have {rows} rows; expected device_iterations * n_shard = {iters} * {n}"
+                " (flatten [batches_per_step, n_shard, ...] with .flatten(end_dim=1))"
+            )
+        collected: List[List[Dict[str, Any]]] = []
+        for it in range(iters):
+            reps = self._split(batch, it)
+            if self.optimizer is not None:
+                res = self.model.train_step_replicas(reps, self.optimizer.lr)  # type: ignore
+            else:
+                with torch.no_grad():
+                    res = self.model.forward_replicas(reps)
+            collected.append(res)
+        if self.options.output_mode == "final":
+            collected = collected[-1:]
+        keys = collected[0][0].keys()
+        out: Dict[str, torch.Tensor] = {}
+        for k in keys:
+            per_it = []
+            for res in collected:
+                vals = [r[k] if r[k].dim() > 0 else r[k].reshape(1) for r in res]
+                x = torch.cat(vals, dim=0)
+                if self.options.gather_outputs and isinstance(self.group, DistributedGroup):
+                    x = self.group.all_gather([x])[0].flatten(end_dim=1)
+                per_it.append(x)
+            out[k] = torch.cat(per_it, dim=0)
+        return out
+
+
+def inference_model(model: BessKGE, options: Optional[Options] = None, group: Optional[ReplicaGroup] = None,
+                    device: Optional[torch.device] = None, dtype: Optional[torch.dtype] = None) -> Runner:
+    """`poptorch.inferenceModel` analogue."""
+    model.eval()
+    return Runner(model, options, group, device, None, dtype)
+
+
+def training_model(model: BessKGE, options: Optional[Options] = None, optimizer: Optional[SGD] = None,
+                   group: Optional[ReplicaGroup] = None, device: Optional[torch.device] = None,
+                   dtype: Optional[torch.dtype] = None) -> Runner:
+    """`poptorch.trainingModel` analogue (forward + backward + sparse update per call)."""
+    model.train()
+    return Runner(model, options, group, device, optimizer or SGD(), dtype)

@@ -1,0 +1,98 @@
+// Shared device/host helpers of the gfx950 BESS kernels.
+#pragma once
+
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/besskge_hip.h"
+
+namespace bess {
+
+// ---- host side: error reporting (thread local text + return codes) --------
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+#define BESS_REQUIRE(cond, ...)                          \
+    do {                                                 \
+        if (!(cond)) return ::bess::fail(BESS_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// scorer properties
+inline bool is_complex_entity(int scorer) { return scorer == BESS_ROTATE || scorer == BESS_COMPLEX; }
+inline bool is_distance(int scorer) { return scorer == BESS_TRANSE || scorer == BESS_ROTATE; }
+int check_desc(const bess_model_desc* d);
+
+// reductions used by the negative-scoring kernels
+enum Reduce : int { RED_DOT = 0, RED_L1 = 1, RED_L2 = 2 };
+inline int reduce_of(const bess_model_desc* d) {
+    if (!is_distance(d->scorer)) return RED_DOT;
+    return d->norm_p == 1 ? RED_L1 : RED_L2;
+}
+
+// ---- device side ------------------------------------------------------------
+typedef _Float16 half_t;
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T v) {
+    return static_cast<float>(v);
+}
+
+// VEC contiguous elements of T -> float registers, one vector load
+template <typename T, int VEC>
+struct VecLoad {
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    __device__ __forceinline__ static void load(const T* __restrict__ p, float (&out)[VEC]) {
+        vec_t v = *reinterpret_cast<const vec_t*>(p);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) out[i] = static_cast<float>(v[i]);
+    }
+};
+template <typename T>
+struct VecLoad<T, 1> {
+    __device__ __forceinline__ static void load(const T* __restrict__ p, float (&out)[1]) {
+        out[0] = static_cast<float>(*p);
+    }
+};
+
+// sum over the 16 lanes of a DPP row; every lane of the row gets the total
+__device__ __forceinline__ float row16_allreduce_sum(float v) {
+#define BESS_DPP_ROR(x, n)                                                                     \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)),     \
+                                                           0x120 | (n), 0xf, 0xf, false))
+    v += BESS_DPP_ROR(v, 8);
+    v += BESS_DPP_ROR(v, 4);
+    v += BESS_DPP_ROR(v, 2);
+    v += BESS_DPP_ROR(v, 1);
+#undef BESS_DPP_ROR
+    return v;
+}
+
+// sum over the 64 lanes of a wave; every lane gets the total
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
+    v = row16_allreduce_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_allreduce_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+__device__ __forceinline__ float sgnf(float x) {
+    return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+}
+
+template <typename T>
+__device__ __forceinline__ const T* row_ptr(const T* base, const int32_t* idx, int64_t i, int width) {
+    const int64_t r = idx ? static_cast<int64_t>(idx[i]) : i;
+    return base + r * width;
+}
+
+}  // namespace bess

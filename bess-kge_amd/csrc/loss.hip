@@ -1,0 +1,207 @@
+// K7 (mask / augment) and K8 (loss + score gradients) of the BESS step on gfx950.
+//
+//   K7: reference bess.py:182-245 - additive BAD_NEGATIVE_SCORE on padding
+//       negatives and on the true head/tail among augmented negatives.
+//   K8: reference loss.py:28-51 (self-adversarial weights = detached softmax),
+//       loss.py:115-134 (log-sigmoid), 179-195 (margin ranking),
+//       224-251 (sampled-softmax cross entropy); always fp32, summed (not
+//       averaged) over the micro-batch (bess.py:254-260).
+//
+// One wavefront per triple row: the row of n_neg scores is streamed 2-3 times
+// (max, normaliser, terms) - it is L2 resident right after the scoring kernel.
+// The scalar loss is reduced in a fixed order (per-row terms, then one
+// single-workgroup tree) so it is bitwise reproducible run to run.
+#include "common.h"
+
+namespace bess {
+
+__global__ __launch_bounds__(256) void k_mask_scores(float* __restrict__ neg, int64_t n_triple,
+                                                     int64_t n_neg, int64_t ld, int diag_step, int ht,
+                                                     int ppp, const uint8_t* __restrict__ mask,
+                                                     int64_t mask_rows, int64_t mask_cols) {
+    const int64_t total = n_triple * n_neg;
+    const int cut = ppp / 2;
+    for (int64_t t = blockIdx.x * 256ll + threadIdx.x; t < total; t += 256ll * gridDim.x) {
+        const int64_t s = t / n_neg;
+        const int64_t j = t - s * n_neg;
+        const int64_t blk = ppp > 0 ? s / ppp : 0;
+        const int p = ppp > 0 ? static_cast<int>(s - blk * ppp) : 0;
+        bool kill = false;
+        if (diag_step > 0) {
+            const int64_t qpos = ht ? (blk * cut + (p % cut)) : s;
+            kill = (j == static_cast<int64_t>(diag_step) * qpos);
+        }
+        const int64_t mj = j - (n_neg - mask_cols);
+        if (mask && mj >= 0) {
+            int64_t mrow = s;
+            if (mask_rows == 1) mrow = 0;
+            else if (mask_rows == 2) mrow = (p >= cut) ? 1 : 0;
+            // the mask overrides the diagonal on its columns (bess.py:227-228)
+            kill = mask[mrow * mask_cols + mj] == 0;
+        }
+        if (kill) neg[s * ld + j] += BESS_BAD_NEGATIVE_SCORE;
+    }
+}
+
+__device__ __forceinline__ float log_sigmoid(float x) {
+    // = -softplus(-x), the stable form torch uses
+    return fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+template <int KIND, bool ADV, bool GRAD>
+__global__ __launch_bounds__(256) void k_loss_rows(bess_loss_desc l, const float* __restrict__ pos,
+                                                   const float* __restrict__ neg, int64_t n_triple,
+                                                   int64_t n_neg, int64_t ld_neg,
+                                                   const float* __restrict__ weight,
+                                                   int64_t weight_len, float* __restrict__ row_loss,
+                                                   float* __restrict__ d_pos,
+                                                   float* __restrict__ d_neg, int64_t ld_dneg) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (s >= n_triple) return;
+    const float* nr = neg + s * ld_neg;
+    float* dn = GRAD ? d_neg + s * ld_dneg : nullptr;
+    const float w = weight[weight_len == 1 ? 0 : s];
+    const float p = pos[s];
+    const int n = static_cast<int>(n_neg);
+
+    if (KIND == BESS_LOSS_SSCE) {
+        // cross entropy of [pos, neg + shift] against class 0
+        float m = p;
+        for (int j = lane; j < n; j += 64) m = fmaxf(m, nr[j] + l.ssce_shift);
+        m = wave_allreduce_max(m);
+        float z = 0.f;
+        for (int j = lane; j < n; j += 64) z += expf(nr[j] + l.ssce_shift - m);
+        z = wave_allreduce_sum(z) + expf(p - m);
+        const float lse = m + logf(z);
+        if (lane == 0) row_loss[s] = l.loss_scale * w * (lse - p);
+        if (GRAD) {
+            const float c = l.loss_scale * w;
+            if (lane == 0) d_pos[s] = c * (expf(p - lse) - 1.f);
+            for (int j = lane; j < n; j += 64) dn[j] = c * expf(nr[j] + l.ssce_shift - lse);
+        }
+        return;
+    }
+
+    // negative weights: softmax(adversarial_scale * neg) (detached) or 1/N
+    float m = 0.f, inv_z = 1.f / static_cast<float>(n);
+    if (ADV) {
+        m = -INFINITY;
+        for (int j = lane; j < n; j += 64) m = fmaxf(m, l.adversarial_scale * nr[j]);
+        m = wave_allreduce_max(m);
+        float z = 0.f;
+        for (int j = lane; j < n; j += 64) z += expf(l.adversarial_scale * nr[j] - m);
+        inv_z = 1.f / wave_allreduce_sum(z);
+    }
+    float acc = 0.f, dsum = 0.f;
+    for (int j = lane; j < n; j += 64) {
+        const float x = nr[j];
+        const float aw = ADV ? expf(l.adversarial_scale * x - m) * inv_z : inv_z;
+        if (KIND == BESS_LOSS_LOGSIGMOID) {
+            acc += aw * log_sigmoid(-x - l.margin);
+            if (GRAD) dn[j] = 0.5f * l.loss_scale * w * aw * sigmoidf(x + l.margin);
+        } else {
+            const float c = x - p + l.margin;
+            acc += aw * fmaxf(c, 0.f);
+            if (GRAD) {
+                const float gj = (c > 0.f) ? l.loss_scale * w * aw : 0.f;
+                dn[j] = gj;
+                dsum += gj;
+            }
+        }
+    }
+    acc = wave_allreduce_sum(acc);
+    if (KIND == BESS_LOSS_LOGSIGMOID) {
+        if (lane == 0) {
+            row_loss[s] = -0.5f * l.loss_scale * w * (log_sigmoid(p + l.margin) + acc);
+            if (GRAD) d_pos[s] = -0.5f * l.loss_scale * w * sigmoidf(-(p + l.margin));
+        }
+    } else {
+        if (GRAD) dsum = wave_allreduce_sum(dsum);
+        if (lane == 0) {
+            row_loss[s] = l.loss_scale * w * acc;
+            if (GRAD) d_pos[s] = -dsum;
+        }
+    }
+}
+
+// fixed-order sum of row_loss -> loss[0]
+__global__ __launch_bounds__(1024) void k_sum_rows(const float* __restrict__ row_loss, int64_t n,
+                                                   float* __restrict__ loss) {
+    __shared__ float part[1024];
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) acc += row_loss[i];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = part[0];
+}
+
+template <int KIND, bool ADV>
+static void launch_loss(bool grad, const bess_loss_desc& l, const float* pos, const float* neg,
+                        int64_t S, int64_t N, int64_t ld, const float* w, int64_t wl, float* rl,
+                        float* dp, float* dn, int64_t ldd, hipStream_t st) {
+    const unsigned grid = static_cast<unsigned>(ceil_div(S, 4));
+    if (grad) k_loss_rows<KIND, ADV, true><<<grid, 256, 0, st>>>(l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd);
+    else k_loss_rows<KIND, ADV, false><<<grid, 256, 0, st>>>(l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd);
+}
+
+}  // namespace bess
+
+using namespace bess;
+
+extern "C" int bess_mask_scores(float* neg, int64_t n_triple, int64_t n_neg, int64_t ld,
+                                int32_t diag_step, int32_t ht, int32_t ppp, const uint8_t* mask,
+                                int64_t mask_rows, int64_t mask_cols, void* stream) {
+    BESS_REQUIRE(n_triple >= 0 && n_neg >= 0 && ld >= n_neg, "mask_scores: bad sizes");
+    if (n_triple == 0 || n_neg == 0) return BESS_OK;
+    BESS_REQUIRE(neg, "mask_scores: NULL scores");
+    BESS_REQUIRE(diag_step >= 0, "mask_scores: negative diag_step");
+    if (mask) {
+        BESS_REQUIRE(mask_cols > 0 && mask_cols <= n_neg, "mask_scores: mask_cols %lld not in (0, n_neg]", (long long)mask_cols);
+        BESS_REQUIRE(mask_rows == 1 || mask_rows == 2 || mask_rows == n_triple,
+                     "mask_scores: mask_rows %lld not 1, 2 or n_triple", (long long)mask_rows);
+    } else {
+        mask_cols = 0;
+    }
+    if (ht || mask_rows == 2)
+        BESS_REQUIRE(ppp >= 2 && (ppp % 2) == 0 && (n_triple % ppp) == 0, "mask_scores: 'ht' needs an even block size dividing n_triple");
+    const int64_t total = n_triple * n_neg;
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    k_mask_scores<<<static_cast<unsigned>(blocks), 256, 0, as_stream(stream)>>>(
+        neg, n_triple, n_neg, ld, diag_step, ht, ppp, mask, mask_rows, mask_cols);
+    return check_launch("mask_scores");
+}
+
+extern "C" int bess_loss_fwd_bwd(const bess_loss_desc* l, const float* pos, const float* neg,
+                                 int64_t n_triple, int64_t n_neg, int64_t ld_neg,
+                                 const float* weight, int64_t weight_len, float* row_loss,
+                                 float* loss, float* d_pos, float* d_neg, int64_t ld_dneg,
+                                 void* stream) {
+    BESS_REQUIRE(l, "loss: NULL descriptor");
+    BESS_REQUIRE(l->kind >= BESS_LOSS_LOGSIGMOID && l->kind <= BESS_LOSS_SSCE, "loss: unknown kind %d", l->kind);
+    BESS_REQUIRE(n_triple > 0 && n_neg > 0 && n_neg < (1ll << 31), "loss: bad sizes");
+    BESS_REQUIRE(pos && neg && weight && row_loss && loss, "loss: NULL pointer");
+    BESS_REQUIRE(weight_len == 1 || weight_len == n_triple, "loss: weight_len must be 1 or n_triple");
+    BESS_REQUIRE(ld_neg >= n_neg, "loss: leading dimension < n_neg");
+    const bool grad = d_pos || d_neg;
+    if (grad) BESS_REQUIRE(d_pos && d_neg && ld_dneg >= n_neg, "loss: gradients need d_pos, d_neg and ld_dneg >= n_neg");
+    hipStream_t st = as_stream(stream);
+    const bool adv = l->adversarial != 0;
+#define BESS_LOSS(KIND, ADV) \
+    launch_loss<KIND, ADV>(grad, *l, pos, neg, n_triple, n_neg, ld_neg, weight, weight_len, row_loss, d_pos, d_neg, ld_dneg, st)
+    switch (l->kind) {
+        case BESS_LOSS_LOGSIGMOID: adv ? BESS_LOSS(BESS_LOSS_LOGSIGMOID, true) : BESS_LOSS(BESS_LOSS_LOGSIGMOID, false); break;
+        case BESS_LOSS_MARGIN: adv ? BESS_LOSS(BESS_LOSS_MARGIN, true) : BESS_LOSS(BESS_LOSS_MARGIN, false); break;
+        default: BESS_LOSS(BESS_LOSS_SSCE, false);
+    }
+#undef BESS_LOSS
+    if (int e = check_launch("loss rows")) return e;
+    k_sum_rows<<<1, 1024, 0, st>>>(row_loss, n_triple, loss);
+    return check_launch("loss sum");
+}

@@ -1,0 +1,292 @@
+// K4 on gfx950: negatives shared by the whole micro-batch.
+//
+//   out[q, j] = sign * reduce_w f(query[q, w], E[neg_idx[j], w])      q < n_query, j < n_neg
+//
+// (reference: `pea.distance_matrix(q, N.view(-1, W), p)` for TransE / RotatE,
+//  scoring.py:194-197, and `torch.matmul(q, N.reshape(-1, W).T)` for DistMult /
+//  ComplEx, scoring.py:251-252.)
+//
+// Every gathered row is reused by all n_query queries, so this regime is
+// compute bound (2-3 flops per (q, j, w)), not HBM bound.  Structure: LDS-tiled
+// 64 x 64 output tile per 256-thread workgroup, 4 x 4 register micro-tile per
+// lane, 16-deep K stages; negative rows are gathered by index straight into the
+// LDS tile (never materialised in HBM).  The p-norm forms have no matrix-core
+// formulation (|a - b| is not bilinear) and run on the VALU; the dot form uses
+// the same tiling here and is the candidate for the f32 MFMA path.
+//
+// Backward reuses one tiled kernel:
+//   dX[a, w] = sum_b coef[a, b] * f'(X[a, w], Y[b, w])
+// called as (X, Y) = (query, negatives) for d_query and (negatives, query) with
+// the coefficient matrix read transposed for d_neg - the sum over the
+// micro-batch happens on chip, so d_neg needs no atomics.
+#include "common.h"
+
+namespace bess {
+
+constexpr int TM = 64;   // tile rows (queries / "a")
+constexpr int TN = 64;   // tile cols (negatives / "w")
+constexpr int KT = 16;   // stage depth
+constexpr int LDP = 68;  // padded LDS leading dimension (floats): 272 B rows, 16 B aligned
+
+// One operand of the tile kernels: rows of `width` scalars, either f32 with
+// identity indexing (the query matrix) or table dtype T gathered through idx.
+template <typename T>
+struct RowSrc {
+    const T* base;
+    const int32_t* idx;
+    int64_t n;
+    __device__ __forceinline__ const T* row(int64_t i, int width) const {
+        const int64_t r = idx ? static_cast<int64_t>(idx[i]) : i;
+        return base + r * width;
+    }
+};
+
+// stage loader: tile[k][m] = src.row(m0 + m)[k0 + k]   (zero outside)
+template <typename T>
+__device__ __forceinline__ void load_stage(const RowSrc<T>& src, int64_t m0, int k0, int W,
+                                           float (*tile)[LDP]) {
+    const int t = threadIdx.x;
+    const int m = t >> 2;         // 0..63
+    const int kc = (t & 3) * 4;   // 0,4,8,12
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m0 + m < src.n) {
+        const T* rp = src.row(m0 + m, W) + k0 + kc;
+        if ((W & 3) == 0 && k0 + kc + 3 < W) {
+            VecLoad<T, 4>::load(rp, v);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (k0 + kc + i < W) v[i] = to_f32(rp[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[kc + i][m] = v[i];
+}
+
+template <typename T, int RED>
+__global__ __launch_bounds__(256) void k_neg_shared_fwd(RowSrc<float> Q, RowSrc<T> E, int W,
+                                                        float sign, float* __restrict__ out,
+                                                        int64_t ld_out) {
+    __shared__ __attribute__((aligned(16))) float Qs[KT][LDP];
+    __shared__ __attribute__((aligned(16))) float Es[KT][LDP];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t q0 = static_cast<int64_t>(blockIdx.y) * TM;
+    const int64_t j0 = static_cast<int64_t>(blockIdx.x) * TN;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+    for (int k0 = 0; k0 < W; k0 += KT) {
+        load_stage<float>(Q, q0, k0, W, Qs);
+        load_stage<T>(E, j0, k0, W, Es);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&Qs[k][ty * 4]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&Es[k][tx * 4]);
+            const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+            const float b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (RED == RED_DOT) {
+                        acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+                    } else if (RED == RED_L1) {
+                        acc[i][j] += fabsf(a[i] - b[j]);
+                    } else {
+                        const float dlt = a[i] - b[j];
+                        acc[i][j] = fmaf(dlt, dlt, acc[i][j]);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t q = q0 + ty * 4 + i;
+        if (q >= Q.n) continue;
+        float* o = out + q * ld_out;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t jj = j0 + tx * 4 + j;
+            if (jj < E.n) {
+                float v = acc[i][j];
+                if (RED == RED_L2) v = sqrtf(v);
+                o[jj] = sign * v;
+            }
+        }
+    }
+}
+
+// dX[a, w] = sum_b coef(a, b) * f'(X[a, w], Y[b, w]);  coef from d_out (and out for p=2)
+//   DOT: coef = g            f' = y
+//   L1 : coef = sign*g       f' = sgn(x - y)
+//   L2 : coef = g / out      f' = x - y        (out = -dist; 0 where dist == 0)
+// g = d_out[a*sa + b*sb], out likewise with (oa, ob) strides.
+template <typename TX, typename TY, int RED>
+__global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY> Y, int W,
+                                                        float sign, const float* __restrict__ d_out,
+                                                        int64_t sa, int64_t sb,
+                                                        const float* __restrict__ out, int64_t oa,
+                                                        int64_t ob, float* __restrict__ dX) {
+    __shared__ __attribute__((aligned(16))) float Cs[KT][LDP];  // [b][a]
+    __shared__ __attribute__((aligned(16))) float Ys[KT][LDP];  // [b][w]
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t a0 = static_cast<int64_t>(blockIdx.y) * TM;
+    const int w0 = blockIdx.x * TN;
+    float acc[4][4], xv[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t a = a0 + ty * 4 + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int w = w0 + tx * 4 + j;
+            acc[i][j] = 0.f;
+            xv[i][j] = (a < X.n && w < W) ? to_f32(X.row(a, W)[w]) : 0.f;
+        }
+    }
+    for (int64_t b0 = 0; b0 < Y.n; b0 += KT) {
+        {  // coefficient stage: Cs[b][a], 16 x 64
+            const int t = threadIdx.x;
+            const int b = t & 15, ac = (t >> 4) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t a = a0 + ac + i;
+                float c = 0.f;
+                if (a < X.n && b0 + b < Y.n) {
+                    const float g = d_out[a * sa + (b0 + b) * sb];
+                    if (RED == RED_L2) {
+                        const float o = out[a * oa + (b0 + b) * ob];
+                        c = (o != 0.f) ? g / o : 0.f;
+                    } else {
+                        c = sign * g;
+                    }
+                }
+                Cs[b][ac + i] = c;
+            }
+        }
+        {  // Y stage: Ys[b][w], 16 x 64
+            const int t = threadIdx.x;
+            const int b = t >> 4, wc = (t & 15) * 4;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (b0 + b < Y.n) {
+                const TY* rp = Y.row(b0 + b, W) + w0 + wc;
+                if ((W & 3) == 0 && w0 + wc + 3 < W) {
+                    VecLoad<TY, 4>::load(rp, v);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (w0 + wc + i < W) v[i] = to_f32(rp[i]);
+                }
+            }
+            *reinterpret_cast<float4*>(&Ys[b][wc]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const float4 c4 = *reinterpret_cast<const float4*>(&Cs[k][ty * 4]);
+            const float4 y4 = *reinterpret_cast<const float4*>(&Ys[k][tx * 4]);
+            const float c[4] = {c4.x, c4.y, c4.z, c4.w};
+            const float y[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (RED == RED_DOT) acc[i][j] = fmaf(c[i], y[j], acc[i][j]);
+                    else if (RED == RED_L1) acc[i][j] = fmaf(c[i], sgnf(xv[i][j] - y[j]), acc[i][j]);
+                    else acc[i][j] = fmaf(c[i], xv[i][j] - y[j], acc[i][j]);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t a = a0 + ty * 4 + i;
+        if (a >= X.n) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int w = w0 + tx * 4 + j;
+            if (w < W) dX[a * W + w] = acc[i][j];
+        }
+    }
+}
+
+template <typename T>
+static int run_fwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<T> E, float* out, int64_t ld,
+                   hipStream_t st) {
+    const dim3 grid(static_cast<unsigned>(ceil_div(E.n, TN)), static_cast<unsigned>(ceil_div(Q.n, TM)));
+    const float sign = is_distance(d->scorer) ? -1.f : 1.f;
+    switch (reduce_of(d)) {
+        case RED_DOT: k_neg_shared_fwd<T, RED_DOT><<<grid, 256, 0, st>>>(Q, E, d->width, sign, out, ld); break;
+        case RED_L1: k_neg_shared_fwd<T, RED_L1><<<grid, 256, 0, st>>>(Q, E, d->width, sign, out, ld); break;
+        default: k_neg_shared_fwd<T, RED_L2><<<grid, 256, 0, st>>>(Q, E, d->width, sign, out, ld);
+    }
+    return check_launch("neg_score_shared_fwd");
+}
+
+template <typename TX, typename TY>
+static void run_bwd_one(const bess_model_desc* d, RowSrc<TX> X, RowSrc<TY> Y, const float* d_out,
+                        int64_t sa, int64_t sb, const float* out, int64_t oa, int64_t ob, float* dX,
+                        hipStream_t st) {
+    const dim3 grid(static_cast<unsigned>(ceil_div(d->width, TN)), static_cast<unsigned>(ceil_div(X.n, TM)));
+    const float sign = is_distance(d->scorer) ? -1.f : 1.f;
+    switch (reduce_of(d)) {
+        case RED_DOT:
+            k_neg_shared_bwd<TX, TY, RED_DOT><<<grid, 256, 0, st>>>(X, Y, d->width, sign, d_out, sa, sb, out, oa, ob, dX);
+            break;
+        case RED_L1:
+            k_neg_shared_bwd<TX, TY, RED_L1><<<grid, 256, 0, st>>>(X, Y, d->width, sign, d_out, sa, sb, out, oa, ob, dX);
+            break;
+        default:
+            k_neg_shared_bwd<TX, TY, RED_L2><<<grid, 256, 0, st>>>(X, Y, d->width, sign, d_out, sa, sb, out, oa, ob, dX);
+    }
+}
+
+}  // namespace bess
+
+using namespace bess;
+
+extern "C" int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* query,
+                                         int64_t n_query, const void* neg_base,
+                                         const int32_t* neg_idx, int64_t n_neg, float* out,
+                                         int64_t ld_out, void* stream) {
+    if (int e = check_desc(d)) return e;
+    BESS_REQUIRE(n_query >= 0 && n_neg >= 0, "neg_score_shared_fwd: bad sizes");
+    if (n_query == 0 || n_neg == 0) return BESS_OK;
+    BESS_REQUIRE(query && neg_base && out, "neg_score_shared_fwd: NULL pointer");
+    BESS_REQUIRE(ld_out >= n_neg, "neg_score_shared_fwd: leading dimension < n_neg");
+    RowSrc<float> Q{query, nullptr, n_query};
+    if (d->dtype == BESS_F32)
+        return run_fwd<float>(d, Q, RowSrc<float>{static_cast<const float*>(neg_base), neg_idx, n_neg}, out,
+                              ld_out, as_stream(stream));
+    return run_fwd<half_t>(d, Q, RowSrc<half_t>{static_cast<const half_t*>(neg_base), neg_idx, n_neg}, out,
+                           ld_out, as_stream(stream));
+}
+
+extern "C" int bess_neg_score_shared_bwd(const bess_model_desc* d, const float* query,
+                                         int64_t n_query, const void* neg_base,
+                                         const int32_t* neg_idx, int64_t n_neg, const float* out,
+                                         int64_t ld_out, const float* d_out, int64_t ld_dout,
+                                         float* d_query, float* d_neg, void* stream) {
+    if (int e = check_desc(d)) return e;
+    BESS_REQUIRE(n_query >= 0 && n_neg >= 0, "neg_score_shared_bwd: bad sizes");
+    if (n_query == 0 || n_neg == 0) return BESS_OK;
+    BESS_REQUIRE(query && neg_base && d_out && d_query && d_neg, "neg_score_shared_bwd: NULL pointer");
+    BESS_REQUIRE(reduce_of(d) != RED_L2 || out, "neg_score_shared_bwd: p=2 needs the forward scores");
+    BESS_REQUIRE(ld_dout >= n_neg && (!out || ld_out >= n_neg), "neg_score_shared_bwd: leading dimension < n_neg");
+    hipStream_t st = as_stream(stream);
+    RowSrc<float> Q{query, nullptr, n_query};
+    if (d->dtype == BESS_F32) {
+        RowSrc<float> E{static_cast<const float*>(neg_base), neg_idx, n_neg};
+        run_bwd_one<float, float>(d, Q, E, d_out, ld_dout, 1, out, ld_out, 1, d_query, st);
+        run_bwd_one<float, float>(d, E, Q, d_out, 1, ld_dout, out, 1, ld_out, d_neg, st);
+    } else {
+        RowSrc<half_t> E{static_cast<const half_t*>(neg_base), neg_idx, n_neg};
+        run_bwd_one<float, half_t>(d, Q, E, d_out, ld_dout, 1, out, ld_out, 1, d_query, st);
+        run_bwd_one<half_t, float>(d, E, Q, d_out, 1, ld_dout, out, 1, ld_out, d_neg, st);
+    }
+    return check_launch("neg_score_shared_bwd");
+}

@@ -1,0 +1,380 @@
+// Per-triple kernels of the BESS hot path on gfx950:
+//   K2+K3  score_triple            (reference scoring.py:321-330,423-434,804-813,905-916)
+//   K2+K6  query transform          (scoring.py:342,354,446-448,460-462,825,837,928-946;
+//                                    utils.py:72-112 complex_multiplication / complex_rotation)
+// and their backward passes.
+//
+// Work unit: one 64-lane wavefront per triple; lanes stride over the embedding
+// (consecutive lanes -> consecutive scalars, 256 B per wave load), partial sums
+// are combined with DPP / cross-row shuffles.  These kernels touch 2-3 rows per
+// triple (S rows in total) - they are the small side of the step; the rows that
+// dominate HBM traffic are the negatives (neg_pertriple.hip / neg_shared.hip).
+//
+// Entity rows of RotatE / ComplEx are stored [re(d) | im(d)]
+// (scoring.py:404-408, 881-885); RotatE relation rows are phases [d].
+#include "common.h"
+
+namespace bess {
+
+struct TripleArgs {
+    const void* head_base;
+    const int32_t* head_idx;
+    const void* tail_base;
+    const int32_t* tail_idx;
+    const void* rel_table;
+    const int32_t* rel_idx;
+    int64_t n;
+    int W;
+    int Wr;
+    int norm_p;
+};
+
+// ------------------------------------------------------------------ forward
+template <typename T, int SCORER>
+__global__ __launch_bounds__(256) void k_score_triple_fwd(TripleArgs a, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (s >= a.n) return;
+    const T* h = row_ptr(static_cast<const T*>(a.head_base), a.head_idx, s, a.W);
+    const T* t = row_ptr(static_cast<const T*>(a.tail_base), a.tail_idx, s, a.W);
+    const T* r = static_cast<const T*>(a.rel_table) + static_cast<int64_t>(a.rel_idx[s]) * a.Wr;
+    float acc = 0.f;
+    if (SCORER == BESS_TRANSE) {
+        for (int e = lane; e < a.W; e += 64) {
+            const float x = to_f32(h[e]) + to_f32(r[e]) - to_f32(t[e]);
+            acc += (a.norm_p == 1) ? fabsf(x) : x * x;
+        }
+    } else if (SCORER == BESS_DISTMULT) {
+        for (int e = lane; e < a.W; e += 64) acc += to_f32(h[e]) * to_f32(r[e]) * to_f32(t[e]);
+    } else {
+        const int d = a.W / 2;
+        for (int e = lane; e < d; e += 64) {
+            const float hr = to_f32(h[e]), hi = to_f32(h[d + e]);
+            const float tr = to_f32(t[e]), ti = to_f32(t[d + e]);
+            float rr, ri;
+            if (SCORER == BESS_ROTATE) {
+                const float ph = to_f32(r[e]);
+                rr = cosf(ph);
+                ri = sinf(ph);
+            } else {
+                rr = to_f32(r[e]);
+                ri = to_f32(r[d + e]);
+            }
+            const float qr = hr * rr - hi * ri;
+            const float qi = hr * ri + hi * rr;
+            if (SCORER == BESS_ROTATE) {
+                const float xr = qr - tr, xi = qi - ti;
+                acc += (a.norm_p == 1) ? (fabsf(xr) + fabsf(xi)) : (xr * xr + xi * xi);
+            } else {
+                acc += qr * tr + qi * ti;
+            }
+        }
+    }
+    acc = wave_allreduce_sum(acc);
+    if (SCORER == BESS_TRANSE || SCORER == BESS_ROTATE) acc = -((a.norm_p == 1) ? acc : sqrtf(acc));
+    if (lane == 0) out[s] = acc;
+}
+
+struct QueryArgs {
+    const void* ent_base;
+    const int32_t* ent_idx;
+    const void* rel_table;
+    const int32_t* rel_idx;
+    int64_t n;
+    int W;
+    int Wr;
+    int side;
+};
+
+template <typename T, int SCORER>
+__global__ __launch_bounds__(256) void k_query_fwd(QueryArgs a, float* __restrict__ query) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (q >= a.n) return;
+    const T* x = row_ptr(static_cast<const T*>(a.ent_base), a.ent_idx, q, a.W);
+    const T* r = static_cast<const T*>(a.rel_table) + static_cast<int64_t>(a.rel_idx[q]) * a.Wr;
+    float* o = query + q * a.W;
+    const bool tail = a.side == BESS_CORRUPT_TAIL;
+    if (SCORER == BESS_TRANSE) {
+        for (int e = lane; e < a.W; e += 64)
+            o[e] = tail ? (to_f32(x[e]) + to_f32(r[e])) : (to_f32(x[e]) - to_f32(r[e]));
+    } else if (SCORER == BESS_DISTMULT) {
+        for (int e = lane; e < a.W; e += 64) o[e] = to_f32(x[e]) * to_f32(r[e]);
+    } else {
+        const int d = a.W / 2;
+        for (int e = lane; e < d; e += 64) {
+            const float xr = to_f32(x[e]), xi = to_f32(x[d + e]);
+            float rr, ri;
+            if (SCORER == BESS_ROTATE) {
+                // heads: rotate the tail by -r (scoring.py:446-448)
+                const float ph = tail ? to_f32(r[e]) : -to_f32(r[e]);
+                rr = cosf(ph);
+                ri = sinf(ph);
+            } else {
+                // heads: conjugate relation times tail (scoring.py:928-932)
+                rr = to_f32(r[e]);
+                ri = tail ? to_f32(r[d + e]) : -to_f32(r[d + e]);
+            }
+            o[e] = xr * rr - xi * ri;
+            o[d + e] = xr * ri + xi * rr;
+        }
+    }
+}
+
+// ----------------------------------------------------------------- backward
+template <typename T, int SCORER>
+__global__ __launch_bounds__(256) void k_score_triple_bwd(TripleArgs a,
+                                                          const float* __restrict__ d_out,
+                                                          float* __restrict__ d_head,
+                                                          float* __restrict__ d_tail,
+                                                          float* __restrict__ d_rel) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (s >= a.n) return;
+    const T* h = row_ptr(static_cast<const T*>(a.head_base), a.head_idx, s, a.W);
+    const T* t = row_ptr(static_cast<const T*>(a.tail_base), a.tail_idx, s, a.W);
+    const int64_t rid = a.rel_idx[s];
+    const T* r = static_cast<const T*>(a.rel_table) + rid * a.Wr;
+    float* dh = d_head + s * a.W;
+    float* dt = d_tail + s * a.W;
+    float* dr = d_rel + rid * a.Wr;
+    const float g = d_out[s];
+
+    if (SCORER == BESS_TRANSE) {
+        float inv = 0.f;
+        if (a.norm_p == 2) {
+            float ss = 0.f;
+            for (int e = lane; e < a.W; e += 64) {
+                const float x = to_f32(h[e]) + to_f32(r[e]) - to_f32(t[e]);
+                ss += x * x;
+            }
+            ss = wave_allreduce_sum(ss);
+            inv = ss > 0.f ? 1.f / sqrtf(ss) : 0.f;
+        }
+        for (int e = lane; e < a.W; e += 64) {
+            const float x = to_f32(h[e]) + to_f32(r[e]) - to_f32(t[e]);
+            const float dx = -g * ((a.norm_p == 1) ? sgnf(x) : x * inv);
+            dh[e] = dx;
+            dt[e] = -dx;
+            if (dx != 0.f) unsafeAtomicAdd(dr + e, dx);
+        }
+    } else if (SCORER == BESS_DISTMULT) {
+        for (int e = lane; e < a.W; e += 64) {
+            const float hv = to_f32(h[e]), rv = to_f32(r[e]), tv = to_f32(t[e]);
+            dh[e] = g * rv * tv;
+            dt[e] = g * hv * rv;
+            unsafeAtomicAdd(dr + e, g * hv * tv);
+        }
+    } else {
+        const int d = a.W / 2;
+        float inv = 0.f;
+        if (SCORER == BESS_ROTATE && a.norm_p == 2) {
+            float ss = 0.f;
+            for (int e = lane; e < d; e += 64) {
+                const float hr = to_f32(h[e]), hi = to_f32(h[d + e]);
+                const float ph = to_f32(r[e]);
+                const float c = cosf(ph), sn = sinf(ph);
+                const float xr = hr * c - hi * sn - to_f32(t[e]);
+                const float xi = hr * sn + hi * c - to_f32(t[d + e]);
+                ss += xr * xr + xi * xi;
+            }
+            ss = wave_allreduce_sum(ss);
+            inv = ss > 0.f ? 1.f / sqrtf(ss) : 0.f;
+        }
+        for (int e = lane; e < d; e += 64) {
+            const float hr = to_f32(h[e]), hi = to_f32(h[d + e]);
+            const float tr = to_f32(t[e]), ti = to_f32(t[d + e]);
+            if (SCORER == BESS_ROTATE) {
+                const float ph = to_f32(r[e]);
+                const float c = cosf(ph), sn = sinf(ph);
+                const float xr = hr * c - hi * sn - tr;
+                const float xi = hr * sn + hi * c - ti;
+                const float dxr = -g * ((a.norm_p == 1) ? sgnf(xr) : xr * inv);
+                const float dxi = -g * ((a.norm_p == 1) ? sgnf(xi) : xi * inv);
+                dh[e] = dxr * c + dxi * sn;
+                dh[d + e] = -dxr * sn + dxi * c;
+                dt[e] = -dxr;
+                dt[d + e] = -dxi;
+                const float dph = dxr * (-hr * sn - hi * c) + dxi * (hr * c - hi * sn);
+                if (dph != 0.f) unsafeAtomicAdd(dr + e, dph);
+            } else {
+                const float rr = to_f32(r[e]), ri = to_f32(r[d + e]);
+                dh[e] = g * (rr * tr + ri * ti);
+                dh[d + e] = g * (-ri * tr + rr * ti);
+                dt[e] = g * (hr * rr - hi * ri);
+                dt[d + e] = g * (hr * ri + hi * rr);
+                unsafeAtomicAdd(dr + e, g * (hr * tr + hi * ti));
+                unsafeAtomicAdd(dr + d + e, g * (-hi * tr + hr * ti));
+            }
+        }
+    }
+}
+
+template <typename T, int SCORER>
+__global__ __launch_bounds__(256) void k_query_bwd(QueryArgs a, const float* __restrict__ d_query,
+                                                   float* __restrict__ d_ent,
+                                                   float* __restrict__ d_rel) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (q >= a.n) return;
+    const T* x = row_ptr(static_cast<const T*>(a.ent_base), a.ent_idx, q, a.W);
+    const int64_t rid = a.rel_idx[q];
+    const T* r = static_cast<const T*>(a.rel_table) + rid * a.Wr;
+    const float* dq = d_query + q * a.W;
+    float* dx = d_ent + q * a.W;
+    float* dr = d_rel + rid * a.Wr;
+    const bool tail = a.side == BESS_CORRUPT_TAIL;
+    if (SCORER == BESS_TRANSE) {
+        for (int e = lane; e < a.W; e += 64) {
+            const float g = dq[e];
+            dx[e] = g;
+            if (g != 0.f) unsafeAtomicAdd(dr + e, tail ? g : -g);
+        }
+    } else if (SCORER == BESS_DISTMULT) {
+        for (int e = lane; e < a.W; e += 64) {
+            const float g = dq[e];
+            dx[e] = g * to_f32(r[e]);
+            unsafeAtomicAdd(dr + e, g * to_f32(x[e]));
+        }
+    } else {
+        const int d = a.W / 2;
+        for (int e = lane; e < d; e += 64) {
+            const float xr = to_f32(x[e]), xi = to_f32(x[d + e]);
+            const float gr = dq[e], gi = dq[d + e];
+            if (SCORER == BESS_ROTATE) {
+                const float sg = tail ? 1.f : -1.f;
+                const float ph = sg * to_f32(r[e]);
+                const float c = cosf(ph), sn = sinf(ph);
+                dx[e] = gr * c + gi * sn;
+                dx[d + e] = -gr * sn + gi * c;
+                const float dph = gr * (-xr * sn - xi * c) + gi * (xr * c - xi * sn);
+                unsafeAtomicAdd(dr + e, sg * dph);
+            } else {
+                const float sg = tail ? 1.f : -1.f;  // conj r for heads
+                const float rr = to_f32(r[e]), ri = sg * to_f32(r[d + e]);
+                dx[e] = gr * rr + gi * ri;
+                dx[d + e] = -gr * ri + gi * rr;
+                unsafeAtomicAdd(dr + e, gr * xr + gi * xi);
+                unsafeAtomicAdd(dr + d + e, sg * (-gr * xi + gi * xr));
+            }
+        }
+    }
+}
+
+template <template <typename, int> class Launcher, typename... Args>
+static int dispatch(const bess_model_desc* d, Args... args) {
+#define BESS_CASE(SC)                                                   \
+    case SC:                                                            \
+        if (d->dtype == BESS_F32) Launcher<float, SC>::run(args...);    \
+        else Launcher<half_t, SC>::run(args...);                        \
+        break;
+    switch (d->scorer) {
+        BESS_CASE(BESS_TRANSE)
+        BESS_CASE(BESS_ROTATE)
+        BESS_CASE(BESS_DISTMULT)
+        BESS_CASE(BESS_COMPLEX)
+    }
+#undef BESS_CASE
+    return BESS_OK;
+}
+
+template <typename T, int SC>
+struct LTripleFwd {
+    static void run(TripleArgs a, float* out, hipStream_t st) {
+        k_score_triple_fwd<T, SC><<<ceil_div(a.n, 4), 256, 0, st>>>(a, out);
+    }
+};
+template <typename T, int SC>
+struct LTripleBwd {
+    static void run(TripleArgs a, const float* d_out, float* dh, float* dt, float* dr, hipStream_t st) {
+        k_score_triple_bwd<T, SC><<<ceil_div(a.n, 4), 256, 0, st>>>(a, d_out, dh, dt, dr);
+    }
+};
+template <typename T, int SC>
+struct LQueryFwd {
+    static void run(QueryArgs a, float* q, hipStream_t st) {
+        k_query_fwd<T, SC><<<ceil_div(a.n, 4), 256, 0, st>>>(a, q);
+    }
+};
+template <typename T, int SC>
+struct LQueryBwd {
+    static void run(QueryArgs a, const float* dq, float* dx, float* dr, hipStream_t st) {
+        k_query_bwd<T, SC><<<ceil_div(a.n, 4), 256, 0, st>>>(a, dq, dx, dr);
+    }
+};
+
+}  // namespace bess
+
+using namespace bess;
+
+static int triple_args(const bess_model_desc* d, const void* hb, const int32_t* hi, const void* tb,
+                       const int32_t* ti, const void* rt, const int32_t* ri, int64_t n,
+                       TripleArgs* a) {
+    if (int e = check_desc(d)) return e;
+    BESS_REQUIRE(n >= 0, "score_triple: negative n_triple");
+    BESS_REQUIRE(n == 0 || (hb && tb && rt && ri), "score_triple: NULL pointer");
+    *a = TripleArgs{hb, hi, tb, ti, rt, ri, n, d->width, d->rel_width, d->norm_p};
+    return BESS_OK;
+}
+
+extern "C" int bess_score_triple_fwd(const bess_model_desc* d, const void* head_base,
+                                     const int32_t* head_idx, const void* tail_base,
+                                     const int32_t* tail_idx, const void* rel_table,
+                                     const int32_t* rel_idx, int64_t n_triple, float* out,
+                                     void* stream) {
+    TripleArgs a;
+    if (int e = triple_args(d, head_base, head_idx, tail_base, tail_idx, rel_table, rel_idx, n_triple, &a))
+        return e;
+    if (n_triple == 0) return BESS_OK;
+    BESS_REQUIRE(out, "score_triple_fwd: NULL out");
+    dispatch<LTripleFwd>(d, a, out, as_stream(stream));
+    return check_launch("score_triple_fwd");
+}
+
+extern "C" int bess_score_triple_bwd(const bess_model_desc* d, const void* head_base,
+                                     const int32_t* head_idx, const void* tail_base,
+                                     const int32_t* tail_idx, const void* rel_table,
+                                     const int32_t* rel_idx, int64_t n_triple, const float* d_out,
+                                     float* d_head, float* d_tail, float* d_rel_table,
+                                     void* stream) {
+    TripleArgs a;
+    if (int e = triple_args(d, head_base, head_idx, tail_base, tail_idx, rel_table, rel_idx, n_triple, &a))
+        return e;
+    if (n_triple == 0) return BESS_OK;
+    BESS_REQUIRE(d_out && d_head && d_tail && d_rel_table, "score_triple_bwd: NULL pointer");
+    dispatch<LTripleBwd>(d, a, d_out, d_head, d_tail, d_rel_table, as_stream(stream));
+    return check_launch("score_triple_bwd");
+}
+
+static int query_args(const bess_model_desc* d, int32_t side, const void* eb, const int32_t* ei,
+                      const void* rt, const int32_t* ri, int64_t n, QueryArgs* a) {
+    if (int e = check_desc(d)) return e;
+    BESS_REQUIRE(side == BESS_CORRUPT_HEAD || side == BESS_CORRUPT_TAIL, "query: bad side %d", side);
+    BESS_REQUIRE(n >= 0, "query: negative n_query");
+    BESS_REQUIRE(n == 0 || (eb && rt && ri), "query: NULL pointer");
+    *a = QueryArgs{eb, ei, rt, ri, n, d->width, d->rel_width, side};
+    return BESS_OK;
+}
+
+extern "C" int bess_query_fwd(const bess_model_desc* d, int32_t side, const void* ent_base,
+                              const int32_t* ent_idx, const void* rel_table,
+                              const int32_t* rel_idx, int64_t n_query, float* query, void* stream) {
+    QueryArgs a;
+    if (int e = query_args(d, side, ent_base, ent_idx, rel_table, rel_idx, n_query, &a)) return e;
+    if (n_query == 0) return BESS_OK;
+    BESS_REQUIRE(query, "query_fwd: NULL out");
+    dispatch<LQueryFwd>(d, a, query, as_stream(stream));
+    return check_launch("query_fwd");
+}
+
+extern "C" int bess_query_bwd(const bess_model_desc* d, int32_t side, const void* ent_base,
+                              const int32_t* ent_idx, const void* rel_table,
+                              const int32_t* rel_idx, int64_t n_query, const float* d_query,
+                              float* d_ent, float* d_rel_table, void* stream) {
+    QueryArgs a;
+    if (int e = query_args(d, side, ent_base, ent_idx, rel_table, rel_idx, n_query, &a)) return e;
+    if (n_query == 0) return BESS_OK;
+    BESS_REQUIRE(d_query && d_ent && d_rel_table, "query_bwd: NULL pointer");
+    dispatch<LQueryBwd>(d, a, d_query, d_ent, d_rel_table, as_stream(stream));
+    return check_launch("query_bwd");
+}

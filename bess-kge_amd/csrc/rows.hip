@@ -1,0 +1,193 @@
+// Row movers of the BESS hot path on gfx950: K1 gather, K9 scatter-add,
+// K10 sparse / dense SGD; plus the library's error plumbing.
+//
+// All three are pure HBM-bound byte movers: one 16-lane DPP row per table row
+// slice, 16 B per lane per access, 64-bit row offsets.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace bess {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        fail(static_cast<int>(e), "%s: %s", what, hipGetErrorString(e));
+        return static_cast<int>(e);
+    }
+    return BESS_OK;
+}
+
+int check_desc(const bess_model_desc* d) {
+    if (!d) return fail(BESS_EINVAL, "model descriptor is NULL");
+    if (d->scorer < BESS_TRANSE || d->scorer > BESS_COMPLEX)
+        return fail(BESS_EINVAL, "unknown scorer %d", d->scorer);
+    if (d->dtype != BESS_F32 && d->dtype != BESS_F16)
+        return fail(BESS_EINVAL, "unknown dtype %d", d->dtype);
+    if (d->width <= 0 || d->rel_width <= 0)
+        return fail(BESS_EINVAL, "non-positive width %d / %d", d->width, d->rel_width);
+    if (is_distance(d->scorer) && d->norm_p != 1 && d->norm_p != 2)
+        return fail(BESS_EINVAL, "scoring norm %d not in {1, 2}", d->norm_p);
+    const bool cplx = is_complex_entity(d->scorer);
+    if (cplx && (d->width % 2)) return fail(BESS_EINVAL, "complex scorer needs even width");
+    int want_rel = d->width;
+    if (d->scorer == BESS_ROTATE) want_rel = d->width / 2;
+    if (d->rel_width != want_rel)
+        return fail(BESS_EINVAL, "rel_width %d does not match scorer (want %d)", d->rel_width, want_rel);
+    return BESS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// K1: out[i, :] = table[idx[i], :].  Units of 16 B ("chunks"); thread t of the
+// grid copies chunk (t % cpr) of row (t / cpr) -> consecutive lanes read
+// consecutive 16 B of one row: fully coalesced for rows >= 256 B.
+template <typename CH>
+__global__ __launch_bounds__(256) void k_gather_rows(const CH* __restrict__ table,
+                                                     const int32_t* __restrict__ idx, int64_t n,
+                                                     int cpr, CH* __restrict__ out) {
+    const int64_t total = n * cpr;
+    for (int64_t t = blockIdx.x * 256ll + threadIdx.x; t < total; t += 256ll * gridDim.x) {
+        const int64_t i = t / cpr;
+        const int c = static_cast<int>(t - i * cpr);
+        out[t] = table[static_cast<int64_t>(idx[i]) * cpr + c];
+    }
+}
+
+// K9: dst[idx[i], :] += scale * src[i, :]   (f32 atomics; a wave-instruction adds
+// 256 contiguous bytes of one row = the shape the memory-side atomic unit
+// takes at full rate)
+__global__ __launch_bounds__(256) void k_scatter_add_rows(float* __restrict__ dst, int width,
+                                                          const int32_t* __restrict__ idx,
+                                                          const float* __restrict__ src, int64_t n,
+                                                          float scale) {
+    const int64_t total = n * width;
+    for (int64_t t = blockIdx.x * 256ll + threadIdx.x; t < total; t += 256ll * gridDim.x) {
+        const int64_t i = t / width;
+        const int c = static_cast<int>(t - i * width);
+        const float v = scale * src[t];
+        if (v != 0.f) unsafeAtomicAdd(dst + static_cast<int64_t>(idx[i]) * width + c, v);
+    }
+}
+
+// K10 on an f16 shard: two halves per lane, packed atomic add
+__global__ __launch_bounds__(256) void k_scatter_add_rows_f16(__half2* __restrict__ dst, int width2,
+                                                              const int32_t* __restrict__ idx,
+                                                              const float2* __restrict__ src,
+                                                              int64_t n, float scale) {
+    const int64_t total = n * width2;
+    for (int64_t t = blockIdx.x * 256ll + threadIdx.x; t < total; t += 256ll * gridDim.x) {
+        const int64_t i = t / width2;
+        const int c = static_cast<int>(t - i * width2);
+        const float2 v = src[t];
+        unsafeAtomicAdd(dst + static_cast<int64_t>(idx[i]) * width2 + c,
+                        __floats2half2_rn(scale * v.x, scale * v.y));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_dense_axpy(T* __restrict__ table,
+                                                    const float* __restrict__ grad, int64_t n,
+                                                    float alpha) {
+    for (int64_t t = blockIdx.x * 256ll + threadIdx.x; t < n; t += 256ll * gridDim.x)
+        table[t] = static_cast<T>(static_cast<float>(table[t]) + alpha * grad[t]);
+}
+
+static int grid_for(int64_t work_items) {
+    int64_t b = ceil_div(work_items, 256);
+    const int64_t cap = 256 * 16;  // 16 blocks per CU, grid-stride beyond
+    return static_cast<int>(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace bess
+
+using namespace bess;
+
+extern "C" int bess_version(void) { return BESS_ABI_VERSION; }
+
+extern "C" int bess_last_error(char* buf, size_t len) {
+    const size_t n = strlen(g_err);
+    if (buf && len) {
+        const size_t c = n < len - 1 ? n : len - 1;
+        memcpy(buf, g_err, c);
+        buf[c] = 0;
+    }
+    return static_cast<int>(n);
+}
+
+extern "C" int bess_gather_rows(int32_t dtype, int32_t width, const void* table,
+                                const int32_t* idx, int64_t n, void* out, void* stream) {
+    BESS_REQUIRE(dtype == BESS_F32 || dtype == BESS_F16, "gather_rows: unknown dtype %d", dtype);
+    BESS_REQUIRE(width > 0 && n >= 0, "gather_rows: bad sizes width=%d n=%lld", width, (long long)n);
+    if (n == 0) return BESS_OK;
+    BESS_REQUIRE(table && idx && out, "gather_rows: NULL pointer");
+    const int64_t row_bytes = static_cast<int64_t>(width) * (dtype == BESS_F32 ? 4 : 2);
+    hipStream_t st = as_stream(stream);
+    if (row_bytes % 16 == 0) {
+        const int cpr = static_cast<int>(row_bytes / 16);
+        k_gather_rows<uint4><<<grid_for(n * cpr), 256, 0, st>>>(
+            static_cast<const uint4*>(table), idx, n, cpr, static_cast<uint4*>(out));
+    } else if (row_bytes % 4 == 0) {
+        const int cpr = static_cast<int>(row_bytes / 4);
+        k_gather_rows<uint32_t><<<grid_for(n * cpr), 256, 0, st>>>(
+            static_cast<const uint32_t*>(table), idx, n, cpr, static_cast<uint32_t*>(out));
+    } else {
+        const int cpr = static_cast<int>(row_bytes / 2);
+        k_gather_rows<uint16_t><<<grid_for(n * cpr), 256, 0, st>>>(
+            static_cast<const uint16_t*>(table), idx, n, cpr, static_cast<uint16_t*>(out));
+    }
+    return check_launch("gather_rows");
+}
+
+extern "C" int bess_scatter_add_rows(float* dst, int32_t width, const int32_t* idx,
+                                     const float* src, int64_t n, float scale, void* stream) {
+    BESS_REQUIRE(width > 0 && n >= 0, "scatter_add_rows: bad sizes");
+    if (n == 0) return BESS_OK;
+    BESS_REQUIRE(dst && idx && src, "scatter_add_rows: NULL pointer");
+    k_scatter_add_rows<<<grid_for(n * width), 256, 0, as_stream(stream)>>>(dst, width, idx, src, n,
+                                                                           scale);
+    return check_launch("scatter_add_rows");
+}
+
+extern "C" int bess_sparse_sgd(int32_t dtype, int32_t width, void* table, const int32_t* idx,
+                               const float* grad, int64_t n, float lr, void* stream) {
+    BESS_REQUIRE(dtype == BESS_F32 || dtype == BESS_F16, "sparse_sgd: unknown dtype %d", dtype);
+    BESS_REQUIRE(width > 0 && n >= 0, "sparse_sgd: bad sizes");
+    if (n == 0) return BESS_OK;
+    BESS_REQUIRE(table && idx && grad, "sparse_sgd: NULL pointer");
+    if (dtype == BESS_F32) {
+        k_scatter_add_rows<<<grid_for(n * width), 256, 0, as_stream(stream)>>>(
+            static_cast<float*>(table), width, idx, grad, n, -lr);
+    } else {
+        if (width % 2) return fail(BESS_EUNSUPPORTED, "sparse_sgd f16 needs an even width");
+        k_scatter_add_rows_f16<<<grid_for(n * (width / 2)), 256, 0, as_stream(stream)>>>(
+            static_cast<__half2*>(table), width / 2, idx, reinterpret_cast<const float2*>(grad), n,
+            -lr);
+    }
+    return check_launch("sparse_sgd");
+}
+
+extern "C" int bess_dense_sgd(int32_t dtype, void* table, const float* grad, int64_t n_elem,
+                              float lr, void* stream) {
+    BESS_REQUIRE(dtype == BESS_F32 || dtype == BESS_F16, "dense_sgd: unknown dtype %d", dtype);
+    if (n_elem <= 0) return BESS_OK;
+    BESS_REQUIRE(table && grad, "dense_sgd: NULL pointer");
+    if (dtype == BESS_F32)
+        k_dense_axpy<float><<<grid_for(n_elem), 256, 0, as_stream(stream)>>>(
+            static_cast<float*>(table), grad, n_elem, -lr);
+    else
+        k_dense_axpy<half_t><<<grid_for(n_elem), 256, 0, as_stream(stream)>>>(
+            static_cast<half_t*>(table), grad, n_elem, -lr);
+    return check_launch("dense_sgd");
+}

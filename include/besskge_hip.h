@@ -1,0 +1,206 @@
+/*
+ * besskge_hip.h - C ABI of the MI355X (gfx950) BESS hot path.
+ *
+ * One shared library, `libbesskge_hip.so`, loaded with ctypes at
+ * `import besskge` - the place where the reference dlopens its PopART
+ * custom-op library (reference besskge/__init__.py:10-37).  The reference has
+ * no exported C functions of its own (its .so only self-registers a PopART
+ * graph pattern, custom_ops/remove_all_reduce_pattern.cpp:45-47); each entry
+ * point below therefore cites the reference *Python* expression it replaces.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = invalid argument (BESS_E*),
+ *     >0 = hipError_t of the failing runtime call; bess_last_error() gives text;
+ *   - no ownership transfer: every buffer is allocated by the caller (PyTorch)
+ *     and passed as a raw device pointer; the library never allocates,
+ *     synchronises or frees;
+ *   - calls are asynchronous on the given hipStream_t (passed as void*);
+ *   - no global mutable state; safe from one host thread per device;
+ *   - index arrays are int32 (the dtype the samplers emit,
+ *     batch_sampler.py:170-178); row offsets are computed in 64 bit, so a
+ *     shard may exceed 4 GiB (config 5: 62.5 M rows x 2 KiB);
+ *   - "rows" arguments come as (base, idx): row i is base[idx[i]*width ...];
+ *     idx == NULL means the identity (row i is base[i*width ...]).  With
+ *     n_shard == 1 `base` is the shard itself and idx the sampler's indices
+ *     (gather fused into the scoring kernel, nothing materialised); with
+ *     n_shard > 1 `base` is the all-to-all receive buffer and idx a static
+ *     re-ordering map.
+ */
+#ifndef BESSKGE_HIP_H
+#define BESSKGE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BESS_ABI_VERSION 1
+
+/* error codes (negative); positive return values are hipError_t */
+#define BESS_OK 0
+#define BESS_EINVAL -1       /* bad enum / size / null pointer            */
+#define BESS_EUNSUPPORTED -2 /* legal but not built (width/alignment...)  */
+
+/* scoring functions (reference besskge/scoring.py:258-462, 746-946) */
+#define BESS_TRANSE 0
+#define BESS_ROTATE 1
+#define BESS_DISTMULT 2
+#define BESS_COMPLEX 3
+
+/* table element types */
+#define BESS_F32 0
+#define BESS_F16 1
+
+/* which entity the negatives replace */
+#define BESS_CORRUPT_HEAD 0 /* score_heads: query built from (r, t) */
+#define BESS_CORRUPT_TAIL 1 /* score_tails: query built from (h, r) */
+
+/* loss functions (reference besskge/loss.py:109-251) */
+#define BESS_LOSS_LOGSIGMOID 0
+#define BESS_LOSS_MARGIN 1
+#define BESS_LOSS_SSCE 2
+
+/* value added to the score of a masked negative (reference bess.py:31) */
+#define BESS_BAD_NEGATIVE_SCORE (-50000.0f)
+
+typedef struct bess_model_desc {
+    int32_t scorer;    /* BESS_TRANSE ...                                  */
+    int32_t norm_p;    /* 1 or 2 (TransE / RotatE), ignored otherwise      */
+    int32_t dtype;     /* element type of entity and relation tables       */
+    int32_t width;     /* W : scalars per entity row (2d for RotatE/ComplEx) */
+    int32_t rel_width; /* Wr: scalars per relation row (d for RotatE)      */
+    int32_t reserved[3];
+} bess_model_desc;
+
+typedef struct bess_loss_desc {
+    int32_t kind;        /* BESS_LOSS_*                                    */
+    int32_t adversarial; /* self-adversarial negative weights (loss.py:39) */
+    float margin;
+    float adversarial_scale;
+    float loss_scale;
+    float ssce_shift; /* log(n_entity-1) - log(N)  (loss.py:233-237)        */
+    int32_t reserved[2];
+} bess_loss_desc;
+
+int bess_version(void);
+/* copies the calling thread's last error text; returns its length */
+int bess_last_error(char* buf, size_t len);
+
+/* K1 - `self.entity_embedding[gather_idx]` (bess.py:332-337, 502-507).
+ * out[i, :] = table[idx[i], :], i < n; dtype preserved. */
+int bess_gather_rows(int32_t dtype, int32_t width, const void* table,
+                     const int32_t* idx, int64_t n, void* out, void* stream);
+
+/* K2+K3 - `score_fn.score_triple(h, r, t)` (scoring.py:321-330, 423-434,
+ * 804-813, 905-916).  out[s] (f32), s < n_triple. */
+int bess_score_triple_fwd(const bess_model_desc* d, const void* head_base,
+                          const int32_t* head_idx, const void* tail_base,
+                          const int32_t* tail_idx, const void* rel_table,
+                          const int32_t* rel_idx, int64_t n_triple, float* out,
+                          void* stream);
+
+/* backward of bess_score_triple_fwd: d_head / d_tail [n_triple, W] f32 are
+ * overwritten; d_rel_table [n_rel, Wr] f32 is accumulated (atomic). */
+int bess_score_triple_bwd(const bess_model_desc* d, const void* head_base,
+                          const int32_t* head_idx, const void* tail_base,
+                          const int32_t* tail_idx, const void* rel_table,
+                          const int32_t* rel_idx, int64_t n_triple,
+                          const float* d_out, float* d_head, float* d_tail,
+                          float* d_rel_table, void* stream);
+
+/* K2+K6 - the query transform in front of score_heads / score_tails
+ * (scoring.py:342,354,446-448,460-462,825,837,928-932,944-946; utils.py:72-112):
+ *   TAIL: h+r | rot(h,r) | h*r | cmul(h,r)     HEAD: t-r | rot(t,-r) | r*t | cmul(conj r,t)
+ * query[q, :] (f32 [n_query, W]) for entity row q and relation rel_idx[q]. */
+int bess_query_fwd(const bess_model_desc* d, int32_t side, const void* ent_base,
+                   const int32_t* ent_idx, const void* rel_table,
+                   const int32_t* rel_idx, int64_t n_query, float* query,
+                   void* stream);
+
+/* backward of bess_query_fwd: d_ent [n_query, W] f32 overwritten,
+ * d_rel_table accumulated (atomic). */
+int bess_query_bwd(const bess_model_desc* d, int32_t side, const void* ent_base,
+                   const int32_t* ent_idx, const void* rel_table,
+                   const int32_t* rel_idx, int64_t n_query, const float* d_query,
+                   float* d_ent, float* d_rel_table, void* stream);
+
+/* K5 - per-triple negatives, `reduce_embedding(q[:,None] o N)` (scoring.py:199,254):
+ *   out[q*ld_out + k] = score(query[q], neg_base[neg_idx[q*n_neg + k]]),  k < n_neg
+ * HBM-bound: one gathered row per scored triple, read straight from the shard. */
+int bess_neg_score_pertriple_fwd(const bess_model_desc* d, const float* query,
+                                 int64_t n_query, const void* neg_base,
+                                 const int32_t* neg_idx, int64_t n_neg, float* out,
+                                 int64_t ld_out, void* stream);
+
+/* backward of K5.  d_out read with ld_dout.  d_query [n_query, W] f32 is
+ * overwritten; d_neg [n_query*n_neg, W] f32 (gradient w.r.t. every gathered
+ * row, same order as neg_idx) is overwritten. */
+int bess_neg_score_pertriple_bwd(const bess_model_desc* d, const float* query,
+                                 int64_t n_query, const void* neg_base,
+                                 const int32_t* neg_idx, int64_t n_neg,
+                                 const float* d_out, int64_t ld_dout,
+                                 float* d_query, float* d_neg, void* stream);
+
+/* K4 - shared negatives, `pea.distance_matrix(q, N)` / `q @ N.T`
+ * (scoring.py:194-197, 251-252):
+ *   out[q*ld_out + j] = score(query[q], neg_base[neg_idx[j]]),  j < n_neg */
+int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* query,
+                              int64_t n_query, const void* neg_base,
+                              const int32_t* neg_idx, int64_t n_neg, float* out,
+                              int64_t ld_out, void* stream);
+
+/* backward of K4.  `out` is the forward result (needed for p = 2).
+ * d_query [n_query, W] and d_neg [n_neg, W] (f32) are overwritten. */
+int bess_neg_score_shared_bwd(const bess_model_desc* d, const float* query,
+                              int64_t n_query, const void* neg_base,
+                              const int32_t* neg_idx, int64_t n_neg,
+                              const float* out, int64_t ld_out, const float* d_out,
+                              int64_t ld_dout, float* d_query, float* d_neg,
+                              void* stream);
+
+/* K7 - mask / augment block of BessKGE.forward (bess.py:182-245), in place:
+ *   neg[s, j] += BAD_NEGATIVE_SCORE  where
+ *     j == diag_step * qpos(s)                       (diag_step > 0: augment)
+ *     or, for the last mask_cols columns, !mask[mrow(s), j - (n_neg - mask_cols)]
+ * qpos/mrow: block = s / ppp, p = s % ppp, cut = ppp/2
+ *   ht == 0: qpos = s                     ht == 1: qpos = block*cut + p % cut
+ *   mask_rows == 1: mrow = 0;  mask_rows == 2: mrow = (p >= cut);  else mrow = s
+ * mask is uint8 (bool) [mask_rows, mask_cols], 1 = real negative. */
+int bess_mask_scores(float* neg, int64_t n_triple, int64_t n_neg, int64_t ld,
+                     int32_t diag_step, int32_t ht, int32_t ppp,
+                     const uint8_t* mask, int64_t mask_rows, int64_t mask_cols,
+                     void* stream);
+
+/* K8 - loss + its gradient w.r.t. the scores (loss.py:28-51,115-134,179-195,
+ * 224-251), fp32.  weight has weight_len (1 or n_triple) entries.
+ * row_loss [n_triple] (caller-provided scratch) receives the per-triple terms,
+ * loss[0] their fixed-order sum (bitwise reproducible); d_pos [n_triple] and
+ * d_neg [n_triple, ld_dneg] are overwritten (pass NULL for both to skip
+ * gradients). */
+int bess_loss_fwd_bwd(const bess_loss_desc* l, const float* pos, const float* neg,
+                      int64_t n_triple, int64_t n_neg, int64_t ld_neg,
+                      const float* weight, int64_t weight_len, float* row_loss,
+                      float* loss, float* d_pos, float* d_neg, int64_t ld_dneg,
+                      void* stream);
+
+/* K9 - sparse scatter-add, backward of K1 (autograd index_put_(accumulate)):
+ *   dst[idx[i], :] += scale * src[i, :]     (f32 atomics, duplicates allowed)
+ * dst is f32 [*, width]. */
+int bess_scatter_add_rows(float* dst, int32_t width, const int32_t* idx,
+                          const float* src, int64_t n, float scale, void* stream);
+
+/* K10 - sparse SGD step on a shard (table dtype f32 or f16):
+ *   table[idx[i], :] -= lr * grad[i, :]     (atomic, duplicates accumulate) */
+int bess_sparse_sgd(int32_t dtype, int32_t width, void* table, const int32_t* idx,
+                    const float* grad, int64_t n, float lr, void* stream);
+
+/* dense axpy on a replicated table: table -= lr * grad (relation table) */
+int bess_dense_sgd(int32_t dtype, void* table, const float* grad, int64_t n_elem,
+                   float lr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BESSKGE_HIP_H */

@@ -1,0 +1,301 @@
+"""CPU oracle of the BESS device step (TEST INFRASTRUCTURE - not product code).
+
+A plain-torch CPU restatement of what the reference computes on the hot path,
+written independently of the product (`bess-kge_amd/`): no HIP, no index maps,
+no collectives - the all-to-all is *simulated by indexing* `[:, :, replica]`,
+the way the reference's own host tests do (`tests/test_negative_sampler.py:
+112-119`, `tests/test_batch_sampler.py:113-123`).
+
+Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
+`bench.py` may import this package, and only as the checker.
+
+Parity pinning: every function here is checked against vectors produced by the
+reference's own code (tests/golden/{scoring,loss,bess}.npz, generator
+tests/golden/make_golden.py) in `tests/test_oracle.py`.
+
+Reference lines restated:
+  score_triple / score_heads / score_tails ... scoring.py:321-354 (TransE),
+      423-462 (RotatE), 804-837 (DistMult), 905-946 (ComplEx);
+      broadcasted_distance scoring.py:176-200, broadcasted_dot_product 231-255;
+      complex_multiplication / complex_rotation utils.py:72-112
+  losses ............ loss.py:28-51, 115-134, 179-195, 224-251
+  embedding_moving .. bess.py:117-278 (forward glue), 322-468 (score_batch)
+  score_moving ...... bess.py:490-603
+`pea.distance_matrix` (not in /root/reference, pinned git 899aec4) is taken as
+the explicit broadcast p-norm ||a_i - b_j||_p.
+"""
+
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+BAD_NEGATIVE_SCORE = -50000.0
+
+TRANSE, ROTATE, DISTMULT, COMPLEX = "TransE", "RotatE", "DistMult", "ComplEx"
+
+
+# ------------------------------------------------------------------ scoring --
+def _cmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    e = a.shape[-1] // 2
+    ar, ai, br, bi = a[..., :e], a[..., e:], b[..., :e], b[..., e:]
+    return torch.cat([ar * br - ai * bi, ar * bi + ai * br], dim=-1)
+
+
+def _rot(v: torch.Tensor, phase: torch.Tensor) -> torch.Tensor:
+    return _cmul(v, torch.cat([torch.cos(phase), torch.sin(phase)], dim=-1))
+
+
+def _is_distance(scorer: str) -> bool:
+    return scorer in (TRANSE, ROTATE)
+
+
+def query(scorer: str, side: str, ent: torch.Tensor, rel: torch.Tensor) -> torch.Tensor:
+    """Query vector in front of the candidate reduction.
+
+    side "t" (tails are corrupted): built from (h, r); side "h": from (r, t).
+    """
+    if scorer == TRANSE:
+        return ent + rel if side == "t" else ent - rel
+    if scorer == ROTATE:
+        return _rot(ent, rel if side == "t" else -rel)
+    if scorer == DISTMULT:
+        return ent * rel
+    if scorer == COMPLEX:
+        if side == "t":
+            return _cmul(ent, rel)
+        e = rel.shape[-1] // 2
+        conj = torch.cat([rel[..., :e], -rel[..., e:]], dim=-1)
+        return _cmul(conj, ent)
+    raise ValueError(scorer)
+
+
+def _reduce(scorer: str, p: int, q: torch.Tensor, cand: torch.Tensor) -> torch.Tensor:
+    """q [..., W] against cand [..., W] (broadcast) -> [...]"""
+    if _is_distance(scorer):
+        return -torch.norm(q - cand, p=p, dim=-1)
+    return torch.sum(q * cand, dim=-1)
+
+
+def score_triple(scorer: str, p: int, h: torch.Tensor, rel_table: torch.Tensor, rid: torch.Tensor,
+                 t: torch.Tensor) -> torch.Tensor:
+    return _reduce(scorer, p, query(scorer, "t", h, rel_table[rid.long()]), t)
+
+
+def score_candidates(scorer: str, p: int, sharing: bool, side: str, ent: torch.Tensor,
+                     rel_table: torch.Tensor, rid: torch.Tensor, cand: torch.Tensor) -> torch.Tensor:
+    """score_heads (side "h", ent = tails) / score_tails (side "t", ent = heads).
+
+    cand [B, N, W].  sharing: every query vs all B*N rows -> [S, B*N];
+    else query s vs cand[s] (B == S, or B == 1 broadcast) -> [S, N].
+    """
+    q = query(scorer, side, ent, rel_table[rid.long()])  # [S, W]
+    if sharing:
+        flat = cand.reshape(-1, cand.shape[-1])
+        return _reduce(scorer, p, q[:, None, :], flat[None, :, :])
+    return _reduce(scorer, p, q[:, None, :], cand)
+
+
+# ------------------------------------------------------------------- losses --
+def negative_weights(neg: torch.Tensor, adversarial: bool, scale: float) -> torch.Tensor:
+    if adversarial:
+        return torch.softmax(scale * neg, dim=-1).detach()
+    return torch.full_like(neg, 1.0 / neg.shape[-1])
+
+
+def loss_value(kind: str, pos: torch.Tensor, neg: torch.Tensor, w: torch.Tensor, margin: float = 0.0,
+               adversarial: bool = False, adversarial_scale: float = 1.0, loss_scale: float = 1.0,
+               n_entity: int = 0) -> torch.Tensor:
+    """kind in {"logsigmoid", "margin", "ssce"}; always fp32 inputs; summed."""
+    if kind == "logsigmoid":
+        a = negative_weights(neg, adversarial, adversarial_scale)
+        per = torch.nn.functional.logsigmoid(pos + margin) + (
+            a * torch.nn.functional.logsigmoid(-neg - margin)).sum(-1)
+        return loss_scale * (-0.5) * (w * per).sum()
+    if kind == "margin":
+        a = negative_weights(neg, adversarial, adversarial_scale)
+        per = (a * torch.relu(neg - pos[:, None] + margin)).sum(-1)
+        return loss_scale * (w * per).sum()
+    if kind == "ssce":
+        shift = float(np.log(n_entity - 1) - np.log(neg.shape[1]))
+        logits = torch.cat([pos[:, None], neg + shift], dim=-1)
+        per = torch.logsumexp(logits, dim=-1) - pos
+        return loss_scale * (w * per).sum()
+    raise ValueError(kind)
+
+
+# ------------------------------------------------------------ full BESS step --
+class StepSpec:
+    """Static description of a BESS micro-batch."""
+
+    def __init__(self, scorer: str, p: int, sharing: bool, scheme: str, flat: bool,
+                 local_sampling: bool = False, augment: bool = False, triple_based: bool = False) -> None:
+        self.scorer, self.p, self.sharing = scorer, p, sharing
+        self.scheme, self.flat = scheme, flat
+        self.local_sampling, self.augment, self.triple_based = local_sampling, augment, triple_based
+
+
+def _rows(table: torch.Tensor, shard: int, idx: torch.Tensor) -> torch.Tensor:
+    return table[shard][idx.long()]
+
+
+def embedding_moving_scores(spec: StepSpec, table: torch.Tensor, rel_table: torch.Tensor, head: torch.Tensor,
+                            relation: torch.Tensor, tail: torch.Tensor, negative: torch.Tensor,
+                            replica: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Scores of one replica for one micro-batch, EmbeddingMoving scheme.
+
+    Whole-step tensors (what the sampler emits for one step, all shards):
+      head, relation [n(replica), n(block), ppp]; tail [n(source), n(replica), ppp];
+      negative [n(source), n(replica), B, K]; table [n, M, W].
+    """
+    n = table.shape[0]
+    r = replica
+    ppp = head.shape[-1]
+    W = table.shape[-1]
+    h = _rows(table, r, head[r]).reshape(-1, W)  # [S, W]
+    rid = relation[r].reshape(-1)
+    # what the all-to-all delivers to replica r: block j from shard j
+    t = torch.stack([_rows(table, j, tail[j, r]) for j in range(n)]).reshape(-1, W)
+    if spec.local_sampling:
+        neg = torch.stack([_rows(table, r, negative[r, j]) for j in range(n)])
+    else:
+        neg = torch.stack([_rows(table, j, negative[j, r]) for j in range(n)])
+    # [n, B, K, W] -> [B, n*K, W]
+    neg = neg.transpose(0, 1).reshape(neg.shape[1], -1, W)
+    pos = score_triple(spec.scorer, spec.p, h, rel_table, rid, t)
+
+    def corrupt(side: str, sel: Optional[torch.Tensor], cand: torch.Tensor) -> torch.Tensor:
+        ent = t if side == "h" else h
+        own = h if side == "h" else t  # positives of the corrupted side
+        rr = rid
+        if sel is not None:
+            ent, own, rr = ent[sel], own[sel], rid[sel]
+        if spec.augment:
+            cand = torch.cat([own.reshape(cand.shape[0], -1, W), cand], dim=1)
+        return score_candidates(spec.scorer, spec.p, spec.sharing, side, ent, rel_table, rr, cand)
+
+    if spec.scheme in ("h", "t"):
+        return pos, corrupt(spec.scheme, None, neg)
+    cut = ppp // 2
+    slot = torch.arange(n * ppp).reshape(n, ppp)
+    sel_h, sel_t = slot[:, :cut].reshape(-1), slot[:, cut:].reshape(-1)
+    if spec.flat:
+        neg_h, neg_t = neg[0:1], neg[1:2]
+    else:
+        per = neg.reshape(n, ppp, -1, W)
+        neg_h = per[:, :cut].reshape(n * cut, -1, W)
+        neg_t = per[:, cut:].reshape(n * (ppp - cut), -1, W)
+    sh = corrupt("h", sel_h, neg_h)
+    st = corrupt("t", sel_t, neg_t)
+    both = torch.cat([sh.reshape(n, cut, -1), st.reshape(n, ppp - cut, -1)], dim=1)
+    return pos, both.reshape(n * ppp, -1)
+
+
+def score_moving_scores(spec: StepSpec, table: torch.Tensor, rel_table: torch.Tensor, head: torch.Tensor,
+                        relation: torch.Tensor, tail: torch.Tensor, negative: torch.Tensor,
+                        replica: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Scores of one replica, ScoreMoving scheme: for every shard j, the
+    replica's queries are scored against the negatives stored on j."""
+    n = table.shape[0]
+    r = replica
+    ppp = head.shape[-1]
+    W = table.shape[-1]
+    cut = ppp // 2
+    h = _rows(table, r, head[r]).reshape(-1, W)
+    rid = relation[r].reshape(-1)
+    t = torch.stack([_rows(table, j, tail[j, r]) for j in range(n)]).reshape(-1, W)
+    pos = score_triple(spec.scorer, spec.p, h, rel_table, rid, t)
+    slot = torch.arange(n * ppp).reshape(n, ppp)
+    blocks = []
+    for j in range(n):
+        loc = negative[j]  # [n(dest), B, K] rows of shard j
+        if spec.triple_based and spec.flat:
+            loc = loc[0:1]
+        if spec.sharing:
+            pool = {  # every query sees all the negatives shard j holds for its side
+                "h": loc if spec.scheme != "ht" else loc[:, 0:1],
+                "t": loc if spec.scheme != "ht" else loc[:, 1:2],
+            }
+            if spec.scheme == "ht" and not spec.flat:
+                per = loc.reshape(loc.shape[0], n, ppp, -1)
+                pool = {"h": per[:, :, :cut], "t": per[:, :, cut:]}
+        else:
+            mine = loc[r]  # [S, K]: the lists of replica r's triples
+            per = mine.reshape(n, ppp, -1)
+            pool = {"h": mine if spec.scheme != "ht" else per[:, :cut].reshape(n * cut, -1),
+                    "t": mine if spec.scheme != "ht" else per[:, cut:].reshape(n * (ppp - cut), -1)}
+
+        def corrupt(side: str, sel: Optional[torch.Tensor]) -> torch.Tensor:
+            ent = t if side == "h" else h
+            rr = rid
+            if sel is not None:
+                ent, rr = ent[sel], rid[sel]
+            idx = pool[side]
+            if spec.sharing:
+                cand = _rows(table, j, idx.reshape(-1)).reshape(1, -1, W)
+            else:
+                cand = _rows(table, j, idx)  # [Sg, K, W]
+            return score_candidates(spec.scorer, spec.p, spec.sharing, side, ent, rel_table, rr, cand)
+
+        if spec.scheme in ("h", "t"):
+            blocks.append(corrupt(spec.scheme, None))
+        else:
+            sh = corrupt("h", slot[:, :cut].reshape(-1))
+            st = corrupt("t", slot[:, cut:].reshape(-1))
+            blocks.append(torch.cat([sh.reshape(n, cut, -1), st.reshape(n, ppp - cut, -1)], dim=1).reshape(n * ppp, -1))
+    return pos, torch.cat(blocks, dim=1)
+
+
+def apply_masks(spec: StepSpec, neg_score: torch.Tensor, n: int, ppp: int, K: int,
+                negative_mask: Optional[torch.Tensor]) -> torch.Tensor:
+    """Padding / augmentation kill (bess.py:182-245).  negative_mask [B', n, L] for this replica."""
+    S, N = neg_score.shape
+    cut = ppp // 2
+    kill = torch.zeros(S, N, dtype=torch.bool)
+    mask2d = None
+    if negative_mask is not None:
+        mask2d = negative_mask.reshape(negative_mask.shape[0], -1)
+        if spec.flat and spec.scheme == "ht":
+            mh = mask2d[0:1].expand(n * cut, -1).reshape(n, cut, -1)
+            mt = mask2d[1:2].expand(n * (ppp - cut), -1).reshape(n, ppp - cut, -1)
+            mask2d = torch.cat([mh, mt], dim=1).reshape(S, -1)
+        mask2d = mask2d.expand(S, -1)
+    if spec.augment:
+        step = 1 if spec.flat else 1 + n * K
+        qpos = torch.arange(S)
+        if spec.scheme == "ht":
+            blk, p_ = qpos // ppp, qpos % ppp
+            qpos = blk * cut + p_ % cut
+        cols = step * qpos
+        ok = cols < N
+        kill[torch.arange(S)[ok], cols[ok]] = True
+        if mask2d is not None:
+            kill[:, N - mask2d.shape[1]:] = ~mask2d
+    elif mask2d is not None:
+        kill[:, N - mask2d.shape[1]:] = ~mask2d
+    return neg_score + BAD_NEGATIVE_SCORE * kill.to(neg_score.dtype)
+
+
+def bess_step(spec: StepSpec, scheme_cls: str, table: torch.Tensor, rel_table: torch.Tensor,
+              batch: Dict[str, torch.Tensor], loss: Optional[dict] = None
+              ) -> Dict[str, List[torch.Tensor]]:
+    """All replicas of one micro-batch.  `batch` holds whole-step tensors
+    (head/relation/tail [n, n, ppp], negative [n, n, B, K], optional
+    negative_mask [n(replica), B', n, L], triple_weight [n, S]).  Returns lists
+    indexed by replica: positive_score, negative_score, loss."""
+    n = table.shape[0]
+    ppp = batch["head"].shape[-1]
+    K = batch["negative"].shape[-1]
+    fn = embedding_moving_scores if scheme_cls == "EmbeddingMoving" else score_moving_scores
+    out: Dict[str, List[torch.Tensor]] = dict(positive_score=[], negative_score=[], loss=[])
+    for r in range(n):
+        pos, neg = fn(spec, table, rel_table, batch["head"], batch["relation"], batch["tail"],
+                      batch["negative"], r)
+        nm = batch["negative_mask"][r] if "negative_mask" in batch else None
+        neg = apply_masks(spec, neg, n, ppp, K, nm)
+        out["positive_score"].append(pos)
+        out["negative_score"].append(neg)
+        if loss is not None:
+            w = batch["triple_weight"][r] if "triple_weight" in batch else torch.ones(1)
+            out["loss"].append(loss_value(pos=pos.float(), neg=neg.float(), w=w, **loss))
+    return out

@@ -1,0 +1,397 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the CPU oracle and vs the
+reference's own outputs (tests/golden/*.npz).
+
+Tolerances.  Scores: the reference's own test tolerance for negative scores,
+rtol=1e-4 / atol=1e-5 (reference tests/test_bess.py:245-246, 255-256, 273-274),
+is applied to positives *and* negatives against the fp32 oracle.  Index / byte
+movers (gather, scatter of exactly representable values) are bit-exact.
+fp16 tables: the kernels accumulate in fp32 from fp16-rounded inputs, the oracle
+is evaluated on the same fp16-rounded inputs in fp32 -> same tolerance.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import kge  # noqa: E402
+
+from conftest import load_golden  # noqa: E402
+from test_oracle import LOSSES, SCORERS, T, bess_cases, load_bess_case, step_batch  # noqa: E402
+
+RTOL, ATOL = 1e-4, 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need a HIP device"
+    return torch.device("cuda", 0)
+
+
+def close(got, want, rtol=RTOL, atol=ATOL, scale=None):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    if scale is not None:  # absolute floor relative to the magnitude of the data
+        atol = max(atol, scale * float(want.abs().max()))
+    torch.testing.assert_close(got, want, rtol=rtol, atol=atol)
+
+
+def make_scorer(name, p, sharing, n_rel, d, ent, rel, dev, dtype=torch.float32):
+    from besskge.scoring import ComplEx, DistMult, RotatE, TransE
+    from besskge.sharding import Sharding
+
+    sharding = Sharding.create(ent.shape[0] * ent.shape[1], ent.shape[0], seed=0)
+    if name == "TransE":
+        fn = TransE(sharing, p, sharding, n_rel, d, ent, rel)
+    elif name == "RotatE":
+        fn = RotatE(sharing, p, sharding, n_rel, d, ent, rel)
+    elif name == "DistMult":
+        fn = DistMult(sharing, sharding, n_rel, d, ent, rel)
+    else:
+        fn = ComplEx(sharing, sharding, n_rel, d, ent, rel)
+    fn = fn.to(dev)
+    if dtype == torch.float16:
+        fn = fn.half()
+    return fn
+
+
+def widths(name, d):
+    return (2 * d if name in ("RotatE", "ComplEx") else d), (2 * d if name == "ComplEx" else d)
+
+
+# ---------------------------------------------------------------- movers ----
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("W", [128, 400, 512, 100, 6])
+def test_gather_rows_bit_exact(dev, dtype, W):
+    from besskge import _native as nat
+
+    g = torch.Generator().manual_seed(W)
+    table = torch.randn(1000, W, generator=g).to(dtype)
+    idx = torch.randint(1000, (777,), generator=g, dtype=torch.int32)
+    out = nat.gather_rows(table.to(dev), idx.to(dev))
+    assert torch.equal(out.cpu(), table[idx.long()])
+    empty = nat.gather_rows(table.to(dev), idx[:0].to(dev))
+    assert empty.shape == (0, W)
+
+
+def test_scatter_add_and_sgd(dev):
+    from besskge import _native as nat
+
+    g = torch.Generator().manual_seed(3)
+    W = 64
+    # small integers: sums are exact in fp32 whatever the order of the atomics
+    src = torch.randint(-8, 9, (500, W), generator=g).float()
+    idx = torch.randint(40, (500,), generator=g, dtype=torch.int32)
+    dst = torch.zeros(40, W)
+    want = dst.clone().index_add_(0, idx.long(), src)
+    got = dst.to(dev)
+    nat.scatter_add_rows(got, idx.to(dev), src.to(dev))
+    assert torch.equal(got.cpu(), want)
+    table = torch.randint(-8, 9, (40, W), generator=g).float()
+    want_t = table - 0.5 * want
+    t32 = table.to(dev)
+    nat.sparse_sgd(t32, idx.to(dev), src.to(dev), 0.5)
+    assert torch.equal(t32.cpu(), want_t)
+    t16 = table.half().to(dev)
+    nat.sparse_sgd(t16, idx.to(dev), src.to(dev), 0.5)
+    close(t16, want_t, rtol=2e-3, atol=0.5)
+    rel = table.clone().to(dev)
+    nat.dense_sgd(rel, want.to(dev), 0.25)
+    assert torch.equal(rel.cpu(), table - 0.25 * want)
+
+
+def test_cpu_tensors_are_refused():
+    from besskge import _native as nat
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        nat.gather_rows(torch.zeros(4, 8), torch.zeros(2, dtype=torch.int32))
+
+
+# --------------------------------------------------------------- scoring ----
+@pytest.mark.parametrize("name,p", SCORERS)
+@pytest.mark.parametrize("sharing", [True, False])
+@pytest.mark.parametrize("B", [1, 10])
+def test_scoring_golden(dev, name, p, sharing, B):
+    """score_triple / score_heads / score_tails + gradients vs the reference's outputs."""
+    g = load_golden("scoring")
+    S, N, d, n_rel, n_ent = (int(x) for x in g["args"])
+    k = f"{name}_p{p}_"
+    c = k + f"s{int(sharing)}_B{B}_"
+    W, Wr = widths(name, d)
+    fn = make_scorer(name, p, sharing, n_rel, d, torch.zeros(1, n_ent, W), T(g[k + "rel"]), dev)
+    fn.relation_embedding.requires_grad_(True)
+    h = T(g[k + "h"]).to(dev).requires_grad_(True)
+    t = T(g[k + "t"]).to(dev).requires_grad_(True)
+    rid = T(g[k + "rid"]).to(dev)
+    neg = T(g[k + ("neg1" if B == 1 else "negS")]).to(dev).requires_grad_(True)
+
+    pos = fn.score_triple(h, rid, t)
+    close(pos, T(g[c + "pos"]))
+    (pos * T(g[k + "g_pos"]).to(dev)).sum().backward()
+    close(h.grad, T(g[c + "pos_dh"]))
+    close(t.grad, T(g[c + "pos_dt"]))
+    close(fn.relation_embedding.grad, T(g[c + "pos_drel"]))
+
+    for method, ent, key, dkey in ((fn.score_heads, t, "heads", "heads_dt"), (fn.score_tails, h, "tails", "tails_dh")):
+        for x in (h, t, neg, fn.relation_embedding):
+            x.grad = None
+        sc = method(neg, rid, t) if key == "heads" else method(h, rid, neg)
+        close(sc, T(g[c + key]))
+        (sc * T(g[c + key + "_g"]).to(dev)).sum().backward()
+        close(neg.grad, T(g[c + key + "_dneg"]))
+        close(ent.grad, T(g[c + dkey]))
+        close(fn.relation_embedding.grad, T(g[c + key + "_drel"]))
+
+
+@pytest.mark.parametrize("name,p", SCORERS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("d,S,N", [(64, 70, 33), (100, 9, 130), (256, 130, 65), (6, 5, 3)])
+def test_scoring_vs_oracle(dev, name, p, dtype, d, S, N):
+    """Ragged sizes, both table dtypes, both regimes, against the CPU oracle."""
+    gen = torch.Generator().manual_seed(d * 1000 + S)
+    W, Wr = widths(name, d)
+    n_rel = 7
+    rel = torch.randn(n_rel, Wr, generator=gen).to(dtype)
+    h = torch.randn(S, W, generator=gen).to(dtype)
+    t = torch.randn(S, W, generator=gen).to(dtype)
+    rid = torch.randint(n_rel, (S,), generator=gen)
+    negS = torch.randn(S, N, W, generator=gen).to(dtype)
+    neg1 = torch.randn(1, N, W, generator=gen).to(dtype)
+    scale = 2e-6  # |error| floor relative to the largest score (fp32 sum of W terms)
+    for sharing, neg in ((True, neg1), (True, negS), (False, negS)):
+        fn = make_scorer(name, p, sharing, n_rel, d, torch.zeros(1, 4, W), rel.float(), dev, dtype)
+        o = dict(scorer=name, p=p)
+        close(fn.score_triple(h.to(dev), rid.to(dev), t.to(dev)),
+              kge.score_triple(name, p, h.float(), rel.float(), rid, t.float()), scale=scale)
+        close(fn.score_heads(neg.to(dev), rid.to(dev), t.to(dev)),
+              kge.score_candidates(sharing=sharing, side="h", ent=t.float(), rel_table=rel.float(), rid=rid,
+                                   cand=neg.float(), **o), scale=scale)
+        close(fn.score_tails(h.to(dev), rid.to(dev), neg.to(dev)),
+              kge.score_candidates(sharing=sharing, side="t", ent=h.float(), rel_table=rel.float(), rid=rid,
+                                   cand=neg.float(), **o), scale=scale)
+
+
+@pytest.mark.parametrize("name,p", SCORERS)
+@pytest.mark.parametrize("sharing", [True, False])
+def test_scoring_gradients_vs_oracle(dev, name, p, sharing):
+    gen = torch.Generator().manual_seed(11)
+    d, S, N, n_rel = 48, 37, 21, 5
+    W, Wr = widths(name, d)
+    rel = torch.randn(n_rel, Wr, generator=gen)
+    h = torch.randn(S, W, generator=gen)
+    t = torch.randn(S, W, generator=gen)
+    rid = torch.randint(n_rel, (S,), generator=gen)
+    neg = torch.randn(S, N, W, generator=gen)
+    gp = torch.randn(S, generator=gen)
+    fn = make_scorer(name, p, sharing, n_rel, d, torch.zeros(1, 4, W), rel, dev)
+    fn.relation_embedding.requires_grad_(True)
+    for side in ("h", "t"):
+        hd, td, nd = (x.clone().to(dev).requires_grad_(True) for x in (h, t, neg))
+        ho, to_, no, ro = (x.clone().requires_grad_(True) for x in (h, t, neg, rel))
+        fn.relation_embedding.grad = None
+        if side == "h":
+            sc = fn.score_heads(nd, rid.to(dev), td)
+            so = kge.score_candidates(name, p, sharing, "h", to_, ro, rid, no)
+        else:
+            sc = fn.score_tails(hd, rid.to(dev), nd)
+            so = kge.score_candidates(name, p, sharing, "t", ho, ro, rid, no)
+        gn = torch.randn(so.shape, generator=gen)
+        pos = fn.score_triple(hd, rid.to(dev), td)
+        po = kge.score_triple(name, p, ho, ro, rid, to_)
+        ((sc * gn.to(dev)).sum() + (pos * gp.to(dev)).sum()).backward()
+        ((so * gn).sum() + (po * gp).sum()).backward()
+        close(hd.grad, ho.grad, scale=2e-6)
+        close(td.grad, to_.grad, scale=2e-6)
+        close(nd.grad, no.grad, scale=2e-6)
+        close(fn.relation_embedding.grad, ro.grad, rtol=1e-4, scale=2e-6)
+
+
+# ---------------------------------------------------------------- losses ----
+@pytest.mark.parametrize("name", list(LOSSES))
+@pytest.mark.parametrize("wname", ["w", "one"])
+def test_loss_golden(dev, name, wname):
+    from besskge.loss import LogSigmoidLoss, MarginRankingLoss, SampledSoftmaxCrossEntropyLoss
+
+    g = load_golden("loss")
+    kw = dict(LOSSES[name])
+    kind = kw.pop("kind")
+    if kind == "logsigmoid":
+        fn = LogSigmoidLoss(kw["margin"], kw["adversarial"], kw.get("adversarial_scale", 1.0), kw.get("loss_scale", 1.0))
+    elif kind == "margin":
+        fn = MarginRankingLoss(kw["margin"], kw["adversarial"], kw.get("adversarial_scale", 1.0), kw.get("loss_scale", 1.0))
+    else:
+        fn = SampledSoftmaxCrossEntropyLoss(kw["n_entity"], kw.get("loss_scale", 1.0))
+    pos = T(g["pos"]).to(dev).requires_grad_(True)
+    neg = T(g["neg"]).to(dev).requires_grad_(True)
+    w = (T(g["w"]) if wname == "w" else torch.tensor([1.0])).to(dev)
+    loss = fn(pos, neg, w)
+    loss.backward()
+    close(loss, T(g[f"{name}_{wname}_loss"]), rtol=1e-5, atol=1e-5)
+    close(pos.grad, T(g[f"{name}_{wname}_dpos"]), rtol=1e-4, atol=1e-6)
+    close(neg.grad, T(g[f"{name}_{wname}_dneg"]), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["logsigmoid", "margin", "ssce"])
+@pytest.mark.parametrize("S,N", [(1, 1), (65, 64), (130, 1000), (7, 4097)])
+def test_loss_vs_oracle(dev, kind, S, N):
+    from besskge import _native as nat
+
+    gen = torch.Generator().manual_seed(S * 7 + N)
+    pos = torch.randn(S, generator=gen) * 4
+    neg = torch.randn(S, N, generator=gen) * 4
+    neg[0, 0] = -50000.0
+    w = torch.rand(S, generator=gen) + 0.5
+    kw = dict(kind=kind, margin=2.5, adversarial=(kind != "ssce"), adversarial_scale=0.3, loss_scale=1.5, n_entity=5000)
+    ld = nat.LossDesc()
+    ld.kind = dict(logsigmoid=0, margin=1, ssce=2)[kind]
+    ld.adversarial, ld.margin, ld.adversarial_scale, ld.loss_scale = int(kind != "ssce"), 2.5, 0.3, 1.5
+    ld.ssce_shift = float(np.log(5000 - 1) - np.log(N))
+    loss, dp, dn = nat.loss_fwd_bwd(ld, pos.to(dev), neg.to(dev), w.to(dev), True)
+    po, no = pos.clone().requires_grad_(True), neg.clone().requires_grad_(True)
+    lo = kge.loss_value(pos=po, neg=no, w=w, **kw)
+    lo.backward()
+    close(loss, lo, rtol=2e-5, atol=1e-4)
+    close(dp, po.grad, rtol=1e-4, atol=1e-6)
+    close(dn, no.grad, rtol=1e-4, atol=1e-6)
+    # bitwise reproducible (fixed-order reduction)
+    loss2, _, _ = nat.loss_fwd_bwd(ld, pos.to(dev), neg.to(dev), w.to(dev), False)
+    assert torch.equal(loss, loss2)
+
+
+# ------------------------------------------------------- whole BESS step ----
+def build_model(c, dev, lr_loss=True):
+    from besskge.bess import EmbeddingMovingBessKGE, ScoreMovingBessKGE
+    from besskge.loss import LogSigmoidLoss, MarginRankingLoss, SampledSoftmaxCrossEntropyLoss
+    from besskge.negative_sampler import RandomShardedNegativeSampler, TripleBasedShardedNegativeSampler
+
+    meta, spec = c["meta"], c["spec"]
+    fn = make_scorer(spec.scorer, spec.p, spec.sharing, meta["n_rel"], meta["d"], c["table"], c["rel"], torch.device("cpu"))
+    loss = None
+    if c["loss_name"] == "logsigmoid":
+        loss = LogSigmoidLoss(margin=3.0, negative_adversarial_sampling=True, negative_adversarial_scale=0.5)
+    elif c["loss_name"] == "margin":
+        loss = MarginRankingLoss(margin=1.0, negative_adversarial_sampling=False)
+    elif c["loss_name"] == "ssce":
+        loss = SampledSoftmaxCrossEntropyLoss(n_entity=meta["n_entity"])
+
+    # BessKGE only reads three flags (and the class) of its negative sampler
+    kind = TripleBasedShardedNegativeSampler if spec.triple_based else RandomShardedNegativeSampler
+    ns = object.__new__(kind)
+    ns.flat_negative_format = spec.flat
+    ns.local_sampling = False
+    ns.corruption_scheme = spec.scheme
+    cls = EmbeddingMovingBessKGE if c["model_cls"] == "EmbeddingMoving" else ScoreMovingBessKGE
+    return cls(negative_sampler=ns, score_fn=fn, loss_fn=loss, return_scores=True, augment_negative=spec.augment)
+
+
+@pytest.mark.parametrize("case", bess_cases())
+def test_bess_forward_golden(dev, case):
+    """BessKGE.forward of all replicas (lock-step on one GPU) reproduces the
+    reference's positive_score / negative_score / loss for every golden case."""
+    from besskge import runtime
+
+    c = load_bess_case(case)
+    meta = c["meta"]
+    n, bps = meta["n_shard"], meta["bps"]
+    model = build_model(c, dev)
+    runner = runtime.inference_model(model, runtime.Options(device_iterations=bps), device=dev)
+    keys = ("head", "relation", "tail", "negative", "negative_mask")
+    res = runner(**{k: c["batch"][k].flatten(end_dim=1) for k in keys if k in c["batch"]})
+    S = c["outs"]["positive_score"].shape[-1]
+    close(res["positive_score"].reshape(bps, n, S), c["outs"]["positive_score"])
+    close(res["negative_score"].reshape(bps, n, S, -1), c["outs"]["negative_score"], atol=2e-3 if c["loss_name"] == "ssce" else ATOL)
+    if c["loss"] is not None:
+        close(res["loss"].reshape(bps, n), c["outs"]["loss"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", [c for c in bess_cases() if c.startswith("tr_EM")])
+def test_bess_train_step_golden(dev, case):
+    """One sparse-SGD step moves the tables by -lr * (the reference's autograd gradient)."""
+    from besskge import runtime
+
+    c = load_bess_case(case)
+    meta = c["meta"]
+    n = meta["n_shard"]
+    lr = 0.125
+    model = build_model(c, dev)
+    runner = runtime.training_model(model, runtime.Options(device_iterations=1), runtime.SGD(lr=lr), device=dev)
+    keys = ("head", "relation", "tail", "negative", "negative_mask")
+    res = runner(**{k: c["batch"][k][0] for k in keys if k in c["batch"]})
+    close(res["loss"].reshape(n), c["outs"]["loss"][0], rtol=1e-4, atol=1e-4)
+    want_ent = c["table"] - lr * c["grads"]["entity"]
+    want_rel = c["rel"] - lr * c["grads"]["relation"].sum(0)
+    close(model.score_fn.entity_embedding, want_ent, rtol=1e-4, atol=2e-5)
+    close(model.score_fn.relation_embedding, want_rel, rtol=1e-4, atol=2e-5)
+
+
+# --------------------------- the reference's own integration test, on HIP ----
+@pytest.mark.parametrize("model_name", ["ScoreMoving", "EmbeddingMoving"])
+@pytest.mark.parametrize("scheme,dup", [("h", False), ("t", False), ("ht", True)])
+@pytest.mark.parametrize("flat", [True, False])
+def test_bess_inference_like_reference(dev, model_name, scheme, dup, flat):
+    """Mirror of reference tests/test_bess.py:54-275: 4 replicas, TransE d=128,
+    500 entities, triple-specific negatives; sharded HIP scores == unsharded
+    oracle scores re-ordered through triple_sort_idx / negative_sort_idx."""
+    from besskge import runtime
+    from besskge.batch_sampler import RigidShardedBatchSampler
+    from besskge.bess import BAD_NEGATIVE_SCORE, EmbeddingMovingBessKGE, ScoreMovingBessKGE
+    from besskge.dataset import KGDataset
+    from besskge.negative_sampler import TripleBasedShardedNegativeSampler
+    from besskge.scoring import TransE
+    from besskge.sharding import PartitionedTripleSet, Sharding
+
+    seed, n_entity, n_rel, n_shard, n_triple = 1234, 500, 10, 4, 1000
+    bps, shard_bs, n_negative, d = 3, 48, 250, 128
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    sharding = Sharding.create(n_entity, n_shard, seed=seed)
+    entity_table = torch.randn(n_shard, sharding.max_entity_per_shard, d)
+    relation_table = torch.randn(n_rel, d)
+    th, tt_, tr = rng.integers(n_entity, size=n_triple), rng.integers(n_entity, size=n_triple), rng.integers(n_rel, size=n_triple)
+    triples = {"test": np.stack([th, tr, tt_], axis=1)}
+    outer = 1 if flat else n_triple
+    neg_h = rng.integers(n_entity, size=(outer, n_negative)).astype(np.int32)
+    neg_t = rng.integers(n_entity, size=(outer, n_negative)).astype(np.int32)
+    ds = KGDataset(n_entity=n_entity, n_relation_type=n_rel, triples=triples,
+                   original_triple_ids={"test": np.arange(n_triple)}, neg_heads={"test": neg_h}, neg_tails={"test": neg_t})
+    pts = PartitionedTripleSet.create_from_dataset(ds, "test", sharding, partition_mode="ht_shardpair")
+    score_fn = TransE(flat, 1, sharding, n_rel, d, entity_table, relation_table)
+    ns = TripleBasedShardedNegativeSampler(pts.neg_heads, pts.neg_tails, sharding, corruption_scheme=scheme,
+                                           seed=seed, return_sort_idx=True, mask_on_gather=False)
+    bs = RigidShardedBatchSampler(pts, ns, shard_bs, bps, seed, duplicate_batch=dup, return_triple_idx=True)
+    cls = EmbeddingMovingBessKGE if model_name == "EmbeddingMoving" else ScoreMovingBessKGE
+    model = cls(negative_sampler=ns, score_fn=score_fn, return_scores=True)
+    runner = runtime.inference_model(model, runtime.Options(device_iterations=bps), device=dev)
+
+    flat_table = entity_table[sharding.entity_to_shard, sharding.entity_to_idx]
+    he, te = flat_table[th], flat_table[tt_]
+    true_pos = kge.score_triple("TransE", 1, he, relation_table, T(tr), te)
+    true_nh = kge.score_candidates("TransE", 1, flat, "h", te, relation_table, T(tr), flat_table[neg_h.astype(np.int64)])
+    true_nt = kge.score_candidates("TransE", 1, flat, "t", he, relation_table, T(tr), flat_table[neg_t.astype(np.int64)])
+    sort_idx = T(pts.triple_sort_idx)
+
+    for batch in bs.get_dataloader(shuffle=False):
+        triple_idx = batch.pop("triple_idx")
+        triple_mask = batch.pop("triple_mask")
+        nsi = batch.pop("negative_sort_idx")
+        res = runner(**{k: v.flatten(end_dim=1) for k, v in batch.items()})
+        pos = res["positive_score"].cpu().reshape(bps, n_shard, n_shard, -1)
+        negs = res["negative_score"].cpu()
+        negs = negs[negs > 0.95 * BAD_NEGATIVE_SCORE].reshape(bps, n_shard, n_shard, -1, n_negative)
+        nsi = nsi.reshape(bps, n_shard, n_shard, -1, n_negative).long()
+        if dup:
+            cut = pos.shape[-1] // 2
+            triple_idx, pos, triple_mask = triple_idx[..., :cut], pos[..., :cut], triple_mask[..., :cut]
+            n1, n2 = torch.split(negs, negs.shape[-2] // 2, dim=-2)
+            s1, s2 = torch.split(nsi, cut, dim=-2)
+        gidx = triple_idx[triple_mask]
+        torch.testing.assert_close(true_pos[sort_idx][gidx], pos[triple_mask], rtol=RTOL, atol=ATOL)
+        if dup:
+            for true, got, s in ((true_nh, n1, s1), (true_nt, n2, s2)):
+                torch.testing.assert_close(torch.take_along_dim(true[sort_idx][gidx], s[triple_mask], dim=-1),
+                                           got[triple_mask], rtol=RTOL, atol=ATOL)
+        else:
+            true = true_nh if scheme == "h" else true_nt
+            torch.testing.assert_close(torch.take_along_dim(true[sort_idx][gidx], nsi[triple_mask], dim=-1),
+                                       negs[triple_mask], rtol=RTOL, atol=ATOL)
