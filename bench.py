@@ -38,7 +38,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-N_ENTITY_PER_SHARD = 93_773
+N_ENTITY_PER_SHARD = 93_773  # overridden by --entities-per-shard (out-of-cache variant)
 N_REL = 51
 D = 256  # complex embedding size -> W = 512
 S = 4096
@@ -103,26 +103,40 @@ def make_batches(n_shard: int, rank: int, sharding, k_pair: int, pool: int, dev:
     return out
 
 
+def usable_cores() -> int:
+    """Host cores this process may really use (affinity mask and cgroup quota,
+    not the machine's core count)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(seconds: float = 12.0):
     """The oracle (CPU restatement of the reference's torch path) on this box's
     host cores, on a bounded sample of the same workload: S_cpu triples x
     K_TOTAL per-triple negatives, ComplEx d=256, table of 93,773 rows."""
     from oracle import kge
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     gen = torch.Generator().manual_seed(0)
     W = 2 * D
-    table = (torch.randn(1, N_ENTITY_PER_SHARD, W, generator=gen) / W)
+    n_ent = 93_773
+    table = (torch.randn(1, n_ent, W, generator=gen) / W)
     rel = torch.randn(N_REL, W, generator=gen) / W
     s_cpu = 256
     spec = kge.StepSpec("ComplEx", 0, False, "t", False)
     rng = np.random.default_rng(0)
     batch = dict(
-        head=torch.from_numpy(rng.integers(N_ENTITY_PER_SHARD, size=(1, 1, s_cpu))),
+        head=torch.from_numpy(rng.integers(n_ent, size=(1, 1, s_cpu))),
         relation=torch.from_numpy(rng.integers(N_REL, size=(1, 1, s_cpu))),
-        tail=torch.from_numpy(rng.integers(N_ENTITY_PER_SHARD, size=(1, 1, s_cpu))),
-        negative=torch.from_numpy(rng.integers(N_ENTITY_PER_SHARD, size=(1, 1, s_cpu, K_TOTAL))),
+        tail=torch.from_numpy(rng.integers(n_ent, size=(1, 1, s_cpu))),
+        negative=torch.from_numpy(rng.integers(n_ent, size=(1, 1, s_cpu, K_TOTAL))),
     )
     loss = dict(kind="logsigmoid", margin=12.0, adversarial=True, adversarial_scale=1.0)
     with torch.no_grad():
@@ -144,13 +158,18 @@ def cpu_baseline(seconds: float = 12.0):
 
 
 def main() -> None:
+    global N_ENTITY_PER_SHARD
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", choices=["score", "train"], default="score")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--entities-per-shard", type=int, default=N_ENTITY_PER_SHARD,
+                    help="rows per shard (default: the ogbl-biokg count; a 192 MB table sits in the "
+                         "256 MiB Infinity Cache - pass e.g. 4000000 for an HBM-resident 8 GB shard)")
     args = ap.parse_args()
+    N_ENTITY_PER_SHARD = args.entities_per_shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -160,10 +179,17 @@ def main() -> None:
             raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    dev = torch.device("cuda", local_rank)
+    # BESS_BENCH_BACKEND=gloo lets several ranks share one GPU (host-staged
+    # collectives) to rehearse the N > 1 code path on a 1-GPU box; the real
+    # multi-GPU run uses RCCL.
+    backend = os.environ.get("BESS_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if args.mode == "train" and world > 1:
         raise SystemExit("--mode train is single-GPU (EmbeddingMoving) in this round")
 
@@ -237,7 +263,7 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "ogbl-biokg-shaped ComplEx d=256 fp32 (W=512), 93,773 entities per shard, "
+                "workload": f"ogbl-biokg-shaped ComplEx d=256 fp32 (W=512), {N_ENTITY_PER_SHARD:,} entities per shard, "
                             f"n_shard={world}, S=4096 positives x 256 per-triple negatives per GPU per step, "
                             f"{'EmbeddingMoving' if world == 1 else 'ScoreMoving'}, mode={args.mode} "
                             "(gather+score+loss" + ("+backward+sparse SGD)" if args.mode == "train" else ")"),

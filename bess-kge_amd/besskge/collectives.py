@@ -81,7 +81,12 @@ class SingleProcessGroup(ReplicaGroup):
 
 
 class DistributedGroup(ReplicaGroup):
-    """One replica per process; rank r of `process_group` holds shard r."""
+    """One replica per process; rank r of `process_group` holds shard r.
+
+    With the "nccl" backend (RCCL) device tensors go straight over xGMI.  With
+    "gloo" (CPU tests, or several ranks sharing one GPU in a test) device
+    tensors are staged through host memory.
+    """
 
     def __init__(self, process_group: Optional[dist.ProcessGroup] = None) -> None:
         if not dist.is_initialized():
@@ -90,26 +95,37 @@ class DistributedGroup(ReplicaGroup):
         self.n_shard = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self.local_shards = [self.rank]
+        self.host_staging = dist.get_backend(process_group) == "gloo"
+
+    def _in(self, x: torch.Tensor) -> torch.Tensor:
+        x = x.contiguous()
+        return x.cpu() if (self.host_staging and x.is_cuda) else x
 
     def all_to_all(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
         (x,) = xs
         if x.shape[0] != self.n_shard:
             raise ValueError(f"all_to_all: leading dim {x.shape[0]} != n_shard {self.n_shard}")
-        x = x.contiguous()
-        out = torch.empty_like(x)
-        dist.all_to_all_single(out, x, group=self.pg)
-        return [out]
+        src = self._in(x)
+        out = torch.empty_like(src)
+        dist.all_to_all_single(out, src, group=self.pg)
+        return [out.to(x.device)]
 
     def all_gather(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
         (x,) = xs
-        x = x.contiguous()
-        out = torch.empty((self.n_shard, *x.shape), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x, group=self.pg)
-        return [out]
+        src = self._in(x)
+        if src.dim() == 0:
+            src = src.reshape(1)
+        # concatenated form ([n * d0, ...]) is the one every backend accepts
+        out = torch.empty((self.n_shard * src.shape[0], *src.shape[1:]), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(out, src, group=self.pg)
+        return [out.reshape(self.n_shard, *x.shape).to(x.device)]
 
     def all_reduce_sum(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
         (x,) = xs
-        dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.pg)
+        src = self._in(x)
+        dist.all_reduce(src, op=dist.ReduceOp.SUM, group=self.pg)
+        if src is not x:
+            x.copy_(src)
         return [x]
 
     def barrier(self) -> None:

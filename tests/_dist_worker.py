@@ -1,0 +1,85 @@
+"""Worker of the multi-process tests (launched by tests/test_distributed.py).
+
+    python tests/_dist_worker.py <mode> <out_dir>       (RANK / WORLD_SIZE / MASTER_* in env)
+
+mode "routing" (CPU, gloo): DistributedGroup collectives + the per-rank view of
+    a sharded batch; every rank dumps what it received.
+mode "bess" (one GPU shared by all ranks, gloo with host staging): the full
+    distributed BessKGE forward / train step through the HIP kernels for golden
+    cases; every rank dumps its outputs.
+"""
+
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+for p in (os.path.join(REPO, "bess-kge_amd"), REPO, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def routing(out_dir: str) -> None:
+    from besskge.collectives import DistributedGroup
+
+    g = DistributedGroup()
+    n, r = g.n_shard, g.rank
+    # block j of rank r carries the value 100*r + j
+    x = torch.stack([torch.full((3, 2), 100.0 * r + j) for j in range(n)])
+    (a2a,) = g.all_to_all([x])
+    (ag,) = g.all_gather([torch.full((2,), float(r))])
+    (ar,) = g.all_reduce_sum([torch.full((4,), float(r + 1))])
+    ids = torch.arange(6, dtype=torch.int32).reshape(n, -1) + 10 * r if n in (2, 3, 6) else torch.zeros(n, 1, dtype=torch.int32)
+    (ag_i,) = g.all_gather([ids])
+    np.savez(os.path.join(out_dir, f"routing_{r}.npz"), a2a=a2a.numpy(), ag=ag.numpy(), ar=ar.numpy(), ag_i=ag_i.numpy())
+
+
+def bess(out_dir: str) -> None:
+    from besskge import runtime
+    from besskge.collectives import DistributedGroup
+    from test_hip_parity import build_model
+    from test_oracle import load_bess_case
+
+    g = DistributedGroup()
+    n, r = g.n_shard, g.rank
+    dev = torch.device("cuda", 0)
+    cases = [c for c in os.environ["BESS_CASES"].split(",") if c]
+    out = {}
+    for case in cases:
+        c = load_bess_case(case)
+        assert c["meta"]["n_shard"] == n
+        bps = c["meta"]["bps"]
+        keys = ("head", "relation", "tail", "negative", "negative_mask")
+        batch = {k: c["batch"][k].flatten(end_dim=1) for k in keys if k in c["batch"]}
+        model = build_model(c, dev)
+        runner = runtime.inference_model(model, runtime.Options(device_iterations=bps), group=g, device=dev)
+        res = runner(**batch)
+        for k, v in res.items():
+            out[f"{case}_fwd_{k}"] = v.float().cpu().numpy()
+        if case.startswith("tr_EM"):
+            model = build_model(c, dev)
+            lr = 0.125
+            runner = runtime.training_model(model, runtime.Options(device_iterations=1), runtime.SGD(lr=lr), group=g, device=dev)
+            res = runner(**{k: v[: n] for k, v in batch.items()})
+            out[f"{case}_train_loss"] = res["loss"].float().cpu().numpy()
+            out[f"{case}_train_entity"] = model.score_fn.entity_embedding.detach().float().cpu().numpy()
+            out[f"{case}_train_relation"] = model.score_fn.relation_embedding.detach().float().cpu().numpy()
+    np.savez(os.path.join(out_dir, f"bess_{r}.npz"), **out)
+
+
+def main() -> None:
+    mode, out_dir = sys.argv[1], sys.argv[2]
+    dist.init_process_group("gloo")
+    try:
+        {"routing": routing, "bess": bess}[mode](out_dir)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
