@@ -34,6 +34,14 @@ inline int reduce_of(const bess_model_desc* d) {
     return d->norm_p == 1 ? RED_L1 : RED_L2;
 }
 
+// fp32 MFMA GEMMs of the bilinear scorers (gemm_mfma.hip)
+int gemm_dot_fwd(int dtype, const float* Q, int64_t S, const void* E, const int32_t* idx, int64_t N, int W,
+                 float* out, int64_t ld, hipStream_t st);
+int gemm_dot_dq(int dtype, const float* G, int64_t ldg, int64_t S, const void* E, const int32_t* idx, int64_t N,
+                int W, float* dQ, hipStream_t st);
+int gemm_dot_de(const float* G, int64_t ldg, int64_t S, const float* Q, int64_t N, int W, float* dE,
+                hipStream_t st);
+
 // ---- device side ------------------------------------------------------------
 typedef _Float16 half_t;
 
@@ -87,6 +95,15 @@ __device__ __forceinline__ float wave_allreduce_max(float v) {
 
 __device__ __forceinline__ float sgnf(float x) {
     return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+}
+
+// sgn(x - y) for operands pre-scaled by 2^100 (exact: power of two): the
+// difference d' = (x - y) * 2^100 is clamped to [-1, 1] by one v_med3.  Exact for
+// x == y and whenever |x - y| >= 2^-100; a smaller non-zero difference needs
+// |x|, |y| < 2^-76, which embeddings never are.  No overflow below 2^27.
+constexpr float SGN_PRESCALE = 1.2676506002282294e30f;  // 2^100
+__device__ __forceinline__ float sgn_prescaled(float d_scaled) {
+    return __builtin_amdgcn_fmed3f(d_scaled, -1.f, 1.f);
 }
 
 template <typename T>

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
                                                         float sign, const float* __restrict__ d_out,
                                                         int64_t sa, int64_t sb,
                                                         const float* __restrict__ out, int64_t oa,
-                                                        int64_t ob, float* __restrict__ dX) {
+                                                        int64_t ob, float* __restrict__ dX,
+                                                        int64_t b_chunk) {
     __shared__ __attribute__((aligned(16))) float Cs[KT][LDP];  // [b][a]
     __shared__ __attribute__((aligned(16))) float Ys[KT][LDP];  // [b][w]
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -146,17 +147,29 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
             const int w = w0 + tx * 4 + j;
             acc[i][j] = 0.f;
             xv[i][j] = (a < X.n && w < W) ? to_f32(X.row(a, W)[w]) : 0.f;
+            if (RED == RED_L1) xv[i][j] *= SGN_PRESCALE;
         }
     }
-    for (int64_t b0 = 0; b0 < Y.n; b0 += KT) {
-        {  // coefficient stage: Cs[b][a], 16 x 64
+    // blockIdx.z owns the slice [b_lo, b_hi) of the reduction; partial sums of
+    // several slices are combined with fp32 atomics (dX zeroed by the host)
+    const int64_t b_lo = static_cast<int64_t>(blockIdx.z) * b_chunk;
+    const int64_t b_hi = min(b_lo + b_chunk, Y.n);
+    for (int64_t b0 = b_lo; b0 < b_hi; b0 += KT) {
+        {  // coefficient stage: Cs[b][a], 16 x 64; lanes run along the unit-stride dim of d_out
             const int t = threadIdx.x;
-            const int b = t & 15, ac = (t >> 4) * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int64_t a = a0 + ac + i;
+                int b, al;
+                if (sb == 1) {  // d_out[a, b] contiguous in b
+                    b = t & 15;
+                    al = (t >> 4) + 16 * i;
+                } else {        // read transposed: contiguous in a
+                    al = t & 63;
+                    b = (t >> 6) + 4 * i;
+                }
+                const int64_t a = a0 + al;
                 float c = 0.f;
-                if (a < X.n && b0 + b < Y.n) {
+                if (a < X.n && b0 + b < b_hi) {
                     const float g = d_out[a * sa + (b0 + b) * sb];
                     if (RED == RED_L2) {
                         const float o = out[a * oa + (b0 + b) * ob];
@@ -165,14 +178,14 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
                         c = sign * g;
                     }
                 }
-                Cs[b][ac + i] = c;
+                Cs[b][al] = c;
             }
         }
         {  // Y stage: Ys[b][w], 16 x 64
             const int t = threadIdx.x;
             const int b = t >> 4, wc = (t & 15) * 4;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (b0 + b < Y.n) {
+            if (b0 + b < b_hi) {
                 const TY* rp = Y.row(b0 + b, W) + w0 + wc;
                 if ((W & 3) == 0 && w0 + wc + 3 < W) {
                     VecLoad<TY, 4>::load(rp, v);
@@ -181,6 +194,10 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
                     for (int i = 0; i < 4; ++i)
                         if (w0 + wc + i < W) v[i] = to_f32(rp[i]);
                 }
+            }
+            if (RED == RED_L1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] *= SGN_PRESCALE;
             }
             *reinterpret_cast<float4*>(&Ys[b][wc]) = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (RED == RED_DOT) acc[i][j] = fmaf(c[i], y[j], acc[i][j]);
-                    else if (RED == RED_L1) acc[i][j] = fmaf(c[i], sgnf(xv[i][j] - y[j]), acc[i][j]);
+                    else if (RED == RED_L1) acc[i][j] = fmaf(c[i], sgn_prescaled(xv[i][j] - y[j]), acc[i][j]);
                     else acc[i][j] = fmaf(c[i], xv[i][j] - y[j], acc[i][j]);
                 }
         }
@@ -209,7 +226,10 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int w = w0 + tx * 4 + j;
-            if (w < W) dX[a * W + w] = acc[i][j];
+            if (w < W) {
+                if (gridDim.z == 1) dX[a * W + w] = acc[i][j];
+                else unsafeAtomicAdd(dX + a * W + w, acc[i][j]);
+            }
         }
     }
 }
@@ -228,21 +248,33 @@ static int run_fwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<T> E, float
 }
 
 template <typename TX, typename TY>
-static void run_bwd_one(const bess_model_desc* d, RowSrc<TX> X, RowSrc<TY> Y, const float* d_out,
-                        int64_t sa, int64_t sb, const float* out, int64_t oa, int64_t ob, float* dX,
-                        hipStream_t st) {
-    const dim3 grid(static_cast<unsigned>(ceil_div(d->width, TN)), static_cast<unsigned>(ceil_div(X.n, TM)));
+static int run_bwd_one(const bess_model_desc* d, RowSrc<TX> X, RowSrc<TY> Y, const float* d_out,
+                       int64_t sa, int64_t sb, const float* out, int64_t oa, int64_t ob, float* dX,
+                       hipStream_t st) {
+    const int64_t tiles = ceil_div(d->width, TN) * ceil_div(X.n, TM);
+    // split the reduction over Y until ~4 workgroups per CU are in flight
+    int64_t split = 1;
+    while (tiles * split < 1024 && ceil_div(Y.n, split * 2) >= 4 * KT) split *= 2;
+    int64_t chunk = ceil_div(ceil_div(Y.n, split), KT) * KT;
+    split = ceil_div(Y.n, chunk);
+    if (split > 1) {
+        hipError_t e = hipMemsetAsync(dX, 0, sizeof(float) * X.n * d->width, st);
+        if (e != hipSuccess) return fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
+    }
+    const dim3 grid(static_cast<unsigned>(ceil_div(d->width, TN)), static_cast<unsigned>(ceil_div(X.n, TM)),
+                    static_cast<unsigned>(split));
     const float sign = is_distance(d->scorer) ? -1.f : 1.f;
     switch (reduce_of(d)) {
         case RED_DOT:
-            k_neg_shared_bwd<TX, TY, RED_DOT><<<grid, 256, 0, st>>>(X, Y, d->width, sign, d_out, sa, sb, out, oa, ob, dX);
+            k_neg_shared_bwd<TX, TY, RED_DOT><<<grid, 256, 0, st>>>(X, Y, d->width, sign, d_out, sa, sb, out, oa, ob, dX, chunk);
             break;
         case RED_L1:
-            k_neg_shared_bwd<TX, TY, RED_L1><<<grid, 256, 0, st>>>(X, Y, d->width, sign, d_out, sa, sb, out, oa, ob, dX);
+            k_neg_shared_bwd<TX, TY, RED_L1><<<grid, 256, 0, st>>>(X, Y, d->width, sign, d_out, sa, sb, out, oa, ob, dX, chunk);
             break;
         default:
-            k_neg_shared_bwd<TX, TY, RED_L2><<<grid, 256, 0, st>>>(X, Y, d->width, sign, d_out, sa, sb, out, oa, ob, dX);
+            k_neg_shared_bwd<TX, TY, RED_L2><<<grid, 256, 0, st>>>(X, Y, d->width, sign, d_out, sa, sb, out, oa, ob, dX, chunk);
     }
+    return BESS_OK;
 }
 
 }  // namespace bess
@@ -258,6 +290,9 @@ extern "C" int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* 
     if (n_query == 0 || n_neg == 0) return BESS_OK;
     BESS_REQUIRE(query && neg_base && out, "neg_score_shared_fwd: NULL pointer");
     BESS_REQUIRE(ld_out >= n_neg, "neg_score_shared_fwd: leading dimension < n_neg");
+    if (reduce_of(d) == RED_DOT)  // bilinear scorers: matrix cores
+        return gemm_dot_fwd(d->dtype, query, n_query, neg_base, neg_idx, n_neg, d->width, out, ld_out,
+                            as_stream(stream));
     RowSrc<float> Q{query, nullptr, n_query};
     if (d->dtype == BESS_F32)
         return run_fwd<float>(d, Q, RowSrc<float>{static_cast<const float*>(neg_base), neg_idx, n_neg}, out,
@@ -278,15 +313,20 @@ extern "C" int bess_neg_score_shared_bwd(const bess_model_desc* d, const float* 
     BESS_REQUIRE(reduce_of(d) != RED_L2 || out, "neg_score_shared_bwd: p=2 needs the forward scores");
     BESS_REQUIRE(ld_dout >= n_neg && (!out || ld_out >= n_neg), "neg_score_shared_bwd: leading dimension < n_neg");
     hipStream_t st = as_stream(stream);
+    if (reduce_of(d) == RED_DOT) {
+        if (int e = gemm_dot_dq(d->dtype, d_out, ld_dout, n_query, neg_base, neg_idx, n_neg, d->width, d_query, st))
+            return e;
+        return gemm_dot_de(d_out, ld_dout, n_query, query, n_neg, d->width, d_neg, st);
+    }
     RowSrc<float> Q{query, nullptr, n_query};
     if (d->dtype == BESS_F32) {
         RowSrc<float> E{static_cast<const float*>(neg_base), neg_idx, n_neg};
-        run_bwd_one<float, float>(d, Q, E, d_out, ld_dout, 1, out, ld_out, 1, d_query, st);
-        run_bwd_one<float, float>(d, E, Q, d_out, 1, ld_dout, out, 1, ld_out, d_neg, st);
+        if (int e = run_bwd_one<float, float>(d, Q, E, d_out, ld_dout, 1, out, ld_out, 1, d_query, st)) return e;
+        if (int e = run_bwd_one<float, float>(d, E, Q, d_out, 1, ld_dout, out, 1, ld_out, d_neg, st)) return e;
     } else {
         RowSrc<half_t> E{static_cast<const half_t*>(neg_base), neg_idx, n_neg};
-        run_bwd_one<float, half_t>(d, Q, E, d_out, ld_dout, 1, out, ld_out, 1, d_query, st);
-        run_bwd_one<half_t, float>(d, E, Q, d_out, 1, ld_dout, out, 1, ld_out, d_neg, st);
+        if (int e = run_bwd_one<float, half_t>(d, Q, E, d_out, ld_dout, 1, out, ld_out, 1, d_query, st)) return e;
+        if (int e = run_bwd_one<half_t, float>(d, E, Q, d_out, 1, ld_dout, out, 1, ld_out, d_neg, st)) return e;
     }
     return check_launch("neg_score_shared_bwd");
 }

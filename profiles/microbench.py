@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmarks (GPU box): times each hot entry point of the C ABI
+on the BASELINE shapes and prints achieved GB/s / TFLOP/s.  Not the headline
+bench (that is bench.py); used to steer kernel work.
+
+    python profiles/microbench.py [filter]
+"""
+
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(REPO, "bess-kge_amd"), REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+from besskge import _native as nat  # noqa: E402
+from besskge._native import RowSource  # noqa: E402
+
+dev = torch.device("cuda", 0)
+SC = dict(TransE=nat.TRANSE, RotatE=nat.ROTATE, DistMult=nat.DISTMULT, ComplEx=nat.COMPLEX)
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def desc(scorer, p, table, W, Wr):
+    return nat.make_desc(SC[scorer], p, table, Wr)
+
+
+def run(name, scorer, p, dtype, M, W, Wr, S, N, shared):
+    g = torch.Generator(device="cpu").manual_seed(0)
+    table = (torch.randn(M, W, generator=g) * 0.1).to(dtype).to(dev)
+    d = desc(scorer, p, table, W, Wr)
+    q = torch.randn(S, W, device=dev)
+    sz = table.element_size()
+    if shared:
+        idx = torch.randint(M, (N,), dtype=torch.int32, device=dev)
+        neg = RowSource(table, idx)
+        out = nat.neg_score_shared_fwd(d, q, neg)
+        go = torch.randn_like(out)
+        t_f = timeit(lambda: nat.neg_score_shared_fwd(d, q, neg))
+        t_b = timeit(lambda: nat.neg_score_shared_bwd(d, q, neg, out, go))
+        ops = (2 if nat.reduce_of(d) == 0 else 3) * S * N * W if hasattr(nat, "reduce_of") else 2 * S * N * W
+        flops = 2.0 * S * N * W
+        print(f"{name:34s} shared  S={S:5d} N={N:5d} W={W:4d} {str(dtype)[6:]:7s} fwd {t_f*1e3:8.1f} us "
+              f"{flops/t_f/1e9:7.1f} TFLOP/s(2SNW) | bwd {t_b*1e3:8.1f} us {2*flops/t_b/1e9:7.1f} TFLOP/s(4SNW)")
+    else:
+        idx = torch.randint(M, (S * N,), dtype=torch.int32, device=dev)
+        neg = RowSource(table, idx)
+        out = nat.neg_score_pertriple_fwd(d, q, neg, N)
+        go = torch.randn_like(out)
+        t_f = timeit(lambda: nat.neg_score_pertriple_fwd(d, q, neg, N))
+        t_b = timeit(lambda: nat.neg_score_pertriple_bwd(d, q, neg, N, go), reps=5)
+        bf = S * N * (W * sz + 8) + S * W * 4
+        bb = S * N * (W * sz + W * 4 + 8) + 2 * S * W * 4
+        print(f"{name:34s} per-tri S={S:5d} N={N:5d} W={W:4d} {str(dtype)[6:]:7s} fwd {t_f*1e3:8.1f} us "
+              f"{bf/t_f/1e6:7.0f} GB/s | bwd {t_b*1e3:8.1f} us {bb/t_b/1e6:7.0f} GB/s")
+
+
+CASES = [
+    # name, scorer, p, dtype, M, W, Wr, S, N, shared
+    ("C2 ComplEx d256 f32 (L3)", "ComplEx", 0, torch.float32, 93_773, 512, 512, 4096, 256, False),
+    ("C2 ComplEx d256 f32 (HBM 8GB)", "ComplEx", 0, torch.float32, 4_000_000, 512, 512, 4096, 256, False),
+    ("C5 DistMult d512 f32 (HBM 8GB)", "DistMult", 0, torch.float32, 4_000_000, 512, 512, 8192, 64, False),
+    ("C3 RotatE d200 f32 p1", "RotatE", 1, torch.float32, 61_591, 400, 200, 4096, 256, False),
+    ("C4 TransE d256 f16 p1 (L3)", "TransE", 1, torch.float16, 312_576, 256, 256, 4096, 256, False),
+    ("C4 TransE d256 f16 p1 (HBM 4GB)", "TransE", 1, torch.float16, 8_000_000, 256, 256, 4096, 256, False),
+    ("C1 TransE d128 f32 p1", "TransE", 1, torch.float32, 10_000, 128, 128, 4096, 256, False),
+    ("C2 ComplEx shared 4096x4096", "ComplEx", 0, torch.float32, 93_773, 512, 512, 4096, 4096, True),
+    ("C5 DistMult shared 8192x4096", "DistMult", 0, torch.float32, 1_000_000, 512, 512, 8192, 4096, True),
+    ("C4 TransE f16 L1 shared 4096x4096", "TransE", 1, torch.float16, 312_576, 256, 256, 4096, 4096, True),
+    ("C4 TransE f16 L1 shared 512x768", "TransE", 1, torch.float16, 312_576, 256, 256, 512, 768, True),
+    ("C3 RotatE L1 shared 4096x4096", "RotatE", 1, torch.float32, 61_591, 400, 200, 4096, 4096, True),
+    ("C1 TransE L2 shared 512x64", "TransE", 2, torch.float32, 10_000, 128, 128, 512, 64, True),
+]
+
+if __name__ == "__main__":
+    flt = sys.argv[1] if len(sys.argv) > 1 else ""
+    print(torch.cuda.get_device_name(0))
+    for c in CASES:
+        if flt in c[0]:
+            run(*c)

@@ -1,0 +1,81 @@
+"""The C ABI library loads (no GPU needed) and exports exactly what
+include/besskge_hip.h declares; the ctypes binding covers every entry point;
+invalid arguments are rejected with an error code + message instead of a crash
+(no kernel is launched in these tests)."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+def header_functions():
+    text = open(os.path.join(REPO, "include", "besskge_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(bess_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from besskge import _native
+
+    lib = _native.load()
+    names = header_functions()
+    assert len(names) >= 16
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert sorted(_native.SIGNATURES) == names, "ctypes binding and header disagree"
+    assert lib.bess_version() == _native.ABI_VERSION == 1
+
+
+def test_struct_layouts_match_header():
+    from besskge import _native
+
+    assert ctypes.sizeof(_native.ModelDesc) == 32
+    assert ctypes.sizeof(_native.LossDesc) == 32
+    assert _native.ModelDesc.width.offset == 12 and _native.ModelDesc.rel_width.offset == 16
+    assert _native.LossDesc.margin.offset == 8 and _native.LossDesc.ssce_shift.offset == 20
+
+
+def last_error(lib):
+    buf = ctypes.create_string_buffer(256)
+    lib.bess_last_error(buf, 256)
+    return buf.value.decode()
+
+
+def test_invalid_arguments_return_error_codes():
+    from besskge import _native
+
+    lib = _native.load()
+    d = _native.ModelDesc()
+    d.scorer, d.norm_p, d.dtype, d.width, d.rel_width = 9, 1, 0, 8, 8
+    assert lib.bess_query_fwd(ctypes.byref(d), 0, 0, 0, 0, 0, 0, 0, 0) == -1
+    assert "unknown scorer" in last_error(lib)
+    d.scorer, d.norm_p = _native.TRANSE, 3
+    assert lib.bess_score_triple_fwd(ctypes.byref(d), 0, 0, 0, 0, 0, 0, 0, 0, 0) == -1
+    assert "norm" in last_error(lib)
+    d.scorer, d.norm_p, d.width, d.rel_width = _native.ROTATE, 1, 8, 8  # RotatE needs Wr = W/2
+    assert lib.bess_query_fwd(ctypes.byref(d), 0, 0, 0, 0, 0, 0, 0, 0) == -1
+    assert "rel_width" in last_error(lib)
+    d.rel_width = 4
+    assert lib.bess_query_fwd(ctypes.byref(d), 7, 0, 0, 0, 0, 0, 0, 0) == -1  # bad side
+    # NULL pointers with non-zero sizes are refused before any launch
+    assert lib.bess_gather_rows(0, 8, 0, 0, 5, 0, 0) == -1
+    assert lib.bess_gather_rows(5, 8, 0, 0, 0, 0, 0) == -1  # bad dtype
+    # empty problems are fine without touching the device
+    assert lib.bess_gather_rows(0, 8, 0, 0, 0, 0, 0) == 0
+    assert lib.bess_scatter_add_rows(0, 8, 0, 0, 0, 1.0, 0) == 0
+    l = _native.LossDesc()
+    l.kind = 7
+    assert lib.bess_loss_fwd_bwd(ctypes.byref(l), 0, 0, 1, 1, 1, 0, 1, 0, 0, 0, 0, 1, 0) == -1
+
+
+def test_import_fails_loudly_without_the_library(tmp_path, monkeypatch):
+    from besskge import _native
+
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "library_path", lambda: tmp_path / "libbesskge_hip.so")
+    with pytest.raises(ImportError, match="Cannot find the HIP extension library"):
+        _native.load()
