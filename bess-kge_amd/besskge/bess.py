@@ -190,6 +190,8 @@ class BessKGE(torch.nn.Module, ABC):
         k = (key, device)
         if k not in self._map_cache:
             self._map_cache[k] = build().to(device=device, dtype=torch.int32).contiguous()
+            # built once, then read from any stream: make sure it has landed
+            torch.cuda.current_stream(device).synchronize()
         return self._map_cache[k]
 
     # ---------------------------------------------------------------- forward

@@ -36,6 +36,11 @@ class Options:
     output_mode: str = "all"
     #: distributed runs: all-gather outputs so every rank sees all replicas
     gather_outputs: bool = False
+    #: inference only: micro-batches of one call are issued round-robin on this
+    #: many HIP streams, so the collectives / small kernels of micro-batch i+1
+    #: overlap the scoring of micro-batch i (they are independent: the tables
+    #: are read-only).  Training steps depend on each other and stay in order.
+    pipeline_streams: int = 2
 
     def deviceIterations(self, n: int) -> "Options":  # noqa: N802 - poptorch spelling
         self.device_iterations = n
@@ -95,6 +100,13 @@ class Runner:
             raise NotImplementedError("training is implemented for EmbeddingMovingBessKGE")
         place_shards(model, group, device, dtype)
 
+    def _side_streams(self, n: int) -> List[torch.cuda.Stream]:
+        have = getattr(self, "_streams", [])
+        while len(have) < n:
+            have.append(torch.cuda.Stream(device=self.device))
+        self._streams = have
+        return have[:n]
+
     def _split(self, batch: Dict[str, torch.Tensor], it: int) -> List[Dict[str, torch.Tensor]]:
         n = self.group.n_shard
         out = []
@@ -116,14 +128,24 @@ class Runner:
                 " (flatten [batches_per_step, n_shard, ...] with .flatten(end_dim=1))"
             )
         collected: List[List[Dict[str, Any]]] = []
+        n_streams = 1 if (self.optimizer is not None or iters == 1) else max(1, self.options.pipeline_streams)
+        main = torch.cuda.current_stream(self.device)
+        streams = [main] if n_streams == 1 else self._side_streams(n_streams)
+        for st in streams:
+            if st is not main:
+                st.wait_stream(main)
         for it in range(iters):
-            reps = self._split(batch, it)
-            if self.optimizer is not None:
-                res = self.model.train_step_replicas(reps, self.optimizer.lr)  # type: ignore
-            else:
-                with torch.no_grad():
-                    res = self.model.forward_replicas(reps)
+            with torch.cuda.stream(streams[it % len(streams)]):
+                reps = self._split(batch, it)
+                if self.optimizer is not None:
+                    res = self.model.train_step_replicas(reps, self.optimizer.lr)  # type: ignore
+                else:
+                    with torch.no_grad():
+                        res = self.model.forward_replicas(reps)
             collected.append(res)
+        for st in streams:
+            if st is not main:
+                main.wait_stream(st)
         if self.options.output_mode == "final":
             collected = collected[-1:]
         keys = collected[0][0].keys()
