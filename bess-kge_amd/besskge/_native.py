@@ -82,6 +82,10 @@ SIGNATURES = {
     "bess_scatter_add_rows": [_vp, _i32, _vp, _vp, _i64, _f32, _vp],
     "bess_sparse_sgd": [_i32, _i32, _vp, _vp, _vp, _i64, _f32, _vp],
     "bess_dense_sgd": [_i32, _vp, _vp, _i64, _f32, _vp],
+    "bess_segment_index_workspace": [_i64, ctypes.POINTER(ctypes.c_size_t)],
+    "bess_build_segment_index": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
+    "bess_neg_pertriple_grad_segments": [_MD, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _vp],
+    "bess_apply_segments_sgd": [_i32, _i32, _vp, _vp, _vp, _i64, _vp, _f32, _vp],
 }
 
 _lib: Optional[ctypes.CDLL] = None
@@ -412,8 +416,9 @@ def neg_score_pertriple_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n
 
 
 def neg_score_pertriple_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n_neg: int,
-                            d_out: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Returns (d_query [nq, W], d_neg [nq*n_neg, W])."""
+                            d_out: torch.Tensor, want_d_neg: bool = True
+                            ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Returns (d_query [nq, W], d_neg [nq*n_neg, W] or None)."""
     nq = int(query.shape[0])
     dev = _neg_operands(d, query, neg, nq * n_neg)
     _same_device([("d_out", d_out), ("query", query)])
@@ -421,12 +426,12 @@ def neg_score_pertriple_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n
     if tuple(d_out.shape) != (nq, n_neg):
         raise ValueError("neg_score_pertriple_bwd: bad `d_out` shape")
     dq = torch.empty((nq, d.width), dtype=torch.float32, device=dev)
-    dn = torch.empty((nq * n_neg, d.width), dtype=torch.float32, device=dev)
+    dn = torch.empty((nq * n_neg, d.width), dtype=torch.float32, device=dev) if want_d_neg else None
     ip, keep = _neg_idx_ptr(neg, dev)
     with torch.cuda.device(dev), _Timed("bess_neg_score_pertriple_bwd", dev):
         rc = load().bess_neg_score_pertriple_bwd(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(), ip,
-                                                 n_neg, d_out.data_ptr(), n_neg, dq.data_ptr(), dn.data_ptr(),
-                                                 _stream(dev))
+                                                 n_neg, d_out.data_ptr(), n_neg, dq.data_ptr(),
+                                                 dn.data_ptr() if want_d_neg else 0, _stream(dev))
     _check(rc, "bess_neg_score_pertriple_bwd")
     del keep
     return dq, dn
@@ -538,3 +543,68 @@ def dense_sgd(table: torch.Tensor, grad: torch.Tensor, lr: float) -> None:
     with torch.cuda.device(dev):
         rc = load().bess_dense_sgd(_dtype_code(table), table.data_ptr(), grad.data_ptr(), table.numel(), lr, _stream(dev))
     _check(rc, "bess_dense_sgd")
+
+
+class SegmentIndex:
+    """References grouped by destination row (see bess_build_segment_index)."""
+
+    __slots__ = ("refs", "seg_rows", "seg_offsets", "n_seg", "n_refs", "max_seg")
+
+    def __init__(self, idx: torch.Tensor, n_rows: int) -> None:
+        dev = _dev(idx, "idx")
+        ip = _idx(idx, "idx")
+        n = int(idx.numel())
+        need = ctypes.c_size_t(0)
+        _check(load().bess_segment_index_workspace(n, ctypes.byref(need)), "bess_segment_index_workspace")
+        ws = torch.empty((need.value,), dtype=torch.uint8, device=dev)
+        self.refs = torch.empty((n,), dtype=torch.int32, device=dev)
+        self.seg_rows = torch.empty((n,), dtype=torch.int32, device=dev)
+        self.seg_offsets = torch.empty((n + 1,), dtype=torch.int32, device=dev)
+        self.n_seg = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.n_refs = n
+        self.max_seg = min(n, int(n_rows))
+        bits = max(1, int(n_rows - 1).bit_length())
+        with torch.cuda.device(dev), _Timed("bess_build_segment_index", dev):
+            rc = load().bess_build_segment_index(ip, n, bits, self.refs.data_ptr(), self.seg_rows.data_ptr(),
+                                                 self.seg_offsets.data_ptr(), self.n_seg.data_ptr(), ws.data_ptr(),
+                                                 need.value, _stream(dev))
+        _check(rc, "bess_build_segment_index")
+
+
+def neg_pertriple_grad_segments(d: ModelDesc, query: torch.Tensor, table: torch.Tensor, n_neg: int,
+                                d_out: torch.Tensor, seg: SegmentIndex,
+                                fused_sgd_lr: Optional[float] = None) -> Optional[torch.Tensor]:
+    """grad_seg [seg.max_seg, W] f32: one gradient row per unique destination row;
+    or, with fused_sgd_lr, apply `table[row] -= lr * grad` in place and return None."""
+    dev = _same_device([("query", query), ("table", table), ("d_out", d_out), ("refs", seg.refs)])
+    _f32(query, "query")
+    _f32(d_out, "d_out")
+    _rows(table, "table", d.width)
+    nq = int(query.shape[0])
+    if _dtype_code(table) != d.dtype or tuple(query.shape) != (nq, d.width) or tuple(d_out.shape) != (nq, n_neg) \
+            or seg.n_refs != nq * n_neg:
+        raise ValueError("neg_pertriple_grad_segments: operand shapes do not match")
+    fused = fused_sgd_lr is not None
+    grad = None if fused else torch.empty((seg.max_seg, d.width), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _Timed("bess_neg_pertriple_grad_segments", dev):
+        rc = load().bess_neg_pertriple_grad_segments(ctypes.byref(d), query.data_ptr(), nq, table.data_ptr(), n_neg,
+                                                     d_out.data_ptr(), n_neg, seg.refs.data_ptr(),
+                                                     seg.seg_rows.data_ptr(), seg.seg_offsets.data_ptr(),
+                                                     seg.n_seg.data_ptr(), seg.max_seg,
+                                                     0 if fused else grad.data_ptr(),
+                                                     float(fused_sgd_lr) if fused else 0.0, _stream(dev))
+    _check(rc, "bess_neg_pertriple_grad_segments")
+    return grad
+
+
+def apply_segments_sgd(table: torch.Tensor, seg: SegmentIndex, grad_seg: torch.Tensor, lr: float) -> None:
+    dev = _same_device([("table", table), ("grad_seg", grad_seg), ("seg_rows", seg.seg_rows)])
+    W = int(table.shape[1])
+    _rows(table, "table", W)
+    _f32(grad_seg, "grad_seg")
+    if tuple(grad_seg.shape) != (seg.max_seg, W):
+        raise ValueError("apply_segments_sgd: grad_seg shape mismatch")
+    with torch.cuda.device(dev), _Timed("bess_apply_segments_sgd", dev):
+        rc = load().bess_apply_segments_sgd(_dtype_code(table), W, table.data_ptr(), seg.seg_rows.data_ptr(),
+                                            seg.n_seg.data_ptr(), seg.max_seg, grad_seg.data_ptr(), lr, _stream(dev))
+    _check(rc, "bess_apply_segments_sgd")

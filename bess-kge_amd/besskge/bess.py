@@ -186,6 +186,13 @@ class BessKGE(torch.nn.Module, ABC):
             )
         return emb.data[slot]
 
+    def _aux_stream(self, device: torch.device) -> torch.cuda.Stream:
+        if not hasattr(self, "_aux_streams"):
+            self._aux_streams: Dict[torch.device, torch.cuda.Stream] = {}
+        if device not in self._aux_streams:
+            self._aux_streams[device] = torch.cuda.Stream(device=device)
+        return self._aux_streams[device]
+
     def _static_map(self, key: Any, build: Any, device: torch.device) -> torch.Tensor:
         k = (key, device)
         if k not in self._map_cache:
@@ -521,7 +528,19 @@ class EmbeddingMovingBessKGE(BessKGE):
         results = []
         d_rel = torch.zeros(rel_table.shape, dtype=torch.float32, device=rel_table.device)
         back: List[torch.Tensor] = []
+        deferred: List[Tuple[torch.Tensor, _NegGroup, torch.Tensor]] = []
         local_updates: List[List[Tuple[torch.Tensor, torch.Tensor]]] = []
+        # The inverted indices only depend on the sampled indices: build them on a
+        # side stream while the forward kernels are still running.
+        seg_index: Dict[int, Any] = {}
+        main = torch.cuda.current_stream(rel_table.device)
+        side = self._aux_stream(rel_table.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for st in steps:
+                for g in st.groups:
+                    if not g.shared and g.neg.base is st.table:
+                        seg_index[id(g)] = nat.SegmentIndex(g.neg.idx, st.table.shape[0])
         for st, b in zip(steps, batches):
             out, d_pos, d_neg = self._finish(st, b, want_grad=True)
             results.append(out)
@@ -555,9 +574,16 @@ class EmbeddingMovingBessKGE(BessKGE):
             for g, go in zip(st.groups, d_outs):
                 if g.shared:
                     dq, dn = nat.neg_score_shared_bwd(desc, g.query, g.neg, g.out, go)
+                    sink(g.neg, dn)
+                elif g.neg.base is st.table:
+                    # per-triple negatives read straight from the shard: no [S*N, W]
+                    # gradient, no atomics - references are grouped by destination row
+                    # and reduced on chip (K9), unique rows updated afterwards (K10)
+                    dq, _ = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go, want_d_neg=False)
+                    deferred.append((st.table, g, go))
                 else:
                     dq, dn = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go)
-                sink(g.neg, dn)
+                    sink(g.neg, dn)
                 dx = nat.query_bwd(desc, g.side, g.ent, rel_table, g.rel_idx, dq, d_rel)
                 sink(g.ent, dx)
             if n > 1:
@@ -571,6 +597,19 @@ class EmbeddingMovingBessKGE(BessKGE):
                 upd.append((st.send_idx.reshape(-1), g.reshape(-1, W)))
         # K9 + K10: sparse SGD on the shard (gradients were all computed from
         # the pre-update tables above)
+        # K9 + K10 for per-triple negatives of the own shard.  Every other gradient
+        # has been computed from the pre-update tables by now.
+        main.wait_stream(side)
+        for table in {id(t): t for t, _, _ in deferred}.values():
+            table.record_stream(main)
+        if len(deferred) == 1:
+            table, g, go = deferred[0]
+            nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go, seg_index[id(g)], fused_sgd_lr=lr)
+        else:
+            grads = [nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go, seg_index[id(g)])
+                     for table, g, go in deferred]
+            for (table, g, _), gseg in zip(deferred, grads):
+                nat.apply_segments_sgd(table, seg_index[id(g)], gseg, lr)
         for st, upd in zip(steps, local_updates):
             for idx, g in upd:
                 nat.sparse_sgd(st.table, idx.contiguous(), g.contiguous(), lr)

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_bwd(NegPtArgs a,
                 }
                 dq[it][v] += dqe;
             }
-            if (valid && c < a.nch) {
+            if (d_neg && valid && c < a.nch) {  // d_neg == NULL: only d_query is wanted
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) dn[c * VEC + v] = de[v];
             }
@@ -325,7 +325,7 @@ extern "C" int bess_neg_score_pertriple_bwd(const bess_model_desc* d, const floa
                                             const int32_t* neg_idx, int64_t n_neg,
                                             const float* d_out, int64_t ld_dout, float* d_query,
                                             float* d_neg, void* stream) {
-    if (n_query > 0 && n_neg > 0 && !(d_out && d_query && d_neg))
+    if (n_query > 0 && n_neg > 0 && !(d_out && d_query))
         return bess::fail(BESS_EINVAL, "neg_score_pertriple_bwd: NULL pointer");
     return bess::run(d, false, query, n_query, neg_base, neg_idx, n_neg, nullptr, d_out, ld_dout,
                      d_query, d_neg, stream);

@@ -1,0 +1,293 @@
+// K9 without atomics: segmented reduction of per-reference gradients into one
+// gradient row per *unique* destination row of the shard, then K10 on those rows.
+//
+// The reference's autograd turns the gather `entity_embedding[idx]` into a dense
+// zero-filled [M, W] gradient + `index_put_(accumulate)` (48 % + 17 % of its CPU
+// step time).  A direct GPU transcription (one fp32 atomic
+// per scalar of every gathered row) runs at the memory-side atomic rate
+// (~1.3 TB/s), 4-5x below plain stores.  Here the references are grouped by
+// destination row (an inverted index built with a stable radix sort, so the
+// summation order - and therefore the result - is bitwise reproducible), each
+// destination is summed in registers by one 16-lane DPP row, and written once.
+//
+// Per-triple negatives: the contribution of reference (q, k) to row
+// e = neg_idx[q, k] is recomputed on the fly from query[q] (L2 / Infinity-Cache
+// resident, S rows), d_out[q, k] and the row itself, so the [S*N, W] gradient of
+// the gathered rows is never materialised:
+//     DOT:  d e += g * query[q]
+//     L1 :  d e += g * sgn(query[q] - e)        (score = -||q - e||_1)
+//     L2 :  d e += g * (query[q] - e) / ||q - e||_2
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace bess {
+
+static inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+struct CubSizes {
+    size_t sort, rle, scan, total_cub;
+};
+
+static hipError_t cub_sizes(int64_t n, CubSizes* cs) {
+    int32_t* p = nullptr;
+    size_t a = 0, b = 0, c = 0;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, a, p, p, p, p, static_cast<int>(n), 0, 32, 0);
+    if (e != hipSuccess) return e;
+    e = hipcub::DeviceRunLengthEncode::Encode(nullptr, b, p, p, p, p, static_cast<int>(n), 0);
+    if (e != hipSuccess) return e;
+    e = hipcub::DeviceScan::ExclusiveSum(nullptr, c, p, p, static_cast<int>(n), 0);
+    if (e != hipSuccess) return e;
+    cs->sort = a;
+    cs->rle = b;
+    cs->scan = c;
+    cs->total_cub = std::max(a, std::max(b, c));
+    return hipSuccess;
+}
+
+__global__ __launch_bounds__(256) void k_iota(int32_t* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) out[i] = static_cast<int32_t>(i);
+}
+
+// seg_offsets[n_seg] = n_refs (close the last segment); ExclusiveSum wrote only n entries
+__global__ void k_close_offsets(int32_t* __restrict__ seg_offsets, const int32_t* __restrict__ n_seg,
+                                int32_t n_refs) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) seg_offsets[*n_seg] = n_refs;
+}
+
+struct SegArgs {
+    const float* query;
+    const void* table;
+    const float* d_out;
+    int64_t ld_dout;
+    const int32_t* refs;         // sorted reference ids (q * n_neg + k)
+    const int32_t* seg_rows;     // destination row of each segment
+    const int32_t* seg_offsets;  // [n_seg + 1]
+    const int32_t* n_seg;        // device scalar
+    int n_neg;
+    int W;
+    int nch;
+    float sign;
+};
+
+// grad_seg != NULL: write the per-row gradient.  grad_seg == NULL: apply SGD in
+// place, table[row] -= lr * grad (each row is owned by exactly one 16-lane
+// group, which read the old value before writing the new one).
+template <typename T, int VEC, int IT, int RED>
+__global__ __launch_bounds__(256) void k_pertriple_grad_segments(SegArgs a, float* __restrict__ grad_seg,
+                                                                 T* table_rw, float lr) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane & 15;
+    const int n_seg = *a.n_seg;
+    const int64_t group0 = (blockIdx.x * 256ll + threadIdx.x) >> 4;
+    const int64_t n_group = (gridDim.x * 256ll) >> 4;
+    const T* table = static_cast<const T*>(a.table);
+    for (int64_t seg = group0; seg < n_seg; seg += n_group) {
+        const int64_t row = a.seg_rows[seg];
+        const int r0 = a.seg_offsets[seg], r1 = a.seg_offsets[seg + 1];
+        float ev[IT][VEC], acc[IT][VEC];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = g + 16 * it;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                ev[it][v] = 0.f;
+                acc[it][v] = 0.f;
+            }
+            if ((RED != RED_DOT || grad_seg == nullptr) && c < a.nch)
+                VecLoad<T, VEC>::load(table + row * a.W + c * VEC, ev[it]);
+        }
+        for (int r = r0; r < r1; ++r) {
+            const int ref = a.refs[r];
+            const int q = ref / a.n_neg;
+            const int k = ref - q * a.n_neg;
+            float go = a.sign * a.d_out[q * a.ld_dout + k];
+            float qv[IT][VEC];
+            const float* qp = a.query + static_cast<int64_t>(q) * a.W;
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = g + 16 * it;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) qv[it][v] = 0.f;
+                if (c < a.nch) VecLoad<float, VEC>::load(qp + c * VEC, qv[it]);
+            }
+            if (RED == RED_L2) {
+                float ss = 0.f;
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const float dlt = qv[it][v] - ev[it][v];
+                        ss = fmaf(dlt, dlt, ss);
+                    }
+                ss = row16_allreduce_sum(ss);
+                go = ss > 0.f ? go / sqrtf(ss) : 0.f;
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    if (RED == RED_DOT) acc[it][v] = fmaf(go, qv[it][v], acc[it][v]);
+                    else if (RED == RED_L1) acc[it][v] -= go * sgnf(qv[it][v] - ev[it][v]);
+                    else acc[it][v] = fmaf(-go, qv[it][v] - ev[it][v], acc[it][v]);
+                }
+        }
+        if (grad_seg) {
+            float* out = grad_seg + seg * a.W;
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = g + 16 * it;
+                if (c < a.nch) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) out[c * VEC + v] = acc[it][v];
+                }
+            }
+        } else {
+            T* out = table_rw + row * a.W;
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = g + 16 * it;
+                if (c < a.nch) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        out[c * VEC + v] = static_cast<T>(ev[it][v] - lr * acc[it][v]);
+                }
+            }
+        }
+    }
+}
+
+// table[seg_rows[s], :] -= lr * grad_seg[s, :]    (unique rows: plain read-modify-write)
+template <typename T>
+__global__ __launch_bounds__(256) void k_apply_segments(T* __restrict__ table, int W,
+                                                        const int32_t* __restrict__ seg_rows,
+                                                        const int32_t* __restrict__ n_seg,
+                                                        const float* __restrict__ grad_seg, float lr) {
+    const int64_t total = static_cast<int64_t>(*n_seg) * W;
+    for (int64_t t = blockIdx.x * 256ll + threadIdx.x; t < total; t += 256ll * gridDim.x) {
+        const int64_t s = t / W;
+        const int c = static_cast<int>(t - s * W);
+        T* p = table + static_cast<int64_t>(seg_rows[s]) * W + c;
+        *p = static_cast<T>(static_cast<float>(*p) - lr * grad_seg[t]);
+    }
+}
+
+template <typename T, int VEC, int IT>
+static void seg_by_red(int red, const SegArgs& a, float* grad_seg, void* table_rw, float lr, unsigned grid,
+                       hipStream_t st) {
+    T* rw = static_cast<T*>(table_rw);
+    if (red == RED_DOT) k_pertriple_grad_segments<T, VEC, IT, RED_DOT><<<grid, 256, 0, st>>>(a, grad_seg, rw, lr);
+    else if (red == RED_L1) k_pertriple_grad_segments<T, VEC, IT, RED_L1><<<grid, 256, 0, st>>>(a, grad_seg, rw, lr);
+    else k_pertriple_grad_segments<T, VEC, IT, RED_L2><<<grid, 256, 0, st>>>(a, grad_seg, rw, lr);
+}
+
+template <typename T, int VEC>
+static int seg_by_it(int it, int red, const SegArgs& a, float* grad_seg, void* rw, float lr, unsigned grid,
+                     hipStream_t st) {
+    if (it <= 1) seg_by_red<T, VEC, 1>(red, a, grad_seg, rw, lr, grid, st);
+    else if (it <= 2) seg_by_red<T, VEC, 2>(red, a, grad_seg, rw, lr, grid, st);
+    else if (it <= 4) seg_by_red<T, VEC, 4>(red, a, grad_seg, rw, lr, grid, st);
+    else if (it <= 8) seg_by_red<T, VEC, 8>(red, a, grad_seg, rw, lr, grid, st);
+    else if (it <= 16) seg_by_red<T, VEC, 16>(red, a, grad_seg, rw, lr, grid, st);
+    else return fail(BESS_EUNSUPPORTED, "grad_segments: row of %d scalars too wide", a.W);
+    return BESS_OK;
+}
+
+}  // namespace bess
+
+using namespace bess;
+
+extern "C" int bess_segment_index_workspace(int64_t n_refs, size_t* bytes) {
+    BESS_REQUIRE(bytes, "segment_index_workspace: NULL out");
+    BESS_REQUIRE(n_refs >= 0 && n_refs < (1ll << 31), "segment_index_workspace: n_refs out of range");
+    CubSizes cs;
+    hipError_t e = cub_sizes(n_refs > 0 ? n_refs : 1, &cs);
+    if (e != hipSuccess) return fail(static_cast<int>(e), "hipcub size query: %s", hipGetErrorString(e));
+    // [sorted keys][iota][counts][cub temp]
+    *bytes = 3 * align_up(sizeof(int32_t) * static_cast<size_t>(n_refs)) + align_up(cs.total_cub) + 256;
+    return BESS_OK;
+}
+
+extern "C" int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int32_t row_bits,
+                                        int32_t* refs_sorted, int32_t* seg_rows, int32_t* seg_offsets,
+                                        int32_t* n_seg, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
+    BESS_REQUIRE(n_refs > 0 && n_refs < (1ll << 31), "build_segment_index: n_refs out of range");
+    BESS_REQUIRE(idx && refs_sorted && seg_rows && seg_offsets && n_seg && workspace, "build_segment_index: NULL pointer");
+    BESS_REQUIRE(row_bits >= 1 && row_bits <= 31, "build_segment_index: row_bits out of range");
+    size_t need = 0;
+    if (int e = bess_segment_index_workspace(n_refs, &need)) return e;
+    BESS_REQUIRE(workspace_bytes >= need, "build_segment_index: workspace of %zu bytes, need %zu", workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    const int n = static_cast<int>(n_refs);
+    char* ws = static_cast<char*>(workspace);
+    const size_t blk = align_up(sizeof(int32_t) * static_cast<size_t>(n_refs));
+    int32_t* keys_sorted = reinterpret_cast<int32_t*>(ws);
+    int32_t* iota = reinterpret_cast<int32_t*>(ws + blk);
+    int32_t* counts = reinterpret_cast<int32_t*>(ws + 2 * blk);
+    void* cub_tmp = ws + 3 * blk;
+    size_t cub_bytes = workspace_bytes - 3 * blk;
+    k_iota<<<static_cast<unsigned>(std::min<int64_t>(ceil_div(n_refs, 256), 2048)), 256, 0, st>>>(iota, n_refs);
+    // stable LSD radix sort on the significant bits only: equal rows keep reference order
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, idx, keys_sorted, iota, refs_sorted, n, 0,
+                                                      row_bits, st);
+    if (e != hipSuccess) return fail(static_cast<int>(e), "radix sort: %s", hipGetErrorString(e));
+    e = hipcub::DeviceRunLengthEncode::Encode(cub_tmp, cub_bytes, keys_sorted, seg_rows, counts, n_seg, n, st);
+    if (e != hipSuccess) return fail(static_cast<int>(e), "run-length encode: %s", hipGetErrorString(e));
+    // counts beyond n_seg are undefined but never read: offsets are consumed up to n_seg only
+    e = hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, counts, seg_offsets, n, st);
+    if (e != hipSuccess) return fail(static_cast<int>(e), "exclusive scan: %s", hipGetErrorString(e));
+    k_close_offsets<<<1, 64, 0, st>>>(seg_offsets, n_seg, static_cast<int32_t>(n_refs));
+    return check_launch("build_segment_index");
+}
+
+extern "C" int bess_neg_pertriple_grad_segments(const bess_model_desc* d, const float* query, int64_t n_query,
+                                                void* table, int64_t n_neg, const float* d_out,
+                                                int64_t ld_dout, const int32_t* refs_sorted,
+                                                const int32_t* seg_rows, const int32_t* seg_offsets,
+                                                const int32_t* n_seg, int64_t max_seg, float* grad_seg,
+                                                float fused_sgd_lr, void* stream) {
+    if (int e = check_desc(d)) return e;
+    BESS_REQUIRE(n_query > 0 && n_neg > 0 && n_query * n_neg < (1ll << 31), "grad_segments: bad sizes");
+    BESS_REQUIRE(query && table && d_out && refs_sorted && seg_rows && seg_offsets && n_seg,
+                 "grad_segments: NULL pointer");
+    BESS_REQUIRE(ld_dout >= n_neg && max_seg > 0, "grad_segments: bad leading dimension / max_seg");
+    const int W = d->width;
+    const int maxvec = d->dtype == BESS_F32 ? 4 : 8;
+    int vec = maxvec;
+    if (W % vec) vec = (d->dtype == BESS_F16 && W % 2 == 0) ? 2 : 1;
+    SegArgs a{query, table, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg,
+              static_cast<int>(n_neg), W, W / vec, is_distance(d->scorer) ? -1.f : 1.f};
+    const int it = static_cast<int>(ceil_div(a.nch, 16));
+    const int red = reduce_of(d);
+    // 16 segments per 256-thread workgroup; grid-stride over the (device-side) segment count
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(max_seg, 16), 256 * 16));
+    hipStream_t st = as_stream(stream);
+    int rc;
+    if (d->dtype == BESS_F32) {
+        rc = (vec == 4) ? seg_by_it<float, 4>(it, red, a, grad_seg, table, fused_sgd_lr, grid, st)
+                        : seg_by_it<float, 1>(it, red, a, grad_seg, table, fused_sgd_lr, grid, st);
+    } else {
+        rc = (vec == 8) ? seg_by_it<half_t, 8>(it, red, a, grad_seg, table, fused_sgd_lr, grid, st)
+             : (vec == 2) ? seg_by_it<half_t, 2>(it, red, a, grad_seg, table, fused_sgd_lr, grid, st)
+                          : seg_by_it<half_t, 1>(it, red, a, grad_seg, table, fused_sgd_lr, grid, st);
+    }
+    if (rc) return rc;
+    return check_launch("neg_pertriple_grad_segments");
+}
+
+extern "C" int bess_apply_segments_sgd(int32_t dtype, int32_t width, void* table, const int32_t* seg_rows,
+                                       const int32_t* n_seg, int64_t max_seg, const float* grad_seg, float lr,
+                                       void* stream) {
+    BESS_REQUIRE(dtype == BESS_F32 || dtype == BESS_F16, "apply_segments_sgd: unknown dtype %d", dtype);
+    BESS_REQUIRE(width > 0 && max_seg > 0, "apply_segments_sgd: bad sizes");
+    BESS_REQUIRE(table && seg_rows && n_seg && grad_seg, "apply_segments_sgd: NULL pointer");
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(max_seg * width, 256), 256 * 16));
+    if (dtype == BESS_F32)
+        k_apply_segments<float><<<grid, 256, 0, as_stream(stream)>>>(static_cast<float*>(table), width, seg_rows,
+                                                                     n_seg, grad_seg, lr);
+    else
+        k_apply_segments<half_t><<<grid, 256, 0, as_stream(stream)>>>(static_cast<half_t*>(table), width, seg_rows,
+                                                                      n_seg, grad_seg, lr);
+    return check_launch("apply_segments_sgd");
+}

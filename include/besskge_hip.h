@@ -136,7 +136,8 @@ int bess_neg_score_pertriple_fwd(const bess_model_desc* d, const float* query,
 
 /* backward of K5.  d_out read with ld_dout.  d_query [n_query, W] f32 is
  * overwritten; d_neg [n_query*n_neg, W] f32 (gradient w.r.t. every gathered
- * row, same order as neg_idx) is overwritten. */
+ * row, same order as neg_idx) is overwritten - or pass d_neg = NULL when the
+ * row gradients are produced by bess_neg_pertriple_grad_segments instead. */
 int bess_neg_score_pertriple_bwd(const bess_model_desc* d, const float* query,
                                  int64_t n_query, const void* neg_base,
                                  const int32_t* neg_idx, int64_t n_neg,
@@ -195,6 +196,45 @@ int bess_scatter_add_rows(float* dst, int32_t width, const int32_t* idx,
  *   table[idx[i], :] -= lr * grad[i, :]     (atomic, duplicates accumulate) */
 int bess_sparse_sgd(int32_t dtype, int32_t width, void* table, const int32_t* idx,
                     const float* grad, int64_t n, float lr, void* stream);
+
+/* K9 without atomics (n_shard == 1, per-triple negatives read straight from
+ * the shard): group the n_refs references idx[i] by destination row with a
+ * stable radix sort (bitwise reproducible sums), reduce each group on chip,
+ * write one gradient row per unique destination, apply the optimiser to those.
+ *
+ * bess_segment_index_workspace: bytes of scratch needed for n_refs references.
+ * bess_build_segment_index: row_bits = bits needed for the largest row id;
+ *   refs_sorted [n_refs] (reference ids ordered by row, ties in reference order),
+ *   seg_rows [n_refs] (row of each segment), seg_offsets [n_refs + 1],
+ *   n_seg [1] (device scalar: number of unique rows, read by the consumers so
+ *   that no host synchronisation is needed). */
+int bess_segment_index_workspace(int64_t n_refs, size_t* bytes);
+int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int32_t row_bits,
+                             int32_t* refs_sorted, int32_t* seg_rows,
+                             int32_t* seg_offsets, int32_t* n_seg, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+/* grad_seg[s, :] (f32 [max_seg, W], rows >= *n_seg untouched) = sum over the
+ * references (q, k) of segment s of d score(query[q], e) / d e * d_out[q, k],
+ * e = table[seg_rows[s]].  Same arithmetic as bess_neg_score_pertriple_bwd's
+ * d_neg, summed per destination row; nothing of size [n_refs, W] is written.
+ * With grad_seg == NULL the SGD step is fused: table[seg_rows[s]] -=
+ * fused_sgd_lr * (that sum), each row read and written by its one owner (use
+ * only when no later gradient computation still needs the old rows). */
+int bess_neg_pertriple_grad_segments(const bess_model_desc* d, const float* query,
+                                     int64_t n_query, void* table, int64_t n_neg,
+                                     const float* d_out, int64_t ld_dout,
+                                     const int32_t* refs_sorted, const int32_t* seg_rows,
+                                     const int32_t* seg_offsets, const int32_t* n_seg,
+                                     int64_t max_seg, float* grad_seg,
+                                     float fused_sgd_lr, void* stream);
+
+/* K10 on unique rows: table[seg_rows[s], :] -= lr * grad_seg[s, :], s < *n_seg
+ * (plain read-modify-write: one rounding per row and step, also for f16). */
+int bess_apply_segments_sgd(int32_t dtype, int32_t width, void* table,
+                            const int32_t* seg_rows, const int32_t* n_seg,
+                            int64_t max_seg, const float* grad_seg, float lr,
+                            void* stream);
 
 /* dense axpy on a replicated table: table -= lr * grad (relation table) */
 int bess_dense_sgd(int32_t dtype, void* table, const float* grad, int64_t n_elem,

@@ -395,3 +395,45 @@ def test_bess_inference_like_reference(dev, model_name, scheme, dup, flat):
             true = true_nh if scheme == "h" else true_nt
             torch.testing.assert_close(torch.take_along_dim(true[sort_idx][gidx], nsi[triple_mask], dim=-1),
                                        negs[triple_mask], rtol=RTOL, atol=ATOL)
+
+
+# ------------------------------------------- K9 segmented reduction (no atomics) ----
+@pytest.mark.parametrize("name,p", SCORERS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_grad_segments_match_scatter_of_row_gradients(dev, name, p, dtype):
+    """grad_seg == index_add of the per-reference row gradients of the plain backward
+    kernel; the unique rows / offsets are exact; two runs are bitwise identical."""
+    from besskge import _native as nat
+    from besskge._native import RowSource
+
+    gen = torch.Generator().manual_seed(5)
+    M, d, S, N = 300, 40, 33, 17
+    W, Wr = widths(name, d)
+    table = torch.randn(M, W, generator=gen).to(dtype).to(dev)
+    q = torch.randn(S, W, generator=gen).to(dev)
+    idx = torch.randint(M, (S * N,), generator=gen, dtype=torch.int32).to(dev)
+    go = torch.randn(S, N, generator=gen).to(dev)
+    desc = nat.make_desc(dict(TransE=0, RotatE=1, DistMult=2, ComplEx=3)[name], max(p, 1), table, Wr)
+    dq_ref, dn = nat.neg_score_pertriple_bwd(desc, q, RowSource(table, idx), N, go)
+    dq, none = nat.neg_score_pertriple_bwd(desc, q, RowSource(table, idx), N, go, want_d_neg=False)
+    assert none is None
+    close(dq, dq_ref, rtol=1e-5, atol=1e-5)  # partial sums over negative blocks are combined atomically
+    seg = nat.SegmentIndex(idx, M)
+    n_seg = int(seg.n_seg.item())
+    uniq, counts = torch.unique(idx.cpu().long(), return_counts=True)
+    assert n_seg == uniq.numel()
+    assert torch.equal(seg.seg_rows[:n_seg].cpu().long(), uniq)
+    assert torch.equal(seg.seg_offsets[: n_seg + 1].cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]))
+    # stable: references of one row stay in reference order
+    refs = seg.refs.cpu().long()
+    assert torch.equal(idx.cpu().long()[refs], torch.sort(idx.cpu().long(), stable=True).values)
+    assert torch.equal(refs, torch.sort(idx.cpu().long(), stable=True).indices)
+    g1 = nat.neg_pertriple_grad_segments(desc, q, table, N, go, seg)
+    g2 = nat.neg_pertriple_grad_segments(desc, q, table, N, go, nat.SegmentIndex(idx, M))
+    assert torch.equal(g1[:n_seg], g2[:n_seg])
+    want = torch.zeros(M, W, dtype=torch.float64).index_add_(0, idx.cpu().long(), dn.cpu().double())
+    close(g1[:n_seg], want[uniq].float(), rtol=1e-4, atol=1e-5, scale=2e-6)
+    t2 = table.clone()
+    nat.apply_segments_sgd(t2, seg, g1, 0.5)
+    want_t = table.float().cpu() - 0.5 * want.float()
+    close(t2, want_t, rtol=2e-3 if dtype == torch.float16 else 1e-5, atol=2e-3 if dtype == torch.float16 else 1e-5)
