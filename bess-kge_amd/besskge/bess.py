@@ -600,8 +600,6 @@ class EmbeddingMovingBessKGE(BessKGE):
         # K9 + K10 for per-triple negatives of the own shard.  Every other gradient
         # has been computed from the pre-update tables by now.
         main.wait_stream(side)
-        for table in {id(t): t for t, _, _ in deferred}.values():
-            table.record_stream(main)
         if len(deferred) == 1:
             table, g, go = deferred[0]
             nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go, seg_index[id(g)], fused_sgd_lr=lr)

@@ -1,0 +1,43 @@
+"""bench.py keeps the driver's contract: one JSON line with the agreed keys, at
+N = 1 and (rehearsed with gloo, two ranks sharing the GPU) at N = 2."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def run(cmd, env=None):
+    res = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode", ["score", "train"])
+def test_bench_single_gpu(mode):
+    d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--mode", mode])
+    assert KEYS <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
+    assert d["unit"] == "triples/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1.5
+    assert "workload" in d["config"]
+
+
+def test_bench_two_ranks_rehearsal():
+    env = dict(os.environ, BESS_BENCH_BACKEND="gloo")
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+             "127.0.0.1", "--master-port", "29577", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], env)
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0
+    assert "ScoreMoving" in d["config"]["workload"]
