@@ -61,6 +61,23 @@ class LossDesc(ctypes.Structure):
     ]
 
 
+class OptDesc(ctypes.Structure):
+    """struct bess_opt_desc"""
+
+    _fields_ = [
+        ("kind", _i32),
+        ("step", _i32),
+        ("lr", _f32),
+        ("momentum", _f32),
+        ("beta1", _f32),
+        ("beta2", _f32),
+        ("eps", _f32),
+        ("weight_decay", _f32),
+    ]
+
+
+OPT_SGD, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
+
 _MD = ctypes.POINTER(ModelDesc)
 _LD = ctypes.POINTER(LossDesc)
 
@@ -86,6 +103,8 @@ SIGNATURES = {
     "bess_build_segment_index": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "bess_neg_pertriple_grad_segments": [_MD, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _vp],
     "bess_apply_segments_sgd": [_i32, _i32, _vp, _vp, _vp, _i64, _vp, _f32, _vp],
+    "bess_segment_sum_rows": [_i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    "bess_apply_segments_opt": [ctypes.POINTER(OptDesc), _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
 }
 
 _lib: Optional[ctypes.CDLL] = None
@@ -608,3 +627,39 @@ def apply_segments_sgd(table: torch.Tensor, seg: SegmentIndex, grad_seg: torch.T
         rc = load().bess_apply_segments_sgd(_dtype_code(table), W, table.data_ptr(), seg.seg_rows.data_ptr(),
                                             seg.n_seg.data_ptr(), seg.max_seg, grad_seg.data_ptr(), lr, _stream(dev))
     _check(rc, "bess_apply_segments_sgd")
+
+
+def segment_sum_rows(src: torch.Tensor, seg: SegmentIndex) -> torch.Tensor:
+    """grad_seg [seg.max_seg, W]: rows of `src` [n_refs, W] summed per destination row."""
+    dev = _same_device([("src", src), ("refs", seg.refs)])
+    _f32(src, "src")
+    if src.dim() != 2 or src.shape[0] != seg.n_refs:
+        raise ValueError("segment_sum_rows: src must be [n_refs, W]")
+    W = int(src.shape[1])
+    out = torch.empty((seg.max_seg, W), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().bess_segment_sum_rows(W, src.data_ptr(), seg.refs.data_ptr(), seg.seg_offsets.data_ptr(),
+                                          seg.n_seg.data_ptr(), seg.max_seg, out.data_ptr(), _stream(dev))
+    _check(rc, "bess_segment_sum_rows")
+    return out
+
+
+def apply_segments_opt(o: OptDesc, table: torch.Tensor, seg: SegmentIndex, grad_seg: torch.Tensor,
+                       state1: Optional[torch.Tensor], state2: Optional[torch.Tensor]) -> None:
+    dev = _same_device([("table", table), ("grad_seg", grad_seg), ("state1", state1), ("state2", state2)])
+    W = int(table.shape[1])
+    _rows(table, "table", W)
+    _f32(grad_seg, "grad_seg")
+    if tuple(grad_seg.shape) != (seg.max_seg, W):
+        raise ValueError("apply_segments_opt: grad_seg shape mismatch")
+    for st, nm in ((state1, "state1"), (state2, "state2")):
+        if st is not None:
+            _f32(st, nm)
+            if tuple(st.shape) != tuple(table.shape):
+                raise ValueError(f"apply_segments_opt: {nm} must have the shape of the table")
+    with torch.cuda.device(dev):
+        rc = load().bess_apply_segments_opt(ctypes.byref(o), _dtype_code(table), W, table.data_ptr(),
+                                            seg.seg_rows.data_ptr(), seg.n_seg.data_ptr(), seg.max_seg,
+                                            grad_seg.data_ptr(), state1.data_ptr() if state1 is not None else 0,
+                                            state2.data_ptr() if state2 is not None else 0, _stream(dev))
+    _check(rc, "bess_apply_segments_opt")

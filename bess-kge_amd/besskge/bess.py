@@ -508,8 +508,43 @@ class EmbeddingMovingBessKGE(BessKGE):
             raise ValueError(f"corruption scheme {scheme!r} not supported")
 
     # ---------------------------------------------------------------- training
-    def train_step_replicas(self, batches: List[_Batch], lr: float) -> List[Dict[str, Any]]:
-        """Forward + backward + sparse SGD update of every local replica.
+    def _opt_state(self, table: torch.Tensor, n_state: int) -> Dict[str, Any]:
+        """Lazily allocated per-row optimiser state of one table."""
+        if not hasattr(self, "_optimizer_state"):
+            self._optimizer_state: Dict[int, Dict[str, Any]] = {}
+        st = self._optimizer_state.setdefault(table.data_ptr(), dict(step=0, s=[]))
+        while len(st["s"]) < n_state:
+            st["s"].append(torch.zeros(table.shape, dtype=torch.float32, device=table.device))
+        return st
+
+    def _apply_optimizer(self, opt: Any, table: torch.Tensor, contributions: List[Tuple[torch.Tensor, torch.Tensor]]
+                         ) -> None:
+        """General K9 + K10: coalesce (row, gradient row) lists per unique row, then
+        one optimiser update per row.  `contributions` all index `table`."""
+        idx = torch.cat([i.reshape(-1) for i, _ in contributions]).contiguous()
+        grad = torch.cat([g for _, g in contributions], dim=0).contiguous()
+        seg = nat.SegmentIndex(idx, table.shape[0])
+        gseg = nat.segment_sum_rows(grad, seg)
+        if opt.kind == nat.OPT_SGD:
+            n_state = 1 if opt.momentum != 0.0 else 0
+        else:
+            n_state = 1 if opt.kind == nat.OPT_ADAGRAD else 2
+        state = self._opt_state(table, n_state)
+        state["step"] += 1
+        o = nat.OptDesc()
+        o.kind, o.step, o.lr = opt.kind, state["step"], float(opt.lr)
+        o.momentum = float(getattr(opt, "momentum", 0.0))
+        o.beta1, o.beta2 = float(getattr(opt, "beta1", 0.9)), float(getattr(opt, "beta2", 0.999))
+        o.eps = float(getattr(opt, "eps", 0.0))
+        o.weight_decay = float(getattr(opt, "weight_decay", 0.0))
+        s = state["s"]
+        nat.apply_segments_opt(o, table, seg, gseg, s[0] if n_state > 0 else None, s[1] if n_state > 1 else None)
+
+    def train_step_replicas(self, batches: List[_Batch], optimizer: Any) -> List[Dict[str, Any]]:
+        """Forward + backward + sparse optimiser update of every local replica.
+
+        `optimizer`: a learning rate (plain SGD) or one of
+        `besskge.runtime.{SGD, Adagrad, Adam}`.
 
         Backward of the reference's autograd graph (`bess.py:322-468`) written
         out: K8' -> K4'/K5' -> K6' -> K3' give the gradient of every gathered
@@ -518,6 +553,8 @@ class EmbeddingMovingBessKGE(BessKGE):
         """
         if self.loss_fn is None:
             raise RuntimeError("train_step needs a loss function")
+        plain = not hasattr(optimizer, "kind") or optimizer.is_plain_sgd
+        lr = float(optimizer.lr) if hasattr(optimizer, "lr") else float(optimizer)
         group = self._group()
         fn = self.score_fn
         n = group.n_shard
@@ -597,29 +634,47 @@ class EmbeddingMovingBessKGE(BessKGE):
                 upd.append((st.send_idx.reshape(-1), g.reshape(-1, W)))
         # K9 + K10: sparse SGD on the shard (gradients were all computed from
         # the pre-update tables above)
-        # K9 + K10 for per-triple negatives of the own shard.  Every other gradient
-        # has been computed from the pre-update tables by now.
+        # K9 + K10.  Every gradient has been computed from the pre-update tables by now.
         main.wait_stream(side)
-        if len(deferred) == 1:
-            table, g, go = deferred[0]
-            nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go, seg_index[id(g)], fused_sgd_lr=lr)
+        if plain:
+            # per-triple negatives of the own shard: segmented reduction, fused SGD
+            if len(deferred) == 1:
+                table, g, go = deferred[0]
+                nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go, seg_index[id(g)],
+                                                fused_sgd_lr=lr)
+            else:
+                grads = [nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go, seg_index[id(g)])
+                         for table, g, go in deferred]
+                for (table, g, _), gseg in zip(deferred, grads):
+                    nat.apply_segments_sgd(table, seg_index[id(g)], gseg, lr)
+            # everything else: sparse atomic SGD on the shard (duplicates accumulate)
+            for st, upd in zip(steps, local_updates):
+                for idx, g in upd:
+                    nat.sparse_sgd(st.table, idx.contiguous(), g.contiguous(), lr)
         else:
-            grads = [nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go, seg_index[id(g)])
-                     for table, g, go in deferred]
-            for (table, g, _), gseg in zip(deferred, grads):
-                nat.apply_segments_sgd(table, seg_index[id(g)], gseg, lr)
-        for st, upd in zip(steps, local_updates):
-            for idx, g in upd:
-                nat.sparse_sgd(st.table, idx.contiguous(), g.contiguous(), lr)
+            # non-linear optimisers need the *summed* gradient of every row first
+            for st, upd in zip(steps, local_updates):
+                contrib = list(upd)
+                for table, g, go in deferred:
+                    if table is st.table:
+                        seg = seg_index[id(g)]
+                        gseg = nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go, seg)
+                        n_rows = int(seg.n_seg.item())  # one host sync per step on this path
+                        contrib.append((seg.seg_rows[:n_rows], gseg[:n_rows]))
+                self._apply_optimizer(optimizer, st.table, contrib)
         # C9: replicated relation table
         # (single process: d_rel already holds the sum over the local replicas)
         (d_rel,) = group.all_reduce_sum([d_rel]) if len(group.local_shards) == 1 else (d_rel,)
-        nat.dense_sgd(rel_table, d_rel, lr)
+        if plain:
+            nat.dense_sgd(rel_table, d_rel, lr)
+        else:
+            all_rows = torch.arange(rel_table.shape[0], dtype=torch.int32, device=rel_table.device)
+            self._apply_optimizer(optimizer, rel_table, [(all_rows, d_rel)])
         return results
 
-    def train_step(self, lr: float, **batch: torch.Tensor) -> Dict[str, Any]:
+    def train_step(self, optimizer: Any, **batch: torch.Tensor) -> Dict[str, Any]:
         """Single-replica convenience wrapper of :meth:`train_step_replicas`."""
-        return self.train_step_replicas([batch], lr)[0]
+        return self.train_step_replicas([batch], optimizer)[0]
 
 
 class ScoreMovingBessKGE(BessKGE):

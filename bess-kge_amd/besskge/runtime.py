@@ -49,13 +49,53 @@ class Options:
 
 @dataclasses.dataclass
 class SGD:
-    """Plain SGD; applied sparsely to the rows a step touched."""
+    """SGD (optionally with momentum / weight decay), applied sparsely to the
+    rows a step touched.  Plain SGD (momentum = weight_decay = 0) takes the
+    atomic / fused fast paths; otherwise contributions are first coalesced per
+    unique row (K9) and the update is "lazy": untouched rows and their momentum
+    buffers do not move."""
 
     lr: float = 0.01
+    momentum: float = 0.0
+    weight_decay: float = 0.0
     #: how replicated-parameter gradients are combined over replicas ("sum" is
     #: d(sum of replica losses); PopTorch's choice is not visible in the
     #: reference repo -> parity unpinned, see DESIGN.md)
     replica_reduction: str = "sum"
+
+    kind = 0  # BESS_OPT_SGD
+
+    @property
+    def is_plain_sgd(self) -> bool:
+        return self.momentum == 0.0 and self.weight_decay == 0.0
+
+
+@dataclasses.dataclass
+class Adagrad:
+    """Row-sparse Adagrad (semantics of torch.optim.Adagrad on sparse gradients)."""
+
+    lr: float = 0.01
+    eps: float = 1e-10
+    weight_decay: float = 0.0
+    replica_reduction: str = "sum"
+    kind = 1  # BESS_OPT_ADAGRAD
+    is_plain_sgd = False
+
+
+@dataclasses.dataclass
+class Adam:
+    """Lazy Adam (torch.optim.SparseAdam semantics: moments of untouched rows are
+    not decayed); `weight_decay` is decoupled (AdamW, as the notebooks' poptorch
+    AdamW) and also applied to touched rows only."""
+
+    lr: float = 0.001
+    beta1: float = 0.9
+    beta2: float = 0.999
+    eps: float = 1e-8
+    weight_decay: float = 0.0
+    replica_reduction: str = "sum"
+    kind = 2  # BESS_OPT_ADAM
+    is_plain_sgd = False
 
 
 def place_shards(model: BessKGE, group: ReplicaGroup, device: torch.device,
@@ -84,7 +124,7 @@ class Runner:
     """Callable that steps a :class:`BessKGE` module like a PopTorch model."""
 
     def __init__(self, model: BessKGE, options: Optional[Options], group: Optional[ReplicaGroup],
-                 device: Optional[torch.device], optimizer: Optional[SGD],
+                 device: Optional[torch.device], optimizer: Optional[Any],
                  dtype: Optional[torch.dtype] = None) -> None:
         self.model = model
         self.options = options or Options()
@@ -138,7 +178,7 @@ class Runner:
             with torch.cuda.stream(streams[it % len(streams)]):
                 reps = self._split(batch, it)
                 if self.optimizer is not None:
-                    res = self.model.train_step_replicas(reps, self.optimizer.lr)  # type: ignore
+                    res = self.model.train_step_replicas(reps, self.optimizer)  # type: ignore
                 else:
                     with torch.no_grad():
                         res = self.model.forward_replicas(reps)
@@ -169,7 +209,7 @@ def inference_model(model: BessKGE, options: Optional[Options] = None, group: Op
     return Runner(model, options, group, device, None, dtype)
 
 
-def training_model(model: BessKGE, options: Optional[Options] = None, optimizer: Optional[SGD] = None,
+def training_model(model: BessKGE, options: Optional[Options] = None, optimizer: Optional[Any] = None,
                    group: Optional[ReplicaGroup] = None, device: Optional[torch.device] = None,
                    dtype: Optional[torch.dtype] = None) -> Runner:
     """`poptorch.trainingModel` analogue (forward + backward + sparse update per call)."""

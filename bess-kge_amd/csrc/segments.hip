@@ -172,6 +172,76 @@ __global__ __launch_bounds__(256) void k_apply_segments(T* __restrict__ table, i
     }
 }
 
+// out[s, :] = sum over the references r of segment s of src[refs[r], :]   (generic K9:
+// any list of (row, gradient row) contributions, e.g. heads + tails + shared negatives)
+__global__ __launch_bounds__(256) void k_segment_sum_rows(const float* __restrict__ src, int W,
+                                                          const int32_t* __restrict__ refs,
+                                                          const int32_t* __restrict__ seg_offsets,
+                                                          const int32_t* __restrict__ n_seg,
+                                                          float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (blockIdx.x * 256ll + threadIdx.x) >> 6;
+    const int64_t n_wave = (gridDim.x * 256ll) >> 6;
+    const int ns = *n_seg;
+    for (int64_t s = wave0; s < ns; s += n_wave) {
+        const int r0 = seg_offsets[s], r1 = seg_offsets[s + 1];
+        for (int c = lane; c < W; c += 64) {
+            float acc = 0.f;
+            for (int r = r0; r < r1; ++r) acc += src[static_cast<int64_t>(refs[r]) * W + c];
+            out[s * W + c] = acc;
+        }
+    }
+}
+
+// Row-sparse optimisers on the unique rows of a step ("lazy" semantics: state of
+// untouched rows is left alone, like torch.optim.SparseAdam / Adagrad on sparse
+// gradients).  state1/state2 are f32 [M, W] (momentum | sum of squares | exp_avg, exp_avg_sq).
+struct OptArgs {
+    int kind;
+    float lr, momentum, beta1, beta2, eps, weight_decay;
+    float bias1, bias2;  // 1 - beta^t for Adam
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_apply_segments_opt(OptArgs o, T* __restrict__ table, int W,
+                                                            const int32_t* __restrict__ seg_rows,
+                                                            const int32_t* __restrict__ n_seg,
+                                                            const float* __restrict__ grad_seg,
+                                                            float* __restrict__ state1,
+                                                            float* __restrict__ state2) {
+    const int64_t total = static_cast<int64_t>(*n_seg) * W;
+    for (int64_t t = blockIdx.x * 256ll + threadIdx.x; t < total; t += 256ll * gridDim.x) {
+        const int64_t s = t / W;
+        const int c = static_cast<int>(t - s * W);
+        const int64_t at = static_cast<int64_t>(seg_rows[s]) * W + c;
+        float p = static_cast<float>(table[at]);
+        float g = grad_seg[t];
+        if (o.kind == BESS_OPT_SGD) {
+            g += o.weight_decay * p;
+            if (o.momentum != 0.f) {
+                const float b = o.momentum * state1[at] + g;
+                state1[at] = b;
+                g = b;
+            }
+            p -= o.lr * g;
+        } else if (o.kind == BESS_OPT_ADAGRAD) {
+            g += o.weight_decay * p;
+            const float ss = state1[at] + g * g;
+            state1[at] = ss;
+            p -= o.lr * g / (sqrtf(ss) + o.eps);
+        } else {  // BESS_OPT_ADAM (decoupled weight decay when weight_decay != 0: AdamW)
+            p -= o.lr * o.weight_decay * p;
+            const float m = o.beta1 * state1[at] + (1.f - o.beta1) * g;
+            const float v = o.beta2 * state2[at] + (1.f - o.beta2) * g * g;
+            state1[at] = m;
+            state2[at] = v;
+            const float step = o.lr * sqrtf(o.bias2) / o.bias1;
+            p -= step * m / (sqrtf(v) + o.eps);
+        }
+        table[at] = static_cast<T>(p);
+    }
+}
+
 template <typename T, int VEC, int IT>
 static void seg_by_red(int red, const SegArgs& a, float* grad_seg, void* table_rw, float lr, unsigned grid,
                        hipStream_t st) {
@@ -290,4 +360,43 @@ extern "C" int bess_apply_segments_sgd(int32_t dtype, int32_t width, void* table
         k_apply_segments<half_t><<<grid, 256, 0, as_stream(stream)>>>(static_cast<half_t*>(table), width, seg_rows,
                                                                       n_seg, grad_seg, lr);
     return check_launch("apply_segments_sgd");
+}
+
+extern "C" int bess_segment_sum_rows(int32_t width, const float* src, const int32_t* refs_sorted,
+                                     const int32_t* seg_offsets, const int32_t* n_seg, int64_t max_seg,
+                                     float* grad_seg, void* stream) {
+    BESS_REQUIRE(width > 0 && max_seg > 0, "segment_sum_rows: bad sizes");
+    BESS_REQUIRE(src && refs_sorted && seg_offsets && n_seg && grad_seg, "segment_sum_rows: NULL pointer");
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(max_seg, 4), 256 * 16));
+    k_segment_sum_rows<<<grid, 256, 0, as_stream(stream)>>>(src, width, refs_sorted, seg_offsets, n_seg, grad_seg);
+    return check_launch("segment_sum_rows");
+}
+
+extern "C" int bess_apply_segments_opt(const bess_opt_desc* o, int32_t dtype, int32_t width, void* table,
+                                       const int32_t* seg_rows, const int32_t* n_seg, int64_t max_seg,
+                                       const float* grad_seg, float* state1, float* state2, void* stream) {
+    BESS_REQUIRE(o, "apply_segments_opt: NULL descriptor");
+    BESS_REQUIRE(o->kind >= BESS_OPT_SGD && o->kind <= BESS_OPT_ADAM, "apply_segments_opt: unknown optimiser %d", o->kind);
+    BESS_REQUIRE(dtype == BESS_F32 || dtype == BESS_F16, "apply_segments_opt: unknown dtype %d", dtype);
+    BESS_REQUIRE(width > 0 && max_seg > 0, "apply_segments_opt: bad sizes");
+    BESS_REQUIRE(table && seg_rows && n_seg && grad_seg, "apply_segments_opt: NULL pointer");
+    if (o->kind == BESS_OPT_SGD && o->momentum != 0.f) BESS_REQUIRE(state1, "SGD with momentum needs state1");
+    if (o->kind == BESS_OPT_ADAGRAD) BESS_REQUIRE(state1, "Adagrad needs state1");
+    if (o->kind == BESS_OPT_ADAM) {
+        BESS_REQUIRE(state1 && state2, "Adam needs state1 and state2");
+        BESS_REQUIRE(o->step >= 1, "Adam needs step >= 1");
+    }
+    OptArgs a{o->kind, o->lr, o->momentum, o->beta1, o->beta2, o->eps, o->weight_decay, 1.f, 1.f};
+    if (o->kind == BESS_OPT_ADAM) {
+        a.bias1 = 1.f - powf(o->beta1, static_cast<float>(o->step));
+        a.bias2 = 1.f - powf(o->beta2, static_cast<float>(o->step));
+    }
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(max_seg * width, 256), 256 * 16));
+    if (dtype == BESS_F32)
+        k_apply_segments_opt<float><<<grid, 256, 0, as_stream(stream)>>>(a, static_cast<float*>(table), width,
+                                                                         seg_rows, n_seg, grad_seg, state1, state2);
+    else
+        k_apply_segments_opt<half_t><<<grid, 256, 0, as_stream(stream)>>>(a, static_cast<half_t*>(table), width,
+                                                                          seg_rows, n_seg, grad_seg, state1, state2);
+    return check_launch("apply_segments_opt");
 }

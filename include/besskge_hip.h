@@ -74,6 +74,22 @@ typedef struct bess_model_desc {
     int32_t reserved[3];
 } bess_model_desc;
 
+/* row-sparse optimisers (K10) */
+#define BESS_OPT_SGD 0     /* + momentum, weight decay                    */
+#define BESS_OPT_ADAGRAD 1
+#define BESS_OPT_ADAM 2    /* lazy Adam; decoupled weight decay = AdamW   */
+
+typedef struct bess_opt_desc {
+    int32_t kind; /* BESS_OPT_* */
+    int32_t step; /* 1-based step count (Adam bias correction) */
+    float lr;
+    float momentum;
+    float beta1;
+    float beta2;
+    float eps;
+    float weight_decay;
+} bess_opt_desc;
+
 typedef struct bess_loss_desc {
     int32_t kind;        /* BESS_LOSS_*                                    */
     int32_t adversarial; /* self-adversarial negative weights (loss.py:39) */
@@ -235,6 +251,23 @@ int bess_apply_segments_sgd(int32_t dtype, int32_t width, void* table,
                             const int32_t* seg_rows, const int32_t* n_seg,
                             int64_t max_seg, const float* grad_seg, float lr,
                             void* stream);
+
+/* generic K9: grad_seg[s, :] = sum of src[refs_sorted[r], :] over the references r
+ * of segment s - coalesces any list of (row, gradient row) contributions
+ * (heads + tails + shared negatives ...) indexed by bess_build_segment_index. */
+int bess_segment_sum_rows(int32_t width, const float* src, const int32_t* refs_sorted,
+                          const int32_t* seg_offsets, const int32_t* n_seg,
+                          int64_t max_seg, float* grad_seg, void* stream);
+
+/* K10 on unique rows with per-row state (f32 [M, W]): SGD(+momentum, weight
+ * decay), Adagrad, Adam / AdamW with "lazy" semantics - only rows touched by
+ * the step move (torch.optim.SparseAdam / sparse Adagrad); replaces the dense
+ * poptorch.optim step of the notebooks, which cannot be afforded on a shard of
+ * tens of GB.  state1 / state2 may be NULL when the optimiser has no such state. */
+int bess_apply_segments_opt(const bess_opt_desc* o, int32_t dtype, int32_t width,
+                            void* table, const int32_t* seg_rows, const int32_t* n_seg,
+                            int64_t max_seg, const float* grad_seg, float* state1,
+                            float* state2, void* stream);
 
 /* dense axpy on a replicated table: table -= lr * grad (relation table) */
 int bess_dense_sgd(int32_t dtype, void* table, const float* grad, int64_t n_elem,
