@@ -328,18 +328,120 @@ class BessKGE(torch.nn.Module, ABC):
                 out["metrics"] = self.evaluation.stacked_metrics_from_ranks(ranks, tm)
         return out, d_pos, d_neg
 
+    # ------------------------------------------------------- optimiser step
+    def _opt_state(self, table: torch.Tensor, n_state: int) -> Dict[str, Any]:
+        """Lazily allocated per-row optimiser state of one table."""
+        if not hasattr(self, "_optimizer_state"):
+            self._optimizer_state: Dict[int, Dict[str, Any]] = {}
+        st = self._optimizer_state.setdefault(table.data_ptr(), dict(step=0, s=[]))
+        while len(st["s"]) < n_state:
+            st["s"].append(torch.zeros(table.shape, dtype=torch.float32, device=table.device))
+        return st
+
+    def _apply_optimizer(self, opt: Any, table: torch.Tensor, contributions: List[Tuple[torch.Tensor, torch.Tensor]]
+                         ) -> None:
+        """General K9 + K10: coalesce (row, gradient row) lists per unique row, then
+        one optimiser update per row.  `contributions` all index `table`."""
+        idx = torch.cat([i.reshape(-1) for i, _ in contributions]).contiguous()
+        grad = torch.cat([g for _, g in contributions], dim=0).contiguous()
+        seg = nat.SegmentIndex(idx, table.shape[0])
+        gseg = nat.segment_sum_rows(grad, seg)
+        if opt.kind == nat.OPT_SGD:
+            n_state = 1 if opt.momentum != 0.0 else 0
+        else:
+            n_state = 1 if opt.kind == nat.OPT_ADAGRAD else 2
+        state = self._opt_state(table, n_state)
+        state["step"] += 1
+        o = nat.OptDesc()
+        o.kind, o.step, o.lr = opt.kind, state["step"], float(opt.lr)
+        o.momentum = float(getattr(opt, "momentum", 0.0))
+        o.beta1, o.beta2 = float(getattr(opt, "beta1", 0.9)), float(getattr(opt, "beta2", 0.999))
+        o.eps = float(getattr(opt, "eps", 0.0))
+        o.weight_decay = float(getattr(opt, "weight_decay", 0.0))
+        s = state["s"]
+        nat.apply_segments_opt(o, table, seg, gseg, s[0] if n_state > 0 else None, s[1] if n_state > 1 else None)
+
+    def _prefetch_segment_indices(self, steps: List[_ReplicaStep]) -> Dict[int, Any]:
+        """The inverted indices of per-triple negatives only depend on the sampled
+        indices: build them on a side stream while the forward kernels still run."""
+        seg_index: Dict[int, Any] = {}
+        dev = self.score_fn.relation_embedding.device
+        main = torch.cuda.current_stream(dev)
+        side = self._aux_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for st in steps:
+                for g in st.groups:
+                    if not g.shared and g.neg.base is st.table:
+                        seg_index[id(g)] = nat.SegmentIndex(g.neg.idx, st.table.shape[0])
+        return seg_index
+
+    def _apply_updates(self, steps: List[_ReplicaStep], local_updates: List[List[Tuple[torch.Tensor, torch.Tensor]]],
+                       deferred: List[Tuple[torch.Tensor, _NegGroup, torch.Tensor]], seg_index: Dict[int, Any],
+                       optimizer: Any, desc: nat.ModelDesc, d_rel: torch.Tensor) -> None:
+        """K9 + K10 on every hosted shard and C9 + update of the relation table."""
+        group = self._group()
+        rel_table = self.score_fn.relation_embedding.data
+        plain = not hasattr(optimizer, "kind") or optimizer.is_plain_sgd
+        lr = float(optimizer.lr) if hasattr(optimizer, "lr") else float(optimizer)
+        main = torch.cuda.current_stream(rel_table.device)
+        side = self._aux_stream(rel_table.device)
+        # K9 + K10.  Every gradient has been computed from the pre-update tables by now.
+        main.wait_stream(side)
+        if plain:
+            # per-triple negatives of the own shard: segmented reduction.  A shard with a
+            # single such group gets the SGD step fused into the reduction; with two
+            # ("ht") all row gradients are formed before the first row is changed.
+            per_table: Dict[int, List[Tuple[torch.Tensor, _NegGroup, torch.Tensor]]] = {}
+            for item in deferred:
+                per_table.setdefault(item[0].data_ptr(), []).append(item)
+            for items in per_table.values():
+                if len(items) == 1:
+                    table, g, go = items[0]
+                    nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go, seg_index[id(g)],
+                                                    fused_sgd_lr=lr)
+                else:
+                    grads = [nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go,
+                                                             seg_index[id(g)]) for table, g, go in items]
+                    for (table, g, _), gseg in zip(items, grads):
+                        nat.apply_segments_sgd(table, seg_index[id(g)], gseg, lr)
+            # everything else: sparse atomic SGD on the shard (duplicates accumulate)
+            for st, upd in zip(steps, local_updates):
+                for idx, g in upd:
+                    nat.sparse_sgd(st.table, idx.contiguous(), g.contiguous(), lr)
+        else:
+            # non-linear optimisers need the *summed* gradient of every row first
+            for st, upd in zip(steps, local_updates):
+                contrib = list(upd)
+                for table, g, go in deferred:
+                    if table is st.table:
+                        seg = seg_index[id(g)]
+                        gseg = nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go, seg)
+                        n_rows = int(seg.n_seg.item())  # one host sync per step on this path
+                        contrib.append((seg.seg_rows[:n_rows], gseg[:n_rows]))
+                self._apply_optimizer(optimizer, st.table, contrib)
+        # C9: replicated relation table
+        # (single process: d_rel already holds the sum over the local replicas)
+        (d_rel,) = group.all_reduce_sum([d_rel]) if len(group.local_shards) == 1 else (d_rel,)
+        if plain:
+            nat.dense_sgd(rel_table, d_rel, lr)
+        else:
+            all_rows = torch.arange(rel_table.shape[0], dtype=torch.int32, device=rel_table.device)
+            self._apply_optimizer(optimizer, rel_table, [(all_rows, d_rel)])
+
+
     # ------------------------------------------------------ group execution
-    def _run_groups(self, st: _ReplicaStep, desc: nat.ModelDesc) -> List[torch.Tensor]:
+    def _run_groups_one(self, g: _NegGroup, desc: nat.ModelDesc) -> torch.Tensor:
         rel = self.score_fn.relation_embedding.data
-        outs = []
-        for g in st.groups:
-            g.query = nat.query_fwd(desc, g.side, g.ent, rel, g.rel_idx)
-            if g.shared:
-                g.out = nat.neg_score_shared_fwd(desc, g.query, g.neg)
-            else:
-                g.out = nat.neg_score_pertriple_fwd(desc, g.query, g.neg, g.n_per_query)
-            outs.append(g.out)
-        return outs
+        g.query = nat.query_fwd(desc, g.side, g.ent, rel, g.rel_idx)
+        if g.shared:
+            g.out = nat.neg_score_shared_fwd(desc, g.query, g.neg)
+        else:
+            g.out = nat.neg_score_pertriple_fwd(desc, g.query, g.neg, g.n_per_query)
+        return g.out
+
+    def _run_groups(self, st: _ReplicaStep, desc: nat.ModelDesc) -> List[torch.Tensor]:
+        return [self._run_groups_one(g, desc) for g in st.groups]
 
 
 class EmbeddingMovingBessKGE(BessKGE):
@@ -508,38 +610,6 @@ class EmbeddingMovingBessKGE(BessKGE):
             raise ValueError(f"corruption scheme {scheme!r} not supported")
 
     # ---------------------------------------------------------------- training
-    def _opt_state(self, table: torch.Tensor, n_state: int) -> Dict[str, Any]:
-        """Lazily allocated per-row optimiser state of one table."""
-        if not hasattr(self, "_optimizer_state"):
-            self._optimizer_state: Dict[int, Dict[str, Any]] = {}
-        st = self._optimizer_state.setdefault(table.data_ptr(), dict(step=0, s=[]))
-        while len(st["s"]) < n_state:
-            st["s"].append(torch.zeros(table.shape, dtype=torch.float32, device=table.device))
-        return st
-
-    def _apply_optimizer(self, opt: Any, table: torch.Tensor, contributions: List[Tuple[torch.Tensor, torch.Tensor]]
-                         ) -> None:
-        """General K9 + K10: coalesce (row, gradient row) lists per unique row, then
-        one optimiser update per row.  `contributions` all index `table`."""
-        idx = torch.cat([i.reshape(-1) for i, _ in contributions]).contiguous()
-        grad = torch.cat([g for _, g in contributions], dim=0).contiguous()
-        seg = nat.SegmentIndex(idx, table.shape[0])
-        gseg = nat.segment_sum_rows(grad, seg)
-        if opt.kind == nat.OPT_SGD:
-            n_state = 1 if opt.momentum != 0.0 else 0
-        else:
-            n_state = 1 if opt.kind == nat.OPT_ADAGRAD else 2
-        state = self._opt_state(table, n_state)
-        state["step"] += 1
-        o = nat.OptDesc()
-        o.kind, o.step, o.lr = opt.kind, state["step"], float(opt.lr)
-        o.momentum = float(getattr(opt, "momentum", 0.0))
-        o.beta1, o.beta2 = float(getattr(opt, "beta1", 0.9)), float(getattr(opt, "beta2", 0.999))
-        o.eps = float(getattr(opt, "eps", 0.0))
-        o.weight_decay = float(getattr(opt, "weight_decay", 0.0))
-        s = state["s"]
-        nat.apply_segments_opt(o, table, seg, gseg, s[0] if n_state > 0 else None, s[1] if n_state > 1 else None)
-
     def train_step_replicas(self, batches: List[_Batch], optimizer: Any) -> List[Dict[str, Any]]:
         """Forward + backward + sparse optimiser update of every local replica.
 
@@ -567,17 +637,7 @@ class EmbeddingMovingBessKGE(BessKGE):
         back: List[torch.Tensor] = []
         deferred: List[Tuple[torch.Tensor, _NegGroup, torch.Tensor]] = []
         local_updates: List[List[Tuple[torch.Tensor, torch.Tensor]]] = []
-        # The inverted indices only depend on the sampled indices: build them on a
-        # side stream while the forward kernels are still running.
-        seg_index: Dict[int, Any] = {}
-        main = torch.cuda.current_stream(rel_table.device)
-        side = self._aux_stream(rel_table.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            for st in steps:
-                for g in st.groups:
-                    if not g.shared and g.neg.base is st.table:
-                        seg_index[id(g)] = nat.SegmentIndex(g.neg.idx, st.table.shape[0])
+        seg_index = self._prefetch_segment_indices(steps)
         for st, b in zip(steps, batches):
             out, d_pos, d_neg = self._finish(st, b, want_grad=True)
             results.append(out)
@@ -632,44 +692,7 @@ class EmbeddingMovingBessKGE(BessKGE):
             returned = group.all_to_all(back)  # C8
             for st, upd, g in zip(steps, local_updates, returned):
                 upd.append((st.send_idx.reshape(-1), g.reshape(-1, W)))
-        # K9 + K10: sparse SGD on the shard (gradients were all computed from
-        # the pre-update tables above)
-        # K9 + K10.  Every gradient has been computed from the pre-update tables by now.
-        main.wait_stream(side)
-        if plain:
-            # per-triple negatives of the own shard: segmented reduction, fused SGD
-            if len(deferred) == 1:
-                table, g, go = deferred[0]
-                nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go, seg_index[id(g)],
-                                                fused_sgd_lr=lr)
-            else:
-                grads = [nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go, seg_index[id(g)])
-                         for table, g, go in deferred]
-                for (table, g, _), gseg in zip(deferred, grads):
-                    nat.apply_segments_sgd(table, seg_index[id(g)], gseg, lr)
-            # everything else: sparse atomic SGD on the shard (duplicates accumulate)
-            for st, upd in zip(steps, local_updates):
-                for idx, g in upd:
-                    nat.sparse_sgd(st.table, idx.contiguous(), g.contiguous(), lr)
-        else:
-            # non-linear optimisers need the *summed* gradient of every row first
-            for st, upd in zip(steps, local_updates):
-                contrib = list(upd)
-                for table, g, go in deferred:
-                    if table is st.table:
-                        seg = seg_index[id(g)]
-                        gseg = nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go, seg)
-                        n_rows = int(seg.n_seg.item())  # one host sync per step on this path
-                        contrib.append((seg.seg_rows[:n_rows], gseg[:n_rows]))
-                self._apply_optimizer(optimizer, st.table, contrib)
-        # C9: replicated relation table
-        # (single process: d_rel already holds the sum over the local replicas)
-        (d_rel,) = group.all_reduce_sum([d_rel]) if len(group.local_shards) == 1 else (d_rel,)
-        if plain:
-            nat.dense_sgd(rel_table, d_rel, lr)
-        else:
-            all_rows = torch.arange(rel_table.shape[0], dtype=torch.int32, device=rel_table.device)
-            self._apply_optimizer(optimizer, rel_table, [(all_rows, d_rel)])
+        self._apply_updates(steps, local_updates, deferred, seg_index, optimizer, desc, d_rel)
         return results
 
     def train_step(self, optimizer: Any, **batch: torch.Tensor) -> Dict[str, Any]:
@@ -708,6 +731,8 @@ class ScoreMovingBessKGE(BessKGE):
             if isinstance(ns, TripleBasedShardedNegativeSampler) and ns.flat_negative_format:
                 neg = neg[0:1]  # replicated along dim 0; one copy is enough (bess.py:511-517)
             st.local_neg = neg  # type: ignore
+            st.local_tail = tail
+            st.sm_head = head  # type: ignore[attr-defined]
             # rows of my shard that other replicas need
             tail_rows = nat.gather_rows(st.table, tail.reshape(-1)).reshape(n, st.ppp, W)
             tails_out.append(tail_rows)
@@ -728,12 +753,14 @@ class ScoreMovingBessKGE(BessKGE):
         for r, st in enumerate(steps):
             dev = st.table.device
             ppp, cut = st.ppp, st.ppp // 2
-            neg = st.local_neg  # type: ignore  # [n | 1, B, K]
+            neg = st.local_neg  # [n | 1, B, K]
             nB, B, K = (int(x) for x in neg.shape)
             relr = rel_all[r]
 
-            def queries(side: int, ent_all: torch.Tensor, transpose: bool, rel_sel: torch.Tensor) -> torch.Tensor:
-                """Query matrix [n * Sg, W] in (processing replica, block, triple) order."""
+            def problem(side: int, ent_all: torch.Tensor, transpose: bool, rel_sel: torch.Tensor,
+                        rows2d: torch.Tensor) -> torch.Tensor:
+                """Score the gathered queries [n * Sg] (processing replica, block, triple order)
+                against rows of my shard; rows2d [Bg, K]."""
                 Sg = int(ent_all.shape[2])
                 rows = ent_all.reshape(-1, W)
                 idx = None
@@ -741,34 +768,31 @@ class ScoreMovingBessKGE(BessKGE):
                     idx = self._static_map(
                         ("smT", n, Sg),
                         lambda: torch.arange(n * n * Sg).reshape(n, n, Sg).transpose(0, 1).reshape(-1), dev)
-                return nat.query_fwd(desc, side, RowSource(rows, idx), rel_table, rel_sel.reshape(-1).contiguous())
-
-            def score(q: torch.Tensor, rows2d: torch.Tensor) -> torch.Tensor:
-                """rows2d [Bg, K] rows of my shard."""
+                rel_q = rel_sel.reshape(-1).contiguous()
+                lst = rows2d.reshape(-1).contiguous()
                 if sharing or rows2d.shape[0] == 1:
-                    return nat.neg_score_shared_fwd(desc, q, RowSource(st.table, rows2d.reshape(-1).contiguous()))
-                if rows2d.shape[0] != q.shape[0]:
-                    raise ValueError("per-triple negatives do not match the gathered queries")
-                return nat.neg_score_pertriple_fwd(desc, q, RowSource(st.table, rows2d.reshape(-1).contiguous()),
-                                                   int(rows2d.shape[1]))
+                    g = _NegGroup(side, None, RowSource(rows, idx), rel_q, RowSource(st.table, lst), True, int(lst.numel()))
+                else:
+                    if rows2d.shape[0] != rows.shape[0]:
+                        raise ValueError("per-triple negatives do not match the gathered queries")
+                    g = _NegGroup(side, None, RowSource(rows, idx), rel_q, RowSource(st.table, lst), False,
+                                  int(rows2d.shape[1]))
+                st.groups.append(g)
+                return self._run_groups_one(g, desc)
 
             if scheme == "h":
-                q = queries(nat.CORRUPT_HEAD, tq_all[r], True, relr)
-                sc = score(q, neg.reshape(nB * B, K))
+                sc = problem(nat.CORRUPT_HEAD, tq_all[r], True, relr, neg.reshape(nB * B, K))
             elif scheme == "t":
-                q = queries(nat.CORRUPT_TAIL, hq_all[r], False, relr)
-                sc = score(q, neg.reshape(nB * B, K))
+                sc = problem(nat.CORRUPT_TAIL, hq_all[r], False, relr, neg.reshape(nB * B, K))
             else:
-                qh = queries(nat.CORRUPT_HEAD, tq_all[r], True, relr[:, :, :cut])
-                qt = queries(nat.CORRUPT_TAIL, hq_all[r], False, relr[:, :, cut:])
                 if ns.flat_negative_format:
                     rows_h, rows_t = neg[:, 0], neg[:, 1]  # [n | 1, K]
                 else:
                     per = neg.reshape(n, n, ppp, K)
                     rows_h = per[:, :, :cut].reshape(-1, K)
                     rows_t = per[:, :, cut:].reshape(-1, K)
-                sh = score(qh, rows_h)
-                stl = score(qt, rows_t)
+                sh = problem(nat.CORRUPT_HEAD, tq_all[r], True, relr[:, :, :cut], rows_h)
+                stl = problem(nat.CORRUPT_TAIL, hq_all[r], False, relr[:, :, cut:], rows_t)
                 sc = torch.cat([sh.reshape(n, n, cut, -1), stl.reshape(n, n, ppp - cut, -1)], dim=2).reshape(
                     n * n * ppp, -1)
             scores_out.append(sc.reshape(n, n * ppp, -1).contiguous())
@@ -781,3 +805,86 @@ class ScoreMovingBessKGE(BessKGE):
             st.positive_score = nat.score_triple_fwd(
                 desc, RowSource(st.table, st.head_idx), st.tail, rel_table, st.rel_idx)
         return steps
+
+    # ---------------------------------------------------------------- training
+    def train_step_replicas(self, batches: List[_Batch], optimizer: Any) -> List[Dict[str, Any]]:
+        """Forward + backward + sparse optimiser update (ScoreMoving).
+
+        Backward of the reference graph `bess.py:490-603`: score gradients travel
+        back to the shards that produced them (all-to-all, transpose of C4); each
+        shard back-propagates into its own negative rows (local update, no
+        communication) and into the gathered queries, whose gradients are summed
+        over shards and returned to the owner (reduce-scatter = transpose of the
+        all-gather C3); positive tails return through an all-to-all (C5').
+        """
+        if self.loss_fn is None:
+            raise RuntimeError("train_step needs a loss function")
+        group = self._group()
+        n = group.n_shard
+        fn = self.score_fn
+        W = self.entity_embedding_size
+        scheme = self.negative_sampler.corruption_scheme
+        steps = self._score_replicas(batches)
+        desc = fn.kernel_desc()
+        rel_table = fn.relation_embedding.data
+        d_rel = torch.zeros(rel_table.shape, dtype=torch.float32, device=rel_table.device)
+        seg_index = self._prefetch_segment_indices(steps)
+        results, d_scores, d_tails = [], [], []
+        local_updates: List[List[Tuple[torch.Tensor, torch.Tensor]]] = []
+        for st, b in zip(steps, batches):
+            out, d_pos, d_neg = self._finish(st, b, want_grad=True)
+            results.append(out)
+            S = d_neg.shape[0]
+            d_scores.append(d_neg.reshape(S, n, -1).transpose(0, 1).contiguous())  # [n(shard), S, Nl]
+            dh, dt = nat.score_triple_bwd(desc, RowSource(st.table, st.head_idx), st.tail, rel_table,
+                                          st.rel_idx, d_pos, d_rel)
+            local_updates.append([(st.head_idx, dh)])
+            d_tails.append(dt.reshape(n, st.ppp, W))
+        d_sc_all = group.all_to_all(d_scores)  # gradients of the scores I computed: [n(j), S, Nl]
+        d_tail_back = group.all_to_all(d_tails)  # C5'
+        deferred: List[Tuple[torch.Tensor, _NegGroup, torch.Tensor]] = []
+        d_tq, d_hq = [], []
+        for st, dsc, dtb, upd in zip(steps, d_sc_all, d_tail_back, local_updates):
+            ppp, cut = st.ppp, st.ppp // 2
+            upd.append((st.local_tail.reshape(-1), dtb.reshape(-1, W)))
+            if len(st.groups) == 1:
+                d_outs = [dsc.reshape(n * n * ppp, -1)]
+            else:
+                d4 = dsc.reshape(n, n, ppp, -1)
+                d_outs = [d4[:, :, :cut].reshape(n * n * cut, -1).contiguous(),
+                          d4[:, :, cut:].reshape(n * n * (ppp - cut), -1).contiguous()]
+            for g, go in zip(st.groups, d_outs):
+                go = go.contiguous()
+                if g.shared:
+                    dq, dn = nat.neg_score_shared_bwd(desc, g.query, g.neg, g.out, go)
+                    upd.append((g.neg.idx, dn))
+                else:
+                    dq, _ = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go, want_d_neg=False)
+                    deferred.append((st.table, g, go))
+                dx = nat.query_bwd(desc, g.side, g.ent, rel_table, g.rel_idx, dq, d_rel)
+                if g.ent.idx is not None:  # undo the [t, j, p] -> [j, t, p] re-ordering
+                    buf = torch.empty_like(dx)
+                    buf[g.ent.idx.long()] = dx
+                    dx = buf
+                (d_tq if g.side == nat.CORRUPT_HEAD else d_hq).append(dx.reshape(n, -1, W))
+        # reduce-scatter (sum over shards) of the query gradients = all-to-all + local sum
+        def to_owner(parts: List[torch.Tensor]) -> List[torch.Tensor]:
+            return [x.sum(dim=0) for x in group.all_to_all(parts)] if parts else []
+
+        back_tq, back_hq = to_owner(d_tq), to_owner(d_hq)
+        for i, (st, upd) in enumerate(zip(steps, local_updates)):
+            cut = st.ppp // 2
+            head2d, tail2d = st.sm_head, st.local_tail  # type: ignore[attr-defined]
+            if scheme == "h":
+                upd.append((tail2d.reshape(-1), back_tq[i].reshape(-1, W)))
+            elif scheme == "t":
+                upd.append((st.head_idx, back_hq[i].reshape(-1, W)))
+            else:
+                upd.append((tail2d[:, :cut].reshape(-1).contiguous(), back_tq[i].reshape(-1, W)))
+                upd.append((head2d[:, cut:].reshape(-1).contiguous(), back_hq[i].reshape(-1, W)))
+        self._apply_updates(steps, local_updates, deferred, seg_index, optimizer, desc, d_rel)
+        return results
+
+    def train_step(self, optimizer: Any, **batch: torch.Tensor) -> Dict[str, Any]:
+        """Single-replica convenience wrapper of :meth:`train_step_replicas`."""
+        return self.train_step_replicas([batch], optimizer)[0]

@@ -136,8 +136,6 @@ class Runner:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
         self.optimizer = optimizer
-        if optimizer is not None and not isinstance(model, EmbeddingMovingBessKGE):
-            raise NotImplementedError("training is implemented for EmbeddingMovingBessKGE")
         place_shards(model, group, device, dtype)
 
     def _side_streams(self, n: int) -> List[torch.cuda.Stream]:

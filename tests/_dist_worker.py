@@ -60,7 +60,7 @@ def bess(out_dir: str) -> None:
         res = runner(**batch)
         for k, v in res.items():
             out[f"{case}_fwd_{k}"] = v.float().cpu().numpy()
-        if case.startswith("tr_EM"):
+        if case.startswith("tr_"):
             model = build_model(c, dev)
             lr = 0.125
             runner = runtime.training_model(model, runtime.Options(device_iterations=1), runtime.SGD(lr=lr), group=g, device=dev)

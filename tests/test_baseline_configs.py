@@ -84,7 +84,7 @@ def run_config(dev, scorer, p, d, dtype, n_shard, n_entity, n_rel, n_triple, sha
     want = kge.bess_step(spec, model, t0, r0, {k: batch[k][0] for k in keys}, lkw)
 
     lr = 0.05
-    if train and model == "EmbeddingMoving":
+    if train:
         runner = runtime.training_model(m, optimizer=runtime.SGD(lr=lr), device=dev, dtype=dtype)
     else:
         runner = runtime.inference_model(m, device=dev, dtype=dtype)
@@ -102,7 +102,7 @@ def run_config(dev, scorer, p, d, dtype, n_shard, n_entity, n_rel, n_triple, sha
         torch.testing.assert_close(neg[r], want["negative_score"][r].detach() + shift, rtol=out_tol["rtol"],
                                    atol=max(out_tol["atol"], scale))
         torch.testing.assert_close(res["loss"].cpu().reshape(n_shard)[r], want["loss"][r].detach(), rtol=2e-4, atol=1e-3)
-    if train and model == "EmbeddingMoving":
+    if train:
         torch.stack(want["loss"]).sum().backward()
         got_ent = m.score_fn.entity_embedding.detach().float().cpu()
         got_rel = m.score_fn.relation_embedding.detach().float().cpu()
@@ -148,7 +148,7 @@ def test_c4_wikikg2_transe_eight_shards(dev, dtype):
 @pytest.mark.parametrize("regime", ["per-triple", "flat"])
 def test_c5_distmult_eight_shards(dev, regime):
     if regime == "per-triple":
-        run_config(dev, "DistMult", 0, 512, torch.float32, 8, 30_000, 100, 100_000, 128, 8, "h", False, False, False, "margin",
+        run_config(dev, "DistMult", 0, 512, torch.float32, 8, 30_000, 100, 100_000, 128, 8, "h", False, False, False, "logsigmoid",
                    model="ScoreMoving")
     else:
         # (smooth loss: a hinge has knife-edge cases where 1[c > 0] flips with the summation order)

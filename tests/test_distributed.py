@@ -84,7 +84,7 @@ def test_distributed_bess_golden(world):
             if c["loss"] is not None:
                 np.testing.assert_allclose(z[f"{case}_fwd_loss"].reshape(bps), c["outs"]["loss"][:, r].numpy(),
                                            rtol=1e-4, atol=1e-4)
-            if case.startswith("tr_EM"):
+            if case.startswith("tr_"):
                 lr = 0.125
                 np.testing.assert_allclose(z[f"{case}_train_loss"].reshape(()), c["outs"]["loss"][0, r].numpy(),
                                            rtol=1e-4, atol=1e-4)

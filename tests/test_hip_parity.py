@@ -305,7 +305,7 @@ def test_bess_forward_golden(dev, case):
         close(res["loss"].reshape(bps, n), c["outs"]["loss"], rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("case", [c for c in bess_cases() if c.startswith("tr_EM")])
+@pytest.mark.parametrize("case", [c for c in bess_cases() if c.startswith("tr_")])
 def test_bess_train_step_golden(dev, case):
     """One sparse-SGD step moves the tables by -lr * (the reference's autograd gradient)."""
     from besskge import runtime
