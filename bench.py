@@ -246,6 +246,27 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # N = 1, score mode: also time the full training step (forward + backward +
+    # sparse SGD, K9/K10) on the same workload, reported as an extra object
+    train_extra = None
+    if world == 1 and args.mode == "score":
+        tsteps = max(5, min(args.steps, 30))
+        for i in range(3):
+            model.train_step_replicas([batches[i % len(batches)]], lr)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(tsteps):
+            model.train_step_replicas([batches[i % len(batches)]], lr)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        train_extra = {
+            "what": "same workload, full training step: gather+score+loss+backward+segmented scatter+sparse SGD",
+            "value": S * (1 + K_TOTAL) * tsteps / dt,
+            "unit": "triples/s",
+            "ms_per_step": 1e3 * dt / tsteps,
+            "steps": tsteps,
+        }
+
     n_neg = K_TOTAL  # negatives per positive, over all shards
     scored_per_step = world * S * (1 + n_neg)
     value = scored_per_step * args.steps / elapsed
@@ -305,6 +326,8 @@ def main() -> None:
         }
         extra = {k: float(np.mean(v)) for k, v in kernel_ms.items() if v}
         line["kernel_avg_ms"] = extra
+        if train_extra is not None:
+            line["train_step"] = train_extra
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

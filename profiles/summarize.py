@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>/ (written by profiles/run_profiles.sh on the GPU box)
+into the tracked summary profiles/<tag>/SUMMARY.md + profiles/pmc_traffic.json.
+
+    python profiles/summarize.py r01
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+out = f"profiles/{tag}"
+os.makedirs(out, exist_ok=True)
+lines = []
+for d, title in (("score", "bench.py --steps 20 --warmup 5 --no-cpu-baseline   (default: score mode)"),
+                 ("train", "bench.py --steps 20 --warmup 5 --no-cpu-baseline --mode train")):
+    f = max(glob.glob(f"{src}/{d}/runc/*_kernel_stats.csv"), key=os.path.getmtime)
+    lines.append(f"## rocprofv3 --kernel-trace --stats -- python3 {title}\n\n")
+    lines.append("| kernel | calls | avg (us) | min (us) | max (us) | % of GPU time |\n|---|---|---|---|---|---|\n")
+    for r in list(csv.DictReader(open(f)))[:18]:
+        lines.append(f"| `{r['Name'][:120]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} |"
+                     f" {float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |\n")
+    lines.append("\n")
+    os.system(f"cp {f} {out}/{d}_kernel_stats.csv")
+pm = {}
+for d in ("pmc_fetch", "pmc_write", "pmc_fetch_hbm"):
+    f = max(glob.glob(f"{src}/{d}/runc/*_counter_collection.csv"), key=os.path.getmtime)
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        if "k_neg_pertriple_fwd" in k[0]:
+            pm[d] = (k[1], len(v), sum(v) / len(v))
+fetch, write, fetch_hbm = pm["pmc_fetch"][2], pm["pmc_write"][2], pm["pmc_fetch_hbm"][2]
+lines.append("## rocprofv3 --pmc (separate passes), kernel k_neg_pertriple_fwd<float, 4, 8, DOT, 2>\n\n")
+lines.append("| pass | counter | dispatches | mean value (KiB) | bytes per launch after the gfx950 correction |\n|---|---|---|---|---|\n")
+lines.append(f"| 93,773-row shard (192 MB, Infinity-Cache resident) | FETCH_SIZE | {pm['pmc_fetch'][1]} | {fetch:.1f} | 2 x {fetch:.0f} x 1024 = {2*fetch*1024:.4g} |\n")
+lines.append(f"| same | WRITE_SIZE | {pm['pmc_write'][1]} | {write:.1f} | {write*1024:.4g} |\n")
+lines.append(f"| 4,000,000-row shard (8.2 GB, HBM resident) | FETCH_SIZE | {pm['pmc_fetch_hbm'][1]} | {fetch_hbm:.1f} | 2 x {fetch_hbm:.0f} x 1024 = {2*fetch_hbm*1024:.4g} |\n")
+lines.append("\nFETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for 16 B/lane coalesced reads on gfx950;"
+             " WRITE_SIZE is used as read (4-byte scattered score stores: uncalibrated width, small).  Algorithmic bytes"
+             " of the launch: 2,164,260,864.\n")
+json.dump({"neg_score_pertriple_fwd_bytes_per_launch": 2 * fetch * 1024 + write * 1024, "fetch_size_kib": fetch,
+           "write_size_kib": write, "fetch_size_kib_hbm_resident_8GB_shard": fetch_hbm,
+           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python3 bench.py --steps 20 --warmup 5"
+                   " --no-cpu-baseline`; traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (profiles/summarize.py)"},
+          open("profiles/pmc_traffic.json", "w"), indent=1)
+for name in ("score.json", "train.json", "score_hbm.json"):
+    os.system(f"cp {src}/{name} {out}/bench_{name}")
+open(f"{out}/SUMMARY.md", "w").write(
+    f"# Round {tag} profiles (MI355X, ROCm 7.2, rocprofv3)\n\nRecipe: `profiles/run_profiles.sh {tag}` on the GPU box (gpurun),"
+    f" then `python profiles/summarize.py {tag}`; the raw stats CSVs and the bench lines of the profiled runs are next to"
+    " this file.\n\n" + "".join(lines))
+print(open(f"{out}/SUMMARY.md").read())
