@@ -796,8 +796,9 @@ class ScoreMovingBessKGE(BessKGE):
                 sc = torch.cat([sh.reshape(n, n, cut, -1), stl.reshape(n, n, ppp - cut, -1)], dim=2).reshape(
                     n * n * ppp, -1)
             scores_out.append(sc.reshape(n, n * ppp, -1).contiguous())
-        scores_back = group.all_to_all(scores_out)  # C4  [n(src), S, Nl]
-        tails_in = group.all_to_all(tails_out)  # C5  [n, ppp, W]
+        # C4 (scores back to the triples' owner, [n(src), S, Nl]) and C5 (positive
+        # tails, [n, ppp, W]) ride one all-to-all when they have the same dtype
+        scores_back, tails_in = self._paired_all_to_all(scores_out, tails_out)
         for st, sb, tl in zip(steps, scores_back, tails_in):
             st.negative_score = sb.transpose(0, 1).flatten(start_dim=1).contiguous()
             st.recv = tl.reshape(-1, W)
@@ -805,6 +806,23 @@ class ScoreMovingBessKGE(BessKGE):
             st.positive_score = nat.score_triple_fwd(
                 desc, RowSource(st.table, st.head_idx), st.tail, rel_table, st.rel_idx)
         return steps
+
+    def _paired_all_to_all(self, xs: List[torch.Tensor], ys: List[torch.Tensor]
+                           ) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+        """all_to_all of two per-replica tensors [n, ...]; one collective (fewer,
+        larger messages over xGMI) when dtypes agree, two otherwise."""
+        group = self._group()
+        if not xs or xs[0].dtype != ys[0].dtype or group.n_shard == 1:
+            return group.all_to_all(xs), group.all_to_all(ys)
+        n = group.n_shard
+        packed = [torch.cat([x.reshape(n, -1), y.reshape(n, -1)], dim=1) for x, y in zip(xs, ys)]
+        out = group.all_to_all(packed)
+        xo, yo = [], []
+        for o, x, y in zip(out, xs, ys):
+            cut = x[0].numel()
+            xo.append(o[:, :cut].reshape(x.shape))
+            yo.append(o[:, cut:].reshape(y.shape))
+        return xo, yo
 
     # ---------------------------------------------------------------- training
     def train_step_replicas(self, batches: List[_Batch], optimizer: Any) -> List[Dict[str, Any]]:
@@ -840,8 +858,8 @@ class ScoreMovingBessKGE(BessKGE):
                                           st.rel_idx, d_pos, d_rel)
             local_updates.append([(st.head_idx, dh)])
             d_tails.append(dt.reshape(n, st.ppp, W))
-        d_sc_all = group.all_to_all(d_scores)  # gradients of the scores I computed: [n(j), S, Nl]
-        d_tail_back = group.all_to_all(d_tails)  # C5'
+        # gradients of the scores I computed ([n(j), S, Nl]) and of my tail rows (C5'), one all-to-all
+        d_sc_all, d_tail_back = self._paired_all_to_all(d_scores, d_tails)
         deferred: List[Tuple[torch.Tensor, _NegGroup, torch.Tensor]] = []
         d_tq, d_hq = [], []
         for st, dsc, dtb, upd in zip(steps, d_sc_all, d_tail_back, local_updates):
