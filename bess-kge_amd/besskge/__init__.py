@@ -25,7 +25,10 @@ from . import (  # noqa: E402,F401
     dataset,
     embedding,
     loss,
+    metric,
     negative_sampler,
+    pipeline,
+    query,
     runtime,
     scoring,
     sharding,
@@ -39,7 +42,10 @@ __all__ = [
     "dataset",
     "embedding",
     "loss",
+    "metric",
     "negative_sampler",
+    "pipeline",
+    "query",
     "runtime",
     "scoring",
     "sharding",

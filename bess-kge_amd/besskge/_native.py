@@ -104,6 +104,9 @@ SIGNATURES = {
     "bess_neg_pertriple_grad_segments": [_MD, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _vp],
     "bess_apply_segments_sgd": [_i32, _i32, _vp, _vp, _vp, _i64, _vp, _f32, _vp],
     "bess_segment_sum_rows": [_i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    "bess_topk_update": [_vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _i32, _vp],
+    "bess_ranks_from_scores": [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp],
+    "bess_ranks_from_indices": [_vp, _vp, _i64, _i64, _i32, _vp, _vp],
     "bess_apply_segments_opt": [ctypes.POINTER(OptDesc), _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
 }
 
@@ -663,3 +666,60 @@ def apply_segments_opt(o: OptDesc, table: torch.Tensor, seg: SegmentIndex, grad_
                                             grad_seg.data_ptr(), state1.data_ptr() if state1 is not None else 0,
                                             state2.data_ptr() if state2 is not None else 0, _stream(dev))
     _check(rc, "bess_apply_segments_opt")
+
+
+def ranks_from_scores(pos: torch.Tensor, cand: torch.Tensor, mode: int, worst_rank_infty: bool) -> torch.Tensor:
+    dev = _same_device([("pos_score", pos), ("candidate_score", cand)])
+    pos = pos.reshape(-1).float().contiguous()
+    cand = cand.float().contiguous()
+    if cand.dim() != 2 or cand.shape[0] != pos.numel():
+        raise ValueError("`pos_score` and `candidate_score` need to have same size at dimension 0")
+    out = torch.empty((pos.numel(),), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().bess_ranks_from_scores(pos.data_ptr(), cand.data_ptr(), pos.numel(), cand.shape[1], cand.shape[1],
+                                           mode, int(worst_rank_infty), out.data_ptr(), _stream(dev))
+    _check(rc, "bess_ranks_from_scores")
+    return out
+
+
+def ranks_from_indices(truth: torch.Tensor, cand: torch.Tensor, worst_rank_infty: bool) -> torch.Tensor:
+    dev = _same_device([("ground_truth", truth), ("candidate_indices", cand)])
+    truth = truth.reshape(-1).to(torch.int64).contiguous()
+    cand = cand.to(torch.int64).contiguous()
+    if cand.dim() != 2 or cand.shape[0] != truth.numel():
+        raise ValueError("`ground_truth` and `candidate_indices` need to have the same size for dimension 0")
+    out = torch.empty((truth.numel(),), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().bess_ranks_from_indices(truth.data_ptr(), cand.data_ptr(), truth.numel(), cand.shape[1],
+                                            int(worst_rank_infty), out.data_ptr(), _stream(dev))
+    _check(rc, "bess_ranks_from_indices")
+    return out
+
+
+def topk_update(scores: torch.Tensor, best_score: torch.Tensor, best_id: torch.Tensor,
+                ids: Optional[torch.Tensor] = None, id_base: int = 0, mask: Optional[torch.Tensor] = None) -> None:
+    """Merge `scores` [rows, L] into the running (best_score, best_id) [rows, kk] lists in place."""
+    dev = _same_device([("scores", scores), ("best_score", best_score), ("best_id", best_id), ("ids", ids),
+                        ("mask", mask)])
+    _f32(scores, "scores")
+    _f32(best_score, "best_score")
+    if scores.dim() != 2 or best_score.dim() != 2 or best_score.shape[0] != scores.shape[0] \
+            or best_id.shape != best_score.shape or best_id.dtype != torch.int32 or not best_id.is_contiguous():
+        raise ValueError("topk_update: best lists must be [rows, kk] (f32 scores, int32 ids)")
+    R, L, kk = int(scores.shape[0]), int(scores.shape[1]), int(best_score.shape[1])
+    ip = ir = 0
+    if ids is not None:
+        if ids.dtype != torch.int32 or ids.dim() != 2 or ids.shape[1] != L or ids.shape[0] not in (1, R) \
+                or not ids.is_contiguous():
+            raise ValueError("topk_update: ids must be a contiguous int32 [1 | rows, L] tensor")
+        ip, ir = ids.data_ptr(), int(ids.shape[0])
+    mp = mr = 0
+    if mask is not None:
+        if mask.dtype != torch.bool or mask.dim() != 2 or mask.shape[1] != L or mask.shape[0] not in (1, R) \
+                or not mask.is_contiguous():
+            raise ValueError("topk_update: mask must be a contiguous bool [1 | rows, L] tensor")
+        mp, mr = mask.data_ptr(), int(mask.shape[0])
+    with torch.cuda.device(dev):
+        rc = load().bess_topk_update(scores.data_ptr(), R, L, L, ip, ir, int(id_base), mp, mr,
+                                     best_score.data_ptr(), best_id.data_ptr(), kk, _stream(dev))
+    _check(rc, "bess_topk_update")

@@ -46,6 +46,9 @@ BAD_NEGATIVE_SCORE = -50000.0
 
 _Batch = Dict[str, torch.Tensor]
 
+# the inference-against-many-candidates variants live in besskge.query and are
+# re-exported at the end of this module, where the reference defines them
+
 
 def _i32(x: torch.Tensor) -> torch.Tensor:
     x = x if x.dtype == torch.int32 else x.to(torch.int32)
@@ -906,3 +909,6 @@ class ScoreMovingBessKGE(BessKGE):
     def train_step(self, optimizer: Any, **batch: torch.Tensor) -> Dict[str, Any]:
         """Single-replica convenience wrapper of :meth:`train_step_replicas`."""
         return self.train_step_replicas([batch], optimizer)[0]
+
+
+from besskge.query import AllScoresBESS, TopKQueryBessKGE  # noqa: E402,F401

@@ -1,0 +1,176 @@
+"""High-level inference pipeline: scores of queries against all entities.
+
+Mirror of the reference interface (`besskge/pipeline.py:23-320`):
+`AllScoresPipeline(batch_sampler, corruption_scheme, score_fn, evaluation,
+filter_triples, candidate_ents, return_scores, return_topk, k, window_size)`;
+calling it returns `scores`, `topk_global_id`, `triple_idx`, `metrics`,
+`metrics_avg`, `ranks` as configured.  The device work is `AllScoresBESS`
+(window scoring on the shards + all-to-all); the re-assembly, filtering and
+ranking of the `[queries, n_entity]` score matrix stays on the device and only
+the requested results are returned on the host.
+"""
+
+from typing import Any, Dict, List, Optional, Union
+
+import numpy as np
+import torch
+from numpy.typing import NDArray
+
+from besskge import _native as nat
+from besskge import runtime
+from besskge.batch_sampler import ShardedBatchSampler
+from besskge.collectives import ReplicaGroup
+from besskge.negative_sampler import PlaceholderNegativeSampler
+from besskge.query import AllScoresBESS
+from besskge.scoring import BaseScoreFunction
+from besskge.utils import get_entity_filter
+
+
+class AllScoresPipeline(torch.nn.Module):
+    """Scores (and metrics) of (h, r, ?) / (?, r, t) queries against all entities,
+    with optional filtering of known triples and restriction to candidate entities."""
+
+    def __init__(
+        self,
+        batch_sampler: ShardedBatchSampler,
+        corruption_scheme: str,
+        score_fn: BaseScoreFunction,
+        evaluation: Optional[Any] = None,
+        filter_triples: Optional[List[Union[torch.Tensor, NDArray[np.int32]]]] = None,
+        candidate_ents: Optional[Union[torch.Tensor, NDArray[np.int32]]] = None,
+        return_scores: bool = False,
+        return_topk: bool = False,
+        k: int = 10,
+        window_size: int = 1000,
+        use_ipu_model: bool = False,
+        group: Optional[ReplicaGroup] = None,
+        device: Optional[torch.device] = None,
+    ) -> None:
+        """
+        :param batch_sampler: sampler over "h_shard" / "t_shard" partitioned queries.
+        :param corruption_scheme: "t" scores (h, r, ?), "h" scores (?, r, t).
+        :param score_fn: trained scoring function.
+        :param evaluation: `besskge.metric.Evaluation`.
+        :param filter_triples: triples (global ids) whose completions are filtered out.
+        :param candidate_ents: global ids of the only entities to consider.
+        :param return_scores: return the filtered `[queries, n_entity]` scores (host memory!).
+        :param return_topk: return the k best global ids per query (after filtering).
+        :param window_size: entities of each shard scored per device call.
+        :param use_ipu_model: accepted for call compatibility, ignored.
+        :param group / device: replica group and HIP device (default: all shards
+            in this process on the current device).
+        """
+        super().__init__()
+        if not (evaluation or return_scores):
+            raise ValueError("Nothing to return. Provide `evaluation` or set `return_scores=True`")
+        if corruption_scheme not in ["h", "t"]:
+            raise ValueError("corruption_scheme needs to be either 'h' or 't'")
+        want_mode = "t_shard" if corruption_scheme == "h" else "h_shard"
+        if batch_sampler.triple_partition_mode != want_mode:
+            raise ValueError(
+                f"Corruption scheme '{corruption_scheme}' requires '{want_mode.replace('_', '-')}'-partitioned triples")
+        self.batch_sampler = batch_sampler
+        self.corruption_scheme = corruption_scheme
+        self.candidate_sampler = PlaceholderNegativeSampler(corruption_scheme=corruption_scheme)
+        self.score_fn = score_fn
+        self.evaluation = evaluation
+        self.return_scores = return_scores
+        self.return_topk = return_topk
+        self.k = k
+        self.window_size = window_size
+        self.bess_module = AllScoresBESS(self.candidate_sampler, self.score_fn, self.window_size)
+        self.dl = batch_sampler.get_dataloader(shuffle=False)
+        self.runner = runtime.inference_model(
+            self.bess_module, runtime.Options(device_iterations=batch_sampler.batches_per_step), group=group,
+            device=device)
+        sharding = self.bess_module.sharding
+        self.filter_triples: Optional[torch.Tensor] = None
+        if filter_triples:
+            # global ids of the sampler's (locally indexed) triples
+            col = 0 if batch_sampler.triple_partition_mode == "h_shard" else 2
+            glob = np.copy(batch_sampler.triples)
+            bounds = np.concatenate([np.array([0]), np.cumsum(batch_sampler.triple_counts)])
+            for i in range(len(bounds) - 1):
+                sl = slice(bounds[i], bounds[i + 1])
+                glob[sl, col] = sharding.shard_and_idx_to_entity[i][glob[sl, col]]
+            self.triples = torch.from_numpy(glob)
+            self.filter_triples = torch.concat(
+                [t if isinstance(t, torch.Tensor) else torch.from_numpy(t) for t in filter_triples], dim=0)
+        self.candidate_mask: Optional[torch.Tensor] = None
+        if candidate_ents is not None:
+            self.candidate_mask = torch.from_numpy(np.setdiff1d(np.arange(sharding.n_entity), candidate_ents))
+        # column order of the assembled scores -> global entity id (first occurrence of every entity)
+        ws, n_step, M = self.window_size, self.bess_module.n_step, sharding.max_entity_per_shard
+        cols = []
+        for i in range(n_step):
+            ent_slice = np.minimum(i * ws + np.arange(ws), M - 1)
+            cols.append(sharding.shard_and_idx_to_entity[:, ent_slice].flatten())
+        self._first = torch.from_numpy(np.unique(np.concatenate(cols), return_index=True)[1])
+
+    def forward(self) -> Dict[str, Any]:
+        """Run over the whole sampler."""
+        ev = self.evaluation
+        sharding = self.bess_module.sharding
+        n, bps = sharding.n_shard, self.batch_sampler.batches_per_step
+        dev = self.runner.device
+        scores, ids, metrics, ranks, topk = [], [], [], [], []
+        n_triple = 0
+        gt_key = "head" if self.corruption_scheme == "h" else "tail"
+        for batch in self.dl:
+            triple_mask = batch.pop("triple_mask")
+            ground_truth = batch.pop(gt_key) if gt_key in batch else None
+            triple_id = batch.pop("triple_idx") if self.batch_sampler.return_triple_idx else None
+            if triple_id is not None:
+                ids.append(triple_id[triple_mask])
+            n_triple += int(triple_mask.sum())
+            inp = {k: v.flatten(end_dim=1) for k, v in batch.items()}
+            parts = []
+            for i in range(self.bess_module.n_step):
+                step = torch.full((n * bps, 1), i, dtype=torch.int32)
+                parts.append(self.runner(step=step, **inp))
+            all_scores = torch.concat(parts, dim=-1)  # [queries, n_step * n * ws] on the device
+            keep = triple_mask.flatten().to(dev)
+            sc = all_scores[keep][:, self._first.to(dev)][:, : sharding.n_entity].float()
+            if self.candidate_mask is not None:
+                sc[:, self.candidate_mask.to(dev)] = -torch.inf
+            rows = torch.arange(sc.shape[0], device=dev)
+            truth = true_scores = None
+            if ground_truth is not None:
+                truth = ground_truth[triple_mask].to(dev).long()
+                true_scores = sc[rows, truth].clone()
+            if self.filter_triples is not None:
+                if triple_id is None:
+                    raise ValueError("filtering needs a batch sampler with return_triple_idx=True")
+                flt = get_entity_filter(self.triples[triple_id[triple_mask]], self.filter_triples,
+                                        filter_mode=self.corruption_scheme).to(dev)
+                sc[flt[:, 0], flt[:, 1]] = -torch.inf
+            if ev:
+                assert truth is not None, "Evaluation requires providing ground truth entities"
+                sc[rows, truth] = -torch.inf  # the true completion does not compete with itself
+                r = ev.ranks_from_scores(true_scores, sc)
+                metrics.append({m: v.cpu() for m, v in ev.dict_metrics_from_ranks(r).items()})
+                if ev.return_ranks:
+                    ranks.append(r.cpu())
+            if truth is not None:
+                sc[rows, truth] = true_scores
+            if self.return_scores:
+                scores.append(sc.cpu())
+            if self.return_topk:
+                top_s = torch.full((sc.shape[0], self.k), -torch.inf, dtype=torch.float32, device=dev)
+                top_i = torch.zeros((sc.shape[0], self.k), dtype=torch.int32, device=dev)
+                nat.topk_update(sc.contiguous(), top_s, top_i)  # column == global entity id
+                topk.append(top_i.cpu().long())
+        out: Dict[str, Any] = dict()
+        if scores:
+            out["scores"] = torch.concat(scores, dim=0)
+        if topk:
+            out["topk_global_id"] = torch.concat(topk, dim=0)
+        if ids:
+            out["triple_idx"] = torch.concat(ids, dim=0)
+        if ev:
+            final = {m: ev.reduction(torch.concat([met[m].reshape(-1) for met in metrics])) for m in metrics[0]}
+            out["metrics"] = final
+            out["metrics_avg"] = {m: v.sum() / n_triple for m, v in final.items()}
+            if ranks:
+                out["ranks"] = torch.concat(ranks, dim=0)
+        return out

@@ -1,0 +1,296 @@
+"""Inference against large candidate sets: top-k completions and all scores.
+
+Mirror of the reference interface (`besskge/bess.py:606-1062`):
+`TopKQueryBessKGE` and `AllScoresBESS`, used with "h_shard" / "t_shard"
+partitioned (h, r, ?) / (?, r, t) queries.  Same data flow as the reference
+(and as `ScoreMovingBessKGE`): queries are all-gathered, every shard scores them
+against *its own* rows, per-query results go back with an all-to-all.
+
+MI355X mapping
+  * scoring a window of the shard is the shared-negative kernel (K4: MFMA GEMM
+    for DistMult / ComplEx, VALU distance matrix for TransE / RotatE) on a
+    contiguous slice of the shard - or the per-triple kernel (K5) for
+    query-specific candidate lists;
+  * the reference's `torch.topk(concat(window, running)) + gather_indices` per
+    window (`bess.py:802-814`) is `bess_topk_update` (K11): a streaming top-k
+    with the running list in registers;
+  * the sliding window is a tiling choice: results do not depend on its size
+    (the reference's `window_size` is accepted and used as the *minimum* tile;
+    the device tile is sized so that the score tile stays a few MiB).
+"""
+
+from typing import Any, Dict, List, Optional, Union
+
+import numpy as np
+import torch
+
+from besskge import _native as nat
+from besskge._native import RowSource
+from besskge.collectives import ReplicaGroup, SingleProcessGroup
+from besskge.negative_sampler import (
+    PlaceholderNegativeSampler,
+    TripleBasedShardedNegativeSampler,
+)
+from besskge.scoring import BaseScoreFunction
+
+BAD_NEGATIVE_SCORE = -50000.0
+_Batch = Dict[str, torch.Tensor]
+
+
+def _i32(x: torch.Tensor) -> torch.Tensor:
+    return (x if x.dtype == torch.int32 else x.to(torch.int32)).contiguous()
+
+
+class _QueryModule(torch.nn.Module):
+    """Shared plumbing: replica group, shard placement, query gathering."""
+
+    def __init__(self, score_fn: BaseScoreFunction, candidate_sampler: Any) -> None:
+        super().__init__()
+        self.sharding = score_fn.sharding
+        self.score_fn = score_fn
+        self.negative_sampler = candidate_sampler
+        if candidate_sampler.corruption_scheme not in ["h", "t"]:
+            raise ValueError(f"{type(self).__name__} only support 'h', 't' corruption scheme")
+        self.entity_embedding = self.score_fn.entity_embedding
+        self.entity_embedding_size: int = self.entity_embedding.shape[-1]
+        self.replica_group: Optional[ReplicaGroup] = None
+        self._shard_slot: Optional[Dict[int, int]] = None
+
+    def attach(self, group: ReplicaGroup, shard_slot: Optional[Dict[int, int]] = None) -> None:
+        """Bind to a replica group (see :meth:`besskge.bess.BessKGE.attach`)."""
+        if group.n_shard != self.sharding.n_shard:
+            raise ValueError(f"group has {group.n_shard} replicas, sharding {self.sharding.n_shard}")
+        self.replica_group = group
+        self._shard_slot = shard_slot
+
+    def _group(self) -> ReplicaGroup:
+        if self.replica_group is None:
+            self.replica_group = SingleProcessGroup(self.sharding.n_shard)
+        return self.replica_group
+
+    def _local_table(self, shard: int) -> torch.Tensor:
+        emb = self.score_fn.entity_embedding
+        slot = shard if self._shard_slot is None else self._shard_slot[shard]
+        if emb.dim() != 3 or slot >= emb.shape[0]:
+            raise RuntimeError(f"entity_embedding {tuple(emb.shape)} does not hold shard {shard}")
+        return emb.data[slot]
+
+    def _gather_queries(self, batches: List[_Batch]) -> List[torch.Tensor]:
+        """Query matrices [n_shard * shard_bs, W] (one per local replica): the known
+        entity of every query of every replica, transformed with its relation."""
+        group = self._group()
+        fn = self.score_fn
+        scheme = self.negative_sampler.corruption_scheme
+        key = "tail" if scheme == "h" else "head"
+        side = nat.CORRUPT_HEAD if scheme == "h" else nat.CORRUPT_TAIL
+        rels, rows = [], []
+        for shard, b in zip(group.local_shards, batches):
+            table = self._local_table(shard)
+            if key not in b or b[key] is None:
+                raise ValueError(f"corruption scheme '{scheme}' needs the `{key}` indices of the queries")
+            ent = _i32(b[key].squeeze(0).to(table.device)).reshape(-1)
+            rels.append(_i32(b["relation"].squeeze(0).to(table.device)).reshape(-1))
+            rows.append(nat.gather_rows(table, ent))
+        rel_all = group.all_gather(rels)  # [n, shard_bs]
+        rows_all = group.all_gather(rows)  # [n, shard_bs, W]
+        desc = fn.kernel_desc()
+        W = self.entity_embedding_size
+        return [nat.query_fwd(desc, side, RowSource(x.reshape(-1, W)), fn.relation_embedding.data,
+                              r.reshape(-1).contiguous()) for x, r in zip(rows_all, rel_all)]
+
+
+class TopKQueryBessKGE(_QueryModule):
+    """Top-k completions of (h, r, ?) / (?, r, t) queries against all entities or
+    against given candidates (reference `bess.py:606-921`).  Inference only."""
+
+    def __init__(
+        self,
+        k: int,
+        candidate_sampler: Union[TripleBasedShardedNegativeSampler, PlaceholderNegativeSampler],
+        score_fn: BaseScoreFunction,
+        evaluation: Optional[Any] = None,
+        return_scores: bool = False,
+        window_size: int = 100,
+    ) -> None:
+        """
+        :param k: number of completions returned per query (k + 1 <= 64).
+        :param candidate_sampler: `PlaceholderNegativeSampler` (score against
+            every entity) or a `TripleBasedShardedNegativeSampler` built with
+            `mask_on_gather=True`.
+        :param score_fn: scoring function.
+        :param evaluation: `besskge.metric.Evaluation` (needs the ground truth).
+        :param return_scores: also return the scores of the k completions.
+        :param window_size: minimum number of candidates scored per tile.
+        """
+        super().__init__(score_fn, candidate_sampler)
+        self.evaluation = evaluation
+        self.return_scores = return_scores
+        self.k = k
+        self.window_size = window_size
+        if k + 1 > 64:
+            raise ValueError("the streaming top-k kernel keeps k + 1 <= 64 entries per query")
+        if self.negative_sampler.flat_negative_format:
+            assert score_fn.negative_sample_sharing, "Using flat negative format requires negative sample sharing"
+        elif score_fn.negative_sample_sharing:
+            raise ValueError("Negative sample sharing cannot be used with non-flat triple-specific negatives")
+        if isinstance(self.negative_sampler, TripleBasedShardedNegativeSampler):
+            assert self.negative_sampler.mask_on_gather, (
+                "TopKQueryBessKGE requires setting mask_on_gather=True in the candidate_sampler")
+
+    def forward(
+        self,
+        relation: torch.Tensor,
+        head: Optional[torch.Tensor] = None,
+        tail: Optional[torch.Tensor] = None,
+        negative: Optional[torch.Tensor] = None,
+        triple_mask: Optional[torch.Tensor] = None,
+        negative_mask: Optional[torch.Tensor] = None,
+    ) -> Dict[str, Any]:
+        """One micro-batch of one replica (see :meth:`forward_replicas`).
+
+        :param relation: (1, shard_bs) relation ids.
+        :param head / tail: (1, shard_bs); the known side holds rows of this
+            shard, the other one (optional) the global id of the ground truth.
+        :param negative: (1, n_shard, B, padded) candidate rows, B = 1 or
+            shard_bs; None = every entity.
+        :param triple_mask: (1, shard_bs) queries that count for the metrics.
+        :param negative_mask: (1, n_shard, B, padded) real (non padding) candidates.
+        """
+        b = dict(relation=relation, head=head, tail=tail, negative=negative, triple_mask=triple_mask,
+                 negative_mask=negative_mask)
+        if len(self._group().local_shards) != 1:
+            raise RuntimeError("forward() steps a single replica; use forward_replicas()")
+        return self.forward_replicas([{k: v for k, v in b.items() if v is not None}])[0]
+
+    def _tile(self, n_query: int) -> int:
+        # score tile [n_query, tile] of about 32 MiB, at least the reference's window
+        return max(self.window_size, min(1 << 16, max(64, (8 << 20) // max(1, n_query))))
+
+    def forward_replicas(self, batches: List[_Batch]) -> List[Dict[str, Any]]:
+        group = self._group()
+        n = group.n_shard
+        fn = self.score_fn
+        desc = fn.kernel_desc()
+        kk = self.k + 1
+        queries = self._gather_queries(batches)
+        best_s, best_i = [], []
+        for shard, b, q in zip(group.local_shards, batches, queries):
+            table = self._local_table(shard)
+            dev = table.device
+            nq = int(q.shape[0])
+            M = int(table.shape[0])
+            bs = torch.full((nq, kk), BAD_NEGATIVE_SCORE, dtype=torch.float32, device=dev)
+            bi = torch.full((nq, kk), M, dtype=torch.int32, device=dev)
+            tile = self._tile(nq)
+            if b.get("negative") is None:
+                for w0 in range(0, M, tile):
+                    w1 = min(M, w0 + tile)
+                    sc = nat.neg_score_shared_fwd(desc, q, RowSource(table[w0:w1]))
+                    nat.topk_update(sc, bs, bi, id_base=w0)
+            else:
+                if b.get("negative_mask") is None:
+                    raise ValueError("candidates need their `negative_mask`")
+                cand = _i32(b["negative"].squeeze(0).to(dev))
+                mask = b["negative_mask"].squeeze(0).to(device=dev, dtype=torch.bool)
+                if self.negative_sampler.flat_negative_format:
+                    cand, mask = cand[0], mask[0]
+                cand = cand.reshape(-1, cand.shape[-1]).contiguous()  # [1 | n * shard_bs, L]
+                mask = mask.reshape(-1, mask.shape[-1]).contiguous()
+                L = int(cand.shape[1])
+                if cand.shape[0] == 1:
+                    for w0 in range(0, L, tile):
+                        w1 = min(L, w0 + tile)
+                        ids = cand[:, w0:w1].contiguous()
+                        sc = nat.neg_score_shared_fwd(desc, q, RowSource(table, ids.reshape(-1)))
+                        nat.topk_update(sc, bs, bi, ids=ids, mask=mask[:, w0:w1].contiguous())
+                else:
+                    if cand.shape[0] != nq:
+                        raise ValueError(f"{cand.shape[0]} candidate lists for {nq} gathered queries")
+                    sc = nat.neg_score_pertriple_fwd(desc, q, RowSource(table, cand.reshape(-1)), L)
+                    nat.topk_update(sc, bs, bi, ids=cand, mask=mask)
+            best_s.append(bs.reshape(n, -1, kk))
+            best_i.append(bi.reshape(n, -1, kk))
+        # per-query lists back to the query's shard (C6)
+        back_s = group.all_to_all(best_s)
+        back_i = group.all_to_all(best_i)
+        counts = torch.from_numpy(np.asarray(self.sharding.shard_counts))
+        to_global = torch.from_numpy(np.asarray(self.sharding.shard_and_idx_to_entity)).to(torch.int32)
+        outs = []
+        for b, s, i in zip(batches, back_s, back_i):
+            dev = s.device
+            cnt = counts.to(device=dev, dtype=torch.int32)[:, None, None]
+            pad = i >= cnt  # padding rows of a shard (and the initial sentinel) never win
+            s = s + BAD_NEGATIVE_SCORE * pad.to(s.dtype)
+            tg = to_global.to(dev)
+            M = tg.shape[1]
+            src = torch.arange(n, device=dev)[:, None, None].expand_as(i)
+            gid = tg[src, i.clamp(max=M - 1).long()]  # [n, shard_bs, kk]
+            shard_bs = int(s.shape[1])
+            flat_s = s.transpose(0, 1).reshape(shard_bs, n * kk).contiguous()
+            flat_g = gid.transpose(0, 1).reshape(shard_bs, n * kk).contiguous()
+            top_s = torch.full((shard_bs, self.k), -float("inf"), dtype=torch.float32, device=dev)
+            top_g = torch.zeros((shard_bs, self.k), dtype=torch.int32, device=dev)
+            nat.topk_update(flat_s, top_s, top_g, ids=flat_g)
+            out: Dict[str, Any] = dict(topk_global_id=top_g)
+            if self.return_scores:
+                out["topk_scores"] = top_s.to(fn.relation_embedding.dtype)
+            if self.evaluation:
+                truth = b.get("tail" if self.negative_sampler.corruption_scheme == "t" else "head")
+                assert truth is not None, "Evaluation requires providing ground truth entities"
+                tm = b.get("triple_mask")
+                tm = tm.flatten().to(dev) if tm is not None else None
+                ranks = self.evaluation.ranks_from_indices(truth.squeeze(0).to(dev), top_g)
+                if self.evaluation.return_ranks:
+                    out["ranks"] = ranks
+                out["metrics"] = self.evaluation.stacked_metrics_from_ranks(ranks, tm)
+            outs.append(out)
+        return outs
+
+
+class AllScoresBESS(_QueryModule):
+    """Scores of the queries against one window of every shard per call
+    (reference `bess.py:924-1062`); `besskge.pipeline.AllScoresPipeline` loops
+    over the windows.  Inference only."""
+
+    def __init__(self, candidate_sampler: PlaceholderNegativeSampler, score_fn: BaseScoreFunction,
+                 window_size: int = 1000) -> None:
+        """
+        :param candidate_sampler: `PlaceholderNegativeSampler` giving the corruption scheme.
+        :param score_fn: scoring function (with negative sample sharing).
+        :param window_size: entities of each shard scored per call.
+        """
+        super().__init__(score_fn, candidate_sampler)
+        if not score_fn.negative_sample_sharing:
+            raise ValueError("AllScoresBESS requires using negative sample sharing")
+        if not isinstance(candidate_sampler, PlaceholderNegativeSampler):
+            raise ValueError("AllScoresBESS requires a `PlaceholderNegativeSampler` candidate_sampler")
+        self.window_size = window_size
+        self.candidate = torch.arange(self.window_size, dtype=torch.int32)
+        self.n_step = int(np.ceil(self.sharding.max_entity_per_shard / self.window_size))
+
+    def forward(self, step: torch.Tensor, relation: torch.Tensor, head: Optional[torch.Tensor] = None,
+                tail: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Scores (shard_bs, n_shard * window_size) of window `step` (one replica)."""
+        b = dict(step=step, relation=relation, head=head, tail=tail)
+        if len(self._group().local_shards) != 1:
+            raise RuntimeError("forward() steps a single replica; use forward_replicas()")
+        return self.forward_replicas([{k: v for k, v in b.items() if v is not None}])[0]
+
+    def forward_replicas(self, batches: List[_Batch]) -> List[torch.Tensor]:
+        group = self._group()
+        n = group.n_shard
+        desc = self.score_fn.kernel_desc()
+        ws = self.window_size
+        queries = self._gather_queries(batches)
+        outs = []
+        for shard, b, q in zip(group.local_shards, batches, queries):
+            table = self._local_table(shard)
+            M = int(table.shape[0])
+            step = int(b["step"].reshape(-1)[0])
+            # rows step*ws .. step*ws+ws-1, clamped to the last row (bess.py:1032-1036)
+            rows = torch.clamp(step * ws + torch.arange(ws, dtype=torch.int32, device=table.device), max=M - 1)
+            sc = nat.neg_score_shared_fwd(desc, q, RowSource(table, rows.contiguous()))
+            outs.append(sc.reshape(n, -1, ws))
+        back = group.all_to_all(outs)  # C7
+        dt = self.score_fn.relation_embedding.dtype
+        return [x.transpose(0, 1).flatten(start_dim=1).contiguous().to(dt) for x in back]

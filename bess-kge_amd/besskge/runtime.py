@@ -20,10 +20,10 @@ from typing import Any, Dict, List, Optional
 
 import torch
 
-from besskge.bess import BessKGE, EmbeddingMovingBessKGE
+from besskge.bess import BessKGE
 from besskge.collectives import DistributedGroup, ReplicaGroup, SingleProcessGroup
 
-_BATCH_KEYS = ("head", "relation", "tail", "negative", "triple_mask", "triple_weight", "negative_mask")
+_BATCH_KEYS = ("head", "relation", "tail", "negative", "triple_mask", "triple_weight", "negative_mask", "step")
 
 
 @dataclasses.dataclass
@@ -158,7 +158,7 @@ class Runner:
         unknown = set(batch) - set(_BATCH_KEYS)
         if unknown:
             raise TypeError(f"unexpected inputs {sorted(unknown)}")
-        rows = batch["head"].shape[0]
+        rows = batch["relation"].shape[0]
         iters = self.options.device_iterations
         if rows != iters * n:
             raise ValueError(
@@ -186,6 +186,9 @@ class Runner:
                 main.wait_stream(st)
         if self.options.output_mode == "final":
             collected = collected[-1:]
+        bare = not isinstance(collected[0][0], dict)  # modules returning one tensor (AllScoresBESS)
+        if bare:
+            collected = [[{"out": r} for r in res] for res in collected]
         keys = collected[0][0].keys()
         out: Dict[str, torch.Tensor] = {}
         for k in keys:
@@ -197,7 +200,7 @@ class Runner:
                     x = self.group.all_gather([x])[0].flatten(end_dim=1)
                 per_it.append(x)
             out[k] = torch.cat(per_it, dim=0)
-        return out
+        return out["out"] if bare else out  # type: ignore[return-value]
 
 
 def inference_model(model: BessKGE, options: Optional[Options] = None, group: Optional[ReplicaGroup] = None,

@@ -126,6 +126,54 @@ __global__ __launch_bounds__(256) void k_loss_rows(bess_loss_desc l, const float
     }
 }
 
+// Prediction rank of the positive among its candidates (reference metric.py:129-182):
+// 1 + #{candidates better}; "better" = '>' (optimistic), '>=' (pessimistic) or the
+// mean of the two (average).  NaN positives count as -inf.  With worst_inf a
+// positive beaten by every candidate gets rank +inf.
+__global__ __launch_bounds__(256) void k_ranks_from_scores(const float* __restrict__ pos,
+                                                           const float* __restrict__ cand, int64_t n_row,
+                                                           int64_t n_cand, int64_t ld, int mode, int worst_inf,
+                                                           float* __restrict__ rank) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (s >= n_row) return;
+    float p = pos[s];
+    if (p != p) p = -INFINITY;
+    const float* row = cand + s * ld;
+    float gt = 0.f, ge = 0.f;
+    for (int64_t j = lane; j < n_cand; j += 64) {
+        const float c = row[j];
+        gt += (c > p) ? 1.f : 0.f;
+        ge += (c >= p) ? 1.f : 0.f;
+    }
+    gt = wave_allreduce_sum(gt);
+    ge = wave_allreduce_sum(ge);
+    if (lane == 0) {
+        const float n = static_cast<float>(n_cand);
+        float better;
+        bool worst;
+        if (mode == 0) { better = gt; worst = gt == n; }
+        else if (mode == 1) { better = ge; worst = ge == n; }
+        else { better = 0.5f * (gt + ge); worst = (gt == n) || (ge == n); }
+        rank[s] = (worst_inf && worst) ? INFINITY : 1.f + better;
+    }
+}
+
+// Rank from ordered candidate ids (reference metric.py:184-217): position (1-based)
+// of the ground truth in the list, else n + 1 (or +inf).
+__global__ __launch_bounds__(256) void k_ranks_from_indices(const int64_t* __restrict__ truth,
+                                                            const int64_t* __restrict__ cand, int64_t n_row,
+                                                            int64_t n_cand, int worst_inf,
+                                                            float* __restrict__ rank) {
+    const int64_t s = blockIdx.x * 256ll + threadIdx.x;
+    if (s >= n_row) return;
+    const int64_t t = truth[s];
+    float r = worst_inf ? INFINITY : static_cast<float>(n_cand + 1);
+    for (int64_t j = n_cand - 1; j >= 0; --j)
+        if (cand[s * n_cand + j] == t) r = static_cast<float>(j + 1);
+    rank[s] = r;
+}
+
 // fixed-order sum of row_loss -> loss[0]
 __global__ __launch_bounds__(1024) void k_sum_rows(const float* __restrict__ row_loss, int64_t n,
                                                    float* __restrict__ loss) {
@@ -204,4 +252,26 @@ extern "C" int bess_loss_fwd_bwd(const bess_loss_desc* l, const float* pos, cons
     if (int e = check_launch("loss rows")) return e;
     k_sum_rows<<<1, 1024, 0, st>>>(row_loss, n_triple, loss);
     return check_launch("loss sum");
+}
+
+extern "C" int bess_ranks_from_scores(const float* pos, const float* cand, int64_t n_row, int64_t n_cand,
+                                      int64_t ld, int32_t mode, int32_t worst_rank_infty, float* rank,
+                                      void* stream) {
+    BESS_REQUIRE(n_row >= 0 && n_cand > 0 && ld >= n_cand, "ranks_from_scores: bad sizes");
+    BESS_REQUIRE(mode >= 0 && mode <= 2, "ranks_from_scores: mode must be 0 (optimistic), 1 (pessimistic), 2 (average)");
+    if (n_row == 0) return BESS_OK;
+    BESS_REQUIRE(pos && cand && rank, "ranks_from_scores: NULL pointer");
+    k_ranks_from_scores<<<static_cast<unsigned>(ceil_div(n_row, 4)), 256, 0, as_stream(stream)>>>(
+        pos, cand, n_row, n_cand, ld, mode, worst_rank_infty, rank);
+    return check_launch("ranks_from_scores");
+}
+
+extern "C" int bess_ranks_from_indices(const int64_t* ground_truth, const int64_t* candidates, int64_t n_row,
+                                       int64_t n_cand, int32_t worst_rank_infty, float* rank, void* stream) {
+    BESS_REQUIRE(n_row >= 0 && n_cand > 0, "ranks_from_indices: bad sizes");
+    if (n_row == 0) return BESS_OK;
+    BESS_REQUIRE(ground_truth && candidates && rank, "ranks_from_indices: NULL pointer");
+    k_ranks_from_indices<<<static_cast<unsigned>(ceil_div(n_row, 256)), 256, 0, as_stream(stream)>>>(
+        ground_truth, candidates, n_row, n_cand, worst_rank_infty, rank);
+    return check_launch("ranks_from_indices");
 }

@@ -202,6 +202,28 @@ int bess_loss_fwd_bwd(const bess_loss_desc* l, const float* pos, const float* ne
                       float* loss, float* d_pos, float* d_neg, int64_t ld_dneg,
                       void* stream);
 
+/* next-1 / K11 - streaming top-k (reference bess.py:771-822 loop body, 889-894):
+ * merge the n_col candidates of every row into its running list of the kk best
+ * (best_score / best_id [n_row, kk], sorted by descending score, in place).
+ * Candidate j of row r has score scores[r*ld + j] (+ BAD_NEGATIVE_SCORE where
+ * mask says padding) and id ids[(ids_rows == 1 ? 0 : r)*n_col + j], or
+ * id_base + j when ids == NULL.  kk <= 64.  Earlier entries win ties. */
+int bess_topk_update(const float* scores, int64_t n_row, int64_t n_col, int64_t ld,
+                     const int32_t* ids, int64_t ids_rows, int32_t id_base,
+                     const uint8_t* mask, int64_t mask_rows, float* best_score,
+                     int32_t* best_id, int32_t kk, void* stream);
+
+/* next-2 - prediction ranks (reference metric.py:129-217), fp32 ranks:
+ * from scores: 1 + #{cand[s, j] better than pos[s]}, mode 0 optimistic ('>'),
+ * 1 pessimistic ('>='), 2 average; from ordered int64 candidate ids: 1-based
+ * position of ground_truth[s], else n_cand + 1 (or +inf with worst_rank_infty). */
+int bess_ranks_from_scores(const float* pos, const float* cand, int64_t n_row,
+                           int64_t n_cand, int64_t ld, int32_t mode,
+                           int32_t worst_rank_infty, float* rank, void* stream);
+int bess_ranks_from_indices(const int64_t* ground_truth, const int64_t* candidates,
+                            int64_t n_row, int64_t n_cand, int32_t worst_rank_infty,
+                            float* rank, void* stream);
+
 /* K9 - sparse scatter-add, backward of K1 (autograd index_put_(accumulate)):
  *   dst[idx[i], :] += scale * src[i, :]     (f32 atomics, duplicates allowed)
  * dst is f32 [*, width]. */

@@ -17,6 +17,9 @@ The fixtures pin, against the reference itself:
   loss.npz              LogSigmoid/MarginRanking/SampledSoftmaxCE + grads (loss.py)
   bess.npz              {EmbeddingMoving,ScoreMoving}BessKGE.forward, n_shard in
                         {1,2,4}, h/t/ht, flat / per-triple, loss, augment, grads (bess.py)
+  metric.npz            Evaluation ranks / metrics                       (metric.py:74-273)
+  topk.npz              TopKQueryBessKGE.forward (+ Evaluation)          (bess.py:606-921)
+  allscores.npz         AllScoresBESS.forward, every window step         (bess.py:924-1062)
 """
 
 import copy
@@ -38,7 +41,12 @@ from besskge.batch_sampler import (  # noqa: E402
     RandomShardedBatchSampler,
     RigidShardedBatchSampler,
 )
-from besskge.bess import EmbeddingMovingBessKGE, ScoreMovingBessKGE  # noqa: E402
+from besskge.bess import (  # noqa: E402
+    AllScoresBESS,
+    EmbeddingMovingBessKGE,
+    ScoreMovingBessKGE,
+    TopKQueryBessKGE,
+)
 from besskge.dataset import KGDataset  # noqa: E402
 from besskge.embedding import (  # noqa: E402
     initialize_entity_embedding,
@@ -49,7 +57,9 @@ from besskge.loss import (  # noqa: E402
     MarginRankingLoss,
     SampledSoftmaxCrossEntropyLoss,
 )
+from besskge.metric import Evaluation  # noqa: E402
 from besskge.negative_sampler import (  # noqa: E402
+    PlaceholderNegativeSampler,
     RandomShardedNegativeSampler,
     TripleBasedShardedNegativeSampler,
     TypeBasedShardedNegativeSampler,
@@ -624,6 +634,151 @@ def gen_bess() -> None:
     put("bess", "cases", np.array(names))
 
 
+
+# --------------------------------------------------------------------------- #
+def gen_metric() -> None:
+    """Evaluation.ranks_from_scores / ranks_from_indices / metrics (metric.py:74-273)."""
+    fix = "metric"
+    torch.manual_seed(4)
+    pos = torch.randn(37) * 2
+    cand = torch.randn(37, 23) * 2
+    cand[:5, :7] = pos[:5, None]  # ties
+    cand[5] = pos[5] + 1.0  # everything better
+    pos[6] = float("nan")
+    truth = torch.randint(40, (37,))
+    ids = torch.stack([torch.randperm(40)[:9] for _ in range(37)])
+    mask = torch.rand(37) > 0.3
+    for k, v in dict(pos=pos, cand=cand, truth=truth, ids=ids, mask=mask).items():
+        put(fix, k, v)
+    for mode in ["optimistic", "pessimistic", "average"]:
+        for winf in [False, True]:
+            for red in ["none", "sum"]:
+                ev = Evaluation(["mrr", "hits@1", "hits@5", "hits@10"], mode=mode, worst_rank_infty=winf,
+                                reduction=red, return_ranks=True)
+                key = f"{mode}_{int(winf)}_{red}_"
+                r1 = ev.ranks_from_scores(pos.clone(), cand)
+                r2 = ev.ranks_from_indices(truth, ids)
+                put(fix, key + "ranks_scores", r1)
+                put(fix, key + "ranks_indices", r2)
+                put(fix, key + "names", np.array(list(ev.metrics.keys())))
+                put(fix, key + "stacked_scores", ev.stacked_metrics_from_ranks(r1, mask))
+                put(fix, key + "stacked_indices", ev.stacked_metrics_from_ranks(r2))
+
+
+def _replica_modules(model: Any, score_fn: Any, ent: torch.Tensor, rel: torch.Tensor, n_shard: int) -> List[Any]:
+    reps = []
+    for r in range(n_shard):
+        m = copy.copy(model)
+        m._modules = dict(model._modules)
+        sf = copy.copy(score_fn)
+        sf._parameters = dict(score_fn._parameters)
+        sf.entity_embedding = torch.nn.Parameter(ent[r].clone())
+        sf.relation_embedding = torch.nn.Parameter(rel.clone())
+        m.score_fn = sf
+        m._parameters = dict(model._parameters)
+        m.entity_embedding = sf.entity_embedding
+        reps.append(m)
+    return reps
+
+
+def run_query_case(case: str, kind: str, scorer: str, p: int, n_shard: int, scheme: str, cand_kind: str,
+                   k: int = 5, window: int = 7) -> None:
+    """TopKQueryBessKGE (kind "topk") or AllScoresBESS (kind "all") on h_shard / t_shard queries."""
+    fix = "topk" if kind == "topk" else "allscores"
+    seed = 1234
+    n_entity, n_rel, n_triple, d, bps, shard_bs, n_cand = 150, 5, 300, 8, 2, 12, 160
+    rng = np.random.default_rng(zlib.crc32(case.encode()))
+    torch.manual_seed(zlib.crc32(case.encode()) % (2**31))
+    W, Wr = widths(scorer, d)
+    sharding = Sharding.create(n_entity, n_shard, seed=seed)
+    ent = torch.randn(n_shard, sharding.max_entity_per_shard, W)
+    rel = torch.randn(n_rel, Wr)
+    triples = np.stack([rng.integers(n_entity, size=n_triple), rng.integers(n_rel, size=n_triple),
+                        rng.integers(n_entity, size=n_triple)], axis=1)
+    flat = cand_kind in ("all", "flat")
+    outer = 1 if flat else n_triple
+    nh = rng.integers(n_entity, size=(outer, n_cand)).astype(np.int32)
+    nt = rng.integers(n_entity, size=(outer, n_cand)).astype(np.int32)
+    ds = make_dataset(n_entity, n_rel, triples, None, nh, nt, part="test")
+    mode = "h_shard" if scheme == "t" else "t_shard"
+    pts = PartitionedTripleSet.create_from_dataset(ds, "test", sharding, partition_mode=mode)
+    if cand_kind == "all":
+        ns = PlaceholderNegativeSampler(corruption_scheme=scheme, seed=seed)
+    else:
+        ns = TripleBasedShardedNegativeSampler(pts.neg_heads, pts.neg_tails, sharding, corruption_scheme=scheme,
+                                               seed=seed, return_sort_idx=False, mask_on_gather=True)
+    bs = RigidShardedBatchSampler(partitioned_triple_set=pts, negative_sampler=ns, shard_bs=shard_bs,
+                                  batches_per_step=bps, seed=seed, duplicate_batch=False, return_triple_idx=True)
+    score_fn = scorer_factory(scorer, p, flat, sharding, n_rel, d, ent, rel)
+    if kind == "topk":
+        ev = Evaluation(["mrr", "hits@1", "hits@5"], mode="average", reduction="none", return_ranks=True)
+        model = TopKQueryBessKGE(k=k, candidate_sampler=ns, score_fn=score_fn, evaluation=ev, return_scores=True,
+                                 window_size=window)
+    else:
+        model = AllScoresBESS(ns, score_fn, window_size=window)
+    batch = bs[next(iter(bs.get_dataloader_sampler(shuffle=False)))]
+    p_ = case + "_"
+    meta = dict(n_entity=n_entity, n_rel=n_rel, n_triple=n_triple, d=d, bps=bps, shard_bs=shard_bs, n_cand=n_cand,
+                n_shard=n_shard, norm=p, k=k, window=window, flat=int(flat))
+    put(fix, p_ + "meta_keys", np.array(list(meta.keys())))
+    put(fix, p_ + "meta_vals", np.array(list(meta.values())))
+    put(fix, p_ + "strs", np.array([kind, scorer, scheme, cand_kind]))
+    put(fix, p_ + "entity_table", ent)
+    put(fix, p_ + "relation_table", rel)
+    put(fix, p_ + "triples", triples)
+    put(fix, p_ + "neg_heads", nh)
+    put(fix, p_ + "neg_tails", nt)
+    put(fix, p_ + "triple_sort_idx", pts.triple_sort_idx)
+    for kk, v in batch.items():
+        put(fix, p_ + "batch_" + kk, v)
+    reps = _replica_modules(model, score_fn, ent, rel, n_shard)
+    keys = ["relation", "head", "tail", "negative", "triple_mask", "negative_mask"]
+    outs: Dict[str, List[Any]] = {}
+    n_step = model.n_step if kind == "all" else 1
+    for it in range(bps):
+        for step in range(n_step):
+
+            def fn(r: int) -> Dict[str, torch.Tensor]:
+                kw = {kk: batch[kk][it, r].unsqueeze(0) for kk in keys if kk in batch}
+                if kind == "all":
+                    kw = {kk: v for kk, v in kw.items() if kk in ("relation", "head", "tail")}
+                    kw.pop("tail" if scheme == "t" else "head", None)
+                    out = reps[r](step=torch.tensor([[step]], dtype=torch.int32), **kw)
+                    return dict(scores=out.detach().clone())
+                out = reps[r](**kw)
+                return {kk: v.detach().clone() for kk, v in out.items() if isinstance(v, torch.Tensor)}
+
+            res = ref_shim.run_replicas(n_shard, fn)
+            for kk in res[0].keys():
+                outs.setdefault(kk, []).append(torch.stack([res[r][kk] for r in range(n_shard)]))
+    for kk, v in outs.items():
+        put(fix, p_ + "out_" + kk, torch.stack(v).reshape(bps, n_step, n_shard, *v[0].shape[1:]) if kind == "all"
+            else torch.stack(v))
+
+
+def gen_topk() -> None:
+    names = []
+    for scorer, p in [("DistMult", 0), ("TransE", 1), ("ComplEx", 0), ("RotatE", 2)]:
+        for scheme in ["h", "t"]:
+            for cand in ["all", "flat", "pt"]:
+                for n in ([1, 4] if scorer == "DistMult" else [2]):
+                    name = f"topk_{scorer}{p}_{scheme}_{cand}_n{n}"
+                    run_query_case(name, "topk", scorer, p, n, scheme, cand)
+                    names.append(name)
+    put("topk", "cases", np.array(names))
+
+
+def gen_allscores() -> None:
+    names = []
+    for scorer, p in [("ComplEx", 0), ("TransE", 1)]:
+        for scheme in ["h", "t"]:
+            for n in [1, 4]:
+                name = f"all_{scorer}{p}_{scheme}_n{n}"
+                run_query_case(name, "all", scorer, p, n, scheme, "all", window=13)
+                names.append(name)
+    put("allscores", "cases", np.array(names))
+
+
 def main() -> None:
     only = sys.argv[1:]
     gens = dict(
@@ -635,6 +790,9 @@ def main() -> None:
         scoring=gen_scoring,
         loss=gen_loss,
         bess=gen_bess,
+        metric=gen_metric,
+        topk=gen_topk,
+        allscores=gen_allscores,
     )
     for name, g in gens.items():
         if only and name not in only:

@@ -120,9 +120,17 @@ def install() -> types.ModuleType:
     class DataLoader:  # noqa: D401 - stub
         pass
 
+    def for_loop(count: int, body: Callable[..., Any], inputs: List[torch.Tensor]) -> List[torch.Tensor]:
+        # poptorch.for_loop(n, body, inputs): feed the outputs back n times (bess.py:845)
+        state = list(inputs)
+        for _ in range(count):
+            state = list(body(*state))
+        return state
+
     poptorch.Options = Options  # type: ignore
     poptorch.DataLoader = DataLoader  # type: ignore
     poptorch.identity_loss = lambda x, reduction="none": x  # type: ignore
+    poptorch.for_loop = for_loop  # type: ignore
     sys.modules["poptorch"] = poptorch
 
     ogb = types.ModuleType("ogb")

@@ -37,11 +37,12 @@ def close(got, want, rtol=RTOL, atol=ATOL, scale=None):
     torch.testing.assert_close(got, want, rtol=rtol, atol=atol)
 
 
-def make_scorer(name, p, sharing, n_rel, d, ent, rel, dev, dtype=torch.float32):
+def make_scorer(name, p, sharing, n_rel, d, ent, rel, dev, dtype=torch.float32, sharding=None):
     from besskge.scoring import ComplEx, DistMult, RotatE, TransE
     from besskge.sharding import Sharding
 
-    sharding = Sharding.create(ent.shape[0] * ent.shape[1], ent.shape[0], seed=0)
+    if sharding is None:  # only n_shard matters for the training / scoring step
+        sharding = Sharding.create(ent.shape[0] * ent.shape[1], ent.shape[0], seed=0)
     if name == "TransE":
         fn = TransE(sharing, p, sharding, n_rel, d, ent, rel)
     elif name == "RotatE":

@@ -1,0 +1,271 @@
+"""next-1 / next-2 on the GPU: TopKQueryBessKGE, AllScoresBESS, AllScoresPipeline
+and Evaluation against vectors produced by the reference (tests/golden/{topk,
+allscores,metric}.npz), the reference's hand-computed metric answers
+(reference tests/test_metric.py:14-75) and the unsharded CPU oracle
+(the comparison the reference's tests/test_bess.py:278-423 and
+tests/test_pipeline.py:42-206 make)."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import kge  # noqa: E402
+
+from conftest import load_golden  # noqa: E402
+from test_hip_parity import make_scorer  # noqa: E402
+from test_oracle import T  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+# ------------------------------------------------------------------ metrics ---
+@pytest.mark.parametrize("worst_rank_infty", [True, False])
+def test_metric_known_answers(dev, worst_rank_infty):
+    from besskge.metric import Evaluation
+
+    names = ["mrr", "hits@1", "hits@5"]
+    pos = torch.tensor([2.1, 5.0, 5.9, 2.0], device=dev)
+    neg = torch.tensor([[2.1, 3.1, 2.1, 5.2, 8.4], [9.8, 5.0, 1.0, 3.2, 5.0], [4.0, 2.3, 5.9, 3.1, 4.5],
+                        [4.0, 2.3, 5.9, 3.1, 4.5]], device=dev)
+    worst = 0.0 if worst_rank_infty else 1.0 / 6
+    res = Evaluation(names, mode="pessimistic", worst_rank_infty=worst_rank_infty)
+    out = res.dict_metrics_from_ranks(res.ranks_from_scores(pos.clone(), neg))
+    torch.testing.assert_close(out["hits@1"].cpu(), torch.tensor([0.0, 0.0, 0.0, 0.0]))
+    torch.testing.assert_close(out["hits@5"].cpu(), torch.tensor([0.0, 1.0, 1.0, 0.0]))
+    torch.testing.assert_close(out["mrr"].cpu(), torch.tensor([worst, 1.0 / 4, 1.0 / 2, worst]))
+    res = Evaluation(names, mode="optimistic", worst_rank_infty=worst_rank_infty)
+    out = res.dict_metrics_from_ranks(res.ranks_from_scores(pos.clone(), neg))
+    torch.testing.assert_close(out["hits@1"].cpu(), torch.tensor([0.0, 0.0, 1.0, 0.0]))
+    torch.testing.assert_close(out["hits@5"].cpu(), torch.tensor([1.0, 1.0, 1.0, 0.0]))
+    torch.testing.assert_close(out["mrr"].cpu(), torch.tensor([1.0 / 4, 1.0 / 2, 1.0, worst]))
+    truth = torch.tensor([6, 0, 2], device=dev)
+    cand = torch.tensor([[6, 1, 45, 33, 28], [5, 2, 12, 0, 44], [27, 9, 1, 6, 17]], device=dev)
+    res = Evaluation(names, worst_rank_infty=worst_rank_infty)
+    out = res.dict_metrics_from_ranks(res.ranks_from_indices(truth, cand))
+    torch.testing.assert_close(out["hits@1"].cpu(), torch.tensor([1.0, 0.0, 0.0]))
+    torch.testing.assert_close(out["hits@5"].cpu(), torch.tensor([1.0, 1.0, 0.0]))
+    torch.testing.assert_close(out["mrr"].cpu(), torch.tensor([1.0, 1.0 / 4, worst]))
+
+
+@pytest.mark.parametrize("mode", ["optimistic", "pessimistic", "average"])
+@pytest.mark.parametrize("winf", [False, True])
+@pytest.mark.parametrize("red", ["none", "sum"])
+def test_metric_golden(dev, mode, winf, red):
+    from besskge.metric import Evaluation
+
+    g = load_golden("metric")
+    ev = Evaluation(["mrr", "hits@1", "hits@5", "hits@10"], mode=mode, worst_rank_infty=winf, reduction=red,
+                    return_ranks=True)
+    key = f"{mode}_{int(winf)}_{red}_"
+    assert list(ev.metrics.keys())[:3] == [str(x) for x in g[key + "names"]][:3]
+    order = [list(ev.metrics.keys()).index(str(x)) for x in g[key + "names"]]
+    r1 = ev.ranks_from_scores(T(g["pos"]).to(dev), T(g["cand"]).to(dev))
+    r2 = ev.ranks_from_indices(T(g["truth"]).to(dev), T(g["ids"]).to(dev))
+    torch.testing.assert_close(r1.cpu(), T(g[key + "ranks_scores"]))
+    torch.testing.assert_close(r2.cpu(), T(g[key + "ranks_indices"]))
+    s1 = ev.stacked_metrics_from_ranks(r1, T(g["mask"]).to(dev))
+    s2 = ev.stacked_metrics_from_ranks(r2)
+    torch.testing.assert_close(s1.cpu()[:, order], T(g[key + "stacked_scores"]))
+    torch.testing.assert_close(s2.cpu()[:, order], T(g[key + "stacked_indices"]))
+
+
+# ------------------------------------------------------- streaming top-k -----
+@pytest.mark.parametrize("rows,L,kk", [(1, 1, 1), (7, 50, 6), (130, 1000, 11), (5, 4097, 64), (33, 63, 20)])
+def test_topk_update_matches_torch(dev, rows, L, kk):
+    from besskge import _native as nat
+
+    gen = torch.Generator().manual_seed(rows * L + kk)
+    best_s = torch.full((rows, kk), -50000.0)
+    best_i = torch.full((rows, kk), -1, dtype=torch.int32)
+    all_s, all_i = [best_s.clone()], [best_i.clone()]
+    bs, bi = best_s.to(dev), best_i.to(dev)
+    base = 0
+    for w in range(3):  # three windows merged one after the other
+        sc = torch.randn(rows, L, generator=gen) * 10
+        ids = (torch.randperm(L, generator=gen)[None, :] + base).to(torch.int32) if w == 1 else None
+        mask = (torch.rand(rows, L, generator=gen) > 0.2) if w == 2 else None
+        nat.topk_update(sc.to(dev), bs, bi, ids=None if ids is None else ids.to(dev), id_base=base,
+                        mask=None if mask is None else mask.to(dev))
+        eff = sc if mask is None else sc + (-50000.0) * (~mask).float()
+        all_s.append(eff)
+        all_i.append((torch.arange(L, dtype=torch.int32)[None, :] + base).expand(rows, L) if ids is None
+                     else ids.expand(rows, L))
+        base += L
+    cat_s, cat_i = torch.cat(all_s, dim=1), torch.cat(all_i, dim=1)
+    want = torch.topk(cat_s, kk, dim=1)
+    torch.testing.assert_close(bs.cpu(), want.values)
+    valid = want.values > -40000  # ids of the (tied) sentinel / masked tail are unspecified
+    assert torch.equal(bi.cpu()[valid], torch.take_along_dim(cat_i, want.indices, dim=1)[valid])
+
+
+# ------------------------------------------------------------- goldens ------
+def load_query_case(fix, case):
+    g = load_golden(fix)
+    p = case + "_"
+    meta = dict(zip((str(k) for k in g[p + "meta_keys"]), (int(v) for v in g[p + "meta_vals"])))
+    kind, scorer, scheme, cand = (str(s) for s in g[p + "strs"])
+    batch = {k[len(p + "batch_"):]: T(g[k]) for k in g.files if k.startswith(p + "batch_")}
+    outs = {k[len(p + "out_"):]: T(g[k]) for k in g.files if k.startswith(p + "out_")}
+    return dict(meta=meta, scorer=scorer, scheme=scheme, cand=cand, batch=batch, outs=outs,
+                table=T(g[p + "entity_table"]), rel=T(g[p + "relation_table"]), triples=g[p + "triples"],
+                neg_heads=g[p + "neg_heads"], neg_tails=g[p + "neg_tails"], sort_idx=g[p + "triple_sort_idx"])
+
+
+def query_cases(fix):
+    return [str(c) for c in load_golden(fix)["cases"]]
+
+
+def candidate_sampler(c):
+    from besskge.negative_sampler import PlaceholderNegativeSampler, TripleBasedShardedNegativeSampler
+
+    if c["cand"] == "all":
+        return PlaceholderNegativeSampler(corruption_scheme=c["scheme"])
+    ns = object.__new__(TripleBasedShardedNegativeSampler)
+    ns.corruption_scheme, ns.local_sampling, ns.mask_on_gather = c["scheme"], False, True
+    ns.flat_negative_format = c["cand"] == "flat"
+    return ns
+
+
+@pytest.mark.parametrize("case", query_cases("topk"))
+def test_topk_query_golden(dev, case):
+    from besskge import runtime
+    from besskge.bess import TopKQueryBessKGE
+    from besskge.metric import Evaluation
+
+    c = load_query_case("topk", case)
+    m = c["meta"]
+    n, bps = m["n_shard"], m["bps"]
+    flat = bool(m["flat"])
+    from besskge.sharding import Sharding
+
+    fn = make_scorer(c["scorer"], m["norm"], flat, m["n_rel"], m["d"], c["table"], c["rel"], torch.device("cpu"),
+                     sharding=Sharding.create(m["n_entity"], n, seed=1234))
+    ev = Evaluation(["mrr", "hits@1", "hits@5"], mode="average", reduction="none", return_ranks=True)
+    model = TopKQueryBessKGE(k=m["k"], candidate_sampler=candidate_sampler(c), score_fn=fn, evaluation=ev,
+                             return_scores=True, window_size=m["window"])
+    runner = runtime.inference_model(model, runtime.Options(device_iterations=bps), device=dev)
+    keys = ("relation", "head", "tail", "negative", "triple_mask", "negative_mask")
+    res = runner(**{k: c["batch"][k].flatten(end_dim=1) for k in keys if k in c["batch"]})
+    want_ids = c["outs"]["topk_global_id"].reshape(bps * n, -1, m["k"])
+    want_sc = c["outs"]["topk_scores"].reshape(bps * n, -1, m["k"])
+    got_ids = res["topk_global_id"].cpu().reshape(bps * n, -1, m["k"])
+    got_sc = res["topk_scores"].float().cpu().reshape(bps * n, -1, m["k"])
+    torch.testing.assert_close(got_sc, want_sc, rtol=1e-4, atol=1e-4)
+    # ids must agree wherever neighbouring scores are not (numerically) tied
+    gap = (want_sc[..., :-1] - want_sc[..., 1:]).abs()
+    clear = torch.ones_like(want_sc, dtype=torch.bool)
+    clear[..., :-1] &= gap > 1e-3
+    clear[..., 1:] &= gap > 1e-3
+    assert torch.equal(got_ids[clear].long(), want_ids[clear].long())
+    # (candidate lists contain duplicate entities: exact ties, but of equal ids)
+    assert float((got_ids.long() == want_ids.long()).float().mean()) > 0.98
+    torch.testing.assert_close(res["ranks"].cpu().reshape(-1), c["outs"]["ranks"].reshape(-1))
+    torch.testing.assert_close(res["metrics"].cpu().reshape(bps * n, 3, -1),
+                               c["outs"]["metrics"].reshape(bps * n, 3, -1))
+
+
+@pytest.mark.parametrize("case", query_cases("allscores"))
+def test_all_scores_golden(dev, case):
+    from besskge import runtime
+    from besskge.bess import AllScoresBESS
+
+    c = load_query_case("allscores", case)
+    m = c["meta"]
+    n, bps = m["n_shard"], m["bps"]
+    from besskge.sharding import Sharding
+
+    fn = make_scorer(c["scorer"], m["norm"], True, m["n_rel"], m["d"], c["table"], c["rel"], torch.device("cpu"),
+                     sharding=Sharding.create(m["n_entity"], n, seed=1234))
+    model = AllScoresBESS(candidate_sampler(c), fn, window_size=m["window"])
+    runner = runtime.inference_model(model, runtime.Options(device_iterations=bps), device=dev)
+    known = "tail" if c["scheme"] == "h" else "head"
+    inp = {k: c["batch"][k].flatten(end_dim=1) for k in ("relation", known)}
+    want = c["outs"]["scores"]  # [bps, n_step, n, shard_bs, n * ws]
+    assert want.shape[1] == model.n_step
+    for step in range(model.n_step):
+        got = runner(step=torch.full((bps * n, 1), step, dtype=torch.int32), **inp)
+        torch.testing.assert_close(got.float().cpu().reshape(bps, n, *want.shape[3:]), want[:, step], rtol=1e-4, atol=1e-4)
+
+
+# --------------------------------------- pipeline vs the unsharded CPU oracle --
+@pytest.mark.parametrize("scheme", ["h", "t"])
+@pytest.mark.parametrize("filtered", [False, True])
+def test_all_scores_pipeline_vs_oracle(dev, scheme, filtered):
+    """Mirror of reference tests/test_pipeline.py:42-206 (ComplEx, 4 shards)."""
+    from besskge.batch_sampler import RigidShardedBatchSampler
+    from besskge.dataset import KGDataset
+    from besskge.metric import Evaluation
+    from besskge.negative_sampler import PlaceholderNegativeSampler
+    from besskge.pipeline import AllScoresPipeline
+    from besskge.scoring import ComplEx
+    from besskge.sharding import PartitionedTripleSet, Sharding
+
+    seed, n_entity, n_rel, n_shard, n_triple, d = 1234, 5000, 50, 4, 640, 64
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    sharding = Sharding.create(n_entity, n_shard, seed=seed)
+    ent = torch.randn(n_shard, sharding.max_entity_per_shard, 2 * d)
+    rel = torch.randn(n_rel, 2 * d)
+    triples = np.stack([rng.integers(n_entity, size=n_triple), rng.integers(n_rel, size=n_triple),
+                        rng.integers(n_entity, size=n_triple)], axis=1)
+    extra = np.stack([rng.integers(n_entity, size=3000), rng.integers(n_rel, size=3000),
+                      rng.integers(n_entity, size=3000)], axis=1)
+    extra[:600, :2] = triples[rng.integers(n_triple, size=600), :2]  # some share (h, r) with test queries
+    extra[600:1200, 1:] = triples[rng.integers(n_triple, size=600), 1:]
+    ds = KGDataset(n_entity=n_entity, n_relation_type=n_rel, triples={"test": triples},
+                   original_triple_ids={"test": np.arange(n_triple)})
+    mode = "h_shard" if scheme == "t" else "t_shard"
+    pts = PartitionedTripleSet.create_from_dataset(ds, "test", sharding, partition_mode=mode)
+    fn = ComplEx(True, sharding, n_rel, d, ent, rel)
+    bs = RigidShardedBatchSampler(pts, PlaceholderNegativeSampler(scheme), shard_bs=80, batches_per_step=2,
+                                  seed=seed, return_triple_idx=True)
+    ev = Evaluation(["mrr", "hits@10"], mode="average", reduction="sum", return_ranks=True)
+    cand_ents = np.sort(rng.choice(n_entity, size=4000, replace=False)) if filtered else None
+    pipe = AllScoresPipeline(bs, scheme, fn, evaluation=ev, filter_triples=[extra] if filtered else None,
+                             candidate_ents=cand_ents, return_scores=True, return_topk=True, k=10, window_size=500,
+                             device=dev)
+    out = pipe()
+    order = pts.triple_sort_idx[out["triple_idx"].numpy()]
+    tr = triples[order]
+    flat = ent[sharding.entity_to_shard, sharding.entity_to_idx]
+    if scheme == "t":
+        full = kge.score_candidates("ComplEx", 0, True, "t", flat[tr[:, 0]], rel, T(tr[:, 1]), flat[None])
+        truth = tr[:, 2]
+    else:
+        full = kge.score_candidates("ComplEx", 0, True, "h", flat[tr[:, 2]], rel, T(tr[:, 1]), flat[None])
+        truth = tr[:, 0]
+    want = full.clone()
+    rows = torch.arange(len(tr))
+    true_sc = want[rows, T(truth)].clone()
+    if filtered:
+        off = np.setdiff1d(np.arange(n_entity), cand_ents)
+        want[:, T(off)] = -torch.inf
+        true_sc = want[rows, T(truth)].clone()
+        col, other = (0, 2) if scheme == "t" else (2, 0)
+        for i, (a, r_) in enumerate(zip(tr[:, col], tr[:, 1])):
+            hit = extra[(extra[:, col] == a) & (extra[:, 1] == r_)][:, other]
+            want[i, T(hit)] = -torch.inf
+    # reference quirk kept: Evaluation.ranks_from_scores replaces non-finite positive scores *in place*
+    # (metric.py:152, `nan_to_num_(-inf)` also maps -inf to the lowest finite float), and the pipeline
+    # writes that tensor back into the returned scores (pipeline.py:266-271)
+    want[rows, T(truth)] = torch.nan_to_num(true_sc, neginf=torch.finfo(torch.float32).min)
+    torch.testing.assert_close(out["scores"], want, rtol=1e-4, atol=1e-3)
+    masked = want.clone()
+    masked[rows, T(truth)] = -torch.inf
+    ts = torch.nan_to_num(true_sc, neginf=torch.finfo(torch.float32).min)[:, None]  # same quirk
+    gt = (masked > ts).sum(-1).float()
+    ge = (masked >= ts).sum(-1).float()
+    want_rank = 1 + 0.5 * (gt + ge)
+    assert float((out["ranks"] != want_rank).float().mean()) < 0.01  # rank flips only at numerical ties
+    torch.testing.assert_close(out["metrics"]["mrr"], (1 / want_rank).sum(), rtol=1e-3, atol=1e-3)
+    top = torch.topk(want, 10, dim=-1)
+    finite = torch.isfinite(top.values).all(-1)
+    agree = (out["topk_global_id"][finite] == top.indices[finite]).float().mean()
+    assert float(agree) > 0.99
+    assert set(out["metrics_avg"]) == {"mrr", "hits@10"} and 0 < float(out["metrics_avg"]["mrr"]) <= 1
