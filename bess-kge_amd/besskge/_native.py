@@ -719,7 +719,7 @@ def topk_update(scores: torch.Tensor, best_score: torch.Tensor, best_id: torch.T
                 or not mask.is_contiguous():
             raise ValueError("topk_update: mask must be a contiguous bool [1 | rows, L] tensor")
         mp, mr = mask.data_ptr(), int(mask.shape[0])
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _Timed("bess_topk_update", dev):
         rc = load().bess_topk_update(scores.data_ptr(), R, L, L, ip, ir, int(id_base), mp, mr,
                                      best_score.data_ptr(), best_id.data_ptr(), kk, _stream(dev))
     _check(rc, "bess_topk_update")

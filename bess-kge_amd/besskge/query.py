@@ -162,9 +162,21 @@ class TopKQueryBessKGE(_QueryModule):
             raise RuntimeError("forward() steps a single replica; use forward_replicas()")
         return self.forward_replicas([{k: v for k, v in b.items() if v is not None}])[0]
 
+    def _sharding_on(self, dev: torch.device):
+        """(shard_counts, shard_and_idx_to_entity) as int32 device tensors, uploaded once."""
+        cache = self.__dict__.setdefault("_sharding_cache", {})
+        if dev not in cache:
+            cache[dev] = (
+                torch.from_numpy(np.asarray(self.sharding.shard_counts)).to(device=dev, dtype=torch.int32),
+                torch.from_numpy(np.asarray(self.sharding.shard_and_idx_to_entity)).to(device=dev, dtype=torch.int32),
+            )
+        return cache[dev]
+
     def _tile(self, n_query: int) -> int:
-        # score tile [n_query, tile] of about 32 MiB, at least the reference's window
-        return max(self.window_size, min(1 << 16, max(64, (8 << 20) // max(1, n_query))))
+        # score tile [n_query, tile] of up to 1 GiB (few, large launches: writing and
+        # re-reading the tile costs 8 B per score, a few % of the scoring itself), at
+        # least the reference's window
+        return max(self.window_size, max(64, (256 << 20) // max(1, n_query)))
 
     def forward_replicas(self, batches: List[_Batch]) -> List[Dict[str, Any]]:
         group = self._group()
@@ -213,15 +225,12 @@ class TopKQueryBessKGE(_QueryModule):
         # per-query lists back to the query's shard (C6)
         back_s = group.all_to_all(best_s)
         back_i = group.all_to_all(best_i)
-        counts = torch.from_numpy(np.asarray(self.sharding.shard_counts))
-        to_global = torch.from_numpy(np.asarray(self.sharding.shard_and_idx_to_entity)).to(torch.int32)
         outs = []
         for b, s, i in zip(batches, back_s, back_i):
             dev = s.device
-            cnt = counts.to(device=dev, dtype=torch.int32)[:, None, None]
-            pad = i >= cnt  # padding rows of a shard (and the initial sentinel) never win
+            cnt, tg = self._sharding_on(dev)
+            pad = i >= cnt[:, None, None]  # padding rows of a shard (and the initial sentinel) never win
             s = s + BAD_NEGATIVE_SCORE * pad.to(s.dtype)
-            tg = to_global.to(dev)
             M = tg.shape[1]
             src = torch.arange(n, device=dev)[:, None, None].expand_as(i)
             gid = tg[src, i.clamp(max=M - 1).long()]  # [n, shard_bs, kk]

@@ -36,36 +36,49 @@ __global__ __launch_bounds__(256) void k_topk_update(const float* __restrict__ s
     const float* srow = scores + row * ld;
     const int32_t* irow = ids ? ids + (ids_rows == 1 ? 0 : row) * n_col : nullptr;
     const uint8_t* mrow = mask ? mask + (mask_rows == 1 ? 0 : row) * n_col : nullptr;
-    for (int64_t c0 = 0; c0 < n_col; c0 += 64) {
-        const int64_t j = c0 + lane;
-        float x = -INFINITY;
-        int32_t xi = 0;
-        if (j < n_col) {
-            x = srow[j];
-            if (mrow && mrow[j] == 0) x += BESS_BAD_NEGATIVE_SCORE;
-            xi = irow ? irow[j] : id_base + static_cast<int32_t>(j);
-        }
-        unsigned long long m = __ballot(x > tau);
-        while (m) {
-            const int l = __ffsll(static_cast<long long>(m)) - 1;
-            const float xv = __shfl(x, l, 64);
-            const int32_t iv = __shfl(xi, l, 64);
-            // entries that stay ahead of the newcomer (>=: earlier entries win ties)
-            const int pos = __popcll(__ballot(lane < kk && bs >= xv));
-            const float up_s = __shfl_up(bs, 1, 64);
-            const int32_t up_i = __shfl_up(bi, 1, 64);
-            if (lane < kk) {
-                if (lane > pos) {
-                    bs = up_s;
-                    bi = up_i;
-                } else if (lane == pos) {
-                    bs = xv;
-                    bi = iv;
-                }
+    // U chunks of 64 candidates are loaded back to back (U independent loads in
+    // flight per lane: the row is streamed, not pointer-chased), then examined
+    constexpr int U = 8;
+    for (int64_t c0 = 0; c0 < n_col; c0 += 64 * U) {
+        float xs[U];
+        int32_t xis[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = c0 + 64 * u + lane;
+            xs[u] = -INFINITY;
+            xis[u] = 0;
+            if (j < n_col) {
+                xs[u] = srow[j];
+                if (mrow && mrow[j] == 0) xs[u] += BESS_BAD_NEGATIVE_SCORE;
+                xis[u] = irow ? irow[j] : id_base + static_cast<int32_t>(j);
             }
-            tau = __shfl(bs, kk - 1, 64);
-            m &= ~(1ull << l);
-            m &= __ballot(x > tau);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float x = xs[u];
+            const int32_t xi = xis[u];
+            unsigned long long m = __ballot(x > tau);
+            while (m) {
+                const int l = __ffsll(static_cast<long long>(m)) - 1;
+                const float xv = __shfl(x, l, 64);
+                const int32_t iv = __shfl(xi, l, 64);
+                // entries that stay ahead of the newcomer (>=: earlier entries win ties)
+                const int pos = __popcll(__ballot(lane < kk && bs >= xv));
+                const float up_s = __shfl_up(bs, 1, 64);
+                const int32_t up_i = __shfl_up(bi, 1, 64);
+                if (lane < kk) {
+                    if (lane > pos) {
+                        bs = up_s;
+                        bi = up_i;
+                    } else if (lane == pos) {
+                        bs = xv;
+                        bi = iv;
+                    }
+                }
+                tau = __shfl(bs, kk - 1, 64);
+                m &= ~(1ull << l);
+                m &= __ballot(x > tau);
+            }
         }
     }
     if (lane < kk) {

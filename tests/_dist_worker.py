@@ -71,11 +71,50 @@ def bess(out_dir: str) -> None:
     np.savez(os.path.join(out_dir, f"bess_{r}.npz"), **out)
 
 
+def topk(out_dir: str) -> None:
+    """Distributed TopKQueryBessKGE / AllScoresBESS on golden cases (all ranks share the GPU)."""
+    from besskge import runtime
+    from besskge.bess import AllScoresBESS, TopKQueryBessKGE
+    from besskge.collectives import DistributedGroup
+    from besskge.sharding import Sharding
+    from test_hip_parity import make_scorer
+    from test_query import candidate_sampler, load_query_case
+
+    g = DistributedGroup()
+    n, r = g.n_shard, g.rank
+    dev = torch.device("cuda", 0)
+    out = {}
+    for spec in [c for c in os.environ["BESS_CASES"].split(",") if c]:
+        fix, case = spec.split(":")
+        c = load_query_case(fix, case)
+        m = c["meta"]
+        bps = m["bps"]
+        fn = make_scorer(c["scorer"], m["norm"], bool(m["flat"]), m["n_rel"], m["d"], c["table"], c["rel"],
+                         torch.device("cpu"), sharding=Sharding.create(m["n_entity"], n, seed=1234))
+        if fix == "topk":
+            model = TopKQueryBessKGE(k=m["k"], candidate_sampler=candidate_sampler(c), score_fn=fn, return_scores=True,
+                                     window_size=m["window"])
+            runner = runtime.inference_model(model, runtime.Options(device_iterations=bps), group=g, device=dev)
+            keys = ("relation", "head", "tail", "negative", "triple_mask", "negative_mask")
+            res = runner(**{k: c["batch"][k].flatten(end_dim=1) for k in keys if k in c["batch"]})
+            out[f"{case}_ids"] = res["topk_global_id"].cpu().numpy()
+            out[f"{case}_scores"] = res["topk_scores"].float().cpu().numpy()
+        else:
+            model = AllScoresBESS(candidate_sampler(c), fn, window_size=m["window"])
+            runner = runtime.inference_model(model, runtime.Options(device_iterations=bps), group=g, device=dev)
+            known = "tail" if c["scheme"] == "h" else "head"
+            inp = {k: c["batch"][k].flatten(end_dim=1) for k in ("relation", known)}
+            steps = [runner(step=torch.full((bps * n, 1), s, dtype=torch.int32), **inp).float().cpu().numpy()
+                     for s in range(model.n_step)]
+            out[f"{case}_scores"] = np.stack(steps)
+    np.savez(os.path.join(out_dir, f"topk_{r}.npz"), **out)
+
+
 def main() -> None:
     mode, out_dir = sys.argv[1], sys.argv[2]
     dist.init_process_group("gloo")
     try:
-        {"routing": routing, "bess": bess}[mode](out_dir)
+        {"routing": routing, "bess": bess, "topk": topk}[mode](out_dir)
         dist.barrier()
     finally:
         dist.destroy_process_group()

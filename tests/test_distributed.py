@@ -92,3 +92,31 @@ def test_distributed_bess_golden(world):
                                            (c["table"][r] - lr * c["grads"]["entity"][r]).numpy(), rtol=1e-4, atol=2e-5)
                 np.testing.assert_allclose(z[f"{case}_train_relation"],
                                            (c["rel"] - lr * c["grads"]["relation"].sum(0)).numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_distributed_queries_golden(world):
+    """TopKQueryBessKGE / AllScoresBESS, one process per shard, vs the reference's outputs."""
+    from test_query import load_query_case, query_cases
+
+    specs = [("topk", c) for c in query_cases("topk") if c.endswith(f"_n{world}")]
+    specs += [("allscores", c) for c in query_cases("allscores") if c.endswith(f"_n{world}")]
+    assert specs
+    out = launch("topk", world, {"BESS_CASES": ",".join(f"{f}:{c}" for f, c in specs)}, timeout=900)
+    per_rank = [np.load(os.path.join(out, f"topk_{r}.npz")) for r in range(world)]
+    for fix, case in specs:
+        c = load_query_case(fix, case)
+        m = c["meta"]
+        for r in range(world):
+            z = per_rank[r]
+            if fix == "topk":
+                want_s = c["outs"]["topk_scores"][:, r].numpy().reshape(-1, m["k"])
+                want_i = c["outs"]["topk_global_id"][:, r].numpy().reshape(-1, m["k"])
+                np.testing.assert_allclose(z[f"{case}_scores"], want_s, rtol=1e-4, atol=1e-4)
+                assert (z[f"{case}_ids"] == want_i).mean() > 0.98
+            else:
+                want = c["outs"]["scores"][:, :, r].numpy()  # [bps, n_step, shard_bs, n * ws]
+                got = z[f"{case}_scores"]  # [n_step, bps * shard_bs, n * ws]
+                got = got.reshape(want.shape[1], want.shape[0], *want.shape[2:]).transpose(1, 0, 2, 3)
+                np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
