@@ -199,3 +199,63 @@ def test_c2_full_size_properties(dev):
     o2 = nat.neg_score_pertriple_fwd(dt, 4 * q, RowSource((4 * table).contiguous(), idx.reshape(-1)), K)
     assert torch.equal(o2, 4 * o1)
     assert bool((o1 <= 0).all())
+
+
+def test_c5_addressing_beyond_4gib(dev):
+    """Config 5 is a 128 GB shard: row offsets must be 64-bit.  A 6.4 GB shard
+    (3.1 M rows x 2 KiB) is filled with a pattern that identifies every row; rows
+    beyond the 2^32-byte boundary are gathered, scored (per-triple and shared
+    kernels), updated (segmented K9/K10 and atomic SGD) and checked."""
+    from besskge import _native as nat
+    from besskge._native import RowSource
+
+    M, W = 3_100_000, 512
+    table = torch.empty(M, W, dtype=torch.float32, device=dev)
+    rid = torch.arange(M, device=dev, dtype=torch.float32)
+    col = torch.arange(W, device=dev, dtype=torch.float32)
+    for lo in range(0, M, 500_000):  # row r, column c holds (r mod 4099) / 4099 + c / 1024
+        hi = min(M, lo + 500_000)
+        table[lo:hi] = (rid[lo:hi, None] % 4099) / 4099 + col[None, :] / 1024
+    g = torch.Generator().manual_seed(1)
+    first_high = (1 << 32) // (W * 4) + 1  # first row that starts beyond 4 GiB
+    idx = torch.cat([torch.randint(first_high, M, (2000,), generator=g), torch.tensor([M - 1, first_high, 0])]).to(torch.int32)
+
+    def rows_cpu(i):
+        i = i.float()
+        return (i[:, None] % 4099) / 4099 + torch.arange(W, dtype=torch.float32)[None, :] / 1024
+
+    got = nat.gather_rows(table, idx.to(dev))
+    # rows differ by >= 1/4099 = 2.4e-4: 1e-6 identifies the row (and absorbs a 1-ulp division difference)
+    torch.testing.assert_close(got.cpu(), rows_cpu(idx), rtol=0, atol=1e-6)
+    S, K = 50, 40
+    q = torch.randn(S, W, generator=g)
+    nidx = idx[: S * K].reshape(S, K)
+    d = nat.make_desc(nat.DISTMULT, 0, table, W)
+    out = nat.neg_score_pertriple_fwd(d, q.to(dev), RowSource(table, nidx.reshape(-1).to(dev)), K)
+    want = torch.einsum("sw,skw->sk", q.double(), rows_cpu(nidx.reshape(-1)).reshape(S, K, W).double())
+    torch.testing.assert_close(out.cpu().double(), want, rtol=1e-5, atol=1e-3)
+    sh = nat.neg_score_shared_fwd(d, q.to(dev), RowSource(table, idx[:300].to(dev)))
+    torch.testing.assert_close(sh.cpu().double(), q.double() @ rows_cpu(idx[:300]).double().T, rtol=1e-5, atol=1e-3)
+    # a contiguous window that straddles the boundary (the TopK / AllScores access pattern)
+    w0 = first_high - 40
+    win = nat.neg_score_shared_fwd(d, q.to(dev), RowSource(table[w0: w0 + 100]))
+    torch.testing.assert_close(win.cpu().double(), q.double() @ rows_cpu(torch.arange(w0, w0 + 100)).double().T,
+                               rtol=1e-5, atol=1e-3)
+    # updates land in the right rows
+    go = torch.randn(S, K, generator=g)
+    seg = nat.SegmentIndex(nidx.reshape(-1).to(dev), M)
+    before = nat.gather_rows(table, idx.to(dev)).cpu()
+    nat.neg_pertriple_grad_segments(d, q.to(dev), table, K, go.to(dev), seg, fused_sgd_lr=0.5)
+    uniq, inv = torch.unique(nidx.reshape(-1).long(), return_inverse=True)
+    gsum = torch.zeros(uniq.numel(), W, dtype=torch.float64).index_add_(
+        0, inv, (go.reshape(-1, 1).double() * q.double().repeat_interleave(K, dim=0)))
+    after = nat.gather_rows(table, uniq.to(torch.int32).to(dev)).cpu()
+    torch.testing.assert_close(after.double(), rows_cpu(uniq).double() - 0.5 * gsum, rtol=1e-5, atol=1e-4)
+    untouched = ~torch.isin(idx.long(), uniq)
+    assert torch.equal(nat.gather_rows(table, idx.to(dev)).cpu()[untouched], before[untouched])
+    nat.sparse_sgd(table, torch.tensor([M - 1], dtype=torch.int32, device=dev), torch.ones(1, W, device=dev), 1.0)
+    last = nat.gather_rows(table, torch.tensor([M - 1], dtype=torch.int32, device=dev)).cpu()
+    base_last = rows_cpu(torch.tensor([M - 1]))
+    if (uniq == M - 1).any():
+        base_last = base_last - 0.5 * gsum[uniq == M - 1].float()
+    torch.testing.assert_close(last, base_last - 1.0, rtol=1e-5, atol=1e-4)
