@@ -41,6 +41,13 @@ class Options:
     #: overlap the scoring of micro-batch i (they are independent: the tables
     #: are read-only).  Training steps depend on each other and stay in order.
     pipeline_streams: int = 2
+    #: capture one micro-batch step (all kernels of forward / forward+backward+
+    #: plain-SGD update, single process) into a hipGraph and replay it: the
+    #: notebook-sized micro-batches (S = 512, K = 32) are launch-bound, a replay
+    #: costs one launch.  Inputs are copied into static buffers; not available
+    #: with torch.distributed groups or stateful optimisers (their per-step
+    #: scalars are kernel arguments).
+    use_graphs: bool = False
 
     def deviceIterations(self, n: int) -> "Options":  # noqa: N802 - poptorch spelling
         self.device_iterations = n
@@ -145,6 +152,61 @@ class Runner:
         self._streams = have
         return have[:n]
 
+    # ------------------------------------------------------------ hipGraph path
+    def _step(self, reps: List[Dict[str, torch.Tensor]]) -> List[Any]:
+        if self.optimizer is not None:
+            return self.model.train_step_replicas(reps, self.optimizer)  # type: ignore
+        with torch.no_grad():
+            return self.model.forward_replicas(reps)
+
+    def _call_with_graphs(self, batch: Dict[str, torch.Tensor], iters: int) -> Dict[str, torch.Tensor]:
+        if isinstance(self.group, DistributedGroup):
+            raise NotImplementedError("use_graphs is for single-process replica groups")
+        if self.optimizer is not None and not getattr(self.optimizer, "is_plain_sgd", True):
+            raise NotImplementedError("use_graphs supports plain SGD (stateful optimisers pass per-step scalars)")
+        n = self.group.n_shard
+        sig = tuple((k, tuple(v.shape[1:]), v.dtype) for k, v in sorted(batch.items()))
+        cache = self.__dict__.setdefault("_graphs", {})
+        if sig not in cache:
+            static = [{k: torch.empty((1, *v.shape[1:]), dtype=v.dtype, device=self.device) for k, v in batch.items()}
+                      for _ in self.group.local_shards]
+            for slot, shard in zip(static, self.group.local_shards):
+                for k, v in batch.items():
+                    slot[k].copy_(v[shard: shard + 1])
+            fn = self.model.score_fn
+            training = self.optimizer is not None
+            # the warm-up steps (index maps, allocator pools) and the capture must not train
+            snapshot = (fn.entity_embedding.data.clone(), fn.relation_embedding.data.clone()) if training else None
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._step(static)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self._step(static)
+            if snapshot is not None:
+                fn.entity_embedding.data.copy_(snapshot[0])
+                fn.relation_embedding.data.copy_(snapshot[1])
+            cache[sig] = (graph, static, outs)
+        graph, static, outs = cache[sig]
+        collected: List[List[Dict[str, Any]]] = []
+        for it in range(iters):
+            for slot, shard in zip(static, self.group.local_shards):
+                for k, v in batch.items():
+                    slot[k].copy_(v[it * n + shard: it * n + shard + 1], non_blocking=True)
+            graph.replay()
+            step_out = []
+            for o in outs:
+                if isinstance(o, dict):
+                    step_out.append({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in o.items()})
+                else:
+                    step_out.append(o.clone())
+            collected.append(step_out)
+        return self._stack_outputs(collected)
+
     def _split(self, batch: Dict[str, torch.Tensor], it: int) -> List[Dict[str, torch.Tensor]]:
         n = self.group.n_shard
         out = []
@@ -165,6 +227,8 @@ class Runner:
                 f"inputs have {rows} rows; expected device_iterations * n_shard = {iters} * {n}"
                 " (flatten [batches_per_step, n_shard, ...] with .flatten(end_dim=1))"
             )
+        if self.options.use_graphs:
+            return self._call_with_graphs(batch, iters)
         collected: List[List[Dict[str, Any]]] = []
         n_streams = 1 if (self.optimizer is not None or iters == 1) else max(1, self.options.pipeline_streams)
         main = torch.cuda.current_stream(self.device)
@@ -184,6 +248,9 @@ class Runner:
         for st in streams:
             if st is not main:
                 main.wait_stream(st)
+        return self._stack_outputs(collected)
+
+    def _stack_outputs(self, collected: List[List[Any]]) -> Dict[str, torch.Tensor]:
         if self.options.output_mode == "final":
             collected = collected[-1:]
         bare = not isinstance(collected[0][0], dict)  # modules returning one tensor (AllScoresBESS)
