@@ -23,6 +23,7 @@ from . import (  # noqa: E402,F401
     bess,
     collectives,
     dataset,
+    device_sampler,
     embedding,
     loss,
     metric,
@@ -40,6 +41,7 @@ __all__ = [
     "bess",
     "collectives",
     "dataset",
+    "device_sampler",
     "embedding",
     "loss",
     "metric",

@@ -78,6 +78,22 @@ class OptDesc(ctypes.Structure):
 
 OPT_SGD, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
 
+
+class Pcg64State(ctypes.Structure):
+    """struct bess_pcg64_state"""
+
+    _fields_ = [
+        ("state_hi", ctypes.c_uint64),
+        ("state_lo", ctypes.c_uint64),
+        ("inc_hi", ctypes.c_uint64),
+        ("inc_lo", ctypes.c_uint64),
+        ("has_uint32", ctypes.c_uint32),
+        ("uinteger", ctypes.c_uint32),
+    ]
+
+
+_PG = ctypes.POINTER(Pcg64State)
+
 _MD = ctypes.POINTER(ModelDesc)
 _LD = ctypes.POINTER(LossDesc)
 
@@ -108,6 +124,9 @@ SIGNATURES = {
     "bess_ranks_from_scores": [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp],
     "bess_ranks_from_indices": [_vp, _vp, _i64, _i64, _i32, _vp, _vp],
     "bess_apply_segments_opt": [ctypes.POINTER(OptDesc), _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "bess_sample_negatives": [_PG, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
+    "bess_sample_bucket_indices": [_PG, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
+    "bess_lookup_triples": [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
 }
 
 _lib: Optional[ctypes.CDLL] = None
@@ -723,3 +742,87 @@ def topk_update(scores: torch.Tensor, best_score: torch.Tensor, best_id: torch.T
         rc = load().bess_topk_update(scores.data_ptr(), R, L, L, ip, ir, int(id_base), mp, mr,
                                      best_score.data_ptr(), best_id.data_ptr(), kk, _stream(dev))
     _check(rc, "bess_topk_update")
+
+
+# --------------------------------------------------------------------------- #
+# device-side index sampling
+def _int_tensor(t: Optional[torch.Tensor], name: str, dtype: torch.dtype, numel: Optional[int] = None) -> int:
+    if t is None:
+        return 0
+    if t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"`{name}` must be contiguous {dtype}, got {t.dtype}")
+    if numel is not None and t.numel() != numel:
+        raise ValueError(f"`{name}` has {t.numel()} elements, expected {numel}")
+    return t.data_ptr()
+
+
+def sample_negatives(gen: Pcg64State, jump_table: torch.Tensor, n_step: int, n_shard: int, src_begin: int,
+                     src_count: int, B: int, K: int, shard_counts: torch.Tensor,
+                     wanted_type: Optional[torch.Tensor] = None, type_counts: Optional[torch.Tensor] = None,
+                     type_offsets: Optional[torch.Tensor] = None, local_sampling: bool = False) -> torch.Tensor:
+    dev = _same_device([("jump_table", jump_table), ("shard_counts", shard_counts), ("wanted_type", wanted_type),
+                        ("type_counts", type_counts), ("type_offsets", type_offsets)])
+    tp = _int_tensor(jump_table, "jump_table", torch.int64, 64 * 4)
+    cp = _int_tensor(shard_counts, "shard_counts", torch.int32, n_shard)
+    n_type = 0
+    if wanted_type is not None:
+        if type_counts is None or type_offsets is None or type_counts.shape != type_offsets.shape \
+                or type_counts.dim() != 2 or type_counts.shape[0] != n_shard:
+            raise ValueError("type tables must both be [n_shard, n_type]")
+        n_type = int(type_counts.shape[1])
+    wp = _int_tensor(wanted_type, "wanted_type", torch.int32, n_step * n_shard * B)
+    tcp = _int_tensor(type_counts, "type_counts", torch.int32)
+    top = _int_tensor(type_offsets, "type_offsets", torch.int32)
+    out = torch.empty((n_step, src_count, n_shard, B, K), dtype=torch.int32, device=dev)
+    with _Timed("bess_sample_negatives", dev):
+        _check(load().bess_sample_negatives(ctypes.byref(gen), tp, n_step, n_shard, src_begin, src_count, B, K, cp,
+                                            wp, tcp, top, n_type, int(local_sampling), out.data_ptr(),
+                                            _stream(dev)), "sample_negatives")
+    return out
+
+
+def sample_bucket_indices(gen: Pcg64State, jump_table: torch.Tensor, shape: Sequence[int], counts: torch.Tensor,
+                          offsets: torch.Tensor) -> torch.Tensor:
+    """`offsets + rng.integers(1 << 63, size=shape) % counts` with counts / offsets
+    broadcast over shape[1:-1] (shape = [step, buckets..., inner])."""
+    dev = _same_device([("jump_table", jump_table), ("counts", counts), ("offsets", offsets)])
+    tp = _int_tensor(jump_table, "jump_table", torch.int64, 64 * 4)
+    n_bucket = 1
+    for s in shape[1:-1]:
+        n_bucket *= int(s)
+    cp = _int_tensor(counts, "counts", torch.int64, n_bucket)
+    op = _int_tensor(offsets, "offsets", torch.int64, n_bucket)
+    out = torch.empty(tuple(int(s) for s in shape), dtype=torch.int64, device=dev)
+    _check(load().bess_sample_bucket_indices(ctypes.byref(gen), tp, out.numel(), int(shape[-1]), n_bucket, cp, op,
+                                             out.data_ptr(), _stream(dev)), "sample_bucket_indices")
+    return out
+
+
+def lookup_triples(triples: torch.Tensor, sample_idx: torch.Tensor, swap_tail: bool,
+                   want: Sequence[str] = ("head", "relation", "tail")) -> dict:
+    """head / relation / tail (int32) of the sampled triples; sample_idx is
+    [step, n, ppp] or [step, n, n, ppp]; the tail is block-transposed when swap_tail."""
+    dev = _same_device([("triples", triples), ("sample_idx", sample_idx)])
+    if triples.dtype != torch.int32 or triples.dim() != 2 or triples.shape[1] != 3 or not triples.is_contiguous():
+        raise ValueError("`triples` must be a contiguous int32 [n_triple, 3] tensor")
+    _int_tensor(sample_idx, "sample_idx", torch.int64)
+    if sample_idx.dim() == 3:
+        n_step, n1, ppp = sample_idx.shape
+        n2 = 1
+    elif sample_idx.dim() == 4:
+        n_step, n1, n2, ppp = sample_idx.shape
+    else:
+        raise ValueError("`sample_idx` must be [step, n, ppp] or [step, n, n, ppp]")
+    if swap_tail and sample_idx.dim() != 4:
+        raise ValueError("the tail transpose needs shard-pair buckets")
+    out = {}
+    for k in want:
+        shape = tuple(sample_idx.shape)
+        if k == "tail" and swap_tail:
+            shape = (n_step, n2, n1, ppp)
+        out[k] = torch.empty(shape, dtype=torch.int32, device=dev)
+    ptr = lambda k: out[k].data_ptr() if k in out else 0  # noqa: E731
+    _check(load().bess_lookup_triples(triples.data_ptr(), triples.shape[0], sample_idx.data_ptr(), n_step, n1, n2,
+                                      ppp, int(swap_tail), ptr("head"), ptr("relation"), ptr("tail"),
+                                      _stream(dev)), "lookup_triples")
+    return out

@@ -210,8 +210,10 @@ class Runner:
     def _split(self, batch: Dict[str, torch.Tensor], it: int) -> List[Dict[str, torch.Tensor]]:
         n = self.group.n_shard
         out = []
-        for shard in self.group.local_shards:
-            row = it * n + shard
+        local = list(self.group.local_shards)
+        own_rows_only = batch["relation"].shape[0] != self.options.device_iterations * n
+        for j, shard in enumerate(local):
+            row = it * len(local) + j if own_rows_only else it * n + shard
             out.append({k: v[row: row + 1].to(self.device, non_blocking=True) for k, v in batch.items()})
         return out
 
@@ -222,10 +224,13 @@ class Runner:
             raise TypeError(f"unexpected inputs {sorted(unknown)}")
         rows = batch["relation"].shape[0]
         iters = self.options.device_iterations
-        if rows != iters * n:
+        n_local = len(list(self.group.local_shards))
+        if rows != iters * n and rows != iters * n_local:
             raise ValueError(
                 f"inputs have {rows} rows; expected device_iterations * n_shard = {iters} * {n}"
-                " (flatten [batches_per_step, n_shard, ...] with .flatten(end_dim=1))"
+                " (flatten [batches_per_step, n_shard, ...] with .flatten(end_dim=1)), or"
+                f" {iters} * {n_local} rows holding only this process's shards"
+                " (DeviceBatchSampler(..., shards=...))"
             )
         if self.options.use_graphs:
             return self._call_with_graphs(batch, iters)

@@ -18,12 +18,18 @@
 //     L1 :  d e += g * sgn(query[q] - e)        (score = -||q - e||_1)
 //     L2 :  d e += g * (query[q] - e) / ||q - e||_2
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include "common.h"
 
 namespace bess {
 
 static inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+// rocPRIM's default sorts up to 2^20 items with ~10 merge passes; the row ids have
+// few significant bits, so the Onesweep LSD radix sort (stable) is 3 passes instead.
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                              rocprim::default_config, 32768>;
 
 struct CubSizes {
     size_t sort, rle, scan, total_cub;
@@ -32,7 +38,8 @@ struct CubSizes {
 static hipError_t cub_sizes(int64_t n, CubSizes* cs) {
     int32_t* p = nullptr;
     size_t a = 0, b = 0, c = 0;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, a, p, p, p, p, static_cast<int>(n), 0, 32, 0);
+    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(nullptr, a, p, p, p, p, static_cast<size_t>(n), 0u, 32u,
+                                                          hipStream_t(0));
     if (e != hipSuccess) return e;
     e = hipcub::DeviceRunLengthEncode::Encode(nullptr, b, p, p, p, p, static_cast<int>(n), 0);
     if (e != hipSuccess) return e;
@@ -299,8 +306,9 @@ extern "C" int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int3
     size_t cub_bytes = workspace_bytes - 3 * blk;
     k_iota<<<static_cast<unsigned>(std::min<int64_t>(ceil_div(n_refs, 256), 2048)), 256, 0, st>>>(iota, n_refs);
     // stable LSD radix sort on the significant bits only: equal rows keep reference order
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, idx, keys_sorted, iota, refs_sorted, n, 0,
-                                                      row_bits, st);
+    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(cub_tmp, cub_bytes, idx, keys_sorted, iota, refs_sorted,
+                                                          static_cast<size_t>(n_refs), 0u,
+                                                          static_cast<unsigned>(row_bits), st);
     if (e != hipSuccess) return fail(static_cast<int>(e), "radix sort: %s", hipGetErrorString(e));
     e = hipcub::DeviceRunLengthEncode::Encode(cub_tmp, cub_bytes, keys_sorted, seg_rows, counts, n_seg, n, st);
     if (e != hipSuccess) return fail(static_cast<int>(e), "run-length encode: %s", hipGetErrorString(e));

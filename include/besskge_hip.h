@@ -100,6 +100,16 @@ typedef struct bess_loss_desc {
     int32_t reserved[2];
 } bess_loss_desc;
 
+/* State of a numpy `Generator(PCG64)` (`rng.bit_generator.state`): 128-bit LCG
+ * state and increment, plus the half of a 64-bit output that `integers()` with a
+ * 32-bit range keeps buffered between calls. */
+typedef struct bess_pcg64_state {
+    uint64_t state_hi, state_lo;
+    uint64_t inc_hi, inc_lo;
+    uint32_t has_uint32;
+    uint32_t uinteger;
+} bess_pcg64_state;
+
 int bess_version(void);
 /* copies the calling thread's last error text; returns its length */
 int bess_last_error(char* buf, size_t len);
@@ -294,6 +304,42 @@ int bess_apply_segments_opt(const bess_opt_desc* o, int32_t dtype, int32_t width
 /* dense axpy on a replicated table: table -= lr * grad (relation table) */
 int bess_dense_sgd(int32_t dtype, void* table, const float* grad, int64_t n_elem,
                    float lr, void* stream);
+
+/* ---- device-side index sampling (bit-exact numpy streams) -------------------
+ * `jump_table` (device, uint64 [64][4] = {a_hi, a_lo, c_hi, c_lo}): the affine map
+ * s -> a*s + c of 2^j generator steps for this generator's increment.  The host
+ * passes the generator state *before* the call and advances its own copy; the
+ * kernels never write generator state. */
+
+/* `RandomShardedNegativeSampler.__call__` (negative_sampler.py:104-132) and, with
+ * `wanted_type`, `TypeBasedShardedNegativeSampler.__call__` (180-230):
+ *   out = rng.integers(1 << 31, size=[n_step, n_shard, n_shard, B, K]).astype(int32)
+ *         % shard_counts[src]  ( % type_counts[src, ty] + type_offsets[src, ty] )
+ * restricted to source shards [src_begin, src_begin + src_count): out is
+ * [n_step, src_count, n_shard, B, K].  wanted_type [n_step, n_shard, B] is the type
+ * every triple of every scoring shard wants; the scoring shard of block [src, dst]
+ * is src when local_sampling, dst otherwise. */
+int bess_sample_negatives(const bess_pcg64_state* gen, const uint64_t* jump_table, int64_t n_step,
+                          int32_t n_shard, int32_t src_begin, int32_t src_count, int64_t B, int64_t K,
+                          const int32_t* shard_counts, const int32_t* wanted_type,
+                          const int32_t* type_counts, const int32_t* type_offsets, int32_t n_type,
+                          int32_t local_sampling, int32_t* out, void* stream);
+
+/* `RandomShardedBatchSampler.sample_triples` (batch_sampler.py:373-399):
+ *   out[f] = offsets[b] + rng.integers(1 << 63, size=n_out)[f] % counts[b],
+ *   b = (f / inner) % n_bucket   (out flat over [n_step, buckets..., inner]) */
+int bess_sample_bucket_indices(const bess_pcg64_state* gen, const uint64_t* jump_table, int64_t n_out,
+                               int64_t inner, int64_t n_bucket, const int64_t* counts,
+                               const int64_t* offsets, int64_t* out, void* stream);
+
+/* `hrt = self.triples[sample_idx]` + the tail block transpose of
+ * `ShardedBatchSampler.__getitem__` (batch_sampler.py:150-167).  triples int32
+ * [n_triple, 3]; sample_idx int64 [n_step, n1, n2, per_part]; head / relation in
+ * that layout, tail as [n_step, n2, n1, per_part] when swap_tail.  Any output may
+ * be NULL. */
+int bess_lookup_triples(const int32_t* triples, int64_t n_triple, const int64_t* sample_idx,
+                        int64_t n_step, int64_t n1, int64_t n2, int64_t per_part, int32_t swap_tail,
+                        int32_t* head, int32_t* relation, int32_t* tail, void* stream);
 
 #ifdef __cplusplus
 }

@@ -110,11 +110,61 @@ def topk(out_dir: str) -> None:
     np.savez(os.path.join(out_dir, f"topk_{r}.npz"), **out)
 
 
+def sampler(out_dir: str) -> None:
+    """Every rank samples only its own rows on the device (`shards=[rank]`) and
+    feeds them to the runner; results must equal the run fed with the host
+    sampler's full batch."""
+    from besskge import runtime
+    from besskge.batch_sampler import RandomShardedBatchSampler
+    from besskge.bess import EmbeddingMovingBessKGE, ScoreMovingBessKGE
+    from besskge.collectives import DistributedGroup
+    from besskge.dataset import KGDataset
+    from besskge.device_sampler import DeviceBatchSampler
+    from besskge.loss import LogSigmoidLoss
+    from besskge.negative_sampler import RandomShardedNegativeSampler
+    from besskge.scoring import TransE
+    from besskge.sharding import PartitionedTripleSet, Sharding
+
+    g = DistributedGroup()
+    n, r = g.n_shard, g.rank
+    dev = torch.device("cuda", 0)
+    n_entity, n_rel, n_triple, bps, shard_bs, K = 600, 7, 4000, 3, 24, 5
+    rng = np.random.default_rng(11)
+    triples = np.stack([rng.integers(n_entity, size=n_triple), rng.integers(n_rel, size=n_triple),
+                        rng.integers(n_entity, size=n_triple)], axis=1)
+    ds = KGDataset(n_entity=n_entity, n_relation_type=n_rel, triples={"train": triples},
+                   original_triple_ids={"train": np.arange(n_triple)})
+    sharding = Sharding.create(n_entity, n, seed=5)
+    pts = PartitionedTripleSet.create_from_dataset(ds, "train", sharding, partition_mode="ht_shardpair")
+    out = {}
+    for name, cls, flat in (("em_flat", EmbeddingMovingBessKGE, True), ("sm_pt", ScoreMovingBessKGE, False)):
+        def make_bs():
+            ns = RandomShardedNegativeSampler(K, sharding, 3, "t", local_sampling=False, flat_negative_format=flat)
+            return RandomShardedBatchSampler(pts, ns, shard_bs, bps, seed=4)
+
+        torch.manual_seed(0)
+        fn = TransE(flat, 1, sharding, n_rel, 32)
+        model = cls(negative_sampler=make_bs().negative_sampler, score_fn=fn,
+                    loss_fn=LogSigmoidLoss(margin=3.0, negative_adversarial_sampling=True))
+        runner = runtime.inference_model(model, runtime.Options(device_iterations=bps), group=g, device=dev)
+        host = make_bs()
+        dbs = DeviceBatchSampler(make_bs(), dev, shards=[r])
+        for step in range(2):
+            full = host[[0]]
+            own = dbs.sample()
+            res_full = runner(**{k: v.flatten(end_dim=1) for k, v in full.items()})
+            res_own = runner(**{k: v.flatten(end_dim=1) for k, v in own.items()})
+            for k in res_full:
+                assert torch.equal(res_full[k], res_own[k]), (name, step, k)
+                out[f"{name}_{step}_{k}"] = res_own[k].float().cpu().numpy()
+    np.savez(os.path.join(out_dir, f"sampler_{r}.npz"), **out)
+
+
 def main() -> None:
     mode, out_dir = sys.argv[1], sys.argv[2]
     dist.init_process_group("gloo")
     try:
-        {"routing": routing, "bess": bess, "topk": topk}[mode](out_dir)
+        {"routing": routing, "bess": bess, "topk": topk, "sampler": sampler}[mode](out_dir)
         dist.barrier()
     finally:
         dist.destroy_process_group()

