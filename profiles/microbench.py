@@ -79,6 +79,10 @@ CASES = [
     ("C4 TransE d256 f16 p1 (L3)", "TransE", 1, torch.float16, 312_576, 256, 256, 4096, 256, False),
     ("C4 TransE d256 f16 p1 (HBM 4GB)", "TransE", 1, torch.float16, 8_000_000, 256, 256, 4096, 256, False),
     ("C1 TransE d128 f32 p1", "TransE", 1, torch.float32, 10_000, 128, 128, 4096, 256, False),
+    # the per-GPU launch of bench.py --gpus N (ScoreMoving: N*S gathered queries x 256/N local negatives)
+    ("scale N=2 ComplEx d256 f32", "ComplEx", 0, torch.float32, 93_773, 512, 512, 8192, 128, False),
+    ("scale N=4 ComplEx d256 f32", "ComplEx", 0, torch.float32, 93_773, 512, 512, 16384, 64, False),
+    ("scale N=8 ComplEx d256 f32", "ComplEx", 0, torch.float32, 93_773, 512, 512, 32768, 32, False),
     ("C2 ComplEx shared 4096x4096", "ComplEx", 0, torch.float32, 93_773, 512, 512, 4096, 4096, True),
     ("C5 DistMult shared 8192x4096", "DistMult", 0, torch.float32, 1_000_000, 512, 512, 8192, 4096, True),
     ("C4 TransE f16 L1 shared 4096x4096", "TransE", 1, torch.float16, 312_576, 256, 256, 4096, 4096, True),
