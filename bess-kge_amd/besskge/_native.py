@@ -19,7 +19,7 @@ import torch
 LIB_NAME = "libbesskge_hip.so"
 ABI_VERSION = 1
 
-TRANSE, ROTATE, DISTMULT, COMPLEX = 0, 1, 2, 3
+TRANSE, ROTATE, DISTMULT, COMPLEX, AFFINE = 0, 1, 2, 3, 4
 F32, F16 = 0, 1
 CORRUPT_HEAD, CORRUPT_TAIL = 0, 1
 LOSS_LOGSIGMOID, LOSS_MARGIN, LOSS_SSCE = 0, 1, 2
@@ -124,6 +124,8 @@ SIGNATURES = {
     "bess_ranks_from_scores": [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp],
     "bess_ranks_from_indices": [_vp, _vp, _i64, _i64, _i32, _vp, _vp],
     "bess_apply_segments_opt": [ctypes.POINTER(OptDesc), _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "bess_normalize_rows": [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
+    "bess_normalize_rows_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
     "bess_sample_negatives": [_PG, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "bess_sample_bucket_indices": [_PG, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "bess_lookup_triples": [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
@@ -417,11 +419,19 @@ def query_bwd(d: ModelDesc, side: int, ent: RowSource, rel_table: torch.Tensor, 
     return dx
 
 
+def query_width(d: ModelDesc) -> int:
+    """Scalars per row of the query matrix the negative-scoring kernels take."""
+    if d.scorer == AFFINE:  # [U | V | R]: one d-wide vector per entity part, plus the offset
+        n_part = int(d.reserved[0])
+        return (n_part + 1) * (d.width // n_part)
+    return int(d.width)
+
+
 def _neg_operands(d: ModelDesc, query: torch.Tensor, neg: RowSource, n_idx: int):
     dev = _same_device([("query", query), ("negative rows", neg.base), ("negative idx", neg.idx)])
     _f32(query, "query")
-    if query.dim() != 2 or query.shape[1] != d.width:
-        raise ValueError(f"`query` must be [n_query, {d.width}], got {tuple(query.shape)}")
+    if query.dim() != 2 or query.shape[1] != query_width(d):
+        raise ValueError(f"`query` must be [n_query, {query_width(d)}], got {tuple(query.shape)}")
     _rows(neg.base, "negative rows", d.width)
     if _dtype_code(neg.base) != d.dtype:
         raise TypeError("negative rows dtype does not match the model descriptor")
@@ -466,7 +476,7 @@ def neg_score_pertriple_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n
     _f32(d_out, "d_out")
     if tuple(d_out.shape) != (nq, n_neg):
         raise ValueError("neg_score_pertriple_bwd: bad `d_out` shape")
-    dq = torch.empty((nq, d.width), dtype=torch.float32, device=dev)
+    dq = torch.empty((nq, query_width(d)), dtype=torch.float32, device=dev)
     dn = torch.empty((nq * n_neg, d.width), dtype=torch.float32, device=dev) if want_d_neg else None
     ip, keep = _neg_idx_ptr(neg, dev)
     with torch.cuda.device(dev), _Timed("bess_neg_score_pertriple_bwd", dev):
@@ -478,9 +488,46 @@ def neg_score_pertriple_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n
     return dq, dn
 
 
+def normalize_rows(neg: RowSource, n_part: int, normalize: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Gather + convert to f32 + L2-normalise every part of the rows: (hat [n, W] f32, inv [n, n_part])."""
+    dev = _same_device([("rows", neg.base), ("idx", neg.idx)])
+    W = int(neg.base.shape[1])
+    _rows(neg.base, "rows", W)
+    n = len(neg)
+    hat = torch.empty((n, W), dtype=torch.float32, device=dev)
+    inv = torch.empty((n, n_part), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().bess_normalize_rows(_dtype_code(neg.base), neg.base.data_ptr(), _idx(neg.idx, "idx"), n, W, n_part,
+                                        int(normalize), hat.data_ptr(), inv.data_ptr(), _stream(dev))
+    _check(rc, "bess_normalize_rows")
+    return hat, inv
+
+
+def normalize_rows_bwd(hat: torch.Tensor, inv: torch.Tensor, d_hat: torch.Tensor) -> torch.Tensor:
+    dev = _same_device([("hat", hat), ("inv", inv), ("d_hat", d_hat)])
+    for t, name in ((hat, "hat"), (inv, "inv"), (d_hat, "d_hat")):
+        _f32(t, name)
+    if hat.shape != d_hat.shape or inv.shape[0] != hat.shape[0]:
+        raise ValueError("normalize_rows_bwd: shape mismatch")
+    out = torch.empty_like(hat)
+    with torch.cuda.device(dev):
+        rc = load().bess_normalize_rows_bwd(hat.data_ptr(), inv.data_ptr(), d_hat.data_ptr(), hat.shape[0],
+                                            hat.shape[1], inv.shape[1], out.data_ptr(), _stream(dev))
+    _check(rc, "bess_normalize_rows_bwd")
+    return out
+
+
+def _affine_candidates(d: ModelDesc, neg: RowSource) -> Tuple[RowSource, torch.Tensor, torch.Tensor]:
+    """The shared kernels of the affine scorers work on dense, normalised f32 candidates."""
+    hat, inv = normalize_rows(neg, int(d.reserved[0]), bool(d.reserved[1] & 1))
+    return RowSource(hat), hat, inv
+
+
 def neg_score_shared_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource) -> torch.Tensor:
     nq, n_neg = int(query.shape[0]), len(neg)
     dev = _neg_operands(d, query, neg, n_neg)
+    if d.scorer == AFFINE:
+        neg, _, _ = _affine_candidates(d, neg)
     out = torch.empty((nq, n_neg), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), _Timed("bess_neg_score_shared_fwd", dev):
         rc = load().bess_neg_score_shared_fwd(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
@@ -500,13 +547,18 @@ def neg_score_shared_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, out:
     _f32(out, "out")
     if tuple(d_out.shape) != (nq, n_neg) or tuple(out.shape) != (nq, n_neg):
         raise ValueError("neg_score_shared_bwd: bad score shapes")
-    dq = torch.empty((nq, d.width), dtype=torch.float32, device=dev)
+    hat = inv = None
+    if d.scorer == AFFINE:
+        neg, hat, inv = _affine_candidates(d, neg)
+    dq = torch.empty((nq, query_width(d)), dtype=torch.float32, device=dev)
     dn = torch.empty((n_neg, d.width), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), _Timed("bess_neg_score_shared_bwd", dev):
         rc = load().bess_neg_score_shared_bwd(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
                                               _idx(neg.idx, "negative idx"), n_neg, out.data_ptr(), n_neg,
                                               d_out.data_ptr(), n_neg, dq.data_ptr(), dn.data_ptr(), _stream(dev))
     _check(rc, "bess_neg_score_shared_bwd")
+    if hat is not None and (d.reserved[1] & 1):
+        dn = normalize_rows_bwd(hat, inv, dn)
     return dq, dn
 
 

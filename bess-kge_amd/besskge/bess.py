@@ -69,6 +69,7 @@ class _NegGroup:
         self.n_per_query = n_per_query
         # filled by forward, consumed by backward
         self.query: Optional[torch.Tensor] = None
+        self.query_ctx: Any = None  # what the scorer's query_bwd needs
         self.out: Optional[torch.Tensor] = None
 
 
@@ -77,6 +78,7 @@ class _ReplicaStep:
 
     def __init__(self) -> None:
         self.table: torch.Tensor = None  # type: ignore  # local shard [M, W]
+        self.triple_ctx: Any = None  # what the scorer's triple_bwd needs
         self.head_idx: torch.Tensor = None  # type: ignore  # [S] rows of the shard
         self.rel_idx: torch.Tensor = None  # type: ignore  # [S]
         self.tail: RowSource = None  # type: ignore  # tails of my triples
@@ -375,7 +377,7 @@ class BessKGE(torch.nn.Module, ABC):
         with torch.cuda.stream(side):
             for st in steps:
                 for g in st.groups:
-                    if not g.shared and g.neg.base is st.table:
+                    if not g.shared and g.neg.base is st.table and self.score_fn.supports_fused_segments:
                         seg_index[id(g)] = nat.SegmentIndex(g.neg.idx, st.table.shape[0])
         return seg_index
 
@@ -435,8 +437,7 @@ class BessKGE(torch.nn.Module, ABC):
 
     # ------------------------------------------------------ group execution
     def _run_groups_one(self, g: _NegGroup, desc: nat.ModelDesc) -> torch.Tensor:
-        rel = self.score_fn.relation_embedding.data
-        g.query = nat.query_fwd(desc, g.side, g.ent, rel, g.rel_idx)
+        g.query, g.query_ctx = self.score_fn.query_fwd(g.side, g.ent, g.rel_idx)
         if g.shared:
             g.out = nat.neg_score_shared_fwd(desc, g.query, g.neg)
         else:
@@ -495,9 +496,8 @@ class EmbeddingMovingBessKGE(BessKGE):
         rel_table = fn.relation_embedding.data
         for st in steps:
             self._build_groups(st, exchange_negatives)
-            st.positive_score = nat.score_triple_fwd(
-                desc, RowSource(st.table, st.head_idx), st.tail, rel_table, st.rel_idx
-            )
+            st.positive_score, st.triple_ctx = fn.triple_fwd(
+                RowSource(st.table, st.head_idx), st.tail, st.rel_idx)
             outs = self._run_groups(st, desc)
             if len(outs) == 1:
                 st.negative_score = outs[0]
@@ -659,8 +659,8 @@ class EmbeddingMovingBessKGE(BessKGE):
                     raise RuntimeError("gradient for an unknown row space")
 
             # K3': positive scores
-            dh, dt = nat.score_triple_bwd(desc, RowSource(st.table, st.head_idx), st.tail, rel_table,
-                                          st.rel_idx, d_pos, d_rel)
+            dh, dt = fn.triple_bwd(RowSource(st.table, st.head_idx), st.tail, st.rel_idx, st.triple_ctx, d_pos,
+                                   d_rel)
             sink(RowSource(st.table, st.head_idx), dh)
             sink(st.tail, dt)
             # K4'/K5' + K6': negative scores
@@ -675,7 +675,7 @@ class EmbeddingMovingBessKGE(BessKGE):
                 if g.shared:
                     dq, dn = nat.neg_score_shared_bwd(desc, g.query, g.neg, g.out, go)
                     sink(g.neg, dn)
-                elif g.neg.base is st.table:
+                elif g.neg.base is st.table and fn.supports_fused_segments:
                     # per-triple negatives read straight from the shard: no [S*N, W]
                     # gradient, no atomics - references are grouped by destination row
                     # and reduced on chip (K9), unique rows updated afterwards (K10)
@@ -684,7 +684,7 @@ class EmbeddingMovingBessKGE(BessKGE):
                 else:
                     dq, dn = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go)
                     sink(g.neg, dn)
-                dx = nat.query_bwd(desc, g.side, g.ent, rel_table, g.rel_idx, dq, d_rel)
+                dx = fn.query_bwd(g.side, g.ent, g.rel_idx, g.query_ctx, dq, d_rel)
                 sink(g.ent, dx)
             if n > 1:
                 if st.ext_src is not None:  # rows appended for augmentation -> their origin
@@ -806,8 +806,8 @@ class ScoreMovingBessKGE(BessKGE):
             st.negative_score = sb.transpose(0, 1).flatten(start_dim=1).contiguous()
             st.recv = tl.reshape(-1, W)
             st.tail = RowSource(st.recv, None)
-            st.positive_score = nat.score_triple_fwd(
-                desc, RowSource(st.table, st.head_idx), st.tail, rel_table, st.rel_idx)
+            st.positive_score, st.triple_ctx = fn.triple_fwd(
+                RowSource(st.table, st.head_idx), st.tail, st.rel_idx)
         return steps
 
     def _paired_all_to_all(self, xs: List[torch.Tensor], ys: List[torch.Tensor]
@@ -857,8 +857,8 @@ class ScoreMovingBessKGE(BessKGE):
             results.append(out)
             S = d_neg.shape[0]
             d_scores.append(d_neg.reshape(S, n, -1).transpose(0, 1).contiguous())  # [n(shard), S, Nl]
-            dh, dt = nat.score_triple_bwd(desc, RowSource(st.table, st.head_idx), st.tail, rel_table,
-                                          st.rel_idx, d_pos, d_rel)
+            dh, dt = fn.triple_bwd(RowSource(st.table, st.head_idx), st.tail, st.rel_idx, st.triple_ctx, d_pos,
+                                   d_rel)
             local_updates.append([(st.head_idx, dh)])
             d_tails.append(dt.reshape(n, st.ppp, W))
         # gradients of the scores I computed ([n(j), S, Nl]) and of my tail rows (C5'), one all-to-all
@@ -879,10 +879,13 @@ class ScoreMovingBessKGE(BessKGE):
                 if g.shared:
                     dq, dn = nat.neg_score_shared_bwd(desc, g.query, g.neg, g.out, go)
                     upd.append((g.neg.idx, dn))
-                else:
+                elif fn.supports_fused_segments:
                     dq, _ = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go, want_d_neg=False)
                     deferred.append((st.table, g, go))
-                dx = nat.query_bwd(desc, g.side, g.ent, rel_table, g.rel_idx, dq, d_rel)
+                else:
+                    dq, dn = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go)
+                    upd.append((g.neg.idx, dn))
+                dx = fn.query_bwd(g.side, g.ent, g.rel_idx, g.query_ctx, dq, d_rel)
                 if g.ent.idx is not None:  # undo the [t, j, p] -> [j, t, p] re-ordering
                     buf = torch.empty_like(dx)
                     buf[g.ent.idx.long()] = dx

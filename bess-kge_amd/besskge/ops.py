@@ -119,6 +119,39 @@ class ScoreNegatives(torch.autograd.Function):
                 dn.reshape(ctx.shapes[1]).to(rows.dtype))
 
 
+class ReduceNegatives(torch.autograd.Function):
+    """K4/K5 alone: scores of candidate rows against a ready-made query matrix
+    (the scorers whose query transform is written with torch ops)."""
+
+    @staticmethod
+    def forward(ctx: Any, desc: nat.ModelDesc, sharing: bool, query: torch.Tensor, neg: torch.Tensor  # type: ignore
+                ) -> torch.Tensor:
+        if neg.dim() != 3:
+            raise ValueError("negative embeddings must be [B, n_negative, W]")
+        B, N = int(neg.shape[0]), int(neg.shape[1])
+        S = int(query.shape[0])
+        shared = sharing or B == 1
+        if not shared and B != S:
+            raise ValueError(f"per-triple negatives need B == batch size ({B} != {S})")
+        rows = _as_rows(neg, desc.width)
+        q = query.float().contiguous()
+        out = nat.neg_score_shared_fwd(desc, q, RowSource(rows)) if shared else \
+            nat.neg_score_pertriple_fwd(desc, q, RowSource(rows), N)
+        ctx.desc, ctx.shared, ctx.N, ctx.neg_shape = desc, shared, N, neg.shape
+        ctx.save_for_backward(q, rows, out)
+        return out
+
+    @staticmethod
+    def backward(ctx: Any, g: torch.Tensor):  # type: ignore
+        q, rows, out = ctx.saved_tensors
+        g = g.float().contiguous()
+        if ctx.shared:
+            dq, dn = nat.neg_score_shared_bwd(ctx.desc, q, RowSource(rows), out, g)
+        else:
+            dq, dn = nat.neg_score_pertriple_bwd(ctx.desc, q, RowSource(rows), ctx.N, g)
+        return None, None, dq, dn.reshape(ctx.neg_shape).to(rows.dtype)
+
+
 class Loss(torch.autograd.Function):
     """K8 fused loss + score gradients."""
 

@@ -95,8 +95,8 @@ class _QueryModule(torch.nn.Module):
         rows_all = group.all_gather(rows)  # [n, shard_bs, W]
         desc = fn.kernel_desc()
         W = self.entity_embedding_size
-        return [nat.query_fwd(desc, side, RowSource(x.reshape(-1, W)), fn.relation_embedding.data,
-                              r.reshape(-1).contiguous()) for x, r in zip(rows_all, rel_all)]
+        return [fn.query_fwd(side, RowSource(x.reshape(-1, W)), r.reshape(-1).contiguous())[0]
+                for x, r in zip(rows_all, rel_all)]
 
 
 class TopKQueryBessKGE(_QueryModule):

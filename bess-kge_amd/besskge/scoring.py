@@ -19,12 +19,20 @@ but every score is computed by `libbesskge_hip.so`:
 There is no torch/CPU implementation behind these methods: tensors must live on
 a HIP device.  Results are fp32 (accumulation is fp32 also for fp16 tables).
 
-The six other scorers of the reference (PairRE, TripleRE, ConvE, BoxE, InterHT,
-TranS) are outside the hot path this package accelerates.
+PairRE, TripleRE, InterHT and TranS (reference
+`scoring.py:465-743, 1418-1750`) share one kernel family: their score is
+`-|| U * c1(e) + V * c2(e) + R ||_p` with per-query vectors U, V, R and the
+(optionally normalised) parts c1, c2 of the candidate row (`csrc/affine.hip`).
+The S x N work - scoring queries against negatives, and its backward - runs in
+those kernels; the per-query transform (S rows: building [U | V | R] from the
+kept entity and the relation) and the positive score are written with torch
+ops on the device and differentiated by autograd.
+
+ConvE and BoxE are not provided.
 """
 
 from abc import ABC, abstractmethod
-from typing import Callable, List, Union
+from typing import Any, Callable, List, Tuple, Union
 
 import torch
 
@@ -71,6 +79,30 @@ class BaseScoreFunction(torch.nn.Module, ABC):
     def _table_dtype(self, x: torch.Tensor) -> torch.Tensor:
         dt = self.relation_embedding.dtype
         return x if x.dtype == dt else x.to(dt)
+
+    # ---- hooks used by the fused BESS step (besskge.bess) -----------------------
+    #: per-triple negatives of the own shard can use the segmented K9 reduction
+    #: (gradient recomputed per reference from the query) instead of a [S*N, W] gradient
+    supports_fused_segments = True
+
+    def query_fwd(self, side: int, ent: nat.RowSource, rel_idx: torch.Tensor) -> Tuple[torch.Tensor, Any]:
+        """Query matrix of a negative-scoring problem and the context its backward needs."""
+        return nat.query_fwd(self.kernel_desc(), side, ent, self.relation_embedding.data, rel_idx), None
+
+    def query_bwd(self, side: int, ent: nat.RowSource, rel_idx: torch.Tensor, ctx: Any, dq: torch.Tensor,
+                  d_rel: torch.Tensor) -> torch.Tensor:
+        """Gradient wrt the rows of `ent`; the relation-table gradient is added to `d_rel`."""
+        return nat.query_bwd(self.kernel_desc(), side, ent, self.relation_embedding.data, rel_idx, dq, d_rel)
+
+    def triple_fwd(self, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor) -> Tuple[torch.Tensor, Any]:
+        """Positive scores [S] (+ backward context)."""
+        return nat.score_triple_fwd(self.kernel_desc(), head, tail, self.relation_embedding.data, rel_idx), None
+
+    def triple_bwd(self, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor, ctx: Any,
+                   d_pos: torch.Tensor, d_rel: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(d_head rows, d_tail rows); the relation-table gradient is added to `d_rel`."""
+        return nat.score_triple_bwd(self.kernel_desc(), head, tail, self.relation_embedding.data, rel_idx, d_pos,
+                                    d_rel)
 
     def score_triple(
         self, head_emb: torch.Tensor, relation_id: torch.Tensor, tail_emb: torch.Tensor
@@ -295,3 +327,282 @@ class ComplEx(MatrixDecompositionScoreFunction):
             " for each entity and relation",
         )
         self.embedding_size = embedding_size
+
+
+# --------------------------------------------------------------------------- #
+# PairRE / TripleRE / InterHT / TranS: affine in the candidate
+def _rows_of(src: nat.RowSource) -> torch.Tensor:
+    return src.base if src.idx is None else nat.gather_rows(src.base, src.idx)
+
+
+class _AffineScoreFunction(DistanceBasedScoreFunction, ABC):
+    """`-|| U * c1 + V * c2 + R ||_p` scorers; see the module docstring."""
+
+    _scorer_id = nat.AFFINE
+    supports_fused_segments = False
+    #: d-wide parts of an entity row (1 | 2)
+    _n_part: int = 1
+    normalize: bool
+    embedding_size: int
+
+    def kernel_desc(self) -> nat.ModelDesc:
+        d = super().kernel_desc()
+        d.reserved[0] = self._n_part
+        d.reserved[1] = int(bool(self.normalize))
+        return d
+
+    def _parts(self, x: torch.Tensor) -> List[torch.Tensor]:
+        parts = list(torch.split(x.float(), self.embedding_size, dim=-1))
+        if self.normalize:
+            parts = [torch.nn.functional.normalize(p, p=2, dim=-1) for p in parts]
+        return parts
+
+    def _rel(self, relation_id: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+        return torch.index_select(table, 0, relation_id.reshape(-1).long()).float()
+
+    @abstractmethod
+    def _delta(self, h: List[torch.Tensor], rel: torch.Tensor, t: List[torch.Tensor]) -> torch.Tensor:
+        """The vector whose p-norm is the (negated) score of a triple."""
+
+    @abstractmethod
+    def _uvr(self, side: int, kept: List[torch.Tensor], rel: torch.Tensor) -> List[torch.Tensor]:
+        """[U, (V,) R] of the queries whose head (side = CORRUPT_HEAD) or tail is replaced."""
+
+    def _score_norm(self, delta: torch.Tensor) -> torch.Tensor:
+        return -torch.norm(delta, p=self.scoring_norm, dim=-1)
+
+    # public API (differentiable through autograd + ops.ReduceNegatives)
+    def score_triple(self, head_emb: torch.Tensor, relation_id: torch.Tensor, tail_emb: torch.Tensor) -> torch.Tensor:
+        return self._score_norm(self._delta(self._parts(head_emb), self._rel(relation_id, self.relation_embedding),
+                                            self._parts(tail_emb)))
+
+    def _score_candidates(self, side: int, kept: torch.Tensor, relation_id: torch.Tensor,
+                          cand: torch.Tensor) -> torch.Tensor:
+        q = torch.cat(self._uvr(side, self._parts(kept), self._rel(relation_id, self.relation_embedding)), dim=-1)
+        return ops.ReduceNegatives.apply(self.kernel_desc(), bool(self.negative_sample_sharing), q.contiguous(),
+                                         self._table_dtype(cand))
+
+    def score_heads(self, head_emb: torch.Tensor, relation_id: torch.Tensor, tail_emb: torch.Tensor) -> torch.Tensor:
+        return self._score_candidates(nat.CORRUPT_HEAD, tail_emb, relation_id, head_emb)
+
+    def score_tails(self, head_emb: torch.Tensor, relation_id: torch.Tensor, tail_emb: torch.Tensor) -> torch.Tensor:
+        return self._score_candidates(nat.CORRUPT_TAIL, head_emb, relation_id, tail_emb)
+
+    # hooks of the fused step: autograd over S rows
+    def query_fwd(self, side: int, ent: nat.RowSource, rel_idx: torch.Tensor) -> Tuple[torch.Tensor, Any]:
+        with torch.enable_grad():
+            rows = _rows_of(ent).detach().float().requires_grad_()
+            rel = self.relation_embedding.detach().float().requires_grad_()
+            q = torch.cat(self._uvr(side, self._parts(rows), self._rel(rel_idx, rel)), dim=-1)
+        return q.detach().contiguous(), (rows, rel, q)
+
+    def query_bwd(self, side: int, ent: nat.RowSource, rel_idx: torch.Tensor, ctx: Any, dq: torch.Tensor,
+                  d_rel: torch.Tensor) -> torch.Tensor:
+        rows, rel, q = ctx
+        d_rows, d_r = torch.autograd.grad(q, [rows, rel], dq)
+        d_rel += d_r
+        return d_rows.contiguous()
+
+    def triple_fwd(self, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor) -> Tuple[torch.Tensor, Any]:
+        with torch.enable_grad():
+            h = _rows_of(head).detach().float().requires_grad_()
+            t = _rows_of(tail).detach().float().requires_grad_()
+            rel = self.relation_embedding.detach().float().requires_grad_()
+            sc = self._score_norm(self._delta(self._parts(h), self._rel(rel_idx, rel), self._parts(t)))
+        return sc.detach().contiguous(), (h, t, rel, sc)
+
+    def triple_bwd(self, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor, ctx: Any,
+                   d_pos: torch.Tensor, d_rel: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        h, t, rel, sc = ctx
+        dh, dt, d_r = torch.autograd.grad(sc, [h, t, rel], d_pos)
+        d_rel += d_r
+        return dh.contiguous(), dt.contiguous()
+
+
+class PairRE(_AffineScoreFunction):
+    """PairRE: -|| h^ * r_h - t^ * r_t ||_p  (reference scoring.py:465-593)."""
+
+    _n_part = 1
+
+    def __init__(
+        self,
+        negative_sample_sharing: bool,
+        scoring_norm: int,
+        sharding: Sharding,
+        n_relation_type: int,
+        embedding_size: int,
+        entity_initializer: _Init = [init_KGE_uniform],
+        relation_initializer: _Init = [init_KGE_uniform],
+        normalize_entities: bool = True,
+        inverse_relations: bool = False,
+    ) -> None:
+        super().__init__(negative_sample_sharing, scoring_norm)
+        self.sharding = sharding
+        self.normalize = normalize_entities
+        if isinstance(relation_initializer, list):
+            relation_initializer = 2 * relation_initializer
+        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size])
+        # [r_h | r_t]: projections of heads and tails
+        self.relation_embedding = initialize_relation_embedding(
+            n_relation_type, inverse_relations, relation_initializer, [embedding_size, embedding_size])
+        assert 2 * self.entity_embedding.shape[-1] == self.relation_embedding.shape[-1] == 2 * embedding_size, (
+            "PairRE requires `embedding_size` embedding parameters for each entity"
+            " and `2*embedding_size` embedding parameters for each relation")
+        self.embedding_size = embedding_size
+
+    def _delta(self, h: List[torch.Tensor], rel: torch.Tensor, t: List[torch.Tensor]) -> torch.Tensor:
+        r_h, r_t = torch.split(rel, self.embedding_size, dim=-1)
+        return h[0] * r_h - t[0] * r_t
+
+    def _uvr(self, side: int, kept: List[torch.Tensor], rel: torch.Tensor) -> List[torch.Tensor]:
+        r_h, r_t = torch.split(rel, self.embedding_size, dim=-1)
+        if side == nat.CORRUPT_TAIL:  # t^ r_t - h^ r_h
+            return [r_t, -(kept[0] * r_h)]
+        return [r_h, -(kept[0] * r_t)]  # h^ r_h - t^ r_t
+
+
+class TripleRE(_AffineScoreFunction):
+    """TripleRE: -|| h^ * (r_h + u) - t^ * (r_t + u) + r_m ||_p  (reference scoring.py:596-743)."""
+
+    _n_part = 1
+
+    def __init__(
+        self,
+        negative_sample_sharing: bool,
+        scoring_norm: int,
+        sharding: Sharding,
+        n_relation_type: int,
+        embedding_size: int,
+        entity_initializer: _Init = [init_KGE_uniform],
+        relation_initializer: _Init = [init_KGE_uniform],
+        normalize_entities: bool = True,
+        u: float = 0.0,
+        inverse_relations: bool = False,
+    ) -> None:
+        super().__init__(negative_sample_sharing, scoring_norm)
+        self.sharding = sharding
+        self.normalize = normalize_entities
+        if isinstance(relation_initializer, list):
+            relation_initializer = 3 * relation_initializer
+        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size])
+        # [r_h | r_m | r_t]: head projection, translation, tail projection
+        self.relation_embedding = initialize_relation_embedding(
+            n_relation_type, inverse_relations, relation_initializer, [embedding_size] * 3)
+        assert 3 * self.entity_embedding.shape[-1] == self.relation_embedding.shape[-1] == 3 * embedding_size, (
+            "TripleRE requires `embedding_size` embedding parameters for each entity"
+            " and `3*embedding_size` embedding parameters for each relation")
+        self.embedding_size = embedding_size
+        self.use_v2 = u > 0.0
+        self.register_buffer("rel_u", torch.tensor([u], dtype=torch.float32))
+
+    def _split(self, rel: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        r_h, r_m, r_t = torch.split(rel, self.embedding_size, dim=-1)
+        if self.use_v2:
+            u = self.rel_u.to(rel.device)
+            r_h, r_t = r_h + u, r_t + u
+        return r_h, r_m, r_t
+
+    def _delta(self, h: List[torch.Tensor], rel: torch.Tensor, t: List[torch.Tensor]) -> torch.Tensor:
+        r_h, r_m, r_t = self._split(rel)
+        return h[0] * r_h - t[0] * r_t + r_m
+
+    def _uvr(self, side: int, kept: List[torch.Tensor], rel: torch.Tensor) -> List[torch.Tensor]:
+        r_h, r_m, r_t = self._split(rel)
+        if side == nat.CORRUPT_TAIL:  # t^ r_t - (h^ r_h + r_m)
+            return [r_t, -(kept[0] * r_h + r_m)]
+        return [r_h, -(kept[0] * r_t - r_m)]  # h^ r_h - (t^ r_t - r_m)
+
+
+class InterHT(_AffineScoreFunction):
+    """InterHT: -|| h^ * (t^_aux + o) + r - t^ * (h^_aux + o) ||_p  (reference scoring.py:1418-1572)."""
+
+    _n_part = 2
+
+    def __init__(
+        self,
+        negative_sample_sharing: bool,
+        scoring_norm: int,
+        sharding: Sharding,
+        n_relation_type: int,
+        embedding_size: int,
+        entity_initializer: _Init = [init_KGE_uniform],
+        relation_initializer: _Init = [init_KGE_uniform],
+        normalize_entities: bool = True,
+        offset: float = 1.0,
+        inverse_relations: bool = False,
+    ) -> None:
+        super().__init__(negative_sample_sharing, scoring_norm)
+        self.sharding = sharding
+        self.normalize = normalize_entities
+        if isinstance(entity_initializer, list):
+            entity_initializer = 2 * entity_initializer
+        # [main | auxiliary]
+        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size] * 2)
+        self.relation_embedding = initialize_relation_embedding(
+            n_relation_type, inverse_relations, relation_initializer, [embedding_size])
+        assert self.entity_embedding.shape[-1] == 2 * self.relation_embedding.shape[-1] == 2 * embedding_size, (
+            "InterHT requires `2*embedding_size` embedding parameters for each entity"
+            " and `embedding_size` embedding parameters for each relation")
+        self.embedding_size = embedding_size
+        self.register_buffer("offset", torch.tensor([offset], dtype=torch.float32))
+
+    def _delta(self, h: List[torch.Tensor], rel: torch.Tensor, t: List[torch.Tensor]) -> torch.Tensor:
+        o = self.offset.to(rel.device)
+        return h[0] * (t[1] + o) + rel - t[0] * (h[1] + o)
+
+    def _uvr(self, side: int, kept: List[torch.Tensor], rel: torch.Tensor) -> List[torch.Tensor]:
+        o = self.offset.to(rel.device)
+        main, aux = kept
+        if side == nat.CORRUPT_TAIL:  # candidates t = (c1 main, c2 aux):  h_m (c2 + o) + r - c1 (h_a + o)
+            return [-(aux + o), main, rel + main * o]
+        return [aux + o, -main, rel - main * o]  # candidates h:  c1 (t_a + o) + r - t_m (c2 + o)
+
+
+class TranS(_AffineScoreFunction):
+    """TranS: -|| h^ * (t~ + o + r_bar) - t^ * (h~ + o - r_hat) + r ||_p  (reference scoring.py:1575-1750)."""
+
+    _n_part = 2
+
+    def __init__(
+        self,
+        negative_sample_sharing: bool,
+        scoring_norm: int,
+        sharding: Sharding,
+        n_relation_type: int,
+        embedding_size: int,
+        entity_initializer: _Init = [init_KGE_uniform],
+        relation_initializer: _Init = [init_KGE_uniform],
+        normalize_entities: bool = True,
+        offset: float = 1.0,
+        inverse_relations: bool = False,
+    ) -> None:
+        super().__init__(negative_sample_sharing, scoring_norm)
+        self.sharding = sharding
+        self.normalize = normalize_entities
+        if isinstance(entity_initializer, list):
+            entity_initializer = 2 * entity_initializer
+        # [main | tilde]
+        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size] * 2)
+        if isinstance(relation_initializer, list):
+            relation_initializer = 3 * relation_initializer
+        # [r | r_bar | r_hat]
+        self.relation_embedding = initialize_relation_embedding(
+            n_relation_type, inverse_relations, relation_initializer, [embedding_size] * 3)
+        assert self.entity_embedding.shape[-1] / 2 == self.relation_embedding.shape[-1] / 3 == embedding_size, (
+            "TranS requires `2*embedding_size` embedding parameters for each entity"
+            " and `3*embedding_size` embedding parameters for each relation")
+        self.embedding_size = embedding_size
+        self.register_buffer("offset", torch.tensor([offset], dtype=torch.float32))
+
+    def _delta(self, h: List[torch.Tensor], rel: torch.Tensor, t: List[torch.Tensor]) -> torch.Tensor:
+        o = self.offset.to(rel.device)
+        r, r_bar, r_hat = torch.split(rel, self.embedding_size, dim=-1)
+        return h[0] * (t[1] + o + r_bar) - t[0] * (h[1] + o - r_hat) + r
+
+    def _uvr(self, side: int, kept: List[torch.Tensor], rel: torch.Tensor) -> List[torch.Tensor]:
+        o = self.offset.to(rel.device)
+        r, r_bar, r_hat = torch.split(rel, self.embedding_size, dim=-1)
+        main, tilde = kept
+        if side == nat.CORRUPT_TAIL:  # h_m (c2 + o + r_bar) - c1 (h~ + o - r_hat) + r
+            return [-(tilde + o - r_hat), main, r + main * (o + r_bar)]
+        return [tilde + o + r_bar, -main, r - main * (o - r_hat)]  # c1 (t~ + o + r_bar) - t_m (c2 + o - r_hat) + r

@@ -24,7 +24,9 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // scorer properties
 inline bool is_complex_entity(int scorer) { return scorer == BESS_ROTATE || scorer == BESS_COMPLEX; }
-inline bool is_distance(int scorer) { return scorer == BESS_TRANSE || scorer == BESS_ROTATE; }
+inline bool is_distance(int scorer) {
+    return scorer == BESS_TRANSE || scorer == BESS_ROTATE || scorer == BESS_AFFINE;
+}
 int check_desc(const bess_model_desc* d);
 
 // reductions used by the negative-scoring kernels
@@ -41,6 +43,16 @@ int gemm_dot_dq(int dtype, const float* G, int64_t ldg, int64_t S, const void* E
                 int W, float* dQ, hipStream_t st);
 int gemm_dot_de(const float* G, int64_t ldg, int64_t S, const float* Q, int64_t N, int W, float* dE,
                 hipStream_t st);
+
+// affine-in-the-candidate distance scorers (affine.hip)
+int affine_pertriple(const bess_model_desc* d, bool fwd, const float* query, int64_t n_query, const void* neg_base,
+                     const int32_t* neg_idx, int64_t n_neg, float* out, const float* d_out, int64_t ld, float* dq,
+                     float* dn, hipStream_t st);
+int affine_shared_fwd(const bess_model_desc* d, const float* query, int64_t S, const float* cand, int64_t N, float* out,
+                      int64_t ld, hipStream_t st);
+int affine_shared_bwd(const bess_model_desc* d, const float* query, int64_t S, const float* cand, int64_t N,
+                      const float* out, int64_t ld_out, const float* d_out, int64_t ld_dout, float* d_query,
+                      float* d_cand, hipStream_t st);
 
 // ---- device side ------------------------------------------------------------
 typedef _Float16 half_t;

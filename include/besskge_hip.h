@@ -48,6 +48,14 @@ extern "C" {
 #define BESS_ROTATE 1
 #define BESS_DISTMULT 2
 #define BESS_COMPLEX 3
+/* PairRE / TripleRE / InterHT / TranS (scoring.py:465-743, 1418-1750), as seen by the
+ * negative-scoring kernels: score = -|| U*c1(e) + V*c2(e) + R ||_p with the query matrix
+ * [n_query, (n_part + 1) * d] = [U | V | R] (V absent for n_part = 1), entity rows of
+ * n_part * d scalars = [c1 | c2], each part optionally L2-normalised.
+ * desc.width = n_part * d, desc.reserved[0] = n_part (1 | 2), desc.reserved[1] bit 0 =
+ * normalise the parts (per-triple kernels only; the shared kernels take candidates that
+ * bess_normalize_rows has already gathered, converted to f32 and normalised). */
+#define BESS_AFFINE 4
 
 /* table element types */
 #define BESS_F32 0
@@ -304,6 +312,18 @@ int bess_apply_segments_opt(const bess_opt_desc* o, int32_t dtype, int32_t width
 /* dense axpy on a replicated table: table -= lr * grad (relation table) */
 int bess_dense_sgd(int32_t dtype, void* table, const float* grad, int64_t n_elem,
                    float lr, void* stream);
+
+/* `torch.nn.functional.normalize(part, p=2, dim=-1)` of every d-wide part of the rows
+ * (scoring.py:549-551 and the like), fused with the gather and the f32 conversion:
+ *   out[i, p*d + w] = row_i[p*d + w] * inv[i, p],  inv = 1 / max(||part||_2, 1e-12)
+ * (inv = 1 when normalize == 0: plain gather + convert).  inv_norm may be NULL. */
+int bess_normalize_rows(int32_t dtype, const void* base, const int32_t* idx, int64_t n_rows,
+                        int32_t width, int32_t n_part, int32_t normalize, float* out,
+                        float* inv_norm, void* stream);
+/* its backward: d_rows = inv * (d_hat - hat * <hat, d_hat>) per part */
+int bess_normalize_rows_bwd(const float* hat, const float* inv_norm, const float* d_hat,
+                            int64_t n_rows, int32_t width, int32_t n_part, float* d_rows,
+                            void* stream);
 
 /* ---- device-side index sampling (bit-exact numpy streams) -------------------
  * `jump_table` (device, uint64 [64][4] = {a_hi, a_lo, c_hi, c_lo}): the affine map

@@ -15,7 +15,8 @@ tests/golden/make_golden.py) in `tests/test_oracle.py`.
 
 Reference lines restated:
   score_triple / score_heads / score_tails ... scoring.py:321-354 (TransE),
-      423-462 (RotatE), 804-837 (DistMult), 905-946 (ComplEx);
+      423-462 (RotatE), 804-837 (DistMult), 905-946 (ComplEx), 540-593 (PairRE),
+      681-743 (TripleRE), 1499-1572 (InterHT), 1661-1750 (TranS);
       broadcasted_distance scoring.py:176-200, broadcasted_dot_product 231-255;
       complex_multiplication / complex_rotation utils.py:72-112
   losses ............ loss.py:28-51, 115-134, 179-195, 224-251
@@ -34,6 +35,33 @@ BAD_NEGATIVE_SCORE = -50000.0
 
 TRANSE, ROTATE, DISTMULT, COMPLEX = "TransE", "RotatE", "DistMult", "ComplEx"
 
+# PairRE / TripleRE / InterHT / TranS (scoring.py:465-743, 1418-1750) and the constructor
+# options the fixtures were generated with (name -> reference class + options)
+AFFINE_VARIANTS = {
+    "PairRE": dict(base="PairRE", normalize=True),
+    "TripleRE": dict(base="TripleRE", normalize=True, u=0.0),
+    "TripleREv2": dict(base="TripleRE", normalize=False, u=0.5),
+    "InterHT": dict(base="InterHT", normalize=True, offset=1.0),
+    "TranS": dict(base="TranS", normalize=True, offset=1.0),
+    "TranSnn": dict(base="TranS", normalize=False, offset=0.5),
+}
+
+
+def entity_width(scorer: str, d: int) -> int:
+    if scorer in (ROTATE, COMPLEX):
+        return 2 * d
+    if scorer in AFFINE_VARIANTS and AFFINE_VARIANTS[scorer]["base"] in ("InterHT", "TranS"):
+        return 2 * d
+    return d
+
+
+def relation_width(scorer: str, d: int) -> int:
+    if scorer == COMPLEX:
+        return 2 * d
+    if scorer in AFFINE_VARIANTS:
+        return {"PairRE": 2 * d, "TripleRE": 3 * d, "InterHT": d, "TranS": 3 * d}[AFFINE_VARIANTS[scorer]["base"]]
+    return d
+
 
 # ------------------------------------------------------------------ scoring --
 def _cmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -48,6 +76,35 @@ def _rot(v: torch.Tensor, phase: torch.Tensor) -> torch.Tensor:
 
 def _is_distance(scorer: str) -> bool:
     return scorer in (TRANSE, ROTATE)
+
+
+def _affine_delta(scorer: str, h: torch.Tensor, rel: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """The vector whose p-norm is the negated score; h, rel, t broadcast against each other
+    over their leading dims (the reference's `unsqueeze(1)` forms)."""
+    cfg = AFFINE_VARIANTS[scorer]
+    base = cfg["base"]
+    d = rel.shape[-1] // {"PairRE": 2, "TripleRE": 3, "InterHT": 1, "TranS": 3}[base]
+
+    def parts(x: torch.Tensor) -> List[torch.Tensor]:
+        ps = list(torch.split(x, d, dim=-1))
+        if cfg["normalize"]:
+            ps = [p / torch.clamp(torch.linalg.vector_norm(p, dim=-1, keepdim=True), min=1e-12) for p in ps]
+        return ps
+
+    hp, tp = parts(h), parts(t)
+    if base == "PairRE":
+        r_h, r_t = rel[..., :d], rel[..., d:]
+        return hp[0] * r_h - tp[0] * r_t
+    if base == "TripleRE":
+        r_h, r_m, r_t = rel[..., :d], rel[..., d:2 * d], rel[..., 2 * d:]
+        if cfg["u"] > 0.0:
+            r_h, r_t = r_h + cfg["u"], r_t + cfg["u"]
+        return hp[0] * r_h - tp[0] * r_t + r_m
+    off = cfg["offset"]
+    if base == "InterHT":
+        return hp[0] * (tp[1] + off) + rel - tp[0] * (hp[1] + off)
+    r, r_bar, r_hat = rel[..., :d], rel[..., d:2 * d], rel[..., 2 * d:]
+    return hp[0] * (tp[1] + off + r_bar) - tp[0] * (hp[1] + off - r_hat) + r
 
 
 def query(scorer: str, side: str, ent: torch.Tensor, rel: torch.Tensor) -> torch.Tensor:
@@ -79,6 +136,8 @@ def _reduce(scorer: str, p: int, q: torch.Tensor, cand: torch.Tensor) -> torch.T
 
 def score_triple(scorer: str, p: int, h: torch.Tensor, rel_table: torch.Tensor, rid: torch.Tensor,
                  t: torch.Tensor) -> torch.Tensor:
+    if scorer in AFFINE_VARIANTS:
+        return -torch.norm(_affine_delta(scorer, h, rel_table[rid.long()], t), p=p, dim=-1)
     return _reduce(scorer, p, query(scorer, "t", h, rel_table[rid.long()]), t)
 
 
@@ -89,6 +148,11 @@ def score_candidates(scorer: str, p: int, sharing: bool, side: str, ent: torch.T
     cand [B, N, W].  sharing: every query vs all B*N rows -> [S, B*N];
     else query s vs cand[s] (B == S, or B == 1 broadcast) -> [S, N].
     """
+    if scorer in AFFINE_VARIANTS:
+        c = cand.reshape(1, -1, cand.shape[-1]) if sharing else cand
+        e, r = ent[:, None, :], rel_table[rid.long()][:, None, :]
+        delta = _affine_delta(scorer, c, r, e) if side == "h" else _affine_delta(scorer, e, r, c)
+        return -torch.norm(delta, p=p, dim=-1)
     q = query(scorer, side, ent, rel_table[rid.long()])  # [S, W]
     if sharing:
         flat = cand.reshape(-1, cand.shape[-1])

@@ -371,25 +371,61 @@ def scorer_factory(name: str, p: int, sharing: bool, sharding: Sharding, n_rel: 
         return DistMult(sharing, sharding, n_rel, d, ent, rel)
     if name == "ComplEx":
         return ComplEx(sharing, sharding, n_rel, d, ent, rel)
+    if name in AFFINE_VARIANTS:
+        from besskge.scoring import InterHT, PairRE, TranS, TripleRE
+
+        cfg = AFFINE_VARIANTS[name]
+        if cfg["base"] == "PairRE":
+            return PairRE(sharing, p, sharding, n_rel, d, ent, rel, normalize_entities=cfg["normalize"])
+        if cfg["base"] == "TripleRE":
+            return TripleRE(sharing, p, sharding, n_rel, d, ent, rel, normalize_entities=cfg["normalize"], u=cfg["u"])
+        if cfg["base"] == "InterHT":
+            return InterHT(sharing, p, sharding, n_rel, d, ent, rel, normalize_entities=cfg["normalize"],
+                           offset=cfg["offset"])
+        return TranS(sharing, p, sharding, n_rel, d, ent, rel, normalize_entities=cfg["normalize"],
+                     offset=cfg["offset"])
     raise ValueError(name)
+
+
+# constructor options of the PairRE / TripleRE / InterHT / TranS fixtures (same table in oracle/kge.py)
+AFFINE_VARIANTS = {
+    "PairRE": dict(base="PairRE", normalize=True),
+    "TripleRE": dict(base="TripleRE", normalize=True, u=0.0),
+    "TripleREv2": dict(base="TripleRE", normalize=False, u=0.5),
+    "InterHT": dict(base="InterHT", normalize=True, offset=1.0),
+    "TranS": dict(base="TranS", normalize=True, offset=1.0),
+    "TranSnn": dict(base="TranS", normalize=False, offset=0.5),
+}
+AFFINE_SCORERS = [("PairRE", 1), ("PairRE", 2), ("TripleRE", 1), ("TripleREv2", 2), ("InterHT", 1), ("InterHT", 2),
+                  ("TranS", 1), ("TranSnn", 2)]
 
 
 SCORERS = [("TransE", 1), ("TransE", 2), ("RotatE", 1), ("RotatE", 2), ("DistMult", 0), ("ComplEx", 0)]
 
 
 def widths(name: str, d: int) -> Any:
+    if name in AFFINE_VARIANTS:
+        base = AFFINE_VARIANTS[name]["base"]
+        return (2 * d if base in ("InterHT", "TranS") else d), {"PairRE": 2, "TripleRE": 3, "InterHT": 1, "TranS": 3}[base] * d
     W = 2 * d if name in ("RotatE", "ComplEx") else d
     Wr = 2 * d if name == "ComplEx" else d
     return W, Wr
 
 
 def gen_scoring() -> None:
-    fix = "scoring"
-    torch.manual_seed(1)
+    _gen_scoring("scoring", SCORERS, 1)
+
+
+def gen_scoring_affine() -> None:
+    _gen_scoring("scoring_affine", AFFINE_SCORERS, 2)
+
+
+def _gen_scoring(fix: str, scorers: Any, seed: int) -> None:
+    torch.manual_seed(seed)
     S, N, d, n_rel, n_ent = 10, 7, 12, 5, 40
     sharding = Sharding.create(n_ent, 1, seed=0)
     put(fix, "args", np.array([S, N, d, n_rel, n_ent]))
-    for name, p in SCORERS:
+    for name, p in scorers:
         W, Wr = widths(name, d)
         ent = torch.randn(1, n_ent, W)
         rel = torch.randn(n_rel, Wr)
@@ -487,8 +523,8 @@ def run_bess_case(
     sharing: bool,
     batch_kind: str = "rigid",
     with_grads: bool = True,
+    fix: str = "bess",
 ) -> None:
-    fix = "bess"
     seed = 1234
     n_entity, n_rel, n_triple = 120, 6, 400
     d = 8
@@ -633,6 +669,24 @@ def gen_bess() -> None:
         names.append(name)
     put("bess", "cases", np.array(names))
 
+
+
+def gen_bess_affine() -> None:
+    """PairRE / TripleRE / InterHT / TranS through the reference's BessKGE.forward + autograd."""
+    EM, SM = EmbeddingMovingBessKGE, ScoreMovingBessKGE
+    cases = []
+    for scorer, p in AFFINE_SCORERS:
+        sn = f"{scorer}{p}"
+        cases.append((f"tr_EM_{sn}_t_flat_n1", EM, scorer, p, 1, "t", "random_flat", "logsigmoid", False, True))
+        cases.append((f"tr_EM_{sn}_h_pt_n1", EM, scorer, p, 1, "h", "random_pt", "logsigmoid", False, False))
+        cases.append((f"tr_EM_{sn}_ht_pt_n2", EM, scorer, p, 2, "ht", "random_pt", "ssce", False, False))
+        cases.append((f"tr_SM_{sn}_t_pt_n2", SM, scorer, p, 2, "t", "random_pt", "logsigmoid", False, False))
+        cases.append((f"tr_SM_{sn}_ht_flat_n2", SM, scorer, p, 2, "ht", "random_flat", "margin", False, True))
+    names = []
+    for name, mcls, scorer, p, n, scheme, nk, loss, aug, sharing in cases:
+        run_bess_case(name, mcls, scorer, p, n, scheme, nk, loss, aug, sharing, fix="bess_affine")
+        names.append(name)
+    put("bess_affine", "cases", np.array(names))
 
 
 # --------------------------------------------------------------------------- #
@@ -793,6 +847,8 @@ def main() -> None:
         metric=gen_metric,
         topk=gen_topk,
         allscores=gen_allscores,
+        scoring_affine=gen_scoring_affine,
+        bess_affine=gen_bess_affine,
     )
     for name, g in gens.items():
         if only and name not in only:

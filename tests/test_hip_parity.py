@@ -18,7 +18,10 @@ pytestmark = pytest.mark.gpu
 from oracle import kge  # noqa: E402
 
 from conftest import load_golden  # noqa: E402
-from test_oracle import LOSSES, SCORERS, T, bess_cases, load_bess_case, step_batch  # noqa: E402
+from test_oracle import (  # noqa: E402
+    AFFINE_SCORERS, LOSSES, SCORERS, T, bess_cases, load_bess_case, scoring_fixture, step_batch)
+
+NATIVE_SCORERS = [s for s in SCORERS if s not in AFFINE_SCORERS]
 
 RTOL, ATOL = 1e-4, 1e-5
 
@@ -38,12 +41,21 @@ def close(got, want, rtol=RTOL, atol=ATOL, scale=None):
 
 
 def make_scorer(name, p, sharing, n_rel, d, ent, rel, dev, dtype=torch.float32, sharding=None):
-    from besskge.scoring import ComplEx, DistMult, RotatE, TransE
+    from besskge.scoring import ComplEx, DistMult, InterHT, PairRE, RotatE, TranS, TransE, TripleRE
     from besskge.sharding import Sharding
 
     if sharding is None:  # only n_shard matters for the training / scoring step
         sharding = Sharding.create(ent.shape[0] * ent.shape[1], ent.shape[0], seed=0)
-    if name == "TransE":
+    if name in kge.AFFINE_VARIANTS:
+        cfg = kge.AFFINE_VARIANTS[name]
+        cls = dict(PairRE=PairRE, TripleRE=TripleRE, InterHT=InterHT, TranS=TranS)[cfg["base"]]
+        kw = dict(normalize_entities=cfg["normalize"])
+        if "u" in cfg:
+            kw["u"] = cfg["u"]
+        if "offset" in cfg:
+            kw["offset"] = cfg["offset"]
+        fn = cls(sharing, p, sharding, n_rel, d, ent, rel, **kw)
+    elif name == "TransE":
         fn = TransE(sharing, p, sharding, n_rel, d, ent, rel)
     elif name == "RotatE":
         fn = RotatE(sharing, p, sharding, n_rel, d, ent, rel)
@@ -58,7 +70,7 @@ def make_scorer(name, p, sharing, n_rel, d, ent, rel, dev, dtype=torch.float32, 
 
 
 def widths(name, d):
-    return (2 * d if name in ("RotatE", "ComplEx") else d), (2 * d if name == "ComplEx" else d)
+    return kge.entity_width(name, d), kge.relation_width(name, d)
 
 
 # ---------------------------------------------------------------- movers ----
@@ -115,7 +127,7 @@ def test_cpu_tensors_are_refused():
 @pytest.mark.parametrize("B", [1, 10])
 def test_scoring_golden(dev, name, p, sharing, B):
     """score_triple / score_heads / score_tails + gradients vs the reference's outputs."""
-    g = load_golden("scoring")
+    g = scoring_fixture(name)
     S, N, d, n_rel, n_ent = (int(x) for x in g["args"])
     k = f"{name}_p{p}_"
     c = k + f"s{int(sharing)}_B{B}_"
@@ -399,7 +411,7 @@ def test_bess_inference_like_reference(dev, model_name, scheme, dup, flat):
 
 
 # ------------------------------------------- K9 segmented reduction (no atomics) ----
-@pytest.mark.parametrize("name,p", SCORERS)
+@pytest.mark.parametrize("name,p", NATIVE_SCORERS)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_grad_segments_match_scatter_of_row_gradients(dev, name, p, dtype):
     """grad_seg == index_add of the per-reference row gradients of the plain backward
