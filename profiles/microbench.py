@@ -91,9 +91,53 @@ CASES = [
     ("C1 TransE L2 shared 512x64", "TransE", 2, torch.float32, 10_000, 128, 128, 512, 64, True),
 ]
 
+def run_affine(name, n_part, normalize, p, dtype, M, d, S, N, shared):
+    """PairRE / TripleRE (n_part 1) and InterHT / TranS (n_part 2) kernel family."""
+    g = torch.Generator(device="cpu").manual_seed(0)
+    W = n_part * d
+    table = (torch.randn(M, W, generator=g) * 0.1).to(dtype).to(dev)
+    dsc = nat.make_desc(nat.AFFINE, p, table, d)
+    dsc.reserved[0], dsc.reserved[1] = n_part, int(normalize)
+    q = torch.randn(S, (n_part + 1) * d, device=dev)
+    sz = table.element_size()
+    if shared:
+        neg = RowSource(table, torch.randint(M, (N,), dtype=torch.int32, device=dev))
+        out = nat.neg_score_shared_fwd(dsc, q, neg)
+        go = torch.randn_like(out)
+        t_f = timeit(lambda: nat.neg_score_shared_fwd(dsc, q, neg))
+        t_b = timeit(lambda: nat.neg_score_shared_bwd(dsc, q, neg, out, go))
+        ops_f = (n_part + 1) * S * N * d  # fma per part + |.| accumulate
+        print(f"{name:34s} shared  S={S:5d} N={N:5d} d={d:4d} {str(dtype)[6:]:7s} fwd {t_f*1e3:8.1f} us "
+              f"{ops_f/t_f/1e9:6.1f} T lane-ops/s | bwd {t_b*1e3:8.1f} us")
+    else:
+        neg = RowSource(table, torch.randint(M, (S * N,), dtype=torch.int32, device=dev))
+        out = nat.neg_score_pertriple_fwd(dsc, q, neg, N)
+        go = torch.randn_like(out)
+        t_f = timeit(lambda: nat.neg_score_pertriple_fwd(dsc, q, neg, N))
+        t_b = timeit(lambda: nat.neg_score_pertriple_bwd(dsc, q, neg, N, go), reps=5)
+        bf = S * N * (W * sz + 8) + S * q.shape[1] * 4
+        bb = S * N * (W * sz + W * 4 + 8) + 2 * S * q.shape[1] * 4
+        print(f"{name:34s} per-tri S={S:5d} N={N:5d} d={d:4d} {str(dtype)[6:]:7s} fwd {t_f*1e3:8.1f} us "
+              f"{bf/t_f/1e6:7.0f} GB/s | bwd {t_b*1e3:8.1f} us {bb/t_b/1e6:7.0f} GB/s")
+
+
+AFFINE_CASES = [
+    # name, n_part, normalize, p, dtype, M, d, S, N, shared
+    ("PairRE d256 f32 norm (L3)", 1, True, 1, torch.float32, 93_773, 256, 4096, 256, False),
+    ("PairRE d512 f32 norm (L3)", 1, True, 1, torch.float32, 93_773, 512, 4096, 256, False),
+    ("TranS d256 f32 norm (L3)", 2, True, 1, torch.float32, 93_773, 256, 4096, 256, False),
+    ("TranS d256 f32 norm (HBM 8GB)", 2, True, 1, torch.float32, 4_000_000, 256, 4096, 256, False),
+    ("InterHT d128 f16 (L3)", 2, True, 2, torch.float16, 312_576, 128, 4096, 256, False),
+    ("PairRE d256 shared 4096x4096", 1, True, 1, torch.float32, 93_773, 256, 4096, 4096, True),
+    ("TranS d256 shared 4096x4096", 2, True, 1, torch.float32, 93_773, 256, 4096, 4096, True),
+]
+
 if __name__ == "__main__":
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     print(torch.cuda.get_device_name(0))
     for c in CASES:
         if flt in c[0]:
             run(*c)
+    for c in AFFINE_CASES:
+        if flt in c[0]:
+            run_affine(*c)
