@@ -433,6 +433,20 @@ class BessKGE(torch.nn.Module, ABC):
         else:
             all_rows = torch.arange(rel_table.shape[0], dtype=torch.int32, device=rel_table.device)
             self._apply_optimizer(optimizer, rel_table, [(all_rows, d_rel)])
+        # dense parameters of the scorer (ConvE's query network): replicated like the relation table
+        dense_grads = self.score_fn.__dict__.pop("dense_grads", {})
+        for p in self.score_fn.dense_parameters():
+            g = dense_grads.get(p)
+            if g is None:
+                continue
+            (g,) = group.all_reduce_sum([g.contiguous()]) if len(group.local_shards) == 1 else (g,)
+            as_table = p.data.view(p.shape[0], -1) if p.dim() > 1 else p.data.view(1, -1)
+            g = g.reshape(as_table.shape).contiguous()
+            if plain:
+                nat.dense_sgd(as_table, g, lr)
+            else:
+                rows = torch.arange(as_table.shape[0], dtype=torch.int32, device=as_table.device)
+                self._apply_optimizer(optimizer, as_table, [(rows, g)])
 
 
     # ------------------------------------------------------ group execution

@@ -124,6 +124,11 @@ def place_shards(model: BessKGE, group: ReplicaGroup, device: torch.device,
     fn.relation_embedding = torch.nn.Parameter(
         fn.relation_embedding.data.to(device=device, dtype=dt).contiguous(), requires_grad=False)
     model.entity_embedding = fn.entity_embedding
+    # whatever else the scorer owns (ConvE's query network, offset buffers): replicated on the device
+    for child in fn.children():
+        child.to(device)
+    for name, buf in list(fn.named_buffers(recurse=False)):
+        setattr(fn, name, buf.to(device))
     model.attach(group, {s: i for i, s in enumerate(group.local_shards)})
 
 

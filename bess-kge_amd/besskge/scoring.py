@@ -28,7 +28,12 @@ those kernels; the per-query transform (S rows: building [U | V | R] from the
 kept entity and the relation) and the positive score are written with torch
 ops on the device and differentiated by autograd.
 
-ConvE and BoxE are not provided.
+ConvE (`scoring.py:949-1146`) keeps its query network (batch-norm, conv,
+linear: dense parameters) as torch modules on the device; what is scored
+against the candidates is a plain dot product over `[embedding | tail bias]`
+rows with the query `[net(h, r) | 1]`, i.e. the DistMult kernels.
+
+BoxE is not provided.
 """
 
 from abc import ABC, abstractmethod
@@ -42,6 +47,7 @@ from besskge.embedding import (
     init_KGE_normal,
     init_KGE_uniform,
     init_uniform_rotation,
+    init_xavier_norm,
     initialize_entity_embedding,
     initialize_relation_embedding,
     refactor_embedding_sharding,
@@ -84,6 +90,18 @@ class BaseScoreFunction(torch.nn.Module, ABC):
     #: per-triple negatives of the own shard can use the segmented K9 reduction
     #: (gradient recomputed per reference from the query) instead of a [S*N, W] gradient
     supports_fused_segments = True
+
+    def dense_parameters(self) -> List[torch.nn.Parameter]:
+        """Parameters besides the two embedding tables (ConvE's network); replicated like the
+        relation table.  Their gradients are collected by `query_bwd` / `triple_bwd` in
+        `dense_grads` (parameter -> fp32 gradient) and consumed by the training step."""
+        return []
+
+    def _collect_dense(self, grads: Any) -> None:
+        store = self.__dict__.setdefault("dense_grads", {})
+        for p, g in zip(self.dense_parameters(), grads):
+            if g is not None:
+                store[p] = g.float() if p not in store else store[p] + g.float()
 
     def query_fwd(self, side: int, ent: nat.RowSource, rel_idx: torch.Tensor) -> Tuple[torch.Tensor, Any]:
         """Query matrix of a negative-scoring problem and the context its backward needs."""
@@ -335,11 +353,58 @@ def _rows_of(src: nat.RowSource) -> torch.Tensor:
     return src.base if src.idx is None else nat.gather_rows(src.base, src.idx)
 
 
-class _AffineScoreFunction(DistanceBasedScoreFunction, ABC):
+class _TorchQueryHooks:
+    """Hooks of the fused step for scorers whose S-row work (query transform,
+    positive score) is written with torch ops: autograd over S rows, the
+    gradient of the embedding rows / relation table / dense parameters handed
+    back to the step."""
+
+    supports_fused_segments = False
+
+    def _query_torch(self, side: int, rows: torch.Tensor, rel: torch.Tensor, rel_idx: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def _triple_torch(self, h: torch.Tensor, rel: torch.Tensor, rel_idx: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def query_fwd(self, side: int, ent: nat.RowSource, rel_idx: torch.Tensor) -> Tuple[torch.Tensor, Any]:
+        track = torch.is_grad_enabled()  # inference runs under no_grad: no graph is kept
+        rows = _rows_of(ent).detach().float().requires_grad_(track)
+        rel = self.relation_embedding.detach().float().requires_grad_(track)  # type: ignore[attr-defined]
+        q = self._query_torch(side, rows, rel, rel_idx)
+        return q.detach().contiguous(), (rows, rel, q)
+
+    def query_bwd(self, side: int, ent: nat.RowSource, rel_idx: torch.Tensor, ctx: Any, dq: torch.Tensor,
+                  d_rel: torch.Tensor) -> torch.Tensor:
+        rows, rel, q = ctx
+        dense = self.dense_parameters()  # type: ignore[attr-defined]
+        grads = torch.autograd.grad(q, [rows, rel] + dense, dq, allow_unused=True)
+        d_rel += grads[1]
+        self._collect_dense(grads[2:])  # type: ignore[attr-defined]
+        return grads[0].contiguous()
+
+    def triple_fwd(self, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor) -> Tuple[torch.Tensor, Any]:
+        track = torch.is_grad_enabled()
+        h = _rows_of(head).detach().float().requires_grad_(track)
+        t = _rows_of(tail).detach().float().requires_grad_(track)
+        rel = self.relation_embedding.detach().float().requires_grad_(track)  # type: ignore[attr-defined]
+        sc = self._triple_torch(h, rel, rel_idx, t)
+        return sc.detach().contiguous(), (h, t, rel, sc)
+
+    def triple_bwd(self, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor, ctx: Any,
+                   d_pos: torch.Tensor, d_rel: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        h, t, rel, sc = ctx
+        dense = self.dense_parameters()  # type: ignore[attr-defined]
+        grads = torch.autograd.grad(sc, [h, t, rel] + dense, d_pos, allow_unused=True)
+        d_rel += grads[2]
+        self._collect_dense(grads[3:])  # type: ignore[attr-defined]
+        return grads[0].contiguous(), grads[1].contiguous()
+
+
+class _AffineScoreFunction(_TorchQueryHooks, DistanceBasedScoreFunction, ABC):
     """`-|| U * c1 + V * c2 + R ||_p` scorers; see the module docstring."""
 
     _scorer_id = nat.AFFINE
-    supports_fused_segments = False
     #: d-wide parts of an entity row (1 | 2)
     _n_part: int = 1
     normalize: bool
@@ -388,35 +453,11 @@ class _AffineScoreFunction(DistanceBasedScoreFunction, ABC):
     def score_tails(self, head_emb: torch.Tensor, relation_id: torch.Tensor, tail_emb: torch.Tensor) -> torch.Tensor:
         return self._score_candidates(nat.CORRUPT_TAIL, head_emb, relation_id, tail_emb)
 
-    # hooks of the fused step: autograd over S rows
-    def query_fwd(self, side: int, ent: nat.RowSource, rel_idx: torch.Tensor) -> Tuple[torch.Tensor, Any]:
-        with torch.enable_grad():
-            rows = _rows_of(ent).detach().float().requires_grad_()
-            rel = self.relation_embedding.detach().float().requires_grad_()
-            q = torch.cat(self._uvr(side, self._parts(rows), self._rel(rel_idx, rel)), dim=-1)
-        return q.detach().contiguous(), (rows, rel, q)
+    def _query_torch(self, side: int, rows: torch.Tensor, rel: torch.Tensor, rel_idx: torch.Tensor) -> torch.Tensor:
+        return torch.cat(self._uvr(side, self._parts(rows), self._rel(rel_idx, rel)), dim=-1)
 
-    def query_bwd(self, side: int, ent: nat.RowSource, rel_idx: torch.Tensor, ctx: Any, dq: torch.Tensor,
-                  d_rel: torch.Tensor) -> torch.Tensor:
-        rows, rel, q = ctx
-        d_rows, d_r = torch.autograd.grad(q, [rows, rel], dq)
-        d_rel += d_r
-        return d_rows.contiguous()
-
-    def triple_fwd(self, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor) -> Tuple[torch.Tensor, Any]:
-        with torch.enable_grad():
-            h = _rows_of(head).detach().float().requires_grad_()
-            t = _rows_of(tail).detach().float().requires_grad_()
-            rel = self.relation_embedding.detach().float().requires_grad_()
-            sc = self._score_norm(self._delta(self._parts(h), self._rel(rel_idx, rel), self._parts(t)))
-        return sc.detach().contiguous(), (h, t, rel, sc)
-
-    def triple_bwd(self, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor, ctx: Any,
-                   d_pos: torch.Tensor, d_rel: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        h, t, rel, sc = ctx
-        dh, dt, d_r = torch.autograd.grad(sc, [h, t, rel], d_pos)
-        d_rel += d_r
-        return dh.contiguous(), dt.contiguous()
+    def _triple_torch(self, h: torch.Tensor, rel: torch.Tensor, rel_idx: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        return self._score_norm(self._delta(self._parts(h), self._rel(rel_idx, rel), self._parts(t)))
 
 
 class PairRE(_AffineScoreFunction):
@@ -606,3 +647,101 @@ class TranS(_AffineScoreFunction):
         if side == nat.CORRUPT_TAIL:  # h_m (c2 + o + r_bar) - c1 (h~ + o - r_hat) + r
             return [-(tilde + o - r_hat), main, r + main * (o + r_bar)]
         return [tilde + o + r_bar, -main, r - main * (o - r_hat)]  # c1 (t~ + o + r_bar) - t_m (c2 + o - r_hat) + r
+
+
+class ConvE(_TorchQueryHooks, MatrixDecompositionScoreFunction):
+    """ConvE: <net(h, r), t> + b_t, scores not passed through a sigmoid; only
+    tails can be corrupted (reference scoring.py:949-1146)."""
+
+    _scorer_id = nat.DISTMULT  # candidates see a dot product over [embedding | bias] rows
+
+    def __init__(
+        self,
+        negative_sample_sharing: bool,
+        sharding: Sharding,
+        n_relation_type: int,
+        embedding_size: int,
+        embedding_height: int,
+        embedding_width: int,
+        entity_initializer: _Init = [init_xavier_norm, torch.nn.init.zeros_],
+        relation_initializer: _Init = [init_xavier_norm],
+        inverse_relations: bool = True,
+        input_channels: int = 1,
+        output_channels: int = 32,
+        kernel_height: int = 3,
+        kernel_width: int = 3,
+        input_dropout: float = 0.2,
+        feature_map_dropout: float = 0.2,
+        hidden_dropout: float = 0.3,
+        batch_normalization: bool = True,
+    ) -> None:
+        super().__init__(negative_sample_sharing)
+        self.sharding = sharding
+        if input_channels * embedding_width * embedding_height != embedding_size:
+            raise ValueError("`embedding_size` needs to be equal to"
+                             " `input_channels * embedding_width * embedding_height`")
+        # [embedding | tail bias]
+        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size, 1])
+        self.relation_embedding = initialize_relation_embedding(
+            n_relation_type, inverse_relations, relation_initializer, [embedding_size])
+        assert self.entity_embedding.shape[-1] - 1 == self.relation_embedding.shape[-1] == embedding_size, (
+            "ConvE requires `embedding_size + 1` embedding parameters for each entity"
+            " and `embedding_size` embedding parameters for each relation")
+        self.embedding_size = embedding_size
+        self.inp_channels = input_channels
+        self.emb_h = embedding_height
+        self.emb_w = embedding_width
+        conv_layers = [
+            torch.nn.Dropout(input_dropout),
+            torch.nn.Conv2d(in_channels=input_channels, out_channels=output_channels,
+                            kernel_size=(kernel_height, kernel_width)),
+            torch.nn.ReLU(),
+            torch.nn.Dropout2d(feature_map_dropout),
+        ]
+        fc_layers = [
+            torch.nn.Linear(output_channels * (2 * embedding_height - kernel_height + 1)
+                            * (embedding_width - kernel_width + 1), embedding_size),
+            torch.nn.Dropout(hidden_dropout),
+            torch.nn.ReLU(),
+        ]
+        if batch_normalization:
+            conv_layers.insert(0, torch.nn.BatchNorm2d(input_channels))
+            conv_layers.insert(3, torch.nn.BatchNorm2d(output_channels))
+            fc_layers.insert(2, torch.nn.BatchNorm1d(embedding_size))
+        self.conv_layers = torch.nn.Sequential(*conv_layers)
+        self.fc_layers = torch.nn.Sequential(*fc_layers)
+
+    def kernel_desc(self) -> nat.ModelDesc:
+        d = super().kernel_desc()
+        d.rel_width = d.width  # the dot-product kernels only see [embedding | bias] rows
+        return d
+
+    def dense_parameters(self) -> List[torch.nn.Parameter]:
+        return list(self.conv_layers.parameters()) + list(self.fc_layers.parameters())
+
+    def _net(self, head: torch.Tensor, rel: torch.Tensor) -> torch.Tensor:
+        shape = (-1, self.inp_channels, self.emb_h, self.emb_w)
+        hr = torch.cat([head[..., :-1].reshape(shape), rel.reshape(shape)], dim=-2)
+        return self.fc_layers(self.conv_layers(hr).flatten(start_dim=1))
+
+    def _query_torch(self, side: int, rows: torch.Tensor, rel: torch.Tensor, rel_idx: torch.Tensor) -> torch.Tensor:
+        if side != nat.CORRUPT_TAIL:
+            raise NotImplementedError("ConvE should not be used with head corruption")
+        q = self._net(rows.float(), torch.index_select(rel, 0, rel_idx.reshape(-1).long()).float())
+        return torch.cat([q, torch.ones_like(q[:, :1])], dim=-1)  # x 1 picks up the tail bias
+
+    def _triple_torch(self, h: torch.Tensor, rel: torch.Tensor, rel_idx: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        q = self._net(h.float(), torch.index_select(rel, 0, rel_idx.reshape(-1).long()).float())
+        t = t.float()
+        return torch.sum(q * t[..., :-1], dim=-1) + t[..., -1]
+
+    def score_triple(self, head_emb: torch.Tensor, relation_id: torch.Tensor, tail_emb: torch.Tensor) -> torch.Tensor:
+        return self._triple_torch(head_emb, self.relation_embedding, relation_id, tail_emb)
+
+    def score_heads(self, head_emb: torch.Tensor, relation_id: torch.Tensor, tail_emb: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError("ConvE should not be used with head corruption")
+
+    def score_tails(self, head_emb: torch.Tensor, relation_id: torch.Tensor, tail_emb: torch.Tensor) -> torch.Tensor:
+        q = self._query_torch(nat.CORRUPT_TAIL, head_emb, self.relation_embedding, relation_id)
+        return ops.ReduceNegatives.apply(self.kernel_desc(), bool(self.negative_sample_sharing), q.contiguous(),
+                                         self._table_dtype(tail_emb))

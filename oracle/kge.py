@@ -16,7 +16,7 @@ tests/golden/make_golden.py) in `tests/test_oracle.py`.
 Reference lines restated:
   score_triple / score_heads / score_tails ... scoring.py:321-354 (TransE),
       423-462 (RotatE), 804-837 (DistMult), 905-946 (ComplEx), 540-593 (PairRE),
-      681-743 (TripleRE), 1499-1572 (InterHT), 1661-1750 (TranS);
+      681-743 (TripleRE), 1499-1572 (InterHT), 1661-1750 (TranS), 1090-1146 (ConvE);
       broadcasted_distance scoring.py:176-200, broadcasted_dot_product 231-255;
       complex_multiplication / complex_rotation utils.py:72-112
   losses ............ loss.py:28-51, 115-134, 179-195, 224-251
@@ -48,6 +48,8 @@ AFFINE_VARIANTS = {
 
 
 def entity_width(scorer: str, d: int) -> int:
+    if scorer == "ConvE":
+        return d + 1
     if scorer in (ROTATE, COMPLEX):
         return 2 * d
     if scorer in AFFINE_VARIANTS and AFFINE_VARIANTS[scorer]["base"] in ("InterHT", "TranS"):
@@ -134,20 +136,55 @@ def _reduce(scorer: str, p: int, q: torch.Tensor, cand: torch.Tensor) -> torch.T
     return torch.sum(q * cand, dim=-1)
 
 
+CONVE = "ConvE"
+
+
+def conve_net(net: Dict[str, torch.Tensor], training: bool, h: torch.Tensor, r: torch.Tensor) -> torch.Tensor:
+    """ConvE's query network (scoring.py:1034-1062, 1100-1110) restated with functional ops:
+    BN2d -> conv 3x3 -> BN2d -> relu -> flatten -> linear -> BN1d -> relu  (dropout rates 0).
+    `net` holds the state dict of the reference's `conv_layers` / `fc_layers`; h [S, d + 1] (bias last)."""
+    F = torch.nn.functional
+    d = r.shape[-1]
+    emb_w = 4
+    emb_h = d // emb_w
+    x = torch.cat([h[..., :-1].reshape(-1, 1, emb_h, emb_w), r.reshape(-1, 1, emb_h, emb_w)], dim=-2)
+
+    def bn(x: torch.Tensor, pre: str) -> torch.Tensor:
+        return F.batch_norm(x, None if training else net[pre + ".running_mean"],
+                            None if training else net[pre + ".running_var"], net[pre + ".weight"],
+                            net[pre + ".bias"], training=training, eps=1e-5)
+
+    x = bn(x, "conv_layers.0")
+    x = F.conv2d(x, net["conv_layers.2.weight"], net["conv_layers.2.bias"])
+    x = torch.relu(bn(x, "conv_layers.3"))
+    x = F.linear(x.flatten(start_dim=1), net["fc_layers.0.weight"], net["fc_layers.0.bias"])
+    return torch.relu(bn(x, "fc_layers.2"))
+
+
 def score_triple(scorer: str, p: int, h: torch.Tensor, rel_table: torch.Tensor, rid: torch.Tensor,
-                 t: torch.Tensor) -> torch.Tensor:
+                 t: torch.Tensor, net: Optional[Dict[str, torch.Tensor]] = None, training: bool = True
+                 ) -> torch.Tensor:
+    if scorer == CONVE:
+        q = conve_net(net, training, h, rel_table[rid.long()])
+        return torch.sum(q * t[..., :-1], dim=-1) + t[..., -1]
     if scorer in AFFINE_VARIANTS:
         return -torch.norm(_affine_delta(scorer, h, rel_table[rid.long()], t), p=p, dim=-1)
     return _reduce(scorer, p, query(scorer, "t", h, rel_table[rid.long()]), t)
 
 
 def score_candidates(scorer: str, p: int, sharing: bool, side: str, ent: torch.Tensor,
-                     rel_table: torch.Tensor, rid: torch.Tensor, cand: torch.Tensor) -> torch.Tensor:
+                     rel_table: torch.Tensor, rid: torch.Tensor, cand: torch.Tensor,
+                     net: Optional[Dict[str, torch.Tensor]] = None, training: bool = True) -> torch.Tensor:
     """score_heads (side "h", ent = tails) / score_tails (side "t", ent = heads).
 
     cand [B, N, W].  sharing: every query vs all B*N rows -> [S, B*N];
     else query s vs cand[s] (B == S, or B == 1 broadcast) -> [S, N].
     """
+    if scorer == CONVE:
+        assert side == "t", "ConvE only corrupts tails"
+        q = conve_net(net, training, ent, rel_table[rid.long()])[:, None, :]
+        c = cand.reshape(1, -1, cand.shape[-1]) if sharing else cand
+        return torch.sum(q * c[..., :-1], dim=-1) + c[..., -1]
     if scorer in AFFINE_VARIANTS:
         c = cand.reshape(1, -1, cand.shape[-1]) if sharing else cand
         e, r = ent[:, None, :], rel_table[rid.long()][:, None, :]
@@ -193,8 +230,10 @@ class StepSpec:
     """Static description of a BESS micro-batch."""
 
     def __init__(self, scorer: str, p: int, sharing: bool, scheme: str, flat: bool,
-                 local_sampling: bool = False, augment: bool = False, triple_based: bool = False) -> None:
+                 local_sampling: bool = False, augment: bool = False, triple_based: bool = False,
+                 net: Optional[Dict[str, torch.Tensor]] = None) -> None:
         self.scorer, self.p, self.sharing = scorer, p, sharing
+        self.net = net  # ConvE: state dict of the query network (evaluated in train mode)
         self.scheme, self.flat = scheme, flat
         self.local_sampling, self.augment, self.triple_based = local_sampling, augment, triple_based
 
@@ -226,7 +265,7 @@ def embedding_moving_scores(spec: StepSpec, table: torch.Tensor, rel_table: torc
         neg = torch.stack([_rows(table, j, negative[j, r]) for j in range(n)])
     # [n, B, K, W] -> [B, n*K, W]
     neg = neg.transpose(0, 1).reshape(neg.shape[1], -1, W)
-    pos = score_triple(spec.scorer, spec.p, h, rel_table, rid, t)
+    pos = score_triple(spec.scorer, spec.p, h, rel_table, rid, t, net=spec.net)
 
     def corrupt(side: str, sel: Optional[torch.Tensor], cand: torch.Tensor) -> torch.Tensor:
         ent = t if side == "h" else h
@@ -236,7 +275,7 @@ def embedding_moving_scores(spec: StepSpec, table: torch.Tensor, rel_table: torc
             ent, own, rr = ent[sel], own[sel], rid[sel]
         if spec.augment:
             cand = torch.cat([own.reshape(cand.shape[0], -1, W), cand], dim=1)
-        return score_candidates(spec.scorer, spec.p, spec.sharing, side, ent, rel_table, rr, cand)
+        return score_candidates(spec.scorer, spec.p, spec.sharing, side, ent, rel_table, rr, cand, net=spec.net)
 
     if spec.scheme in ("h", "t"):
         return pos, corrupt(spec.scheme, None, neg)
@@ -268,8 +307,15 @@ def score_moving_scores(spec: StepSpec, table: torch.Tensor, rel_table: torch.Te
     h = _rows(table, r, head[r]).reshape(-1, W)
     rid = relation[r].reshape(-1)
     t = torch.stack([_rows(table, j, tail[j, r]) for j in range(n)]).reshape(-1, W)
-    pos = score_triple(spec.scorer, spec.p, h, rel_table, rid, t)
+    pos = score_triple(spec.scorer, spec.p, h, rel_table, rid, t, net=spec.net)
     slot = torch.arange(n * ppp).reshape(n, ppp)
+    q_conve = None
+    if spec.scorer == CONVE:
+        # the shard that scores sees the gathered queries of *all* replicas in one batch
+        # (bess.py:519-560): the batch-norm statistics of the query network are taken over all of them
+        h_all = torch.cat([_rows(table, rr, head[rr]).reshape(-1, W) for rr in range(n)])
+        rid_all = torch.cat([relation[rr].reshape(-1) for rr in range(n)])
+        q_conve = conve_net(spec.net, True, h_all, rel_table[rid_all.long()])[r * n * ppp:(r + 1) * n * ppp]
     blocks = []
     for j in range(n):
         loc = negative[j]  # [n(dest), B, K] rows of shard j
@@ -299,7 +345,9 @@ def score_moving_scores(spec: StepSpec, table: torch.Tensor, rel_table: torch.Te
                 cand = _rows(table, j, idx.reshape(-1)).reshape(1, -1, W)
             else:
                 cand = _rows(table, j, idx)  # [Sg, K, W]
-            return score_candidates(spec.scorer, spec.p, spec.sharing, side, ent, rel_table, rr, cand)
+            if q_conve is not None:
+                return torch.sum(q_conve[:, None, :] * cand[..., :-1], dim=-1) + cand[..., -1]
+            return score_candidates(spec.scorer, spec.p, spec.sharing, side, ent, rel_table, rr, cand, net=spec.net)
 
         if spec.scheme in ("h", "t"):
             blocks.append(corrupt(spec.scheme, None))

@@ -57,6 +57,8 @@ def bess(out_dir: str) -> None:
         batch = {k: c["batch"][k].flatten(end_dim=1) for k in keys if k in c["batch"]}
         model = build_model(c, dev)
         runner = runtime.inference_model(model, runtime.Options(device_iterations=bps), group=g, device=dev)
+        if c["net"] is not None:
+            model.train()  # ConvE fixtures: train mode (batch statistics), no dropout
         res = runner(**batch)
         for k, v in res.items():
             out[f"{case}_fwd_{k}"] = v.float().cpu().numpy()

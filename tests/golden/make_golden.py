@@ -371,6 +371,19 @@ def scorer_factory(name: str, p: int, sharing: bool, sharding: Sharding, n_rel: 
         return DistMult(sharing, sharding, n_rel, d, ent, rel)
     if name == "ComplEx":
         return ComplEx(sharing, sharding, n_rel, d, ent, rel)
+    if name == "ConvE":
+        from besskge.scoring import ConvE
+
+        fn = ConvE(sharing, sharding, n_rel, d, d // 4, 4, ent, rel, inverse_relations=False, input_dropout=0.0,
+                   feature_map_dropout=0.0, hidden_dropout=0.0)
+        # non-trivial batch-norm parameters and running statistics
+        for m in list(fn.conv_layers) + list(fn.fc_layers):
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.normal_(0.0, 0.2)
+                m.running_mean.normal_(0.0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+        return fn
     if name in AFFINE_VARIANTS:
         from besskge.scoring import InterHT, PairRE, TranS, TripleRE
 
@@ -403,7 +416,86 @@ AFFINE_SCORERS = [("PairRE", 1), ("PairRE", 2), ("TripleRE", 1), ("TripleREv2", 
 SCORERS = [("TransE", 1), ("TransE", 2), ("RotatE", 1), ("RotatE", 2), ("DistMult", 0), ("ComplEx", 0)]
 
 
+def net_state(fn: Any) -> Dict[str, torch.Tensor]:
+    """Parameters and buffers of ConvE's query network, by state-dict name."""
+    return {k: v.detach().clone() for k, v in fn.state_dict().items()
+            if k.startswith("conv_layers") or k.startswith("fc_layers")}
+
+
+def gen_scoring_conve() -> None:
+    """ConvE (scoring.py:949-1146): triple and tail scores, eval and train mode (no dropout),
+    gradients wrt embeddings, relation table and the network parameters."""
+    fix = "scoring_conve"
+    torch.manual_seed(3)
+    S, N, d, n_rel, n_ent = 10, 7, 12, 5, 40
+    sharding = Sharding.create(n_ent, 1, seed=0)
+    put(fix, "args", np.array([S, N, d, n_rel, n_ent]))
+    W = d + 1
+    ent = torch.randn(1, n_ent, W)
+    rel = torch.randn(n_rel, d)
+    h, t = torch.randn(S, W), torch.randn(S, W)
+    rid = torch.randint(n_rel, (S,))
+    neg1, negS = torch.randn(1, N, W), torch.randn(S, N, W)
+    g_pos = torch.randn(S)
+    for k, v in dict(rel=rel, h=h, t=t, rid=rid, neg1=neg1, negS=negS, g_pos=g_pos).items():
+        put(fix, k, v)
+    base = scorer_factory("ConvE", 0, True, sharding, n_rel, d, ent, rel.clone())
+    for k, v in net_state(base).items():
+        put(fix, "net_" + k, v)
+    for mode in ["eval", "train"]:
+        for sharing in [True, False]:
+            for B, neg in [(1, neg1), (S, negS)]:
+                fn = copy.deepcopy(base)
+                fn.negative_sample_sharing = sharing
+                fn.train(mode == "train")
+                hh = h.clone().requires_grad_(True)
+                tt = t.clone().requires_grad_(True)
+                nn_ = neg.clone().requires_grad_(True)
+                c = f"{mode}_s{int(sharing)}_B{B}_"
+                pos = fn.score_triple(hh, rid, tt)
+                (pos * g_pos).sum().backward()
+                put(fix, c + "pos", pos)
+                put(fix, c + "pos_dh", hh.grad)
+                put(fix, c + "pos_dt", tt.grad)
+                put(fix, c + "pos_drel", fn.relation_embedding.grad)
+                for name, prm in fn.named_parameters():
+                    if name.startswith("conv_layers") or name.startswith("fc_layers"):
+                        put(fix, c + "pos_dnet_" + name, prm.grad)
+                fn = copy.deepcopy(base)
+                fn.negative_sample_sharing = sharing
+                fn.train(mode == "train")
+                hh = h.clone().requires_grad_(True)
+                st = fn.score_tails(hh, rid, nn_)
+                g_neg = torch.randn_like(st)
+                (st * g_neg).sum().backward()
+                put(fix, c + "tails", st)
+                put(fix, c + "tails_g", g_neg)
+                put(fix, c + "tails_dneg", nn_.grad)
+                put(fix, c + "tails_dh", hh.grad)
+                put(fix, c + "tails_drel", fn.relation_embedding.grad)
+                for name, prm in fn.named_parameters():
+                    if name.startswith("conv_layers") or name.startswith("fc_layers"):
+                        put(fix, c + "tails_dnet_" + name, prm.grad)
+
+
+def gen_bess_conve() -> None:
+    EM, SM = EmbeddingMovingBessKGE, ScoreMovingBessKGE
+    cases = [
+        ("tr_EM_ConvE0_t_flat_n1", EM, "ConvE", 0, 1, "t", "random_flat", "logsigmoid", False, True),
+        ("tr_EM_ConvE0_t_pt_n1", EM, "ConvE", 0, 1, "t", "random_pt", "ssce", False, False),
+        ("tr_EM_ConvE0_t_flat_n2", EM, "ConvE", 0, 2, "t", "random_flat", "margin", False, True),
+        ("tr_SM_ConvE0_t_pt_n2", SM, "ConvE", 0, 2, "t", "random_pt", "logsigmoid", False, False),
+    ]
+    names = []
+    for name, mcls, scorer, p, n, scheme, nk, loss, aug, sharing in cases:
+        run_bess_case(name, mcls, scorer, p, n, scheme, nk, loss, aug, sharing, fix="bess_conve")
+        names.append(name)
+    put("bess_conve", "cases", np.array(names))
+
+
 def widths(name: str, d: int) -> Any:
+    if name == "ConvE":
+        return d + 1, d
     if name in AFFINE_VARIANTS:
         base = AFFINE_VARIANTS[name]["base"]
         return (2 * d if base in ("InterHT", "TranS") else d), {"PairRE": 2, "TripleRE": 3, "InterHT": 1, "TranS": 3}[base] * d
@@ -594,6 +686,9 @@ def run_bess_case(
     put(fix, p_ + "strs", np.array([model_cls.__name__, scorer, scheme, neg_kind, loss_name, batch_kind]))
     put(fix, p_ + "entity_table", ent)
     put(fix, p_ + "relation_table", rel)
+    if scorer == "ConvE":  # the query network, in the (default) train mode: batch statistics, no dropout
+        for k, v in net_state(score_fn).items():
+            put(fix, p_ + "net_" + k, v)
     for k, v in batch.items():
         put(fix, p_ + "batch_" + k, v)
 
@@ -631,6 +726,10 @@ def run_bess_case(
     if loss_fn is not None and with_grads:
         put(fix, p_ + "grad_entity", torch.stack([reps[r].score_fn.entity_embedding.grad for r in range(n_shard)]))
         put(fix, p_ + "grad_relation", torch.stack([reps[r].score_fn.relation_embedding.grad for r in range(n_shard)]))
+        if scorer == "ConvE":  # the network is shared by the replica copies: its .grad is the sum over replicas
+            for name, prm in score_fn.named_parameters():
+                if name.startswith("conv_layers") or name.startswith("fc_layers"):
+                    put(fix, p_ + "gradnet_" + name, prm.grad)
 
 
 def gen_bess() -> None:
@@ -779,6 +878,9 @@ def run_query_case(case: str, kind: str, scorer: str, p: int, n_shard: int, sche
     put(fix, p_ + "strs", np.array([kind, scorer, scheme, cand_kind]))
     put(fix, p_ + "entity_table", ent)
     put(fix, p_ + "relation_table", rel)
+    if scorer == "ConvE":  # the query network, in the (default) train mode: batch statistics, no dropout
+        for k, v in net_state(score_fn).items():
+            put(fix, p_ + "net_" + k, v)
     put(fix, p_ + "triples", triples)
     put(fix, p_ + "neg_heads", nh)
     put(fix, p_ + "neg_tails", nt)
@@ -849,6 +951,8 @@ def main() -> None:
         allscores=gen_allscores,
         scoring_affine=gen_scoring_affine,
         bess_affine=gen_bess_affine,
+        scoring_conve=gen_scoring_conve,
+        bess_conve=gen_bess_conve,
     )
     for name, g in gens.items():
         if only and name not in only:

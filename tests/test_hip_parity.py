@@ -40,13 +40,18 @@ def close(got, want, rtol=RTOL, atol=ATOL, scale=None):
     torch.testing.assert_close(got, want, rtol=rtol, atol=atol)
 
 
-def make_scorer(name, p, sharing, n_rel, d, ent, rel, dev, dtype=torch.float32, sharding=None):
-    from besskge.scoring import ComplEx, DistMult, InterHT, PairRE, RotatE, TranS, TransE, TripleRE
+def make_scorer(name, p, sharing, n_rel, d, ent, rel, dev, dtype=torch.float32, sharding=None, net=None):
+    from besskge.scoring import ComplEx, ConvE, DistMult, InterHT, PairRE, RotatE, TranS, TransE, TripleRE
     from besskge.sharding import Sharding
 
     if sharding is None:  # only n_shard matters for the training / scoring step
         sharding = Sharding.create(ent.shape[0] * ent.shape[1], ent.shape[0], seed=0)
-    if name in kge.AFFINE_VARIANTS:
+    if name == "ConvE":
+        fn = ConvE(sharing, sharding, n_rel, d, d // 4, 4, ent, rel, inverse_relations=False, input_dropout=0.0,
+                   feature_map_dropout=0.0, hidden_dropout=0.0)
+        missing, unexpected = fn.load_state_dict(net, strict=False)
+        assert not unexpected and set(missing) == {"entity_embedding", "relation_embedding"}
+    elif name in kge.AFFINE_VARIANTS:
         cfg = kge.AFFINE_VARIANTS[name]
         cls = dict(PairRE=PairRE, TripleRE=TripleRE, InterHT=InterHT, TranS=TranS)[cfg["base"]]
         kw = dict(normalize_entities=cfg["normalize"])
@@ -279,7 +284,8 @@ def build_model(c, dev, lr_loss=True):
     from besskge.negative_sampler import RandomShardedNegativeSampler, TripleBasedShardedNegativeSampler
 
     meta, spec = c["meta"], c["spec"]
-    fn = make_scorer(spec.scorer, spec.p, spec.sharing, meta["n_rel"], meta["d"], c["table"], c["rel"], torch.device("cpu"))
+    fn = make_scorer(spec.scorer, spec.p, spec.sharing, meta["n_rel"], meta["d"], c["table"], c["rel"],
+                     torch.device("cpu"), net=c.get("net"))
     loss = None
     if c["loss_name"] == "logsigmoid":
         loss = LogSigmoidLoss(margin=3.0, negative_adversarial_sampling=True, negative_adversarial_scale=0.5)
@@ -309,6 +315,8 @@ def test_bess_forward_golden(dev, case):
     n, bps = meta["n_shard"], meta["bps"]
     model = build_model(c, dev)
     runner = runtime.inference_model(model, runtime.Options(device_iterations=bps), device=dev)
+    if c["net"] is not None:
+        model.train()  # the ConvE fixtures were produced in train mode (batch statistics, no dropout)
     keys = ("head", "relation", "tail", "negative", "negative_mask")
     res = runner(**{k: c["batch"][k].flatten(end_dim=1) for k in keys if k in c["batch"]})
     S = c["outs"]["positive_score"].shape[-1]
@@ -336,6 +344,45 @@ def test_bess_train_step_golden(dev, case):
     want_rel = c["rel"] - lr * c["grads"]["relation"].sum(0)
     close(model.score_fn.entity_embedding, want_ent, rtol=1e-4, atol=2e-5)
     close(model.score_fn.relation_embedding, want_rel, rtol=1e-4, atol=2e-5)
+    for name, prm in model.score_fn.named_parameters():  # ConvE: the query network moves too
+        if name in c["grads_net"]:
+            close(prm, c["net"][name] - lr * c["grads_net"][name], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+@pytest.mark.parametrize("sharing", [True, False])
+@pytest.mark.parametrize("B", [1, 10])
+def test_conve_scoring_golden(dev, mode, sharing, B):
+    """ConvE: torch query network + dot-product kernels over [embedding | bias] rows, vs the
+    reference's outputs and gradients (embeddings, relation table, network parameters)."""
+    g = load_golden("scoring_conve")
+    S, N, d, n_rel, n_ent = (int(x) for x in g["args"])
+    net = {k[len("net_"):]: T(g[k]) for k in g.files if k.startswith("net_")}
+    c = f"{mode}_s{int(sharing)}_B{B}_"
+    rid = T(g["rid"]).to(dev)
+    for what in ("pos", "tails"):
+        fn = make_scorer("ConvE", 0, sharing, n_rel, d, torch.zeros(1, n_ent, d + 1), T(g["rel"]), dev, net=net)
+        fn.train(mode == "train")
+        fn.relation_embedding.requires_grad_(True)
+        h = T(g["h"]).to(dev).requires_grad_(True)
+        if what == "pos":
+            t = T(g["t"]).to(dev).requires_grad_(True)
+            sc = fn.score_triple(h, rid, t)
+            (sc * T(g["g_pos"]).to(dev)).sum().backward()
+            close(t.grad, T(g[c + "pos_dt"]))
+        else:
+            neg = T(g["neg1" if B == 1 else "negS"]).to(dev).requires_grad_(True)
+            sc = fn.score_tails(h, rid, neg)
+            (sc * T(g[c + "tails_g"]).to(dev)).sum().backward()
+            close(neg.grad, T(g[c + "tails_dneg"]))
+        close(sc, T(g[c + what]))
+        close(h.grad, T(g[c + what + "_dh"]), rtol=1e-3, atol=1e-5)
+        close(fn.relation_embedding.grad, T(g[c + what + "_drel"]), rtol=1e-3, atol=1e-5)
+        for name, prm in fn.named_parameters():
+            if name.startswith(("conv_layers", "fc_layers")):
+                close(prm.grad, T(g[c + what + "_dnet_" + name]), rtol=1e-3, atol=1e-4)
+    with pytest.raises(NotImplementedError):
+        fn.score_heads(h, rid, h)
 
 
 # --------------------------- the reference's own integration test, on HIP ----
