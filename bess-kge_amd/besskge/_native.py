@@ -19,7 +19,7 @@ import torch
 LIB_NAME = "libbesskge_hip.so"
 ABI_VERSION = 1
 
-TRANSE, ROTATE, DISTMULT, COMPLEX, AFFINE = 0, 1, 2, 3, 4
+TRANSE, ROTATE, DISTMULT, COMPLEX, AFFINE, BOXE = 0, 1, 2, 3, 4, 5
 F32, F16 = 0, 1
 CORRUPT_HEAD, CORRUPT_TAIL = 0, 1
 LOSS_LOGSIGMOID, LOSS_MARGIN, LOSS_SSCE = 0, 1, 2
@@ -424,6 +424,8 @@ def query_width(d: ModelDesc) -> int:
     if d.scorer == AFFINE:  # [U | V | R]: one d-wide vector per entity part, plus the offset
         n_part = int(d.reserved[0])
         return (n_part + 1) * (d.width // n_part)
+    if d.scorer == BOXE:  # [S | C | H] for each of the two candidate parts
+        return 3 * d.width
     return int(d.width)
 
 

@@ -33,7 +33,9 @@ linear: dense parameters) as torch modules on the device; what is scored
 against the candidates is a plain dot product over `[embedding | tail bias]`
 rows with the query `[net(h, r) | 1]`, i.e. the DistMult kernels.
 
-BoxE is not provided.
+BoxE (`scoring.py:1149-1415`): the relation-side preprocessing (width
+normalisation, box size, tanh of the box) and the positive score are torch ops
+over S rows; candidates are scored by the `csrc/boxe.hip` kernels.
 """
 
 from abc import ABC, abstractmethod
@@ -46,6 +48,7 @@ from besskge import ops
 from besskge.embedding import (
     init_KGE_normal,
     init_KGE_uniform,
+    init_uniform_norm,
     init_uniform_rotation,
     init_xavier_norm,
     initialize_entity_embedding,
@@ -745,3 +748,107 @@ class ConvE(_TorchQueryHooks, MatrixDecompositionScoreFunction):
         q = self._query_torch(nat.CORRUPT_TAIL, head_emb, self.relation_embedding, relation_id)
         return ops.ReduceNegatives.apply(self.kernel_desc(), bool(self.negative_sample_sharing), q.contiguous(),
                                          self._table_dtype(tail_emb))
+
+
+class BoxE(_TorchQueryHooks, DistanceBasedScoreFunction):
+    """BoxE (reference scoring.py:1149-1415): entities are [base | bump]; the head is
+    bumped by the tail's bump and vice versa, and each bumped point is scored by a
+    piecewise distance to its relation box."""
+
+    _scorer_id = nat.BOXE
+
+    def __init__(
+        self,
+        negative_sample_sharing: bool,
+        scoring_norm: int,
+        sharding: Sharding,
+        n_relation_type: int,
+        embedding_size: int,
+        entity_initializer: _Init = [torch.nn.init.uniform_],
+        relation_initializer: _Init = [torch.nn.init.uniform_, init_uniform_norm],
+        apply_tanh: bool = True,
+        dist_func_per_dim: bool = True,
+        eps: float = 1e-6,
+        inverse_relations: bool = False,
+    ) -> None:
+        super().__init__(negative_sample_sharing, scoring_norm)
+        self.apply_tanh = apply_tanh
+        self.dist_func_per_dim = dist_func_per_dim
+        self.eps = eps
+        self.sharding = sharding
+        if isinstance(entity_initializer, list):
+            entity_initializer = 2 * entity_initializer
+        if isinstance(relation_initializer, list):
+            relation_initializer = 4 * [relation_initializer[0]] + 2 * [relation_initializer[1]]
+        # [base | bump]
+        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size] * 2)
+        # [head centre | tail centre | head width | tail width | head size, tail size]
+        self.relation_embedding = initialize_relation_embedding(
+            n_relation_type, inverse_relations, relation_initializer, [embedding_size] * 4 + [1, 1])
+        assert 2 * self.entity_embedding.shape[-1] == self.relation_embedding.shape[-1] - 2 == 4 * embedding_size, (
+            "BoxE requires `2*embedding_size` embedding parameters for each entity"
+            " and `4*embedding_size + 2` embedding parameters for each relation")
+        self.embedding_size = embedding_size
+
+    def kernel_desc(self) -> nat.ModelDesc:
+        d = super().kernel_desc()
+        d.reserved[0] = int(bool(self.apply_tanh)) | (int(bool(self.dist_func_per_dim)) << 1)
+        return d
+
+    def _boxes(self, rel: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(centre, half width) [S, 2 (head box, tail box), d] after the reference's normalisation."""
+        d = self.embedding_size
+        center = rel[:, : 2 * d].reshape(-1, 2, d)
+        width = rel[:, 2 * d: 4 * d].reshape(-1, 2, d).abs()
+        size = rel[:, 4 * d:].reshape(-1, 2, 1)
+        geo_mean = torch.exp(torch.mean(torch.log(torch.clamp(width, min=self.eps)), dim=-1, keepdim=True))
+        width = width / torch.clamp(geo_mean, min=self.eps) * (1.0 + torch.nn.functional.elu(size))
+        if self.apply_tanh:
+            low = torch.tanh(center - 0.5 * width)
+            up = torch.tanh(low + width)
+            center, width = 0.5 * (low + up), up - low
+        return center, 0.5 * width
+
+    def _box_distance(self, point: torch.Tensor, center: torch.Tensor, half: torch.Tensor) -> torch.Tensor:
+        """-(||f_head|| + ||f_tail||) for bumped points [..., 2, d]."""
+        if self.apply_tanh:
+            point = torch.tanh(point)
+        dist = (point - center).abs()
+        grow = 1.0 + 2.0 * half
+        inside = dist <= half
+        if not self.dist_func_per_dim:
+            inside = inside.all(dim=-1, keepdim=True)
+        f = torch.where(inside, dist / grow, dist * grow - half * (grow - 1.0 / grow))
+        return -torch.norm(f, p=self.scoring_norm, dim=-1).sum(-1)
+
+    def _triple_torch(self, h: torch.Tensor, rel: torch.Tensor, rel_idx: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        d = self.embedding_size
+        center, half = self._boxes(torch.index_select(rel, 0, rel_idx.reshape(-1).long()).float())
+        # head box sees h_base + t_bump, tail box sees t_base + h_bump
+        point = h.float().reshape(-1, 2, d) + t.float().reshape(-1, 2, d).flip(-2)
+        return self._box_distance(point, center, half)
+
+    def _query_torch(self, side: int, rows: torch.Tensor, rel: torch.Tensor, rel_idx: torch.Tensor) -> torch.Tensor:
+        d = self.embedding_size
+        center, half = self._boxes(torch.index_select(rel, 0, rel_idx.reshape(-1).long()).float())
+        kept = rows.float().reshape(-1, 2, d)
+        # candidate part 0 (base) is shifted by the kept bump, part 1 (bump) by the kept base; the
+        # base of a candidate tail meets the tail box, the base of a candidate head the head box
+        box = (1, 0) if side == nat.CORRUPT_TAIL else (0, 1)
+        return torch.cat([kept[:, 1], center[:, box[0]], half[:, box[0]],
+                          kept[:, 0], center[:, box[1]], half[:, box[1]]], dim=-1)
+
+    def score_triple(self, head_emb: torch.Tensor, relation_id: torch.Tensor, tail_emb: torch.Tensor) -> torch.Tensor:
+        return self._triple_torch(head_emb, self.relation_embedding, relation_id, tail_emb)
+
+    def _score_candidates(self, side: int, kept: torch.Tensor, relation_id: torch.Tensor,
+                          cand: torch.Tensor) -> torch.Tensor:
+        q = self._query_torch(side, kept, self.relation_embedding, relation_id)
+        return ops.ReduceNegatives.apply(self.kernel_desc(), bool(self.negative_sample_sharing), q.contiguous(),
+                                         self._table_dtype(cand))
+
+    def score_heads(self, head_emb: torch.Tensor, relation_id: torch.Tensor, tail_emb: torch.Tensor) -> torch.Tensor:
+        return self._score_candidates(nat.CORRUPT_HEAD, tail_emb, relation_id, head_emb)
+
+    def score_tails(self, head_emb: torch.Tensor, relation_id: torch.Tensor, tail_emb: torch.Tensor) -> torch.Tensor:
+        return self._score_candidates(nat.CORRUPT_TAIL, head_emb, relation_id, tail_emb)

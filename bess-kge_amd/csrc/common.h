@@ -25,7 +25,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // scorer properties
 inline bool is_complex_entity(int scorer) { return scorer == BESS_ROTATE || scorer == BESS_COMPLEX; }
 inline bool is_distance(int scorer) {
-    return scorer == BESS_TRANSE || scorer == BESS_ROTATE || scorer == BESS_AFFINE;
+    return scorer == BESS_TRANSE || scorer == BESS_ROTATE || scorer == BESS_AFFINE || scorer == BESS_BOXE;
 }
 int check_desc(const bess_model_desc* d);
 
@@ -53,6 +53,11 @@ int affine_shared_fwd(const bess_model_desc* d, const float* query, int64_t S, c
 int affine_shared_bwd(const bess_model_desc* d, const float* query, int64_t S, const float* cand, int64_t N,
                       const float* out, int64_t ld_out, const float* d_out, int64_t ld_dout, float* d_query,
                       float* d_cand, hipStream_t st);
+
+// BoxE (boxe.hip): one kernel family for per-triple and shared negatives
+int boxe_negatives(const bess_model_desc* d, bool fwd, bool shared, const float* query, int64_t n_query,
+                   const void* neg_base, const int32_t* neg_idx, int64_t n_neg, float* out, const float* d_out,
+                   int64_t ld, float* dq, float* dn, hipStream_t st);
 
 // ---- device side ------------------------------------------------------------
 typedef _Float16 half_t;

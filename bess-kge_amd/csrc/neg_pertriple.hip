@@ -269,6 +269,9 @@ static int run(const bess_model_desc* d, bool fwd, const float* query, int64_t n
     BESS_REQUIRE(query && neg_base && neg_idx, "neg_score_pertriple: NULL pointer");
     BESS_REQUIRE(ld >= n_neg, "neg_score_pertriple: leading dimension %lld < n_neg %lld", (long long)ld,
                  (long long)n_neg);
+    if (d->scorer == BESS_BOXE)
+        return boxe_negatives(d, fwd, false, query, n_query, neg_base, neg_idx, n_neg, out, d_out, ld, dq, dn,
+                              as_stream(stream));
     if (d->scorer == BESS_AFFINE)
         return affine_pertriple(d, fwd, query, n_query, neg_base, neg_idx, n_neg, out, d_out, ld, dq, dn,
                                 as_stream(stream));

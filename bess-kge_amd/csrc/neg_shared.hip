@@ -345,6 +345,9 @@ extern "C" int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* 
     if (n_query == 0 || n_neg == 0) return BESS_OK;
     BESS_REQUIRE(query && neg_base && out, "neg_score_shared_fwd: NULL pointer");
     BESS_REQUIRE(ld_out >= n_neg, "neg_score_shared_fwd: leading dimension < n_neg");
+    if (d->scorer == BESS_BOXE)
+        return boxe_negatives(d, true, true, query, n_query, neg_base, neg_idx, n_neg, out, nullptr, ld_out, nullptr,
+                              nullptr, as_stream(stream));
     if (d->scorer == BESS_AFFINE) {
         BESS_REQUIRE(!neg_idx, "neg_score_shared_fwd: affine scorers take dense f32 candidates (bess_normalize_rows)");
         return affine_shared_fwd(d, query, n_query, static_cast<const float*>(neg_base), n_neg, out, ld_out,
@@ -373,6 +376,9 @@ extern "C" int bess_neg_score_shared_bwd(const bess_model_desc* d, const float* 
     BESS_REQUIRE(reduce_of(d) != RED_L2 || out, "neg_score_shared_bwd: p=2 needs the forward scores");
     BESS_REQUIRE(ld_dout >= n_neg && (!out || ld_out >= n_neg), "neg_score_shared_bwd: leading dimension < n_neg");
     hipStream_t st = as_stream(stream);
+    if (d->scorer == BESS_BOXE)
+        return boxe_negatives(d, false, true, query, n_query, neg_base, neg_idx, n_neg, nullptr, d_out, ld_dout,
+                              d_query, d_neg, st);
     if (d->scorer == BESS_AFFINE) {
         BESS_REQUIRE(!neg_idx, "neg_score_shared_bwd: affine scorers take dense f32 candidates (bess_normalize_rows)");
         BESS_REQUIRE(d->norm_p != 2 || out, "neg_score_shared_bwd: p=2 needs the forward scores");

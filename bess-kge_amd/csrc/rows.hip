@@ -32,10 +32,15 @@ int check_launch(const char* what) {
 
 int check_desc(const bess_model_desc* d) {
     if (!d) return fail(BESS_EINVAL, "model descriptor is NULL");
-    if (d->scorer < BESS_TRANSE || d->scorer > BESS_AFFINE)
+    if (d->scorer < BESS_TRANSE || d->scorer > BESS_BOXE)
         return fail(BESS_EINVAL, "unknown scorer %d", d->scorer);
     if (d->dtype != BESS_F32 && d->dtype != BESS_F16)
         return fail(BESS_EINVAL, "unknown dtype %d", d->dtype);
+    if (d->scorer == BESS_BOXE) {
+        if (d->width <= 0 || d->width % 2) return fail(BESS_EINVAL, "BoxE: entity width %d is not 2 d", d->width);
+        if (d->norm_p != 1 && d->norm_p != 2) return fail(BESS_EINVAL, "scoring norm %d not in {1, 2}", d->norm_p);
+        return BESS_OK;
+    }
     if (d->scorer == BESS_AFFINE) {
         const int n_part = d->reserved[0];
         if (n_part != 1 && n_part != 2) return fail(BESS_EINVAL, "affine scorer: n_part %d not in {1, 2}", n_part);

@@ -56,6 +56,11 @@ extern "C" {
  * normalise the parts (per-triple kernels only; the shared kernels take candidates that
  * bess_normalize_rows has already gathered, converted to f32 and normalised). */
 #define BESS_AFFINE 4
+/* BoxE (scoring.py:1149-1415) as seen by the negative-scoring kernels: entity rows
+ * [base | bump] (desc.width = 2 d), query matrix [n_query, 6 d] =
+ * [S_0 | C_0 | H_0 | S_1 | C_1 | H_1] (shift, box centre, half width met by candidate part
+ * 0 / 1); desc.reserved[0] bit 0 = apply_tanh, bit 1 = dist_func_per_dim.  See csrc/boxe.hip. */
+#define BESS_BOXE 5
 
 /* table element types */
 #define BESS_F32 0

@@ -16,7 +16,7 @@ tests/golden/make_golden.py) in `tests/test_oracle.py`.
 Reference lines restated:
   score_triple / score_heads / score_tails ... scoring.py:321-354 (TransE),
       423-462 (RotatE), 804-837 (DistMult), 905-946 (ComplEx), 540-593 (PairRE),
-      681-743 (TripleRE), 1499-1572 (InterHT), 1661-1750 (TranS), 1090-1146 (ConvE);
+      681-743 (TripleRE), 1499-1572 (InterHT), 1661-1750 (TranS), 1090-1146 (ConvE), 1250-1415 (BoxE);
       broadcasted_distance scoring.py:176-200, broadcasted_dot_product 231-255;
       complex_multiplication / complex_rotation utils.py:72-112
   losses ............ loss.py:28-51, 115-134, 179-195, 224-251
@@ -47,7 +47,14 @@ AFFINE_VARIANTS = {
 }
 
 
+# BoxE fixtures (scoring.py:1149-1415): name -> (apply_tanh, dist_func_per_dim)
+BOXE_VARIANTS = {"BoxE": (True, True), "BoxEnt": (False, False), "BoxEall": (True, False), "BoxEpd": (False, True)}
+BOXE_EPS = 1e-6
+
+
 def entity_width(scorer: str, d: int) -> int:
+    if scorer in BOXE_VARIANTS:
+        return 2 * d
     if scorer == "ConvE":
         return d + 1
     if scorer in (ROTATE, COMPLEX):
@@ -58,6 +65,8 @@ def entity_width(scorer: str, d: int) -> int:
 
 
 def relation_width(scorer: str, d: int) -> int:
+    if scorer in BOXE_VARIANTS:
+        return 4 * d + 2
     if scorer == COMPLEX:
         return 2 * d
     if scorer in AFFINE_VARIANTS:
@@ -139,6 +148,34 @@ def _reduce(scorer: str, p: int, q: torch.Tensor, cand: torch.Tensor) -> torch.T
 CONVE = "ConvE"
 
 
+def boxe_score(scorer: str, p: int, bumped: torch.Tensor, rel: torch.Tensor) -> torch.Tensor:
+    """`BoxE.boxe_score` (scoring.py:1250-1340): bumped [..., 2, d] (head-box point, tail-box point),
+    rel [..., 4d + 2] broadcastable against it."""
+    tanh, per_dim = BOXE_VARIANTS[scorer]
+    d = bumped.shape[-1]
+    center = rel[..., : 2 * d].reshape(*rel.shape[:-1], 2, d)
+    width = rel[..., 2 * d: 4 * d].reshape(*rel.shape[:-1], 2, d).abs()
+    size = rel[..., 4 * d:]
+    gm = torch.exp(torch.mean(torch.log(torch.clamp(width, min=BOXE_EPS)), dim=-1, keepdim=True))
+    width = width / torch.clamp(gm, min=BOXE_EPS)
+    width = width * (1.0 + torch.nn.functional.elu(size.unsqueeze(-1)))
+    if tanh:
+        low = torch.tanh(center - 0.5 * width)
+        up = torch.tanh(low + width)
+        center = 0.5 * (low + up)
+        width = up - low
+        dist = torch.abs(torch.tanh(bumped) - center)
+    else:
+        dist = torch.abs(bumped - center)
+    wp1 = 1.0 + width
+    k = 0.5 * width * (wp1 - 1.0 / wp1)
+    inside = dist <= 0.5 * width
+    if not per_dim:
+        inside = torch.all(inside, dim=-1, keepdim=True)
+    final = torch.where(inside, dist / wp1, dist * wp1 - k)
+    return -torch.norm(final, p=p, dim=-1).sum(-1)
+
+
 def conve_net(net: Dict[str, torch.Tensor], training: bool, h: torch.Tensor, r: torch.Tensor) -> torch.Tensor:
     """ConvE's query network (scoring.py:1034-1062, 1100-1110) restated with functional ops:
     BN2d -> conv 3x3 -> BN2d -> relu -> flatten -> linear -> BN1d -> relu  (dropout rates 0).
@@ -164,6 +201,10 @@ def conve_net(net: Dict[str, torch.Tensor], training: bool, h: torch.Tensor, r: 
 def score_triple(scorer: str, p: int, h: torch.Tensor, rel_table: torch.Tensor, rid: torch.Tensor,
                  t: torch.Tensor, net: Optional[Dict[str, torch.Tensor]] = None, training: bool = True
                  ) -> torch.Tensor:
+    if scorer in BOXE_VARIANTS:
+        d = h.shape[-1] // 2
+        bumped = h.reshape(-1, 2, d) + t.reshape(-1, 2, d)[:, [1, 0]]
+        return boxe_score(scorer, p, bumped, rel_table[rid.long()])
     if scorer == CONVE:
         q = conve_net(net, training, h, rel_table[rid.long()])
         return torch.sum(q * t[..., :-1], dim=-1) + t[..., -1]
@@ -180,6 +221,12 @@ def score_candidates(scorer: str, p: int, sharing: bool, side: str, ent: torch.T
     cand [B, N, W].  sharing: every query vs all B*N rows -> [S, B*N];
     else query s vs cand[s] (B == S, or B == 1 broadcast) -> [S, N].
     """
+    if scorer in BOXE_VARIANTS:
+        d = ent.shape[-1] // 2
+        c = cand.reshape(1, -1, cand.shape[-1]) if sharing else cand
+        c2, e2 = c.reshape(c.shape[0], -1, 2, d), ent.reshape(-1, 1, 2, d)
+        bumped = (c2 + e2[:, :, [1, 0]]) if side == "h" else (e2 + c2[:, :, [1, 0]])
+        return boxe_score(scorer, p, bumped, rel_table[rid.long()][:, None, :])
     if scorer == CONVE:
         assert side == "t", "ConvE only corrupts tails"
         q = conve_net(net, training, ent, rel_table[rid.long()])[:, None, :]

@@ -371,6 +371,11 @@ def scorer_factory(name: str, p: int, sharing: bool, sharding: Sharding, n_rel: 
         return DistMult(sharing, sharding, n_rel, d, ent, rel)
     if name == "ComplEx":
         return ComplEx(sharing, sharding, n_rel, d, ent, rel)
+    if name in BOXE_VARIANTS:
+        from besskge.scoring import BoxE
+
+        tanh, per_dim = BOXE_VARIANTS[name]
+        return BoxE(sharing, p, sharding, n_rel, d, ent, rel, apply_tanh=tanh, dist_func_per_dim=per_dim)
     if name == "ConvE":
         from besskge.scoring import ConvE
 
@@ -409,6 +414,8 @@ AFFINE_VARIANTS = {
     "TranS": dict(base="TranS", normalize=True, offset=1.0),
     "TranSnn": dict(base="TranS", normalize=False, offset=0.5),
 }
+BOXE_VARIANTS = {"BoxE": (True, True), "BoxEnt": (False, False), "BoxEall": (True, False), "BoxEpd": (False, True)}
+BOXE_SCORERS = [("BoxE", 1), ("BoxE", 2), ("BoxEnt", 1), ("BoxEall", 2), ("BoxEpd", 2)]
 AFFINE_SCORERS = [("PairRE", 1), ("PairRE", 2), ("TripleRE", 1), ("TripleREv2", 2), ("InterHT", 1), ("InterHT", 2),
                   ("TranS", 1), ("TranSnn", 2)]
 
@@ -493,7 +500,29 @@ def gen_bess_conve() -> None:
     put("bess_conve", "cases", np.array(names))
 
 
+def gen_scoring_boxe() -> None:
+    _gen_scoring("scoring_boxe", BOXE_SCORERS, 4)
+
+
+def gen_bess_boxe() -> None:
+    EM, SM = EmbeddingMovingBessKGE, ScoreMovingBessKGE
+    cases = []
+    for scorer, p in BOXE_SCORERS:
+        sn = f"{scorer}{p}"
+        cases.append((f"tr_EM_{sn}_t_flat_n1", EM, scorer, p, 1, "t", "random_flat", "logsigmoid", False, True))
+        cases.append((f"tr_EM_{sn}_h_pt_n1", EM, scorer, p, 1, "h", "random_pt", "logsigmoid", False, False))
+        cases.append((f"tr_EM_{sn}_ht_pt_n2", EM, scorer, p, 2, "ht", "random_pt", "ssce", False, False))
+        cases.append((f"tr_SM_{sn}_ht_flat_n2", SM, scorer, p, 2, "ht", "random_flat", "margin", False, True))
+    names = []
+    for name, mcls, scorer, p, n, scheme, nk, loss, aug, sharing in cases:
+        run_bess_case(name, mcls, scorer, p, n, scheme, nk, loss, aug, sharing, fix="bess_boxe")
+        names.append(name)
+    put("bess_boxe", "cases", np.array(names))
+
+
 def widths(name: str, d: int) -> Any:
+    if name in BOXE_VARIANTS:
+        return 2 * d, 4 * d + 2
     if name == "ConvE":
         return d + 1, d
     if name in AFFINE_VARIANTS:
@@ -951,6 +980,8 @@ def main() -> None:
         allscores=gen_allscores,
         scoring_affine=gen_scoring_affine,
         bess_affine=gen_bess_affine,
+        scoring_boxe=gen_scoring_boxe,
+        bess_boxe=gen_bess_boxe,
         scoring_conve=gen_scoring_conve,
         bess_conve=gen_bess_conve,
     )

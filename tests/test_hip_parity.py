@@ -19,9 +19,9 @@ from oracle import kge  # noqa: E402
 
 from conftest import load_golden  # noqa: E402
 from test_oracle import (  # noqa: E402
-    AFFINE_SCORERS, LOSSES, SCORERS, T, bess_cases, load_bess_case, scoring_fixture, step_batch)
+    AFFINE_SCORERS, BOXE_SCORERS, LOSSES, SCORERS, T, bess_cases, load_bess_case, scoring_fixture, step_batch)
 
-NATIVE_SCORERS = [s for s in SCORERS if s not in AFFINE_SCORERS]
+NATIVE_SCORERS = [s for s in SCORERS if s not in AFFINE_SCORERS + BOXE_SCORERS]
 
 RTOL, ATOL = 1e-4, 1e-5
 
@@ -41,12 +41,15 @@ def close(got, want, rtol=RTOL, atol=ATOL, scale=None):
 
 
 def make_scorer(name, p, sharing, n_rel, d, ent, rel, dev, dtype=torch.float32, sharding=None, net=None):
-    from besskge.scoring import ComplEx, ConvE, DistMult, InterHT, PairRE, RotatE, TranS, TransE, TripleRE
+    from besskge.scoring import BoxE, ComplEx, ConvE, DistMult, InterHT, PairRE, RotatE, TranS, TransE, TripleRE
     from besskge.sharding import Sharding
 
     if sharding is None:  # only n_shard matters for the training / scoring step
         sharding = Sharding.create(ent.shape[0] * ent.shape[1], ent.shape[0], seed=0)
-    if name == "ConvE":
+    if name in kge.BOXE_VARIANTS:
+        tanh, per_dim = kge.BOXE_VARIANTS[name]
+        fn = BoxE(sharing, p, sharding, n_rel, d, ent, rel, apply_tanh=tanh, dist_func_per_dim=per_dim)
+    elif name == "ConvE":
         fn = ConvE(sharing, sharding, n_rel, d, d // 4, 4, ent, rel, inverse_relations=False, input_dropout=0.0,
                    feature_map_dropout=0.0, hidden_dropout=0.0)
         missing, unexpected = fn.load_state_dict(net, strict=False)
