@@ -233,7 +233,8 @@ def main() -> None:
     # only the dominant kernel is bracketed with HIP events: timing events are
     # barriers on the stream and cost ~0.9 ms/step when put around every kernel
     # of a training step (the other kernels' durations are in profiles/)
-    timed = ["bess_neg_score_pertriple_fwd"]
+    # (in train mode the same pass also accumulates d_query: entry point ..._fwd_dq)
+    timed = ["bess_neg_score_pertriple_fwd", "bess_neg_score_pertriple_fwd_dq"]
     nat.start_kernel_timing(timed)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -276,7 +277,7 @@ def main() -> None:
     rows = S * world * k_pair if world > 1 else S * k_pair  # rows gathered per launch on this GPU
     nq = S * world if world > 1 else S
     algo_bytes = rows * (W * sz + 4 + 4) + nq * W * 4
-    fwd = kernel_ms.get("bess_neg_score_pertriple_fwd", [])
+    fwd = kernel_ms.get("bess_neg_score_pertriple_fwd", []) or kernel_ms.get("bess_neg_score_pertriple_fwd_dq", [])
     avg_ms = float(np.mean(fwd)) if fwd else float("nan")
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if fwd else float("nan")
     traffic = None
@@ -313,7 +314,8 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_neg_pertriple_fwd (bess_neg_score_pertriple_fwd)",
+                "kernel": "k_neg_pertriple_fwd (bess_neg_score_pertriple_fwd)" if args.mode == "score" else
+                          "k_neg_pertriple_fwd<FUSE> + k_combine_dq (bess_neg_score_pertriple_fwd_dq)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

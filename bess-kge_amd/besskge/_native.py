@@ -124,6 +124,8 @@ SIGNATURES = {
     "bess_ranks_from_scores": [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp],
     "bess_ranks_from_indices": [_vp, _vp, _i64, _i64, _i32, _vp, _vp],
     "bess_apply_segments_opt": [ctypes.POINTER(OptDesc), _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "bess_neg_pertriple_items": [_i64, _i64, ctypes.POINTER(ctypes.c_int32)],
+    "bess_neg_score_pertriple_fwd_dq": [_MD, _LD, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
     "bess_normalize_rows": [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
     "bess_normalize_rows_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
     "bess_sample_negatives": [_PG, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
@@ -466,6 +468,38 @@ def neg_score_pertriple_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n
     _check(rc, "bess_neg_score_pertriple_fwd")
     del keep
     return out
+
+
+def neg_score_pertriple_fwd_dq(d: ModelDesc, l: LossDesc, query: torch.Tensor, neg: RowSource, n_neg: int,
+                               pos: Optional[torch.Tensor], weight: torch.Tensor
+                               ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Fused training forward: (scores [nq, n_neg], d loss / d query [nq, W]) in one pass over
+    the negative rows.  Only valid when the loss is taken over exactly these scores, unmasked."""
+    nq = int(query.shape[0])
+    dev = _neg_operands(d, query, neg, nq * n_neg)
+    _same_device([("pos", pos), ("weight", weight), ("query", query)])
+    _f32(weight, "weight")
+    if weight.numel() not in (1, nq):
+        raise ValueError("triple weights must have 1 or n_query entries")
+    if pos is not None:
+        _f32(pos, "pos")
+        if pos.numel() != nq:
+            raise ValueError("`pos` must have n_query entries")
+    items = ctypes.c_int32(0)
+    _check(load().bess_neg_pertriple_items(nq, n_neg, ctypes.byref(items)), "bess_neg_pertriple_items")
+    out = torch.empty((nq, n_neg), dtype=torch.float32, device=dev)
+    dq = torch.empty((nq, d.width), dtype=torch.float32, device=dev)
+    st_ml = torch.empty((nq, items.value, 2), dtype=torch.float32, device=dev)
+    st_acc = torch.empty((nq, items.value, d.width), dtype=torch.float32, device=dev)
+    ip, keep = _neg_idx_ptr(neg, dev)
+    with torch.cuda.device(dev), _Timed("bess_neg_score_pertriple_fwd_dq", dev):
+        rc = load().bess_neg_score_pertriple_fwd_dq(
+            ctypes.byref(d), ctypes.byref(l), query.data_ptr(), nq, neg.base.data_ptr(), ip, n_neg,
+            pos.data_ptr() if pos is not None else 0, weight.data_ptr(), weight.numel(), out.data_ptr(), n_neg,
+            dq.data_ptr(), st_ml.data_ptr(), st_acc.data_ptr(), _stream(dev))
+    _check(rc, "bess_neg_score_pertriple_fwd_dq")
+    del keep
+    return out, dq
 
 
 def neg_score_pertriple_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n_neg: int,

@@ -71,6 +71,7 @@ class _NegGroup:
         self.query: Optional[torch.Tensor] = None
         self.query_ctx: Any = None  # what the scorer's query_bwd needs
         self.out: Optional[torch.Tensor] = None
+        self.dq: Optional[torch.Tensor] = None  # d loss / d query from the fused training forward
 
 
 class _ReplicaStep:
@@ -450,16 +451,40 @@ class BessKGE(torch.nn.Module, ABC):
 
 
     # ------------------------------------------------------ group execution
-    def _run_groups_one(self, g: _NegGroup, desc: nat.ModelDesc) -> torch.Tensor:
+    def _run_groups_one(self, g: _NegGroup, desc: nat.ModelDesc, st: Optional[_ReplicaStep] = None,
+                        fuse: Optional[Dict[str, Any]] = None) -> torch.Tensor:
         g.query, g.query_ctx = self.score_fn.query_fwd(g.side, g.ent, g.rel_idx)
         if g.shared:
             g.out = nat.neg_score_shared_fwd(desc, g.query, g.neg)
+        elif fuse is not None and st is not None and g.neg.base is st.table:
+            # training, nothing masked afterwards: scores and d loss / d query in one pass (the
+            # backward then never re-reads the negative rows)
+            pos, w = st.positive_score, fuse["weight"]
+            if g.sel is not None:
+                pos = pos[g.sel].contiguous()
+                w = w if w.numel() == 1 else w[g.sel].contiguous()
+            g.out, g.dq = nat.neg_score_pertriple_fwd_dq(desc, fuse["loss"](g.n_per_query), g.query, g.neg,
+                                                         g.n_per_query, pos, w)
         else:
             g.out = nat.neg_score_pertriple_fwd(desc, g.query, g.neg, g.n_per_query)
         return g.out
 
-    def _run_groups(self, st: _ReplicaStep, desc: nat.ModelDesc) -> List[torch.Tensor]:
-        return [self._run_groups_one(g, desc) for g in st.groups]
+    def _run_groups(self, st: _ReplicaStep, desc: nat.ModelDesc, fuse: Optional[Dict[str, Any]] = None
+                    ) -> List[torch.Tensor]:
+        return [self._run_groups_one(g, desc, st, fuse) for g in st.groups]
+
+    def _fusable(self, batch: _Batch) -> Optional[Dict[str, Any]]:
+        """Can the training forward of this micro-batch also produce d loss / d query?  Needs a
+        loss taken over exactly the scores of one per-triple group, with nothing masked."""
+        if self.loss_fn is None or not self.score_fn.supports_fused_segments or self.augment_negative:
+            return None
+        if batch.get("negative_mask") is not None or not hasattr(self.loss_fn, "kernel_desc"):
+            return None
+        dev = self.score_fn.relation_embedding.device
+        w = batch.get("triple_weight")
+        w = torch.ones(1, dtype=torch.float32, device=dev) if w is None else \
+            w.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+        return dict(weight=w, loss=self.loss_fn.kernel_desc)
 
 
 class EmbeddingMovingBessKGE(BessKGE):
@@ -508,11 +533,14 @@ class EmbeddingMovingBessKGE(BessKGE):
 
         desc = fn.kernel_desc()
         rel_table = fn.relation_embedding.data
+        done: List[_ReplicaStep] = []
         for st in steps:
             self._build_groups(st, exchange_negatives)
             st.positive_score, st.triple_ctx = fn.triple_fwd(
                 RowSource(st.table, st.head_idx), st.tail, st.rel_idx)
-            outs = self._run_groups(st, desc)
+            fuse = getattr(self, "_train_fuse", None)
+            outs = self._run_groups(st, desc, fuse[len(done)] if fuse else None)
+            done.append(st)
             if len(outs) == 1:
                 st.negative_score = outs[0]
             else:
@@ -646,7 +674,11 @@ class EmbeddingMovingBessKGE(BessKGE):
         fn = self.score_fn
         n = group.n_shard
         W = self.entity_embedding_size
-        steps = self._score_replicas(batches)
+        self._train_fuse = [self._fusable(b) for b in batches]
+        try:
+            steps = self._score_replicas(batches)
+        finally:
+            self._train_fuse = None
         desc = fn.kernel_desc()
         rel_table = fn.relation_embedding.data
         results = []
@@ -693,7 +725,11 @@ class EmbeddingMovingBessKGE(BessKGE):
                     # per-triple negatives read straight from the shard: no [S*N, W]
                     # gradient, no atomics - references are grouped by destination row
                     # and reduced on chip (K9), unique rows updated afterwards (K10)
-                    dq, _ = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go, want_d_neg=False)
+                    if g.dq is not None:  # came out of the fused forward
+                        dq = g.dq
+                    else:
+                        dq, _ = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go,
+                                                            want_d_neg=False)
                     deferred.append((st.table, g, go))
                 else:
                     dq, dn = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go)

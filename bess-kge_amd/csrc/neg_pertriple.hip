@@ -37,9 +37,29 @@ struct NegPtArgs {
     float sign;
 };
 
-template <typename T, int VEC, int IT, int RED, int UNROLL>
+// Fused training forward (FUSE): besides the scores, accumulate the loss gradient wrt the query,
+//     d_query[q] = sum_k dL/ds(q, k) * ds(q, k)/dq,
+// in the same pass over the rows, so the backward never re-reads them.  dL/ds of all three
+// losses has the form  C_q * g(s_k) * exp(beta * s_k) / sum_k' exp(beta * s_k')  (self-adversarial
+// softmax weights, or the softmax of the sampled-softmax cross entropy; beta = 0 gives the
+// uniform 1/N): an online-softmax accumulation (running max m, normaliser l, weighted sum
+// acc - as in flash attention) needs no second pass.  Every work item writes its partial
+// (m, l, acc[W]); k_combine_dq merges the items of a query and applies C_q / l.
+struct FuseArgs {
+    const float* pos;   // [n_query] positive scores (margin ranking); may be NULL otherwise
+    int kind;           // BESS_LOSS_*
+    float beta;         // adversarial_scale | 1 (ssce) | 0 (uniform weights)
+    float margin;
+    float shift;        // ssce: log(n_entity - 1) - log(N), added to the negative scores
+    float* st_ml;       // [n_query, items, 2]
+    float* st_acc;      // [n_query, items, W]
+};
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+template <typename T, int VEC, int IT, int RED, int UNROLL, bool FUSE>
 __global__ __launch_bounds__(256) void k_neg_pertriple_fwd(NegPtArgs a, float* __restrict__ out,
-                                                           int64_t ld_out) {
+                                                           int64_t ld_out, FuseArgs f) {
     const int lane = threadIdx.x & 63;
     const int g = lane & 15;
     const int sub = lane >> 4;
@@ -66,6 +86,16 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_fwd(NegPtArgs a, float* _
     const T* base = static_cast<const T*>(a.base);
     const int32_t* idx = a.idx + q * a.n_neg;
     float* orow = out + q * ld_out;
+    // online-softmax state of this 16-lane row group (FUSE)
+    float fm = -INFINITY, fl = 0.f, facc[IT][VEC];
+    float fpos = 0.f;
+    if (FUSE) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) facc[it][v] = 0.f;
+        if (f.kind == BESS_LOSS_MARGIN) fpos = f.pos[q];
+    }
 
     for (int kb = k0; kb < k1; kb += 4 * UNROLL) {  // kb is wave-uniform
         float ev[UNROLL][IT][VEC];
@@ -107,7 +137,88 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_fwd(NegPtArgs a, float* _
             acc = row16_allreduce_sum(acc);
             if (RED == RED_L2) acc = sqrtf(acc);
             if (g == 0 && valid[u]) orow[kb + sub + 4 * u] = a.sign * acc;
+            if (FUSE && valid[u]) {  // uniform within the 16-lane group
+                const float sc = a.sign * acc;
+                const float z = f.beta * (sc + f.shift);
+                const float m_new = fmaxf(fm, z);
+                const float corr = expf(fm - m_new);
+                const float e = expf(z - m_new);
+                float gs = 1.f;
+                if (f.kind == BESS_LOSS_LOGSIGMOID) gs = sigmoid_f(sc + f.margin);
+                else if (f.kind == BESS_LOSS_MARGIN) gs = (sc - fpos + f.margin > 0.f) ? 1.f : 0.f;
+                const float p = e * gs;
+                fl = fmaf(fl, corr, e);
+                fm = m_new;
+                const float inv_norm = (RED == RED_L2 && acc > 0.f) ? 1.f / acc : 0.f;
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        float dsdq;  // d score / d query_w
+                        if (RED == RED_DOT) dsdq = ev[u][it][v];
+                        else if (RED == RED_L1) dsdq = -sgnf(qv[it][v] - ev[u][it][v]);
+                        else dsdq = -(qv[it][v] - ev[u][it][v]) * inv_norm;
+                        facc[it][v] = fmaf(facc[it][v], corr, p * dsdq);
+                    }
+            }
         }
+    }
+    if (FUSE) {
+        // merge the four row groups of the wave, then one partial per work item
+        float m_all = fmaxf(fm, __shfl_xor(fm, 16, 64));
+        m_all = fmaxf(m_all, __shfl_xor(m_all, 32, 64));
+        const float sc = (fm == -INFINITY) ? 0.f : expf(fm - m_all);
+        float l = fl * sc;
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int64_t slot = q * a.items_per_query + (item - q * a.items_per_query);
+        if (lane == 0) {
+            f.st_ml[slot * 2 + 0] = m_all;
+            f.st_ml[slot * 2 + 1] = l;
+        }
+        float* ap = f.st_acc + slot * a.W;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = g + 16 * it;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float x = facc[it][v] * sc;
+                x += __shfl_xor(x, 16, 64);
+                x += __shfl_xor(x, 32, 64);
+                if (sub == 0 && c < a.nch) ap[c * VEC + v] = x;
+            }
+        }
+    }
+}
+
+// d_query[q, :] = C_q / L_q * sum_items exp(m_i - m) acc_i,  m = max_i m_i (and the positive for
+// ssce), L_q = sum_i exp(m_i - m) l_i (+ exp(pos - m) for ssce);  C_q = loss_scale * w_q (x 1/2
+// for the log-sigmoid loss).  One wave per query.
+__global__ __launch_bounds__(256) void k_combine_dq(const float* __restrict__ st_ml, const float* __restrict__ st_acc,
+                                                    int64_t n_query, int items, int W, int kind, float loss_scale,
+                                                    const float* __restrict__ pos, const float* __restrict__ weight,
+                                                    int64_t weight_len, float* __restrict__ d_query) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (q >= n_query) return;
+    float m = -INFINITY;
+    for (int i = 0; i < items; ++i) m = fmaxf(m, st_ml[(q * items + i) * 2]);
+    if (kind == BESS_LOSS_SSCE) m = fmaxf(m, pos[q]);
+    float L = (kind == BESS_LOSS_SSCE) ? expf(pos[q] - m) : 0.f;
+    for (int i = 0; i < items; ++i) {
+        const float mi = st_ml[(q * items + i) * 2];
+        if (mi != -INFINITY) L += st_ml[(q * items + i) * 2 + 1] * expf(mi - m);
+    }
+    const float w = weight[weight_len == 1 ? 0 : q];
+    const float C = (kind == BESS_LOSS_LOGSIGMOID ? 0.5f : 1.f) * loss_scale * w;
+    const float scale = L > 0.f ? C / L : 0.f;
+    for (int c = lane; c < W; c += 64) {
+        float x = 0.f;
+        for (int i = 0; i < items; ++i) {
+            const float mi = st_ml[(q * items + i) * 2];
+            if (mi != -INFINITY) x = fmaf(st_acc[(q * items + i) * W + c], expf(mi - m), x);
+        }
+        d_query[q * W + c] = scale * x;
     }
 }
 
@@ -216,12 +327,19 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_bwd(NegPtArgs a,
 }
 
 // ---- host dispatch ---------------------------------------------------------
+static thread_local const FuseArgs* g_fuse = nullptr;  // set by the fused entry point around run()
+
 template <typename T, int VEC, int IT, int RED>
 static void launch_fwd(const NegPtArgs& a, float* out, int64_t ld, hipStream_t st) {
     const int64_t items = a.n_query * a.items_per_query;
     constexpr int EPL = IT * VEC;  // scalars per lane per row
     constexpr int UNROLL = EPL <= 16 ? 4 : (EPL <= 32 ? 2 : 1);
-    k_neg_pertriple_fwd<T, VEC, IT, RED, UNROLL><<<ceil_div(items, 4), 256, 0, st>>>(a, out, ld);
+    if (g_fuse) {
+        constexpr int FU = EPL <= 16 ? 2 : 1;  // the running d_query sum takes EPL more registers
+        k_neg_pertriple_fwd<T, VEC, IT, RED, FU, true><<<ceil_div(items, 4), 256, 0, st>>>(a, out, ld, *g_fuse);
+    } else {
+        k_neg_pertriple_fwd<T, VEC, IT, RED, UNROLL, false><<<ceil_div(items, 4), 256, 0, st>>>(a, out, ld, FuseArgs{});
+    }
 }
 template <typename T, int VEC, int IT, int RED>
 static void launch_bwd(const NegPtArgs& a, const float* d_out, int64_t ld, float* dq, float* dn,
@@ -260,6 +378,12 @@ static int by_it(int it, int red, bool fwd, const NegPtArgs& a, float* out, cons
     return BESS_OK;
 }
 
+static int negatives_per_item(int64_t n_query, int64_t n_neg) {
+    int nb = 64;
+    while (nb > 8 && n_query * ceil_div(n_neg, nb) < 256 * 16 * 2) nb >>= 1;
+    return nb;
+}
+
 static int run(const bess_model_desc* d, bool fwd, const float* query, int64_t n_query,
                const void* neg_base, const int32_t* neg_idx, int64_t n_neg, float* out,
                const float* d_out, int64_t ld, float* dq, float* dn, void* stream) {
@@ -290,10 +414,8 @@ static int run(const bess_model_desc* d, bool fwd, const float* query, int64_t n
     a.nch = W / vec;
     // 64 negatives per work item: ~128 KiB of rows per wave at 2 KiB rows; shrink the
     // item when the launch would not fill 256 CUs x 16 waves
-    int nb = 64;
-    while (nb > 8 && n_query * ceil_div(n_neg, nb) < 256 * 16 * 2) nb >>= 1;
-    a.nb = nb;
-    a.items_per_query = static_cast<int>(ceil_div(n_neg, nb));
+    a.nb = negatives_per_item(n_query, n_neg);
+    a.items_per_query = static_cast<int>(ceil_div(n_neg, a.nb));
     a.sign = is_distance(d->scorer) ? -1.f : 1.f;
     const int it = static_cast<int>(ceil_div(a.nch, 16));
     const int red = reduce_of(d);
@@ -335,4 +457,43 @@ extern "C" int bess_neg_score_pertriple_bwd(const bess_model_desc* d, const floa
         return bess::fail(BESS_EINVAL, "neg_score_pertriple_bwd: NULL pointer");
     return bess::run(d, false, query, n_query, neg_base, neg_idx, n_neg, nullptr, d_out, ld_dout,
                      d_query, d_neg, stream);
+}
+
+extern "C" int bess_neg_pertriple_items(int64_t n_query, int64_t n_neg, int32_t* items) {
+    if (!items || n_query < 0 || n_neg < 0) return bess::fail(BESS_EINVAL, "neg_pertriple_items: bad argument");
+    *items = n_neg > 0 ? static_cast<int32_t>(bess::ceil_div(n_neg, bess::negatives_per_item(n_query, n_neg))) : 0;
+    return BESS_OK;
+}
+
+extern "C" int bess_neg_score_pertriple_fwd_dq(const bess_model_desc* d, const bess_loss_desc* l, const float* query,
+                                               int64_t n_query, const void* neg_base, const int32_t* neg_idx,
+                                               int64_t n_neg, const float* pos, const float* weight,
+                                               int64_t weight_len, float* out, int64_t ld_out, float* d_query,
+                                               float* state_ml, float* state_acc, void* stream) {
+    using namespace bess;
+    if (int e = check_desc(d)) return e;
+    BESS_REQUIRE(l, "neg_score_pertriple_fwd_dq: NULL loss descriptor");
+    BESS_REQUIRE(d->scorer <= BESS_COMPLEX, "neg_score_pertriple_fwd_dq: scorer %d has no fused form", d->scorer);
+    BESS_REQUIRE(l->kind == BESS_LOSS_LOGSIGMOID || l->kind == BESS_LOSS_MARGIN || l->kind == BESS_LOSS_SSCE,
+                 "neg_score_pertriple_fwd_dq: unknown loss %d", l->kind);
+    if (n_query <= 0 || n_neg <= 0) return BESS_OK;
+    BESS_REQUIRE(out && d_query && state_ml && state_acc && weight && (weight_len == 1 || weight_len == n_query),
+                 "neg_score_pertriple_fwd_dq: NULL pointer or bad weight length");
+    BESS_REQUIRE(pos || l->kind == BESS_LOSS_LOGSIGMOID, "neg_score_pertriple_fwd_dq: this loss needs the positive scores");
+    FuseArgs f;
+    f.pos = pos;
+    f.kind = l->kind;
+    f.beta = l->kind == BESS_LOSS_SSCE ? 1.f : (l->adversarial ? l->adversarial_scale : 0.f);
+    f.margin = l->margin;
+    f.shift = l->kind == BESS_LOSS_SSCE ? l->ssce_shift : 0.f;
+    f.st_ml = state_ml;
+    f.st_acc = state_acc;
+    g_fuse = &f;
+    const int rc = run(d, true, query, n_query, neg_base, neg_idx, n_neg, out, nullptr, ld_out, nullptr, nullptr, stream);
+    g_fuse = nullptr;
+    if (rc) return rc;
+    const int items = static_cast<int>(ceil_div(n_neg, negatives_per_item(n_query, n_neg)));
+    k_combine_dq<<<static_cast<unsigned>(ceil_div(n_query, 4)), 256, 0, as_stream(stream)>>>(
+        state_ml, state_acc, n_query, items, d->width, l->kind, l->loss_scale, pos, weight, weight_len, d_query);
+    return check_launch("neg_score_pertriple_fwd_dq");
 }

@@ -318,6 +318,21 @@ int bess_apply_segments_opt(const bess_opt_desc* o, int32_t dtype, int32_t width
 int bess_dense_sgd(int32_t dtype, void* table, const float* grad, int64_t n_elem,
                    float lr, void* stream);
 
+/* Fused training forward of the per-triple regime: the scores of bess_neg_score_pertriple_fwd
+ * *and* d loss / d query, in one pass over the negative rows (online-softmax accumulation of the
+ * loss weights; see csrc/neg_pertriple.hip).  Valid when nothing is masked out of the scores
+ * afterwards (no negative_mask, no augmentation) and the loss is taken over exactly these n_neg
+ * scores; TransE / RotatE / DistMult / ComplEx.  pos [n_query] (needed by margin ranking and ssce),
+ * weight [1 | n_query] = triple weights.  state_ml [n_query, items, 2] and state_acc
+ * [n_query, items, W] are scratch, items from bess_neg_pertriple_items(). */
+int bess_neg_pertriple_items(int64_t n_query, int64_t n_neg, int32_t* items);
+int bess_neg_score_pertriple_fwd_dq(const bess_model_desc* d, const bess_loss_desc* l,
+                                    const float* query, int64_t n_query, const void* neg_base,
+                                    const int32_t* neg_idx, int64_t n_neg, const float* pos,
+                                    const float* weight, int64_t weight_len, float* out,
+                                    int64_t ld_out, float* d_query, float* state_ml,
+                                    float* state_acc, void* stream);
+
 /* `torch.nn.functional.normalize(part, p=2, dim=-1)` of every d-wide part of the rows
  * (scoring.py:549-551 and the like), fused with the gather and the f32 conversion:
  *   out[i, p*d + w] = row_i[p*d + w] * inv[i, p],  inv = 1 / max(||part||_2, 1e-12)

@@ -534,3 +534,41 @@ def test_graph_replay_matches_reference(dev, case):
         close(res["loss"].reshape(n), c["outs"]["loss"][0], rtol=1e-4, atol=1e-4)
         close(model.score_fn.entity_embedding, c["table"] - lr * c["grads"]["entity"], rtol=1e-4, atol=2e-5)
         close(model.score_fn.relation_embedding, c["rel"] - lr * c["grads"]["relation"].sum(0), rtol=1e-4, atol=2e-5)
+
+
+# ------------------------------------ fused training forward (scores + d loss / d query) ----
+@pytest.mark.parametrize("name,p", NATIVE_SCORERS)
+@pytest.mark.parametrize("loss", list(LOSSES))
+@pytest.mark.parametrize("dtype,wname", [(torch.float32, "w"), (torch.float16, "one")])
+def test_fused_forward_dq_matches_two_pass(dev, name, p, loss, dtype, wname):
+    """One pass over the negative rows (online-softmax accumulation of the loss weights) gives the
+    scores of the plain forward and the d_query of loss kernel + backward kernel."""
+    from besskge import _native as nat
+    from besskge._native import RowSource
+    from besskge.loss import LogSigmoidLoss, MarginRankingLoss, SampledSoftmaxCrossEntropyLoss
+
+    kw = dict(LOSSES[loss])
+    kind = kw.pop("kind")
+    if kind == "logsigmoid":
+        fn = LogSigmoidLoss(kw["margin"], kw["adversarial"], kw.get("adversarial_scale", 1.0), kw.get("loss_scale", 1.0))
+    elif kind == "margin":
+        fn = MarginRankingLoss(kw["margin"], kw["adversarial"], kw.get("adversarial_scale", 1.0), kw.get("loss_scale", 1.0))
+    else:
+        fn = SampledSoftmaxCrossEntropyLoss(kw["n_entity"], kw.get("loss_scale", 1.0))
+    gen = torch.Generator().manual_seed(7)
+    for M, d, S, N in ((300, 40, 33, 150), (500, 256, 70, 256), (50, 6, 5, 3)):
+        W, Wr = widths(name, d)
+        table = (0.5 * torch.randn(M, W, generator=gen)).to(dtype).to(dev)
+        q = (0.5 * torch.randn(S, W, generator=gen)).to(dev)
+        idx = torch.randint(M, (S * N,), generator=gen, dtype=torch.int32).to(dev)
+        pos = torch.randn(S, generator=gen).to(dev)
+        w = (torch.rand(S, generator=gen) + 0.5).to(dev) if wname == "w" else torch.ones(1, device=dev)
+        desc = nat.make_desc(dict(TransE=0, RotatE=1, DistMult=2, ComplEx=3)[name], max(p, 1), table, Wr)
+        ld = fn.kernel_desc(N)
+        neg = RowSource(table, idx)
+        out, dq = nat.neg_score_pertriple_fwd_dq(desc, ld, q, neg, N, pos, w)
+        ref = nat.neg_score_pertriple_fwd(desc, q, neg, N)
+        assert torch.equal(out, ref)
+        _, _, dn = nat.loss_fwd_bwd(ld, pos, ref, w, True)
+        dq_ref, _ = nat.neg_score_pertriple_bwd(desc, q, neg, N, dn, want_d_neg=False)
+        close(dq, dq_ref, rtol=2e-4, atol=1e-6, scale=4e-6)
