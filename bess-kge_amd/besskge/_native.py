@@ -124,7 +124,7 @@ SIGNATURES = {
     "bess_ranks_from_scores": [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp],
     "bess_ranks_from_indices": [_vp, _vp, _i64, _i64, _i32, _vp, _vp],
     "bess_apply_segments_opt": [ctypes.POINTER(OptDesc), _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
-    "bess_neg_pertriple_items": [_i64, _i64, ctypes.POINTER(ctypes.c_int32)],
+    "bess_neg_pertriple_items": [_MD, _i64, _i64, ctypes.POINTER(ctypes.c_int32)],
     "bess_neg_score_pertriple_fwd_dq": [_MD, _LD, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
     "bess_normalize_rows": [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
     "bess_normalize_rows_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
@@ -486,7 +486,7 @@ def neg_score_pertriple_fwd_dq(d: ModelDesc, l: LossDesc, query: torch.Tensor, n
         if pos.numel() != nq:
             raise ValueError("`pos` must have n_query entries")
     items = ctypes.c_int32(0)
-    _check(load().bess_neg_pertriple_items(nq, n_neg, ctypes.byref(items)), "bess_neg_pertriple_items")
+    _check(load().bess_neg_pertriple_items(ctypes.byref(d), nq, n_neg, ctypes.byref(items)), "bess_neg_pertriple_items")
     out = torch.empty((nq, n_neg), dtype=torch.float32, device=dev)
     dq = torch.empty((nq, d.width), dtype=torch.float32, device=dev)
     st_ml = torch.empty((nq, items.value, 2), dtype=torch.float32, device=dev)

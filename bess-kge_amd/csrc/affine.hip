@@ -95,13 +95,7 @@ __device__ __forceinline__ void aff_load_row(const T* rp, int g, int d, int nch,
     for (int p = 0; p < NPART; ++p)
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int c = g + 16 * it;
-            if (c < nch) {
-                VecLoad<T, VEC>::load(rp + p * d + c * VEC, ev[p][it]);
-            } else {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) ev[p][it][v] = 0.f;
-            }
+            load_chunk<T, VEC>(rp + p * d, g + 16 * it, nch, ev[p][it]);
         }
 }
 
@@ -111,13 +105,7 @@ __device__ __forceinline__ void aff_load_query(const float* qp, int g, int d, in
     for (int p = 0; p <= NPART; ++p)
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int c = g + 16 * it;
-            if (c < nch) {
-                VecLoad<float, VEC>::load(qp + p * d + c * VEC, qv[p][it]);
-            } else {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) qv[p][it][v] = 0.f;
-            }
+            load_chunk<float, VEC>(qp + p * d, g + 16 * it, nch, qv[p][it]);
         }
 }
 

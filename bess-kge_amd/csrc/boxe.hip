@@ -46,14 +46,9 @@ struct BoxQuery {
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 const int ch = g + 16 * it;
-                if (ch < nch) {
-                    VecLoad<float, VEC>::load(qp + (3 * p + 0) * d + ch * VEC, s[p][it]);
-                    VecLoad<float, VEC>::load(qp + (3 * p + 1) * d + ch * VEC, c[p][it]);
-                    VecLoad<float, VEC>::load(qp + (3 * p + 2) * d + ch * VEC, h[p][it]);
-                } else {
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) s[p][it][v] = c[p][it][v] = h[p][it][v] = 0.f;
-                }
+                load_chunk<float, VEC>(qp + (3 * p + 0) * d, ch, nch, s[p][it]);
+                load_chunk<float, VEC>(qp + (3 * p + 1) * d, ch, nch, c[p][it]);
+                load_chunk<float, VEC>(qp + (3 * p + 2) * d, ch, nch, h[p][it]);
             }
     }
 };
@@ -64,13 +59,7 @@ __device__ __forceinline__ void box_load_row(const T* rp, int g, int d, int nch,
     for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int ch = g + 16 * it;
-            if (ch < nch) {
-                VecLoad<T, VEC>::load(rp + p * d + ch * VEC, ev[p][it]);
-            } else {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) ev[p][it][v] = 0.f;
-            }
+            load_chunk<T, VEC>(rp + p * d, g + 16 * it, nch, ev[p][it]);
         }
 }
 

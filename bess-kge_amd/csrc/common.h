@@ -84,6 +84,18 @@ struct VecLoad<T, 1> {
     }
 };
 
+// Chunk c (VEC scalars) of a row of nch chunks, zeros past the end - without a branch: the load
+// is unconditional at a clamped (valid) address and the result is selected.  A per-lane
+// `if (c < nch) load` makes the compiler emit exec-masked blocks separated by
+// s_waitcnt vmcnt(0), which serialises the row loads of an iteration.
+template <typename T, int VEC>
+__device__ __forceinline__ void load_chunk(const T* __restrict__ row, int c, int nch, float (&out)[VEC]) {
+    VecLoad<T, VEC>::load(row + min(c, nch - 1) * VEC, out);
+    const bool live = c < nch;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) out[i] = live ? out[i] : 0.f;
+}
+
 // sum over the 16 lanes of a DPP row; every lane of the row gets the total
 __device__ __forceinline__ float row16_allreduce_sum(float v) {
 #define BESS_DPP_ROR(x, n)                                                                     \

@@ -74,13 +74,7 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_fwd(NegPtArgs a, float* _
     const float* qp = a.query + q * a.W;
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int c = g + 16 * it;
-        if (c < a.nch) {
-            VecLoad<float, VEC>::load(qp + c * VEC, qv[it]);
-        } else {
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) qv[it][v] = 0.f;
-        }
+        load_chunk<float, VEC>(qp, g + 16 * it, a.nch, qv[it]);
     }
 
     const T* base = static_cast<const T*>(a.base);
@@ -97,6 +91,11 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_fwd(NegPtArgs a, float* _
         if (f.kind == BESS_LOSS_MARGIN) fpos = f.pos[q];
     }
 
+    // the row index of the *next* group of rows is fetched while the current rows are in
+    // flight: no row load waits behind its own index load (matters most for short rows)
+    int32_t nrow[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) nrow[u] = idx[min(k0 + sub + 4 * u, k1 - 1)];
     for (int kb = k0; kb < k1; kb += 4 * UNROLL) {  // kb is wave-uniform
         float ev[UNROLL][IT][VEC];
         bool valid[UNROLL];
@@ -104,17 +103,11 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_fwd(NegPtArgs a, float* _
         for (int u = 0; u < UNROLL; ++u) {
             const int k = kb + sub + 4 * u;
             valid[u] = k < k1;
-            const int ks = valid[u] ? k : (k1 - 1);  // keep the wave converged
-            const T* rp = base + static_cast<int64_t>(idx[ks]) * a.W;
+            const T* rp = base + static_cast<int64_t>(nrow[u]) * a.W;  // clamped: keeps the wave converged
+            nrow[u] = idx[min(k + 4 * UNROLL, k1 - 1)];
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                const int c = g + 16 * it;
-                if (c < a.nch) {
-                    VecLoad<T, VEC>::load(rp + c * VEC, ev[u][it]);
-                } else {
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) ev[u][it][v] = 0.f;
-                }
+                load_chunk<T, VEC>(rp, g + 16 * it, a.nch, ev[u][it]);
             }
         }
 #pragma unroll
@@ -251,7 +244,7 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_bwd(NegPtArgs a,
             qv[it][v] = 0.f;
             dq[it][v] = 0.f;
         }
-        if (c < a.nch) VecLoad<float, VEC>::load(qp + c * VEC, qv[it]);
+        load_chunk<float, VEC>(qp, c, a.nch, qv[it]);
     }
     const T* base = static_cast<const T*>(a.base);
     const int32_t* idx = a.idx + q * a.n_neg;
@@ -267,7 +260,7 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_bwd(NegPtArgs a,
             const int c = g + 16 * it;
 #pragma unroll
             for (int v = 0; v < VEC; ++v) ev[it][v] = 0.f;
-            if (c < a.nch) VecLoad<T, VEC>::load(rp + c * VEC, ev[it]);
+            load_chunk<T, VEC>(rp, c, a.nch, ev[it]);
         }
         float go = valid ? a.sign * d_out[q * ld_dout + ks] : 0.f;
         if (RED == RED_L2) {
@@ -378,8 +371,12 @@ static int by_it(int it, int red, bool fwd, const NegPtArgs& a, float* out, cons
     return BESS_OK;
 }
 
-static int negatives_per_item(int64_t n_query, int64_t n_neg) {
+// ~128 KiB of rows per work item (64 negatives of 2 KiB, up to 256 of 512 B: a wave then runs
+// enough iterations to amortise its start-up); shrink the item when the launch would not fill
+// 256 CUs x 16 waves
+static int negatives_per_item(int64_t n_query, int64_t n_neg, int64_t row_bytes) {
     int nb = 64;
+    while (nb < 256 && nb * row_bytes < 131072) nb <<= 1;
     while (nb > 8 && n_query * ceil_div(n_neg, nb) < 256 * 16 * 2) nb >>= 1;
     return nb;
 }
@@ -414,7 +411,7 @@ static int run(const bess_model_desc* d, bool fwd, const float* query, int64_t n
     a.nch = W / vec;
     // 64 negatives per work item: ~128 KiB of rows per wave at 2 KiB rows; shrink the
     // item when the launch would not fill 256 CUs x 16 waves
-    a.nb = negatives_per_item(n_query, n_neg);
+    a.nb = negatives_per_item(n_query, n_neg, static_cast<int64_t>(W) * (d->dtype == BESS_F32 ? 4 : 2));  // == row_bytes_of(d)
     a.items_per_query = static_cast<int>(ceil_div(n_neg, a.nb));
     a.sign = is_distance(d->scorer) ? -1.f : 1.f;
     const int it = static_cast<int>(ceil_div(a.nch, 16));
@@ -459,9 +456,14 @@ extern "C" int bess_neg_score_pertriple_bwd(const bess_model_desc* d, const floa
                      d_query, d_neg, stream);
 }
 
-extern "C" int bess_neg_pertriple_items(int64_t n_query, int64_t n_neg, int32_t* items) {
-    if (!items || n_query < 0 || n_neg < 0) return bess::fail(BESS_EINVAL, "neg_pertriple_items: bad argument");
-    *items = n_neg > 0 ? static_cast<int32_t>(bess::ceil_div(n_neg, bess::negatives_per_item(n_query, n_neg))) : 0;
+static int64_t row_bytes_of(const bess_model_desc* d) {
+    return static_cast<int64_t>(d->width) * (d->dtype == BESS_F32 ? 4 : 2);
+}
+
+extern "C" int bess_neg_pertriple_items(const bess_model_desc* d, int64_t n_query, int64_t n_neg, int32_t* items) {
+    if (!d || !items || n_query < 0 || n_neg < 0) return bess::fail(BESS_EINVAL, "neg_pertriple_items: bad argument");
+    *items = n_neg > 0 ? static_cast<int32_t>(bess::ceil_div(n_neg, bess::negatives_per_item(n_query, n_neg, row_bytes_of(d))))
+                       : 0;
     return BESS_OK;
 }
 
@@ -492,7 +494,7 @@ extern "C" int bess_neg_score_pertriple_fwd_dq(const bess_model_desc* d, const b
     const int rc = run(d, true, query, n_query, neg_base, neg_idx, n_neg, out, nullptr, ld_out, nullptr, nullptr, stream);
     g_fuse = nullptr;
     if (rc) return rc;
-    const int items = static_cast<int>(ceil_div(n_neg, negatives_per_item(n_query, n_neg)));
+    const int items = static_cast<int>(ceil_div(n_neg, negatives_per_item(n_query, n_neg, row_bytes_of(d))));
     k_combine_dq<<<static_cast<unsigned>(ceil_div(n_query, 4)), 256, 0, as_stream(stream)>>>(
         state_ml, state_acc, n_query, items, d->width, l->kind, l->loss_scale, pos, weight, weight_len, d_query);
     return check_launch("neg_score_pertriple_fwd_dq");

@@ -101,8 +101,7 @@ __global__ __launch_bounds__(256) void k_pertriple_grad_segments(SegArgs a, floa
                 ev[it][v] = 0.f;
                 acc[it][v] = 0.f;
             }
-            if ((RED != RED_DOT || grad_seg == nullptr) && c < a.nch)
-                VecLoad<T, VEC>::load(table + row * a.W + c * VEC, ev[it]);
+            if (RED != RED_DOT || grad_seg == nullptr) load_chunk<T, VEC>(table + row * a.W, c, a.nch, ev[it]);
         }
         for (int r = r0; r < r1; ++r) {
             const int ref = a.refs[r];
@@ -116,7 +115,7 @@ __global__ __launch_bounds__(256) void k_pertriple_grad_segments(SegArgs a, floa
                 const int c = g + 16 * it;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) qv[it][v] = 0.f;
-                if (c < a.nch) VecLoad<float, VEC>::load(qp + c * VEC, qv[it]);
+                load_chunk<float, VEC>(qp, c, a.nch, qv[it]);
             }
             if (RED == RED_L2) {
                 float ss = 0.f;

@@ -325,7 +325,7 @@ int bess_dense_sgd(int32_t dtype, void* table, const float* grad, int64_t n_elem
  * scores; TransE / RotatE / DistMult / ComplEx.  pos [n_query] (needed by margin ranking and ssce),
  * weight [1 | n_query] = triple weights.  state_ml [n_query, items, 2] and state_acc
  * [n_query, items, W] are scratch, items from bess_neg_pertriple_items(). */
-int bess_neg_pertriple_items(int64_t n_query, int64_t n_neg, int32_t* items);
+int bess_neg_pertriple_items(const bess_model_desc* d, int64_t n_query, int64_t n_neg, int32_t* items);
 int bess_neg_score_pertriple_fwd_dq(const bess_model_desc* d, const bess_loss_desc* l,
                                     const float* query, int64_t n_query, const void* neg_base,
                                     const int32_t* neg_idx, int64_t n_neg, const float* pos,

@@ -16,16 +16,17 @@ __global__ __launch_bounds__(256) void k_read(const float4* __restrict__ p, size
 __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ p, float4* __restrict__ q, size_t n) {
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += 256ull * gridDim.x) q[i] = p[i];
 }
-// one 16-lane group per random 2 KiB row (8 x 16 B per lane), rows chosen by a hash
+// one 16-lane group per random row of J x 256 B (J x 16 B per lane), rows chosen by a hash
+template <int J>
 __global__ __launch_bounds__(256) void k_rows(const float4* __restrict__ p, size_t n_rows, size_t n_read, float* out) {
     const size_t grp = (blockIdx.x * 256ull + threadIdx.x) >> 4;
     const int g = threadIdx.x & 15;
     float4 acc = make_float4(0, 0, 0, 0);
     for (size_t r = grp; r < n_read; r += (256ull * gridDim.x) >> 4) {
         const size_t row = (r * 2654435761ull + 12345ull) % n_rows;
-        const float4* rp = p + row * 128;
+        const float4* rp = p + row * (16 * J);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < J; ++j) {
             float4 v = rp[g + 16 * j];
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
@@ -55,8 +56,12 @@ int main() {
     }
     run("stream copy 8 GiB -> 8 GiB (read + write)", 2.0 * bytes, [&] { k_copy<<<8192, 256>>>(a, b, n); });
     const size_t n_rows = bytes / 2048;
-    run("random 2 KiB rows, 1 Mi rows of 4 Mi (HBM)", 2048.0 * (1 << 20), [&] { k_rows<<<16384, 256>>>(a, n_rows, 1 << 20, out); });
-    run("random 2 KiB rows, 4 Mi rows of 4 Mi (HBM)", 2048.0 * (4 << 20), [&] { k_rows<<<16384, 256>>>(a, n_rows, 4 << 20, out); });
-    run("random 2 KiB rows, 1 Mi rows of 93,773 (L3)", 2048.0 * (1 << 20), [&] { k_rows<<<16384, 256>>>(a, 93773, 1 << 20, out); });
+    run("random 2 KiB rows, 1 Mi rows of 4 Mi (HBM)", 2048.0 * (1 << 20), [&] { k_rows<8><<<16384, 256>>>(a, n_rows, 1 << 20, out); });
+    run("random 2 KiB rows, 4 Mi rows of 4 Mi (HBM)", 2048.0 * (4 << 20), [&] { k_rows<8><<<16384, 256>>>(a, n_rows, 4 << 20, out); });
+    run("random 2 KiB rows, 1 Mi rows of 93,773 (L3)", 2048.0 * (1 << 20), [&] { k_rows<8><<<16384, 256>>>(a, 93773, 1 << 20, out); });
+    run("random 1 KiB rows, 4 Mi rows of 8 Mi (HBM)", 1024.0 * (4 << 20), [&] { k_rows<4><<<16384, 256>>>(a, bytes / 1024, 4 << 20, out); });
+    run("random 512 B rows, 4 Mi rows of 16 Mi (HBM)", 512.0 * (4 << 20), [&] { k_rows<2><<<16384, 256>>>(a, bytes / 512, 4 << 20, out); });
+    run("random 512 B rows, 4 Mi rows of 8 Mi (4 GiB, HBM)", 512.0 * (4 << 20), [&] { k_rows<2><<<16384, 256>>>(a, bytes / 1024, 4 << 20, out); });
+    run("random 512 B rows, 1 Mi rows of 312,576 (L3)", 512.0 * (1 << 20), [&] { k_rows<2><<<16384, 256>>>(a, 312576, 1 << 20, out); });
     return 0;
 }
