@@ -250,6 +250,17 @@ class BessKGE(torch.nn.Module, ABC):
         steps = self._score_replicas(batches)
         return [self._finish(st, b, want_grad=False)[0] for st, b in zip(steps, batches)]
 
+    # Two-phase form of forward_replicas for software pipelining over micro-batches:
+    # `forward_begin` issues what the scoring has to wait for (row gathers and the collectives
+    # that distribute queries), `forward_finish` does the rest.  Calling begin(i + 1) before
+    # finish(i) puts the all-gathers of micro-batch i + 1 in front of the score all-to-all of
+    # micro-batch i in the (in-order) collective queue, so they run under its scoring kernel.
+    def forward_begin(self, batches: List[_Batch]) -> Dict[str, Any]:
+        return dict(batches=batches)
+
+    def forward_finish(self, ctx: Dict[str, Any]) -> List[Dict[str, Any]]:
+        return self.forward_replicas(ctx["batches"])
+
     def _score_replicas(self, batches: List[_Batch]) -> List[_ReplicaStep]:
         group = self._group()
         if len(batches) != len(group.local_shards):
@@ -762,14 +773,27 @@ class ScoreMovingBessKGE(BessKGE):
     """
 
     def score_batch_replicas(self, batches: List[_Batch]) -> List[_ReplicaStep]:
+        return self._score_finish(self._score_begin(batches))
+
+    def forward_begin(self, batches: List[_Batch]) -> Dict[str, Any]:
+        group = self._group()
+        if len(batches) != len(group.local_shards):
+            raise ValueError(f"{len(batches)} batches for {len(group.local_shards)} local replicas")
+        squeezed = [{k: _i32(b[k].squeeze(0)) for k in ("head", "relation", "tail", "negative")} for b in batches]
+        ctx = self._score_begin(squeezed)
+        ctx["batches"] = batches
+        return ctx
+
+    def forward_finish(self, ctx: Dict[str, Any]) -> List[Dict[str, Any]]:
+        steps = self._score_finish(ctx)
+        return [self._finish(st, b, want_grad=False)[0] for st, b in zip(steps, ctx["batches"])]
+
+    def _score_begin(self, batches: List[_Batch]) -> Dict[str, Any]:
+        """K1 gathers and the all-gathers C2 / C3 (reference bess.py:502-518)."""
         group = self._group()
         n = group.n_shard
         ns = self.negative_sampler
-        fn = self.score_fn
         W = self.entity_embedding_size
-        desc = fn.kernel_desc()
-        rel_table = fn.relation_embedding.data
-        sharing = bool(fn.negative_sample_sharing)
         scheme = ns.corruption_scheme
         steps: List[_ReplicaStep] = []
         tails_out, heads_q, tails_q, rels = [], [], [], []
@@ -801,6 +825,20 @@ class ScoreMovingBessKGE(BessKGE):
         rel_all = group.all_gather(rels)  # C2  [n(j), n, ppp]
         tq_all = group.all_gather(tails_q) if tails_q else None  # C3  [n(t), n(j), ., W]
         hq_all = group.all_gather(heads_q) if heads_q else None  # C3  [n(j), n(t), ., W]
+        return dict(steps=steps, tails_out=tails_out, rel_all=rel_all, tq_all=tq_all, hq_all=hq_all)
+
+    def _score_finish(self, ctx: Dict[str, Any]) -> List[_ReplicaStep]:
+        """Local scoring of the gathered queries, score all-to-all C4 + C5, positive scores."""
+        group = self._group()
+        n = group.n_shard
+        ns = self.negative_sampler
+        fn = self.score_fn
+        W = self.entity_embedding_size
+        desc = fn.kernel_desc()
+        sharing = bool(fn.negative_sample_sharing)
+        scheme = ns.corruption_scheme
+        steps, tails_out = ctx["steps"], ctx["tails_out"]
+        rel_all, tq_all, hq_all = ctx["rel_all"], ctx["tq_all"], ctx["hq_all"]
 
         scores_out = []
         for r, st in enumerate(steps):

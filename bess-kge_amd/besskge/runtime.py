@@ -246,7 +246,23 @@ class Runner:
         for st in streams:
             if st is not main:
                 st.wait_stream(main)
-        for it in range(iters):
+        pipelined = (self.optimizer is None and isinstance(self.group, DistributedGroup) and iters > 1
+                     and hasattr(self.model, "forward_begin"))
+        if pipelined:
+            # one process per GPU: issue the gathers / all-gathers of micro-batch it + 1 before the
+            # scoring of micro-batch it (BessKGE.forward_begin / forward_finish)
+            with torch.no_grad():
+                with torch.cuda.stream(streams[0]):
+                    ctx = self.model.forward_begin(self._split(batch, 0))
+                for it in range(iters):
+                    nxt = None
+                    if it + 1 < iters:
+                        with torch.cuda.stream(streams[(it + 1) % len(streams)]):
+                            nxt = self.model.forward_begin(self._split(batch, it + 1))
+                    with torch.cuda.stream(streams[it % len(streams)]):
+                        collected.append(self.model.forward_finish(ctx))
+                    ctx = nxt
+        for it in range(0 if not pipelined else iters, iters):
             with torch.cuda.stream(streams[it % len(streams)]):
                 reps = self._split(batch, it)
                 if self.optimizer is not None:

@@ -121,6 +121,23 @@ def run_affine(name, n_part, normalize, p, dtype, M, d, S, N, shared):
               f"{bf/t_f/1e6:7.0f} GB/s | bwd {t_b*1e3:8.1f} us {bb/t_b/1e6:7.0f} GB/s")
 
 
+def run_movers():
+    """K1 gather and K9/K10 sparse update on config-2-like rows (2 KiB) and config-4-like (512 B)."""
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for name, M, W, dtype, n in (("f32 2 KiB rows (L3)", 93_773, 512, torch.float32, 1 << 20),
+                                 ("f32 2 KiB rows (HBM 8GB)", 4_000_000, 512, torch.float32, 1 << 20),
+                                 ("f16 512 B rows (HBM 4GB)", 8_000_000, 256, torch.float16, 1 << 20)):
+        table = torch.zeros(M, W, dtype=dtype, device=dev)
+        idx = torch.randint(M, (n,), generator=g, dtype=torch.int32).to(dev)
+        out = nat.gather_rows(table, idx)
+        t_g = timeit(lambda: nat.gather_rows(table, idx, out))
+        grad = torch.randn(n, W, device=dev)
+        t_s = timeit(lambda: nat.sparse_sgd(table, idx, grad, 1e-3), reps=5)
+        sz = table.element_size()
+        print(f"movers {name:28s} gather {t_g*1e3:8.1f} us {2*n*W*sz/t_g/1e6:7.0f} GB/s (read+write) | "
+              f"atomic sparse SGD {t_s*1e3:8.1f} us {n*W*(4+sz)/t_s/1e6:7.0f} GB/s")
+
+
 AFFINE_CASES = [
     # name, n_part, normalize, p, dtype, M, d, S, N, shared
     ("PairRE d256 f32 norm (L3)", 1, True, 1, torch.float32, 93_773, 256, 4096, 256, False),
@@ -141,3 +158,5 @@ if __name__ == "__main__":
     for c in AFFINE_CASES:
         if flt in c[0]:
             run_affine(*c)
+    if flt in "movers":
+        run_movers()
