@@ -33,7 +33,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_fetch_hbm"):
     for r in csv.DictReader(open(f)):
         agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for k, v in agg.items():
-        if "k_neg_pertriple_fwd" in k[0]:
+        if "k_neg_pertriple_fwd" in k[0] and "false>" in k[0]:  # the plain forward, not the fused training variant
             pm[d] = (k[1], len(v), sum(v) / len(v))
 fetch, write, fetch_hbm = pm["pmc_fetch"][2], pm["pmc_write"][2], pm["pmc_fetch_hbm"][2]
 lines.append("## rocprofv3 --pmc (separate passes), kernel k_neg_pertriple_fwd<float, 4, 8, DOT, 2>\n\n")
