@@ -710,7 +710,8 @@ def neg_pertriple_grad_segments(d: ModelDesc, query: torch.Tensor, table: torch.
     _f32(d_out, "d_out")
     _rows(table, "table", d.width)
     nq = int(query.shape[0])
-    if _dtype_code(table) != d.dtype or tuple(query.shape) != (nq, d.width) or tuple(d_out.shape) != (nq, n_neg) \
+    if _dtype_code(table) != d.dtype or tuple(query.shape) != (nq, query_width(d)) \
+            or tuple(d_out.shape) != (nq, n_neg) \
             or seg.n_refs != nq * n_neg:
         raise ValueError("neg_pertriple_grad_segments: operand shapes do not match")
     fused = fused_sgd_lr is not None

@@ -487,7 +487,7 @@ class BessKGE(torch.nn.Module, ABC):
     def _fusable(self, batch: _Batch) -> Optional[Dict[str, Any]]:
         """Can the training forward of this micro-batch also produce d loss / d query?  Needs a
         loss taken over exactly the scores of one per-triple group, with nothing masked."""
-        if self.loss_fn is None or not self.score_fn.supports_fused_segments or self.augment_negative:
+        if self.loss_fn is None or not self.score_fn.supports_fused_forward or self.augment_negative:
             return None
         if batch.get("negative_mask") is not None or not hasattr(self.loss_fn, "kernel_desc"):
             return None

@@ -93,6 +93,9 @@ class BaseScoreFunction(torch.nn.Module, ABC):
     #: per-triple negatives of the own shard can use the segmented K9 reduction
     #: (gradient recomputed per reference from the query) instead of a [S*N, W] gradient
     supports_fused_segments = True
+    #: the training forward can accumulate d loss / d query next to the scores
+    #: (`bess_neg_score_pertriple_fwd_dq`)
+    supports_fused_forward = True
 
     def dense_parameters(self) -> List[torch.nn.Parameter]:
         """Parameters besides the two embedding tables (ConvE's network); replicated like the
@@ -363,6 +366,7 @@ class _TorchQueryHooks:
     back to the step."""
 
     supports_fused_segments = False
+    supports_fused_forward = False
 
     def _query_torch(self, side: int, rows: torch.Tensor, rel: torch.Tensor, rel_idx: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
@@ -408,6 +412,7 @@ class _AffineScoreFunction(_TorchQueryHooks, DistanceBasedScoreFunction, ABC):
     """`-|| U * c1 + V * c2 + R ||_p` scorers; see the module docstring."""
 
     _scorer_id = nat.AFFINE
+    supports_fused_segments = True  # csrc/affine.hip: k_aff_grad_segments
     #: d-wide parts of an entity row (1 | 2)
     _n_part: int = 1
     normalize: bool

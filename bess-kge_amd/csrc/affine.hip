@@ -20,6 +20,8 @@
 //   shared (VALU bound): 64 x 64 LDS tile kernel over *dense fp32, already
 //     normalised* candidates (bess_normalize_rows gathers + converts + normalises the
 //     N candidate rows first; its backward maps the gradient back).
+#include <algorithm>
+
 #include "common.h"
 
 namespace bess {
@@ -333,6 +335,144 @@ int affine_pertriple(const bess_model_desc* d, bool fwd, const float* query, int
 #undef BESS_AFF
     if (rc) return rc;
     return check_launch(fwd ? "neg_score_pertriple_fwd (affine)" : "neg_score_pertriple_bwd (affine)");
+}
+
+// K9 for the per-triple negatives of the own shard (the affine counterpart of
+// k_pertriple_grad_segments): one 16-lane group per unique destination row.  The row and
+// its part norms are loaded once; every reference (q, k) of the segment contributes
+// d score / d c_p = s * U_p with s recomputed from query[q] and d_out[q, k]; the
+// normalisation backward is linear, so it is applied once to the summed gradient.
+struct AffSegArgs {
+    const float* query;          // [n_query, (NPART + 1) * d]
+    const void* table;
+    const float* d_out;
+    int64_t ld_dout;
+    const int32_t* refs;
+    const int32_t* seg_rows;
+    const int32_t* seg_offsets;
+    const int32_t* n_seg;
+    int n_neg;
+    int d;
+    int nch;
+    int normalize;
+};
+
+template <typename T, int VEC, int IT, int NPART, int P>
+__global__ __launch_bounds__(256) void k_aff_grad_segments(AffSegArgs a, float* __restrict__ grad_seg, T* table_rw,
+                                                           float lr) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane & 15;
+    const int n_seg = *a.n_seg;
+    const int64_t group0 = (blockIdx.x * 256ll + threadIdx.x) >> 4;
+    const int64_t n_group = (gridDim.x * 256ll) >> 4;
+    const T* table = static_cast<const T*>(a.table);
+    const int W = NPART * a.d;
+    for (int64_t seg = group0; seg < n_seg; seg += n_group) {
+        const int64_t row = a.seg_rows[seg];
+        const int r0 = a.seg_offsets[seg], r1 = a.seg_offsets[seg + 1];
+        float ev[NPART][IT][VEC], inv[NPART], dc[NPART][IT][VEC];
+        aff_load_row<T, VEC, IT, NPART>(table + row * W, g, a.d, a.nch, ev);
+        aff_inv_norm<VEC, IT, NPART>(ev, a.normalize, inv);
+#pragma unroll
+        for (int p = 0; p < NPART; ++p)
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) dc[p][it][v] = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const int ref = a.refs[r];
+            const int q = ref / a.n_neg;
+            const int k = ref - q * a.n_neg;
+            float go = -a.d_out[q * a.ld_dout + k];
+            float qv[NPART + 1][IT][VEC];
+            aff_load_query<VEC, IT, NPART>(a.query + static_cast<int64_t>(q) * (NPART + 1) * a.d, g, a.d, a.nch, qv);
+            if (P == 2) {
+                float ss = 0.f;
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const float dlt = aff_delta<VEC, IT, NPART>(qv, ev, inv, it, v);
+                        ss = fmaf(dlt, dlt, ss);
+                    }
+                ss = row16_allreduce_sum(ss);
+                go = ss > 0.f ? go / sqrtf(ss) : 0.f;
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const float dlt = aff_delta<VEC, IT, NPART>(qv, ev, inv, it, v);
+                    const float sc = (P == 1) ? go * sgnf(dlt) : go * dlt;
+#pragma unroll
+                    for (int p = 0; p < NPART; ++p) dc[p][it][v] = fmaf(sc, qv[p][it][v], dc[p][it][v]);
+                }
+        }
+#pragma unroll
+        for (int p = 0; p < NPART; ++p) {
+            float dot = 0.f;
+            if (a.normalize) {
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) dot = fmaf(ev[p][it][v] * inv[p], dc[p][it][v], dot);
+                dot = row16_allreduce_sum(dot);
+                if (inv[p] >= 1.f / NORM_EPS) dot = 0.f;
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = g + 16 * it;
+                if (c < a.nch) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const float hat = ev[p][it][v] * inv[p];
+                        const float de = a.normalize ? inv[p] * (dc[p][it][v] - hat * dot) : dc[p][it][v];
+                        const int64_t o = p * a.d + c * VEC + v;
+                        if (grad_seg) grad_seg[seg * W + o] = de;
+                        else table_rw[row * W + o] = static_cast<T>(ev[p][it][v] - lr * de);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int VEC, int NPART>
+static int aff_seg_by_it(int it, int p, const AffSegArgs& a, float* grad_seg, void* rw, float lr, unsigned grid,
+                         hipStream_t st) {
+    T* t = static_cast<T*>(rw);
+#define BESS_AFS(ITV)                                                                               \
+    (p == 1 ? k_aff_grad_segments<T, VEC, ITV, NPART, 1><<<grid, 256, 0, st>>>(a, grad_seg, t, lr)   \
+            : k_aff_grad_segments<T, VEC, ITV, NPART, 2><<<grid, 256, 0, st>>>(a, grad_seg, t, lr))
+    if (it <= 1) BESS_AFS(1);
+    else if (it <= 2) BESS_AFS(2);
+    else if (it <= 4) BESS_AFS(4);
+    else if (it <= 8) BESS_AFS(8);
+    else return fail(BESS_EUNSUPPORTED, "affine scorers: part of %d scalars too wide", a.d);
+#undef BESS_AFS
+    return BESS_OK;
+}
+
+int affine_grad_segments(const bess_model_desc* d, const float* query, void* table, int64_t n_neg,
+                         const float* d_out, int64_t ld_dout, const int32_t* refs_sorted, const int32_t* seg_rows,
+                         const int32_t* seg_offsets, const int32_t* n_seg, int64_t max_seg, float* grad_seg,
+                         float fused_sgd_lr, hipStream_t st) {
+    const int n_part = d->reserved[0];
+    const int dd = d->width / n_part;
+    const int vec = (dd % 4 == 0) ? 4 : 1;
+    AffSegArgs a{query, table, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg, static_cast<int>(n_neg),
+                 dd, dd / vec, d->reserved[1] & 1};
+    const int it = static_cast<int>(ceil_div(a.nch, 16));
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(max_seg, 16), 256 * 16));
+    int rc;
+#define BESS_AFSD(T, V)                                                                                       \
+    (n_part == 1 ? aff_seg_by_it<T, V, 1>(it, d->norm_p, a, grad_seg, table, fused_sgd_lr, grid, st)          \
+                 : aff_seg_by_it<T, V, 2>(it, d->norm_p, a, grad_seg, table, fused_sgd_lr, grid, st))
+    if (d->dtype == BESS_F32) rc = vec == 4 ? BESS_AFSD(float, 4) : BESS_AFSD(float, 1);
+    else rc = vec == 4 ? BESS_AFSD(half_t, 4) : BESS_AFSD(half_t, 1);
+#undef BESS_AFSD
+    if (rc) return rc;
+    return check_launch("neg_pertriple_grad_segments (affine)");
 }
 
 // ---------------------------------------------------------------------------

@@ -572,3 +572,34 @@ def test_fused_forward_dq_matches_two_pass(dev, name, p, loss, dtype, wname):
         _, _, dn = nat.loss_fwd_bwd(ld, pos, ref, w, True)
         dq_ref, _ = nat.neg_score_pertriple_bwd(desc, q, neg, N, dn, want_d_neg=False)
         close(dq, dq_ref, rtol=2e-4, atol=1e-6, scale=4e-6)
+
+
+@pytest.mark.parametrize("n_part,normalize,p", [(1, True, 1), (1, False, 2), (2, True, 2), (2, False, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_affine_grad_segments_match_scatter_of_row_gradients(dev, n_part, normalize, p, dtype):
+    """K9 of the PairRE / TripleRE / InterHT / TranS family: the segmented reduction (per-reference
+    gradient recomputed from the query, normalisation backward applied once per row) equals
+    index_add of the backward kernel's row gradients."""
+    from besskge import _native as nat
+    from besskge._native import RowSource
+
+    gen = torch.Generator().manual_seed(9)
+    for M, d, S, N in ((300, 40, 33, 17), (64, 6, 9, 5)):
+        W = n_part * d
+        table = torch.randn(M, W, generator=gen).to(dtype).to(dev)
+        q = torch.randn(S, (n_part + 1) * d, generator=gen).to(dev)
+        idx = torch.randint(M, (S * N,), generator=gen, dtype=torch.int32).to(dev)
+        go = torch.randn(S, N, generator=gen).to(dev)
+        desc = nat.make_desc(nat.AFFINE, p, table, d)
+        desc.reserved[0], desc.reserved[1] = n_part, int(normalize)
+        _, dn = nat.neg_score_pertriple_bwd(desc, q, RowSource(table, idx), N, go)
+        seg = nat.SegmentIndex(idx, M)
+        n_seg = int(seg.n_seg.item())
+        uniq = torch.unique(idx.cpu().long())
+        g1 = nat.neg_pertriple_grad_segments(desc, q, table, N, go, seg)
+        want = torch.zeros(M, W, dtype=torch.float64).index_add_(0, idx.cpu().long(), dn.cpu().double())
+        close(g1[:n_seg], want[uniq].float(), rtol=1e-4, atol=1e-5, scale=4e-6)
+        t2 = table.clone()
+        nat.neg_pertriple_grad_segments(desc, q, t2, N, go, seg, fused_sgd_lr=0.5)
+        tol = 2e-3 if dtype == torch.float16 else 1e-5
+        close(t2, table.float().cpu() - 0.5 * want.float(), rtol=tol, atol=tol, scale=4e-6)
