@@ -147,13 +147,33 @@ def cpu_baseline(seconds: float = 12.0):
             kge.bess_step(spec, "EmbeddingMoving", table, rel, batch, loss)
             reps += 1
         dt = time.perf_counter() - t0
+    # forward + backward (torch autograd: dense zero-filled table gradient + index_put, the
+    # reference's CPU training path), a few passes
+    tg = table.clone().requires_grad_(True)
+    rg = rel.clone().requires_grad_(True)
+    t1 = time.perf_counter()
+    reps_b = 0
+    while reps_b < 2 or time.perf_counter() - t1 < seconds / 2:
+        tg.grad = rg.grad = None
+        res = kge.bess_step(spec, "EmbeddingMoving", tg, rg, batch, loss)
+        torch.stack(res["loss"]).sum().backward()
+        reps_b += 1
+    dt_b = time.perf_counter() - t1
+    model = ""
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
     return dict(
         value=reps * s_cpu * (1 + K_TOTAL) / dt,
         unit="triples/s",
         cores=cores,
         kind="port",
+        cpu_model=model,
         sample=f"{reps} passes of {s_cpu} triples x {K_TOTAL} per-triple negatives (forward: gather+score+loss), "
                f"torch CPU fp32, {cores} threads, {dt:.1f} s",
+        train_value=reps_b * s_cpu * (1 + K_TOTAL) / dt_b,
+        train_sample=f"{reps_b} passes forward + autograd backward of the same sample, {dt_b:.1f} s",
     )
 
 
