@@ -395,7 +395,7 @@ def _query_operands(d: ModelDesc, ent: RowSource, rel_table: torch.Tensor, rel_i
 
 def query_fwd(d: ModelDesc, side: int, ent: RowSource, rel_table: torch.Tensor, rel_idx: torch.Tensor) -> torch.Tensor:
     dev, n = _query_operands(d, ent, rel_table, rel_idx)
-    q = torch.empty((n, d.width), dtype=torch.float32, device=dev)
+    q = torch.empty((n, query_width(d)), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = load().bess_query_fwd(ctypes.byref(d), side, ent.base.data_ptr(), _idx(ent.idx, "entity idx"),
                                    rel_table.data_ptr(), rel_idx.data_ptr(), n, q.data_ptr(), _stream(dev))
@@ -410,7 +410,7 @@ def query_bwd(d: ModelDesc, side: int, ent: RowSource, rel_table: torch.Tensor, 
     _same_device([("d_query", d_query), ("d_rel_table", d_rel_table), ("x", ent.base)])
     _f32(d_query, "d_query")
     _f32(d_rel_table, "d_rel_table")
-    if tuple(d_query.shape) != (n, d.width) or tuple(d_rel_table.shape) != tuple(rel_table.shape):
+    if tuple(d_query.shape) != (n, query_width(d)) or tuple(d_rel_table.shape) != tuple(rel_table.shape):
         raise ValueError("query_bwd: gradient shapes do not match")
     dx = torch.empty((n, d.width), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):

@@ -23,10 +23,10 @@ PairRE, TripleRE, InterHT and TranS (reference
 `scoring.py:465-743, 1418-1750`) share one kernel family: their score is
 `-|| U * c1(e) + V * c2(e) + R ||_p` with per-query vectors U, V, R and the
 (optionally normalised) parts c1, c2 of the candidate row (`csrc/affine.hip`).
-The S x N work - scoring queries against negatives, and its backward - runs in
-those kernels; the per-query transform (S rows: building [U | V | R] from the
-kept entity and the relation) and the positive score are written with torch
-ops on the device and differentiated by autograd.
+The fused BESS step runs entirely in those kernels (query transform
+`[U | V | R]`, negative scoring, positive score = tail-corruption score of the one
+true tail, and all backwards); the public `score_*` methods express the S-row
+query transform with torch ops so that they stay differentiable through autograd.
 
 ConvE (`scoring.py:949-1146`) keeps its query network (batch-norm, conv,
 linear: dense parameters) as torch modules on the device; what is scored
@@ -38,6 +38,7 @@ normalisation, box size, tanh of the box) and the positive score are torch ops
 over S rows; candidates are scored by the `csrc/boxe.hip` kernels.
 """
 
+import struct
 from abc import ABC, abstractmethod
 from typing import Any, Callable, List, Tuple, Union
 
@@ -418,11 +419,42 @@ class _AffineScoreFunction(_TorchQueryHooks, DistanceBasedScoreFunction, ABC):
     normalize: bool
     embedding_size: int
 
+    #: member of the family as csrc/affine.hip numbers them (0 PairRE, 1 TripleRE, 2 InterHT, 3 TranS)
+    _member: int = 0
+
+    def _constant(self) -> float:
+        """The model's additive constant (TripleRE: u, InterHT / TranS: offset)."""
+        return 0.0
+
     def kernel_desc(self) -> nat.ModelDesc:
         d = super().kernel_desc()
         d.reserved[0] = self._n_part
-        d.reserved[1] = int(bool(self.normalize))
+        d.reserved[1] = int(bool(self.normalize)) | (self._member << 8)
+        d.reserved[2] = struct.unpack("i", struct.pack("f", self._constant()))[0]
         return d
+
+    # hooks of the fused step: HIP query transform (k_aff_query_fwd / bwd); the positive score is
+    # the tail-corruption score of the one true tail (the same vector up to sign inside the norm)
+    supports_fused_forward = False
+
+    def query_fwd(self, side: int, ent: nat.RowSource, rel_idx: torch.Tensor) -> Tuple[torch.Tensor, Any]:
+        return nat.query_fwd(self.kernel_desc(), side, ent, self.relation_embedding.data, rel_idx), None
+
+    def query_bwd(self, side: int, ent: nat.RowSource, rel_idx: torch.Tensor, ctx: Any, dq: torch.Tensor,
+                  d_rel: torch.Tensor) -> torch.Tensor:
+        return nat.query_bwd(self.kernel_desc(), side, ent, self.relation_embedding.data, rel_idx, dq, d_rel)
+
+    def triple_fwd(self, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor) -> Tuple[torch.Tensor, Any]:
+        desc = self.kernel_desc()
+        q = nat.query_fwd(desc, nat.CORRUPT_TAIL, head, self.relation_embedding.data, rel_idx)
+        return nat.neg_score_pertriple_fwd(desc, q, tail, 1).reshape(-1), q
+
+    def triple_bwd(self, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor, ctx: Any,
+                   d_pos: torch.Tensor, d_rel: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        desc = self.kernel_desc()
+        dq, dt = nat.neg_score_pertriple_bwd(desc, ctx, tail, 1, d_pos.reshape(-1, 1).contiguous())
+        dh = nat.query_bwd(desc, nat.CORRUPT_TAIL, head, self.relation_embedding.data, rel_idx, dq, d_rel)
+        return dh, dt
 
     def _parts(self, x: torch.Tensor) -> List[torch.Tensor]:
         parts = list(torch.split(x.float(), self.embedding_size, dim=-1))
@@ -472,6 +504,7 @@ class PairRE(_AffineScoreFunction):
     """PairRE: -|| h^ * r_h - t^ * r_t ||_p  (reference scoring.py:465-593)."""
 
     _n_part = 1
+    _member = 0
 
     def __init__(
         self,
@@ -514,6 +547,10 @@ class TripleRE(_AffineScoreFunction):
     """TripleRE: -|| h^ * (r_h + u) - t^ * (r_t + u) + r_m ||_p  (reference scoring.py:596-743)."""
 
     _n_part = 1
+    _member = 1
+
+    def _constant(self) -> float:
+        return float(self.rel_u) if self.use_v2 else 0.0
 
     def __init__(
         self,
@@ -566,6 +603,10 @@ class InterHT(_AffineScoreFunction):
     """InterHT: -|| h^ * (t^_aux + o) + r - t^ * (h^_aux + o) ||_p  (reference scoring.py:1418-1572)."""
 
     _n_part = 2
+    _member = 2
+
+    def _constant(self) -> float:
+        return float(self.offset)
 
     def __init__(
         self,
@@ -611,6 +652,10 @@ class TranS(_AffineScoreFunction):
     """TranS: -|| h^ * (t~ + o + r_bar) - t^ * (h~ + o - r_hat) + r ||_p  (reference scoring.py:1575-1750)."""
 
     _n_part = 2
+    _member = 3
+
+    def _constant(self) -> float:
+        return float(self.offset)
 
     def __init__(
         self,

@@ -21,6 +21,7 @@
 //     normalised* candidates (bess_normalize_rows gathers + converts + normalises the
 //     N candidate rows first; its backward maps the gradient back).
 #include <algorithm>
+#include <string.h>
 
 #include "common.h"
 
@@ -75,6 +76,207 @@ __global__ __launch_bounds__(256) void k_normalize_rows_bwd(const float* __restr
         if (s >= 1.f / NORM_EPS) dot = 0.f;  // clamped norm: x / eps is linear
         for (int w = lane; w < d; w += 64) op[w] = s * (gp[w] - hp[w] * dot);
     }
+}
+
+// ---------------------------------------------------------------------------
+// Query transform: [U | V | R] from the kept entity (head when tails are corrupted, tail when
+// heads are) and the relation row, and its backward.  k0, k1 = (normalised) parts of the kept
+// entity, o = the model's offset constant (TripleRE: u, added to r_h and r_t).
+//
+//   PairRE   rel [r_h | r_t]          tails: U = r_t            R = -k0 r_h
+//                                     heads: U = r_h            R = -k0 r_t
+//   TripleRE rel [r_h | r_m | r_t]    tails: U = r_t + o        R = -(k0 (r_h + o) + r_m)
+//                                     heads: U = r_h + o        R = -(k0 (r_t + o) - r_m)
+//   InterHT  rel [r]                  tails: U = -(k1 + o)      V =  k0   R = r + k0 o
+//                                     heads: U =   k1 + o       V = -k0   R = r - k0 o
+//   TranS    rel [r | r_bar | r_hat]  tails: U = -(k1 + o - r_hat)  V =  k0   R = r + k0 (o + r_bar)
+//                                     heads: U =   k1 + o + r_bar   V = -k0   R = r - k0 (o - r_hat)
+// (reference scoring.py:540-593, 681-743, 1499-1572, 1661-1750, rearranged so that the candidate
+// enters as U c1 + V c2 + R.)  One wave per row.
+enum AffKind : int { AFF_PAIRRE = 0, AFF_TRIPLERE = 1, AFF_INTERHT = 2, AFF_TRANS = 3 };
+
+struct AffQueryArgs {
+    const void* ent_base;
+    const int32_t* ent_idx;
+    const void* rel_table;
+    const int32_t* rel_idx;
+    int64_t n;
+    int d, n_part, rel_width, kind, tails, normalize;
+    float o;
+};
+
+template <typename T>
+__device__ __forceinline__ void aff_kept_inv(const T* x, int d, int n_part, int normalize, int lane, float (&inv)[2]) {
+    inv[0] = inv[1] = 1.f;
+    if (!normalize) return;
+    for (int p = 0; p < n_part; ++p) {
+        float ss = 0.f;
+        for (int w = lane; w < d; w += 64) {
+            const float v = to_f32(x[p * d + w]);
+            ss = fmaf(v, v, ss);
+        }
+        ss = wave_allreduce_sum(ss);
+        inv[p] = 1.f / fmaxf(sqrtf(ss), NORM_EPS);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_aff_query_fwd(AffQueryArgs a, float* __restrict__ query) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (q >= a.n) return;
+    const int d = a.d;
+    const T* x = row_ptr(static_cast<const T*>(a.ent_base), a.ent_idx, q, a.n_part * d);
+    const T* r = static_cast<const T*>(a.rel_table) + static_cast<int64_t>(a.rel_idx[q]) * a.rel_width;
+    float inv[2];
+    aff_kept_inv<T>(x, d, a.n_part, a.normalize, lane, inv);
+    float* out = query + q * (a.n_part + 1) * d;
+    const float o = a.o, sg = a.tails ? 1.f : -1.f;
+    for (int w = lane; w < d; w += 64) {
+        const float k0 = to_f32(x[w]) * inv[0];
+        if (a.kind == AFF_PAIRRE) {
+            const float r_h = to_f32(r[w]), r_t = to_f32(r[d + w]);
+            out[w] = a.tails ? r_t : r_h;
+            out[d + w] = -(k0 * (a.tails ? r_h : r_t));
+        } else if (a.kind == AFF_TRIPLERE) {
+            const float r_h = to_f32(r[w]) + o, r_m = to_f32(r[d + w]), r_t = to_f32(r[2 * d + w]) + o;
+            out[w] = a.tails ? r_t : r_h;
+            out[d + w] = a.tails ? -(k0 * r_h + r_m) : -(k0 * r_t - r_m);
+        } else {
+            const float k1 = to_f32(x[d + w]) * inv[1];
+            if (a.kind == AFF_INTERHT) {
+                out[w] = -sg * (k1 + o);
+                out[d + w] = sg * k0;
+                out[2 * d + w] = to_f32(r[w]) + sg * k0 * o;
+            } else {
+                const float r_bar = to_f32(r[d + w]), r_hat = to_f32(r[2 * d + w]);
+                out[w] = a.tails ? -(k1 + o - r_hat) : (k1 + o + r_bar);
+                out[d + w] = sg * k0;
+                out[2 * d + w] = to_f32(r[w]) + (a.tails ? k0 * (o + r_bar) : -k0 * (o - r_hat));
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_aff_query_bwd(AffQueryArgs a, const float* __restrict__ d_query,
+                                                       float* __restrict__ d_ent, float* __restrict__ d_rel) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (q >= a.n) return;
+    const int d = a.d;
+    const T* x = row_ptr(static_cast<const T*>(a.ent_base), a.ent_idx, q, a.n_part * d);
+    const int64_t rid = a.rel_idx[q];
+    const T* r = static_cast<const T*>(a.rel_table) + rid * a.rel_width;
+    float* dr = d_rel + rid * a.rel_width;
+    float inv[2];
+    aff_kept_inv<T>(x, d, a.n_part, a.normalize, lane, inv);
+    const float* g = d_query + q * (a.n_part + 1) * d;
+    float* de = d_ent + q * a.n_part * d;
+    const float o = a.o, sg = a.tails ? 1.f : -1.f;
+    // pass 1: gradient wrt the normalised kept parts (staged in d_ent), relation gradient, <k, dk>
+    float dot[2] = {0.f, 0.f};
+    for (int w = lane; w < d; w += 64) {
+        const float k0 = to_f32(x[w]) * inv[0];
+        float dk0, dk1 = 0.f;
+        if (a.kind == AFF_PAIRRE) {
+            const float dU = g[w], dR = g[d + w];
+            const float r_h = to_f32(r[w]), r_t = to_f32(r[d + w]);
+            dk0 = -dR * (a.tails ? r_h : r_t);
+            unsafeAtomicAdd(dr + (a.tails ? d : 0) + w, dU);            // U is r_t (tails) / r_h (heads)
+            unsafeAtomicAdd(dr + (a.tails ? 0 : d) + w, -dR * k0);      // the other projection
+        } else if (a.kind == AFF_TRIPLERE) {
+            const float dU = g[w], dR = g[d + w];
+            const float r_h = to_f32(r[w]) + o, r_t = to_f32(r[2 * d + w]) + o;
+            dk0 = -dR * (a.tails ? r_h : r_t);
+            unsafeAtomicAdd(dr + (a.tails ? 2 * d : 0) + w, dU);
+            unsafeAtomicAdd(dr + (a.tails ? 0 : 2 * d) + w, -dR * k0);
+            unsafeAtomicAdd(dr + d + w, a.tails ? -dR : dR);
+        } else {
+            const float k1 = to_f32(x[d + w]) * inv[1];
+            const float dU = g[w], dV = g[d + w], dR = g[2 * d + w];
+            if (a.kind == AFF_INTERHT) {
+                dk1 = -sg * dU;
+                dk0 = sg * (dV + dR * o);
+                unsafeAtomicAdd(dr + w, dR);
+            } else {
+                const float r_bar = to_f32(r[d + w]), r_hat = to_f32(r[2 * d + w]);
+                dk1 = -sg * dU;
+                unsafeAtomicAdd(dr + w, dR);
+                if (a.tails) {
+                    dk0 = dV + dR * (o + r_bar);
+                    unsafeAtomicAdd(dr + 2 * d + w, dU);        // U = -(k1 + o - r_hat)
+                    unsafeAtomicAdd(dr + d + w, dR * k0);       // R = r + k0 (o + r_bar)
+                } else {
+                    dk0 = -dV - dR * (o - r_hat);
+                    unsafeAtomicAdd(dr + d + w, dU);            // U = k1 + o + r_bar
+                    unsafeAtomicAdd(dr + 2 * d + w, dR * k0);   // R = r - k0 (o - r_hat)
+                }
+            }
+            de[d + w] = dk1;
+            dot[1] = fmaf(k1, dk1, dot[1]);
+        }
+        de[w] = dk0;
+        dot[0] = fmaf(k0, dk0, dot[0]);
+    }
+    // pass 2: through the normalisation, d x = inv (d k - k <k, d k>)
+    for (int p = 0; p < a.n_part; ++p) {
+        float dt = a.normalize ? wave_allreduce_sum(dot[p]) : 0.f;
+        if (inv[p] >= 1.f / NORM_EPS) dt = 0.f;
+        if (!a.normalize) continue;
+        for (int w = lane; w < d; w += 64) {
+            const float k = to_f32(x[p * d + w]) * inv[p];
+            de[p * d + w] = inv[p] * (de[p * d + w] - k * dt);
+        }
+    }
+}
+
+static int aff_query_args(const bess_model_desc* d, int32_t side, const void* ent_base, const int32_t* ent_idx,
+                          const void* rel_table, const int32_t* rel_idx, int64_t n, AffQueryArgs* a) {
+    BESS_REQUIRE(side == BESS_CORRUPT_HEAD || side == BESS_CORRUPT_TAIL, "query (affine): bad side %d", side);
+    BESS_REQUIRE(n >= 0, "query (affine): negative size");
+    if (n == 0) return BESS_OK;
+    BESS_REQUIRE(ent_base && rel_table && rel_idx, "query (affine): NULL pointer");
+    const int n_part = d->reserved[0];
+    const int dd = d->width / n_part;
+    const int kind = (d->reserved[1] >> 8) & 0xff;
+    BESS_REQUIRE(kind >= AFF_PAIRRE && kind <= AFF_TRANS, "query (affine): unknown family member %d", kind);
+    const int want_rel = (kind == AFF_PAIRRE ? 2 : kind == AFF_INTERHT ? 1 : 3) * dd;
+    const int want_part = (kind == AFF_PAIRRE || kind == AFF_TRIPLERE) ? 1 : 2;
+    BESS_REQUIRE(d->rel_width == want_rel && n_part == want_part,
+                 "query (affine): member %d needs %d entity part(s) and relation rows of %d scalars (got %d, %d)", kind,
+                 want_part, want_rel, n_part, d->rel_width);
+    float o;
+    static_assert(sizeof(o) == sizeof(d->reserved[2]), "constant travels bit-cast in reserved[2]");
+    memcpy(&o, &d->reserved[2], sizeof(o));
+    *a = AffQueryArgs{ent_base, ent_idx, rel_table, rel_idx, n, dd, n_part, d->rel_width, kind,
+                      side == BESS_CORRUPT_TAIL, d->reserved[1] & 1, o};
+    return BESS_OK;
+}
+
+int affine_query_fwd(const bess_model_desc* d, int32_t side, const void* ent_base, const int32_t* ent_idx,
+                     const void* rel_table, const int32_t* rel_idx, int64_t n, float* query, hipStream_t st) {
+    AffQueryArgs a;
+    if (int e = aff_query_args(d, side, ent_base, ent_idx, rel_table, rel_idx, n, &a)) return e;
+    if (n == 0) return BESS_OK;
+    BESS_REQUIRE(query, "query_fwd (affine): NULL out");
+    const unsigned blocks = static_cast<unsigned>(ceil_div(n, 4));
+    if (d->dtype == BESS_F32) k_aff_query_fwd<float><<<blocks, 256, 0, st>>>(a, query);
+    else k_aff_query_fwd<half_t><<<blocks, 256, 0, st>>>(a, query);
+    return check_launch("query_fwd (affine)");
+}
+
+int affine_query_bwd(const bess_model_desc* d, int32_t side, const void* ent_base, const int32_t* ent_idx,
+                     const void* rel_table, const int32_t* rel_idx, int64_t n, const float* d_query, float* d_ent,
+                     float* d_rel, hipStream_t st) {
+    AffQueryArgs a;
+    if (int e = aff_query_args(d, side, ent_base, ent_idx, rel_table, rel_idx, n, &a)) return e;
+    if (n == 0) return BESS_OK;
+    BESS_REQUIRE(d_query && d_ent && d_rel, "query_bwd (affine): NULL pointer");
+    const unsigned blocks = static_cast<unsigned>(ceil_div(n, 4));
+    if (d->dtype == BESS_F32) k_aff_query_bwd<float><<<blocks, 256, 0, st>>>(a, d_query, d_ent, d_rel);
+    else k_aff_query_bwd<half_t><<<blocks, 256, 0, st>>>(a, d_query, d_ent, d_rel);
+    return check_launch("query_bwd (affine)");
 }
 
 // ---------------------------------------------------------------------------

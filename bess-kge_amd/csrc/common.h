@@ -48,6 +48,11 @@ int gemm_dot_de(const float* G, int64_t ldg, int64_t S, const float* Q, int64_t 
 int affine_pertriple(const bess_model_desc* d, bool fwd, const float* query, int64_t n_query, const void* neg_base,
                      const int32_t* neg_idx, int64_t n_neg, float* out, const float* d_out, int64_t ld, float* dq,
                      float* dn, hipStream_t st);
+int affine_query_fwd(const bess_model_desc* d, int32_t side, const void* ent_base, const int32_t* ent_idx,
+                     const void* rel_table, const int32_t* rel_idx, int64_t n, float* query, hipStream_t st);
+int affine_query_bwd(const bess_model_desc* d, int32_t side, const void* ent_base, const int32_t* ent_idx,
+                     const void* rel_table, const int32_t* rel_idx, int64_t n, const float* d_query, float* d_ent,
+                     float* d_rel, hipStream_t st);
 int affine_grad_segments(const bess_model_desc* d, const float* query, void* table, int64_t n_neg,
                          const float* d_out, int64_t ld_dout, const int32_t* refs_sorted, const int32_t* seg_rows,
                          const int32_t* seg_offsets, const int32_t* n_seg, int64_t max_seg, float* grad_seg,

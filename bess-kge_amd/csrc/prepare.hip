@@ -359,6 +359,10 @@ static int query_args(const bess_model_desc* d, int32_t side, const void* eb, co
 extern "C" int bess_query_fwd(const bess_model_desc* d, int32_t side, const void* ent_base,
                               const int32_t* ent_idx, const void* rel_table,
                               const int32_t* rel_idx, int64_t n_query, float* query, void* stream) {
+    if (d && d->scorer == BESS_AFFINE) {
+        if (int e = check_desc(d)) return e;
+        return affine_query_fwd(d, side, ent_base, ent_idx, rel_table, rel_idx, n_query, query, as_stream(stream));
+    }
     QueryArgs a;
     if (int e = query_args(d, side, ent_base, ent_idx, rel_table, rel_idx, n_query, &a)) return e;
     if (n_query == 0) return BESS_OK;
@@ -371,6 +375,11 @@ extern "C" int bess_query_bwd(const bess_model_desc* d, int32_t side, const void
                               const int32_t* ent_idx, const void* rel_table,
                               const int32_t* rel_idx, int64_t n_query, const float* d_query,
                               float* d_ent, float* d_rel_table, void* stream) {
+    if (d && d->scorer == BESS_AFFINE) {
+        if (int e = check_desc(d)) return e;
+        return affine_query_bwd(d, side, ent_base, ent_idx, rel_table, rel_idx, n_query, d_query, d_ent, d_rel_table,
+                                as_stream(stream));
+    }
     QueryArgs a;
     if (int e = query_args(d, side, ent_base, ent_idx, rel_table, rel_idx, n_query, &a)) return e;
     if (n_query == 0) return BESS_OK;

@@ -54,7 +54,12 @@ extern "C" {
  * n_part * d scalars = [c1 | c2], each part optionally L2-normalised.
  * desc.width = n_part * d, desc.reserved[0] = n_part (1 | 2), desc.reserved[1] bit 0 =
  * normalise the parts (per-triple kernels only; the shared kernels take candidates that
- * bess_normalize_rows has already gathered, converted to f32 and normalised). */
+ * bess_normalize_rows has already gathered, converted to f32 and normalised).
+ * bess_query_fwd / bess_query_bwd build [U | V | R] from the kept entity and the relation row
+ * (and back-propagate through it, including the normalisation); for them desc.reserved[1]
+ * bits 8-15 name the member (0 PairRE, 1 TripleRE, 2 InterHT, 3 TranS), desc.reserved[2] holds
+ * the bits of the float constant (TripleRE u, InterHT / TranS offset) and desc.rel_width the
+ * relation row (2d, 3d, d, 3d). */
 #define BESS_AFFINE 4
 /* BoxE (scoring.py:1149-1415) as seen by the negative-scoring kernels: entity rows
  * [base | bump] (desc.width = 2 d), query matrix [n_query, 6 d] =

@@ -603,3 +603,50 @@ def test_affine_grad_segments_match_scatter_of_row_gradients(dev, n_part, normal
         nat.neg_pertriple_grad_segments(desc, q, t2, N, go, seg, fused_sgd_lr=0.5)
         tol = 2e-3 if dtype == torch.float16 else 1e-5
         close(t2, table.float().cpu() - 0.5 * want.float(), rtol=tol, atol=tol, scale=4e-6)
+
+
+@pytest.mark.parametrize("name,p", AFFINE_SCORERS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_affine_query_kernels_match_torch_formulas(dev, name, p, dtype):
+    """k_aff_query_fwd / bwd (the [U | V | R] transform used by the fused step) against the torch
+    expressions of the public API and their autograd, both corruption sides; and the positive score
+    as the tail-corruption score of the one true tail."""
+    from besskge import _native as nat
+    from besskge._native import RowSource
+
+    gen = torch.Generator().manual_seed(21)
+    for d, S, M in ((40, 37, 90), (6, 5, 11)):
+        W, Wr = widths(name, d)
+        n_rel = 5
+        rel = torch.randn(n_rel, Wr, generator=gen).to(dtype)
+        table = torch.randn(M, W, generator=gen).to(dtype)
+        fn = make_scorer(name, p, False, n_rel, d, torch.zeros(1, 4, W), rel.float(), dev, dtype)
+        tab = table.to(dev)
+        idx = torch.randint(M, (S,), generator=gen, dtype=torch.int32).to(dev)
+        rid = torch.randint(n_rel, (S,), generator=gen, dtype=torch.int32).to(dev)
+        for side in (nat.CORRUPT_HEAD, nat.CORRUPT_TAIL):
+            q, _ = fn.query_fwd(side, RowSource(tab, idx), rid)
+            rows = tab[idx.long()].float().requires_grad_(True)
+            relp = fn.relation_embedding.detach().float().requires_grad_(True)
+            want = torch.cat(fn._uvr(side, fn._parts(rows), fn._rel(rid, relp)), dim=-1)
+            close(q, want, scale=2e-6)
+            dq = torch.randn(want.shape, generator=gen).to(dev)
+            d_rel = torch.zeros(n_rel, Wr, device=dev)
+            dx = fn.query_bwd(side, RowSource(tab, idx), rid, None, dq, d_rel)
+            g_rows, g_rel = torch.autograd.grad(want, [rows, relp], dq)
+            close(dx, g_rows, scale=4e-6)
+            close(d_rel, g_rel, scale=4e-6)
+        tidx = torch.randint(M, (S,), generator=gen, dtype=torch.int32).to(dev)
+        pos, ctx = fn.triple_fwd(RowSource(tab, idx), RowSource(tab, tidx), rid)
+        h = tab[idx.long()].float().requires_grad_(True)
+        t = tab[tidx.long()].float().requires_grad_(True)
+        relp = fn.relation_embedding.detach().float().requires_grad_(True)
+        want = fn._score_norm(fn._delta(fn._parts(h), fn._rel(rid, relp), fn._parts(t)))
+        close(pos, want, scale=2e-6)
+        gp = torch.randn(S, generator=gen).to(dev)
+        d_rel = torch.zeros(n_rel, Wr, device=dev)
+        dh, dt = fn.triple_bwd(RowSource(tab, idx), RowSource(tab, tidx), rid, ctx, gp, d_rel)
+        gh, gt, gr = torch.autograd.grad(want, [h, t, relp], gp)
+        close(dh, gh, scale=4e-6)
+        close(dt, gt, scale=4e-6)
+        close(d_rel, gr, scale=4e-6)
