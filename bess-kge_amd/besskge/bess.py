@@ -199,6 +199,14 @@ class BessKGE(torch.nn.Module, ABC):
             self._aux_streams[device] = torch.cuda.Stream(device=device)
         return self._aux_streams[device]
 
+    def _unit_weight(self, device: torch.device) -> torch.Tensor:
+        """[1.0] on the device, made once (the default triple weight of every step)."""
+        cache = self.__dict__.setdefault("_unit_weights", {})
+        if device not in cache:
+            cache[device] = torch.ones(1, dtype=torch.float32, device=device)
+            torch.cuda.current_stream(device).synchronize()
+        return cache[device]
+
     def _static_map(self, key: Any, build: Any, device: torch.device) -> torch.Tensor:
         k = (key, device)
         if k not in self._map_cache:
@@ -321,8 +329,9 @@ class BessKGE(torch.nn.Module, ABC):
         if self.loss_fn:
             w = batch.get("triple_weight")
             if w is None:
-                w = torch.ones(1, dtype=torch.float32, device=dev)
-            w = w.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+                w = self._unit_weight(dev)
+            else:
+                w = w.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
             ld = self.loss_fn.kernel_desc(int(neg.shape[1]))
             loss, d_pos, d_neg = nat.loss_fwd_bwd(ld, pos, neg, w, want_grad)
             out["loss"] = loss
@@ -494,8 +503,7 @@ class BessKGE(torch.nn.Module, ABC):
             return None
         dev = self.score_fn.relation_embedding.device
         w = batch.get("triple_weight")
-        w = torch.ones(1, dtype=torch.float32, device=dev) if w is None else \
-            w.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+        w = self._unit_weight(dev) if w is None else w.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
         return dict(weight=w, loss=self.loss_fn.kernel_desc)
 
 
@@ -546,11 +554,11 @@ class EmbeddingMovingBessKGE(BessKGE):
         desc = fn.kernel_desc()
         rel_table = fn.relation_embedding.data
         done: List[_ReplicaStep] = []
+        fuse = getattr(self, "_train_fuse", None)
         for st in steps:
             self._build_groups(st, exchange_negatives)
             st.positive_score, st.triple_ctx = fn.triple_fwd(
                 RowSource(st.table, st.head_idx), st.tail, st.rel_idx)
-            fuse = getattr(self, "_train_fuse", None)
             outs = self._run_groups(st, desc, fuse[len(done)] if fuse else None)
             done.append(st)
             if len(outs) == 1:
