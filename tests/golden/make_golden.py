@@ -520,6 +520,38 @@ def gen_bess_boxe() -> None:
     put("bess_boxe", "cases", np.array(names))
 
 
+def gen_dataset() -> None:
+    """KGDataset.from_dataframe / from_triples (dataset.py:83-239): label encoding, type blocks, split."""
+    import pandas as pd
+
+    fix = "dataset"
+    rng = np.random.default_rng(5)
+    ents = np.array([f"ent{i}" for i in range(120)])
+    rels = np.array([f"rel{i}" for i in range(6)])
+    h, r, t = rng.choice(ents, 700), rng.choice(rels, 700), rng.choice(ents, 700)
+    kinds = rng.choice(np.array(["drug", "gene", "disease", "function"]), len(ents))
+    for k, v in dict(h=h, r=r, t=t, ents=ents, kinds=kinds).items():
+        put(fix, k, v)
+    df = pd.DataFrame(dict(head=h, relation=r, tail=t))
+    types = dict(zip(ents.tolist(), kinds.tolist()))
+    cases = {
+        "plain": KGDataset.from_dataframe(df, "head", "relation", "tail"),
+        "typed": KGDataset.from_dataframe(df, "head", "relation", "tail", entity_types=types, split=(0.6, 0.2, 0.2), seed=7),
+        "parts": KGDataset.from_dataframe({"train": df.iloc[:500], "test": df.iloc[500:]}, "head", "relation", "tail",
+                                          entity_types=types),
+    }
+    for name, ds in cases.items():
+        put(fix, f"{name}_n", np.array([ds.n_entity, ds.n_relation_type]))
+        put(fix, f"{name}_entity_dict", np.array(ds.entity_dict))
+        put(fix, f"{name}_relation_dict", np.array(ds.relation_dict))
+        if ds.type_offsets is not None:
+            put(fix, f"{name}_type_names", np.array(list(ds.type_offsets.keys())))
+            put(fix, f"{name}_type_firsts", np.array(list(ds.type_offsets.values())))
+        for part, tr in ds.triples.items():
+            put(fix, f"{name}_triples_{part}", tr)
+            put(fix, f"{name}_ids_{part}", ds.original_triple_ids[part])
+
+
 def widths(name: str, d: int) -> Any:
     if name in BOXE_VARIANTS:
         return 2 * d, 4 * d + 2
@@ -980,6 +1012,7 @@ def main() -> None:
         allscores=gen_allscores,
         scoring_affine=gen_scoring_affine,
         bess_affine=gen_bess_affine,
+        dataset=gen_dataset,
         scoring_boxe=gen_scoring_boxe,
         bess_boxe=gen_bess_boxe,
         scoring_conve=gen_scoring_conve,
