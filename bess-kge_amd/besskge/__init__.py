@@ -18,6 +18,12 @@ from . import _native
 
 _native.load()
 
+
+def load_custom_ops_so() -> None:
+    """Name kept from the reference (`besskge/__init__.py:10-34`): (re)load the native library."""
+    _native.load()
+
+
 from . import (  # noqa: E402,F401
     batch_sampler,
     bess,

@@ -242,6 +242,26 @@ class DistanceBasedScoreFunction(BaseScoreFunction, ABC):
         self.negative_sample_sharing = negative_sample_sharing
         self.scoring_norm = scoring_norm
 
+    def reduce_embedding(self, v: torch.Tensor) -> torch.Tensor:
+        """p-norm over the embedding dimension (reference scoring.py:163-174)."""
+        return torch.norm(v, p=self.scoring_norm, dim=-1)
+
+    def broadcasted_distance(self, v1: torch.Tensor, v2: torch.Tensor) -> torch.Tensor:
+        """Distances of queries v1 [batch, W] to candidates v2 [B, n_neg, W]: [batch, B * n_neg]
+        with negative sample sharing, [batch, n_neg] otherwise (reference scoring.py:176-200);
+        the HIP negative-scoring kernels with an identity query transform."""
+        return -ops.ReduceNegatives.apply(_plain_desc(nat.TRANSE, self.scoring_norm, v2), bool(self.negative_sample_sharing),
+                                          v1.float().contiguous(), v2)
+
+
+def _plain_desc(scorer: int, norm_p: int, rows: torch.Tensor) -> nat.ModelDesc:
+    """Descriptor of a bare reduction (`-||q - e||_p` or `<q, e>`) over rows of this dtype / width."""
+    d = nat.ModelDesc()
+    d.scorer, d.norm_p = scorer, int(norm_p)
+    d.dtype = nat._dtype_code(rows)
+    d.width = d.rel_width = int(rows.shape[-1])
+    return d
+
 
 class MatrixDecompositionScoreFunction(BaseScoreFunction, ABC):
     """Scorers of the form <query, entity>."""
@@ -249,6 +269,16 @@ class MatrixDecompositionScoreFunction(BaseScoreFunction, ABC):
     def __init__(self, negative_sample_sharing: bool) -> None:
         super().__init__()
         self.negative_sample_sharing = negative_sample_sharing
+
+    def reduce_embedding(self, v: torch.Tensor) -> torch.Tensor:
+        """Sum over the embedding dimension (reference scoring.py:219-229)."""
+        return torch.sum(v, dim=-1)
+
+    def broadcasted_dot_product(self, v1: torch.Tensor, v2: torch.Tensor) -> torch.Tensor:
+        """Dot products of queries v1 [batch, W] with candidates v2 [B, n_neg, W]: [batch, B * n_neg]
+        with negative sample sharing, [batch, n_neg] otherwise (reference scoring.py:231-255)."""
+        return ops.ReduceNegatives.apply(_plain_desc(nat.DISTMULT, 0, v2), bool(self.negative_sample_sharing),
+                                         v1.float().contiguous(), v2)
 
 
 class TransE(DistanceBasedScoreFunction):
@@ -870,6 +900,15 @@ class BoxE(_TorchQueryHooks, DistanceBasedScoreFunction):
             inside = inside.all(dim=-1, keepdim=True)
         f = torch.where(inside, dist / grow, dist * grow - half * (grow - 1.0 / grow))
         return -torch.norm(f, p=self.scoring_norm, dim=-1).sum(-1)
+
+    def boxe_score(self, bumped_ht: torch.Tensor, center_ht: torch.Tensor, width_ht: torch.Tensor,
+                   box_size: torch.Tensor) -> torch.Tensor:
+        """BoxE score of bumped points [..., 2, d] against boxes given by raw centres, widths
+        [..., 2, d] and sizes [..., 2], with broadcasting (reference scoring.py:1250-1340)."""
+        rel = torch.cat([center_ht.flatten(start_dim=-2), width_ht.flatten(start_dim=-2), box_size], dim=-1)
+        lead = rel.shape[:-1]
+        center, half = self._boxes(rel.reshape(-1, rel.shape[-1]).float())
+        return self._box_distance(bumped_ht.float(), center.reshape(*lead, 2, -1), half.reshape(*lead, 2, -1))
 
     def _triple_torch(self, h: torch.Tensor, rel: torch.Tensor, rel_idx: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
         d = self.embedding_size

@@ -650,3 +650,32 @@ def test_affine_query_kernels_match_torch_formulas(dev, name, p, dtype):
         close(dh, gh, scale=4e-6)
         close(dt, gt, scale=4e-6)
         close(d_rel, gr, scale=4e-6)
+
+
+@pytest.mark.parametrize("sharing", [True, False])
+def test_public_broadcast_helpers(dev, sharing):
+    """DistanceBasedScoreFunction.broadcasted_distance / MatrixDecompositionScoreFunction
+    .broadcasted_dot_product / reduce_embedding / BoxE.boxe_score keep the reference's semantics
+    (scoring.py:163-255, 1250-1340)."""
+    gen = torch.Generator().manual_seed(3)
+    S, N, d, n_rel = 9, 13, 20, 4
+    q = torch.randn(S, d, generator=gen)
+    neg = torch.randn(1 if sharing else S, N, d, generator=gen)
+    for p in (1, 2):
+        fn = make_scorer("TransE", p, sharing, n_rel, d, torch.zeros(1, 4, d), torch.zeros(n_rel, d), dev)
+        got = fn.broadcasted_distance(q.to(dev), neg.to(dev))
+        want = torch.norm(q[:, None, :] - (neg.reshape(1, -1, d) if sharing else neg), p=p, dim=-1)
+        close(got, want, scale=2e-6)
+        close(fn.reduce_embedding(q.to(dev)), torch.norm(q, p=p, dim=-1))
+    fn = make_scorer("DistMult", 0, sharing, n_rel, d, torch.zeros(1, 4, d), torch.zeros(n_rel, d), dev)
+    got = fn.broadcasted_dot_product(q.to(dev), neg.to(dev))
+    want = (q[:, None, :] * (neg.reshape(1, -1, d) if sharing else neg)).sum(-1)
+    close(got, want, scale=2e-6)
+    close(fn.reduce_embedding(q.to(dev)), q.sum(-1))
+    for name, p in (("BoxE", 1), ("BoxEnt", 2)):
+        box = make_scorer(name, p, sharing, n_rel, d, torch.zeros(1, 4, 2 * d), torch.zeros(n_rel, 4 * d + 2), dev)
+        bumped = torch.randn(S, N, 2, d, generator=gen)
+        rel = torch.randn(S, 1, 4 * d + 2, generator=gen)
+        got = box.boxe_score(bumped.to(dev), rel[..., : 2 * d].reshape(S, 1, 2, d).to(dev),
+                             rel[..., 2 * d: 4 * d].reshape(S, 1, 2, d).to(dev), rel[..., 4 * d:].to(dev))
+        close(got, kge.boxe_score(name, p, bumped, rel), scale=2e-6)
