@@ -194,24 +194,44 @@ __global__ __launch_bounds__(256) void k_combine_dq(const float* __restrict__ st
     const int lane = threadIdx.x & 63;
     const int64_t q = blockIdx.x * 4ll + (threadIdx.x >> 6);
     if (q >= n_query) return;
+    // (m_i, l_i) of the items, strided over the lanes
     float m = -INFINITY;
-    for (int i = 0; i < items; ++i) m = fmaxf(m, st_ml[(q * items + i) * 2]);
+    for (int i = lane; i < items; i += 64) m = fmaxf(m, st_ml[(q * items + i) * 2]);
+    m = wave_allreduce_max(m);
     if (kind == BESS_LOSS_SSCE) m = fmaxf(m, pos[q]);
-    float L = (kind == BESS_LOSS_SSCE) ? expf(pos[q] - m) : 0.f;
-    for (int i = 0; i < items; ++i) {
+    float L = 0.f;
+    for (int i = lane; i < items; i += 64) {
         const float mi = st_ml[(q * items + i) * 2];
         if (mi != -INFINITY) L += st_ml[(q * items + i) * 2 + 1] * expf(mi - m);
     }
+    L = wave_allreduce_sum(L);
+    if (kind == BESS_LOSS_SSCE) L += expf(pos[q] - m);
     const float w = weight[weight_len == 1 ? 0 : q];
     const float C = (kind == BESS_LOSS_LOGSIGMOID ? 0.5f : 1.f) * loss_scale * w;
     const float scale = L > 0.f ? C / L : 0.f;
-    for (int c = lane; c < W; c += 64) {
-        float x = 0.f;
-        for (int i = 0; i < items; ++i) {
-            const float mi = st_ml[(q * items + i) * 2];
-            if (mi != -INFINITY) x = fmaf(st_acc[(q * items + i) * W + c], expf(mi - m), x);
+    const float* ap = st_acc + q * items * W;
+    float* dq = d_query + q * W;
+    if ((W & 3) == 0) {
+        for (int c = lane * 4; c < W; c += 256) {
+            float x[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < items; ++i) {
+                const float mi = st_ml[(q * items + i) * 2];  // wave-uniform, cached
+                if (mi == -INFINITY) continue;
+                const float f = expf(mi - m);
+                const float4 v = *reinterpret_cast<const float4*>(ap + static_cast<int64_t>(i) * W + c);
+                x[0] = fmaf(v.x, f, x[0]); x[1] = fmaf(v.y, f, x[1]); x[2] = fmaf(v.z, f, x[2]); x[3] = fmaf(v.w, f, x[3]);
+            }
+            *reinterpret_cast<float4*>(dq + c) = make_float4(scale * x[0], scale * x[1], scale * x[2], scale * x[3]);
         }
-        d_query[q * W + c] = scale * x;
+    } else {
+        for (int c = lane; c < W; c += 64) {
+            float x = 0.f;
+            for (int i = 0; i < items; ++i) {
+                const float mi = st_ml[(q * items + i) * 2];
+                if (mi != -INFINITY) x = fmaf(ap[static_cast<int64_t>(i) * W + c], expf(mi - m), x);
+            }
+            dq[c] = scale * x;
+        }
     }
 }
 
