@@ -556,10 +556,11 @@ def test_fused_forward_dq_matches_two_pass(dev, name, p, loss, dtype, wname):
     else:
         fn = SampledSoftmaxCrossEntropyLoss(kw["n_entity"], kw.get("loss_scale", 1.0))
     gen = torch.Generator().manual_seed(7)
-    for M, d, S, N in ((300, 40, 33, 150), (500, 256, 70, 256), (50, 6, 5, 3)):
+    for M, d, S, N, amp in ((300, 40, 33, 150, 0.5), (500, 256, 70, 256, 0.5), (50, 6, 5, 3, 0.5), (40, 8, 4, 1, 0.5),
+                            (300, 16, 9, 200, 6.0)):  # amp 6: scores of +-1e3, the softmax is one-hot
         W, Wr = widths(name, d)
-        table = (0.5 * torch.randn(M, W, generator=gen)).to(dtype).to(dev)
-        q = (0.5 * torch.randn(S, W, generator=gen)).to(dev)
+        table = (amp * torch.randn(M, W, generator=gen)).to(dtype).to(dev)
+        q = (amp * torch.randn(S, W, generator=gen)).to(dev)
         idx = torch.randint(M, (S * N,), generator=gen, dtype=torch.int32).to(dev)
         pos = torch.randn(S, generator=gen).to(dev)
         w = (torch.rand(S, generator=gen) + 0.5).to(dev) if wname == "w" else torch.ones(1, device=dev)
