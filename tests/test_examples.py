@@ -23,3 +23,21 @@ def test_train_and_evaluate_example(argv):
     # 2000 candidates: chance level of hits@10 is 0.005
     assert res["hits@10"] > 0.2, res
     assert res["mrr"] > 0.1, res
+
+
+def test_multi_process_example_learns():
+    """One process per shard (2 ranks sharing the GPU, gloo): own-slice device sampling,
+    distributed training step and distributed top-k evaluation."""
+    import re
+    import subprocess
+
+    env = dict(os.environ, BESS_BACKEND="gloo", OMP_NUM_THREADS="1")
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "examples", "train_multi_gpu.py"),
+           "--steps", "150"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    m = re.search(r"mrr ([0-9.]+)\s+hits@10 ([0-9.]+)", res.stdout)
+    assert m, res.stdout[-2000:]
+    assert float(m.group(2)) > 0.2 and float(m.group(1)) > 0.1
