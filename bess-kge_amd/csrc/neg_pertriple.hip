@@ -340,16 +340,14 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_bwd(NegPtArgs a,
 }
 
 // ---- host dispatch ---------------------------------------------------------
-static thread_local const FuseArgs* g_fuse = nullptr;  // set by the fused entry point around run()
-
 template <typename T, int VEC, int IT, int RED>
-static void launch_fwd(const NegPtArgs& a, float* out, int64_t ld, hipStream_t st) {
+static void launch_fwd(const NegPtArgs& a, float* out, int64_t ld, const FuseArgs* fuse, hipStream_t st) {
     const int64_t items = a.n_query * a.items_per_query;
     constexpr int EPL = IT * VEC;  // scalars per lane per row
     constexpr int UNROLL = EPL <= 16 ? 4 : (EPL <= 32 ? 2 : 1);
-    if (g_fuse) {
+    if (fuse) {
         constexpr int FU = EPL <= 16 ? 2 : 1;  // the running d_query sum takes EPL more registers
-        k_neg_pertriple_fwd<T, VEC, IT, RED, FU, true><<<ceil_div(items, 4), 256, 0, st>>>(a, out, ld, *g_fuse);
+        k_neg_pertriple_fwd<T, VEC, IT, RED, FU, true><<<ceil_div(items, 4), 256, 0, st>>>(a, out, ld, *fuse);
     } else {
         k_neg_pertriple_fwd<T, VEC, IT, RED, UNROLL, false><<<ceil_div(items, 4), 256, 0, st>>>(a, out, ld, FuseArgs{});
     }
@@ -363,30 +361,30 @@ static void launch_bwd(const NegPtArgs& a, const float* d_out, int64_t ld, float
 
 template <typename T, int VEC, int IT>
 static void by_red(int red, bool fwd, const NegPtArgs& a, float* out, const float* d_out, int64_t ld,
-                   float* dq, float* dn, hipStream_t st) {
+                   float* dq, float* dn, const FuseArgs* fuse, hipStream_t st) {
     switch (red) {
         case RED_DOT:
-            fwd ? launch_fwd<T, VEC, IT, RED_DOT>(a, out, ld, st)
+            fwd ? launch_fwd<T, VEC, IT, RED_DOT>(a, out, ld, fuse, st)
                 : launch_bwd<T, VEC, IT, RED_DOT>(a, d_out, ld, dq, dn, st);
             break;
         case RED_L1:
-            fwd ? launch_fwd<T, VEC, IT, RED_L1>(a, out, ld, st)
+            fwd ? launch_fwd<T, VEC, IT, RED_L1>(a, out, ld, fuse, st)
                 : launch_bwd<T, VEC, IT, RED_L1>(a, d_out, ld, dq, dn, st);
             break;
         default:
-            fwd ? launch_fwd<T, VEC, IT, RED_L2>(a, out, ld, st)
+            fwd ? launch_fwd<T, VEC, IT, RED_L2>(a, out, ld, fuse, st)
                 : launch_bwd<T, VEC, IT, RED_L2>(a, d_out, ld, dq, dn, st);
     }
 }
 
 template <typename T, int VEC>
 static int by_it(int it, int red, bool fwd, const NegPtArgs& a, float* out, const float* d_out,
-                 int64_t ld, float* dq, float* dn, hipStream_t st) {
-    if (it <= 1) by_red<T, VEC, 1>(red, fwd, a, out, d_out, ld, dq, dn, st);
-    else if (it <= 2) by_red<T, VEC, 2>(red, fwd, a, out, d_out, ld, dq, dn, st);
-    else if (it <= 4) by_red<T, VEC, 4>(red, fwd, a, out, d_out, ld, dq, dn, st);
-    else if (it <= 8) by_red<T, VEC, 8>(red, fwd, a, out, d_out, ld, dq, dn, st);
-    else if (it <= 16) by_red<T, VEC, 16>(red, fwd, a, out, d_out, ld, dq, dn, st);
+                 int64_t ld, float* dq, float* dn, const FuseArgs* fuse, hipStream_t st) {
+    if (it <= 1) by_red<T, VEC, 1>(red, fwd, a, out, d_out, ld, dq, dn, fuse, st);
+    else if (it <= 2) by_red<T, VEC, 2>(red, fwd, a, out, d_out, ld, dq, dn, fuse, st);
+    else if (it <= 4) by_red<T, VEC, 4>(red, fwd, a, out, d_out, ld, dq, dn, fuse, st);
+    else if (it <= 8) by_red<T, VEC, 8>(red, fwd, a, out, d_out, ld, dq, dn, fuse, st);
+    else if (it <= 16) by_red<T, VEC, 16>(red, fwd, a, out, d_out, ld, dq, dn, fuse, st);
     else return fail(BESS_EUNSUPPORTED, "neg_score_pertriple: row of %d scalars too wide", a.W);
     return BESS_OK;
 }
@@ -403,7 +401,8 @@ static int negatives_per_item(int64_t n_query, int64_t n_neg, int64_t row_bytes)
 
 static int run(const bess_model_desc* d, bool fwd, const float* query, int64_t n_query,
                const void* neg_base, const int32_t* neg_idx, int64_t n_neg, float* out,
-               const float* d_out, int64_t ld, float* dq, float* dn, void* stream) {
+               const float* d_out, int64_t ld, float* dq, float* dn, void* stream,
+               const FuseArgs* fuse = nullptr) {
     if (int e = check_desc(d)) return e;
     BESS_REQUIRE(n_query >= 0 && n_neg >= 0 && n_neg < (1ll << 31), "neg_score_pertriple: bad sizes");
     if (n_query == 0 || n_neg == 0) return BESS_OK;
@@ -443,12 +442,12 @@ static int run(const bess_model_desc* d, bool fwd, const float* query, int64_t n
     }
     int rc = BESS_OK;
     if (d->dtype == BESS_F32) {
-        if (vec == 4) rc = by_it<float, 4>(it, red, fwd, a, out, d_out, ld, dq, dn, st);
-        else rc = by_it<float, 1>(it, red, fwd, a, out, d_out, ld, dq, dn, st);
+        if (vec == 4) rc = by_it<float, 4>(it, red, fwd, a, out, d_out, ld, dq, dn, fuse, st);
+        else rc = by_it<float, 1>(it, red, fwd, a, out, d_out, ld, dq, dn, fuse, st);
     } else {
-        if (vec == 8) rc = by_it<half_t, 8>(it, red, fwd, a, out, d_out, ld, dq, dn, st);
-        else if (vec == 2) rc = by_it<half_t, 2>(it, red, fwd, a, out, d_out, ld, dq, dn, st);
-        else rc = by_it<half_t, 1>(it, red, fwd, a, out, d_out, ld, dq, dn, st);
+        if (vec == 8) rc = by_it<half_t, 8>(it, red, fwd, a, out, d_out, ld, dq, dn, fuse, st);
+        else if (vec == 2) rc = by_it<half_t, 2>(it, red, fwd, a, out, d_out, ld, dq, dn, fuse, st);
+        else rc = by_it<half_t, 1>(it, red, fwd, a, out, d_out, ld, dq, dn, fuse, st);
     }
     if (rc) return rc;
     return check_launch(fwd ? "neg_score_pertriple_fwd" : "neg_score_pertriple_bwd");
@@ -510,9 +509,8 @@ extern "C" int bess_neg_score_pertriple_fwd_dq(const bess_model_desc* d, const b
     f.shift = l->kind == BESS_LOSS_SSCE ? l->ssce_shift : 0.f;
     f.st_ml = state_ml;
     f.st_acc = state_acc;
-    g_fuse = &f;
-    const int rc = run(d, true, query, n_query, neg_base, neg_idx, n_neg, out, nullptr, ld_out, nullptr, nullptr, stream);
-    g_fuse = nullptr;
+    const int rc = run(d, true, query, n_query, neg_base, neg_idx, n_neg, out, nullptr, ld_out, nullptr, nullptr, stream,
+                       &f);
     if (rc) return rc;
     const int items = static_cast<int>(ceil_div(n_neg, negatives_per_item(n_query, n_neg, row_bytes_of(d))));
     k_combine_dq<<<static_cast<unsigned>(ceil_div(n_query, 4)), 256, 0, as_stream(stream)>>>(
