@@ -30,6 +30,7 @@ _c_f32p = ctypes.POINTER(ctypes.c_float)
 _c_u8p = ctypes.POINTER(ctypes.c_uint8)
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
+_RETURNS_I64 = ("bess_neg_score_shared_workspace",)  # every other entry returns an int status
 _i32 = ctypes.c_int32
 _f32 = ctypes.c_float
 
@@ -109,6 +110,8 @@ SIGNATURES = {
     "bess_neg_score_pertriple_fwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
     "bess_neg_score_pertriple_bwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
     "bess_neg_score_shared_fwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
+    "bess_neg_score_shared_workspace": [_MD, _i64, _i64],
+    "bess_neg_score_shared_fwd_ws": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp],
     "bess_neg_score_shared_bwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
     "bess_mask_scores": [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _vp],
     "bess_loss_fwd_bwd": [_LD, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
@@ -203,7 +206,7 @@ def load() -> ctypes.CDLL:
         except AttributeError as e:
             raise ImportError(f"{path} does not export {name}") from e
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_int64 if name in _RETURNS_I64 else ctypes.c_int
     if lib.bess_version() != ABI_VERSION:
         raise ImportError(
             f"{path}: ABI version {lib.bess_version()} != expected {ABI_VERSION}"
@@ -565,10 +568,15 @@ def neg_score_shared_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource) -> t
     if d.scorer == AFFINE:
         neg, _, _ = _affine_candidates(d, neg)
     out = torch.empty((nq, n_neg), dtype=torch.float32, device=dev)
+    lib = load()
+    # scratch of the split-fp16 matrix-core path (0 for the other scorers / small shapes); from
+    # torch's caching allocator, so it is stream-ordered and safe under graph capture
+    ws_bytes = int(lib.bess_neg_score_shared_workspace(ctypes.byref(d), nq, n_neg))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
     with torch.cuda.device(dev), _Timed("bess_neg_score_shared_fwd", dev):
-        rc = load().bess_neg_score_shared_fwd(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
+        rc = lib.bess_neg_score_shared_fwd_ws(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
                                               _idx(neg.idx, "negative idx"), n_neg, out.data_ptr(), n_neg,
-                                              _stream(dev))
+                                              ws.data_ptr() if ws is not None else None, ws_bytes, _stream(dev))
     _check(rc, "bess_neg_score_shared_fwd")
     return out
 

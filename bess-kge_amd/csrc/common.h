@@ -39,6 +39,11 @@ inline int reduce_of(const bess_model_desc* d) {
 // fp32 MFMA GEMMs of the bilinear scorers (gemm_mfma.hip)
 int gemm_dot_fwd(int dtype, const float* Q, int64_t S, const void* E, const int32_t* idx, int64_t N, int W,
                  float* out, int64_t ld, hipStream_t st);
+// split-fp16 MFMA variant of gemm_dot_fwd (gemm_split.hip): workspace it wants for a shape
+// (0 = leave the shape to the fp32 kernels) and the product through that workspace
+int64_t gemm_split_workspace(int64_t S, int64_t N, int W);
+int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const int32_t* idx, int64_t N, int W,
+                   float* out, int64_t ld, void* ws, int64_t ws_bytes, hipStream_t st);
 int gemm_dot_dq(int dtype, const float* G, int64_t ldg, int64_t S, const void* E, const int32_t* idx, int64_t N,
                 int W, float* dQ, hipStream_t st);
 int gemm_dot_de(const float* G, int64_t ldg, int64_t S, const float* Q, int64_t N, int W, float* dE,

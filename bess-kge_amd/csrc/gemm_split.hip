@@ -1,0 +1,442 @@
+// Forward GEMM of the bilinear scorers (DistMult / ComplEx, shared negatives and the
+// all-entities scoring of TopK / AllScores) on the fp16 matrix cores at fp32 accuracy:
+//
+//     out[q, j] = Q[q, :] . E[idx[j], :]                 (reference scoring.py:251-252)
+//
+// gfx950 has no fp32-input MFMA faster than the vector unit (v_mfma_f32_32x32x2_f32 = 157 TFLOP/s,
+// gemm_mfma.hip), but v_mfma_f32_32x32x16_f16 runs 16 x faster per product.  Every fp32 operand
+// is therefore split into two fp16 numbers
+//
+//     x = hi + lo / 2048,   hi = fp16(x),   lo = fp16((x - hi) * 2048)       (x - hi is exact)
+//
+// which together carry 22 significand bits (lo is kept scaled so that it is a normal fp16
+// number whenever hi is), and the product is evaluated as
+//
+//     Q . E = Qhi.Ehi + (Qhi.Elo + Qlo.Ehi) / 2048          (fp32 accumulation inside the MFMA)
+//
+// in two fp32 accumulators (main, correction), summed once at the end.  The dropped lo.lo term
+// and the rounding of lo are each <= 2^-22 of |x||y| per product - below the fp32 rounding of
+// the reference's own accumulation over W (measured against a float64 product: 3-4e-7 of
+// max|out| vs 1e-6 for an fp32 fma chain, profiles/bench_gemm_split.py) - so the parity
+// tolerance (rtol 1e-4 / atol 1e-5, test_bess.py:245-246) is untouched; the cost is 3 fp16
+// MFMAs per 16 k instead of 8 fp32 MFMAs of twice their length.  fp16 tables have lo == 0
+// exactly: 2 MFMAs.  Operands must be finite and |x| < 65504 (fp16 range; KGE embeddings are
+// O(1)); BESS_GEMM_FP32=1 in the environment keeps the exact fp32 MFMA kernel instead.
+//
+// Two kernels, with a caller-provided workspace between them:
+//   k_split_rows   gathers the rows (by index), splits them and writes, per row and per block
+//                  of 32 k, one 128-B line [32 hi | 32 lo] (k padded with zeros to a multiple
+//                  of 32).  Splitting inside the GEMM instead costs 6 VALU operations per
+//                  element for every tile that reads the element (32 x for a 4096 x 4096
+//                  problem) and made the loader waves, not the matrix pipe, the bound
+//                  (184 TFLOP/s; profiles/ubench/gemm_split_probe.hip).
+//   k_gemm_split_f16   one 512-thread workgroup per CU, persistent over its 128 x 128 tiles:
+//     waves 4-7 (producers) copy lines global -> registers (3 K slices in flight) -> LDS, over
+//               a flat sequence of (tile, slice) pairs, so the loads of the next tile are in
+//               flight while the consumers finish the current one.  The LDS image keeps the
+//               line per row, its 16-B slots XOR-swizzled by the row so that the ds_read_b128
+//               fragment reads are conflict free.
+//     waves 0-3 (consumers): 64 x 64 of the tile each = 2 x 2 MFMA tiles x {main, corr}; per 16 k:
+//               8 ds_read_b128, 12 MFMAs.  The barrier that releases a slice sits between its
+//               two k steps (after both have been read into registers), so the fragment reads of
+//               the next slice are issued under the MFMAs of this one.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace bess {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int SK = 32;            // k slice held by one LDS image
+constexpr int ROW_B = 128;        // bytes per image row: 32 hi | 32 lo
+constexpr int IMG_B = 128 * ROW_B;
+
+struct SplitSrc {
+    const void* base;
+    const int32_t* idx;  // optional row index
+    int64_t rows;
+    int64_t ld;
+};
+
+// 16-B slot `c` (0..7) of image row `row`, swizzled: rows r, r+2, .. r+14 of one parity land
+// on the 8 slots of their half of the 256-B bank row
+__device__ __forceinline__ int slot_off(int row, int c) { return row * ROW_B + ((c ^ ((row >> 1) & 7)) << 4); }
+
+// ---- pre-pass: rows (gathered by index) -> split lines --------------------------------------
+// One thread per 8 consecutive k of one row.  dst row r, block b (32 k): 128 B at
+// dst + (r * n_blk + b) * 128 = [32 hi | 32 lo]; k >= W is written as zero.
+template <typename T, bool VEC>
+__device__ __forceinline__ void split_rows_body(const SplitSrc& src, int W, int n_blk, char* __restrict__ dst,
+                                                int64_t gid) {
+    const int chunks = n_blk * 4;  // 8-k chunks per row
+    const int64_t r = gid / chunks;
+    if (r >= src.rows) return;
+    const int c = static_cast<int>(gid - r * chunks);
+    const int k = c * 8;
+    const int64_t rr = src.idx ? static_cast<int64_t>(src.idx[r]) : r;
+    const T* row = static_cast<const T*>(src.base) + rr * src.ld;
+    float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (VEC) {  // W % 8 == 0: a chunk is inside or outside
+        if (k < W) VecLoad<T, 8>::load(row + k, x);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (k + i < W) x[i] = static_cast<float>(row[k + i]);
+    }
+    h8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hi[i] = static_cast<_Float16>(x[i]);
+        lo[i] = static_cast<_Float16>((x[i] - static_cast<float>(hi[i])) * 2048.f);
+    }
+    char* line = dst + (r * n_blk + (c >> 2)) * ROW_B + (c & 3) * 16;
+    *reinterpret_cast<h8*>(line) = hi;
+    *reinterpret_cast<h8*>(line + 64) = lo;
+}
+
+// both operands of a product in one launch: blocks [0, blocks_a) split `a`, the rest `b`
+template <typename TB, bool VEC>
+__global__ __launch_bounds__(256) void k_split_rows(SplitSrc a, char* __restrict__ dst_a, int blocks_a, SplitSrc b,
+                                                    char* __restrict__ dst_b, int W, int n_blk) {
+    if (static_cast<int>(blockIdx.x) < blocks_a)
+        split_rows_body<float, VEC>(a, W, n_blk, dst_a, static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x);
+    else
+        split_rows_body<TB, VEC>(b, W, n_blk, dst_b,
+                                 static_cast<int64_t>(blockIdx.x - blocks_a) * 256 + threadIdx.x);
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// one producer thread's share of a slice: 16-B piece (t & 7) of the lines of rows p * 32 + (t >> 3)
+struct LineLoader {
+    const char* ptr[4];
+    __device__ __forceinline__ void init(const char* img, int64_t rows, int64_t pitch, int64_t r0) {
+        const int t = threadIdx.x & 255;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)  // rows past the end are clamped: their products are never stored
+            ptr[p] = img + min(r0 + p * 32 + (t >> 3), rows - 1) * pitch + (t & 7) * 16;
+    }
+    __device__ __forceinline__ void load(int slice, u32x4 (&v)[4]) const {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#ifdef BESS_PROBE_NO_LOAD  // profiles/ubench/gemm_split_probe.hip: producers without global traffic
+            v[p] = u32x4{static_cast<unsigned>(slice), 1u, 2u, 3u};
+#else
+            v[p] = *reinterpret_cast<const u32x4*>(ptr[p] + static_cast<int64_t>(slice) * ROW_B);
+#endif
+        }
+    }
+};
+
+__device__ __forceinline__ void line_store(char* img, const u32x4 (&v)[4]) {
+    const int t = threadIdx.x & 255;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(img + slot_off(p * 32 + (t >> 3), t & 7)) = v[p];
+}
+
+__device__ __forceinline__ f32x16 mma16(h8 a, h8 b, f32x16 c) {
+#ifdef BESS_PROBE_NO_MFMA  // consumers without the matrix pipe
+    c[0] += static_cast<float>(a[0]) * static_cast<float>(b[0]);
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// profiles/ubench/gemm_split_probe.hip -DBESS_PROBE_TICKS: clocks the two roles spend waiting at the
+// per-slice barrier (workgroup 0 overwrites C[0..3] with {producer wait, consumer wait, total, slices})
+#ifdef BESS_PROBE_TICKS
+#define BESS_TICK_BARRIER(acc)                                      \
+    {                                                               \
+        const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); \
+        __syncthreads();                                            \
+        acc += __builtin_amdgcn_s_memtime() - t0_;                  \
+    }
+#else
+#define BESS_TICK_BARRIER(acc) __syncthreads()
+#endif
+
+// A, B: split images of M and N rows (n_slice lines each); C[m, n] = A[m] . B[n]
+template <bool B_LO>
+__global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__ A, const char* __restrict__ B,
+                                                        int64_t M, int64_t N, int n_slice,
+                                                        float* __restrict__ C, int64_t ldc, int tiles_x,
+                                                        int n_tiles) {
+    __shared__ __attribute__((aligned(16))) char lds[2][2][IMG_B];  // [buffer][operand]
+    const int slot = blockIdx.x, slots = gridDim.x;
+    const int my_tiles = (n_tiles - slot + slots - 1) / slots;
+    const int total = my_tiles * n_slice;  // (tile, slice) pairs of this workgroup, in order
+    const int64_t pitch = static_cast<int64_t>(n_slice) * ROW_B;
+
+    unsigned long long pw = 0, cw = 0;  // BESS_PROBE_TICKS
+    (void)pw;
+    (void)cw;
+#ifdef BESS_PROBE_TICKS
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
+    if (threadIdx.x >= 256) {  // ---- producers
+        u32x4 va[3][4], vb[3][4];  // register ring: slices g, g + 1, g + 2
+        LineLoader la, lb;
+        // load cursor: runs two slices ahead of the store cursor and stops on the last slice
+        // (the surplus loads at the end re-read it and are never stored).  Every call issues the
+        // same 8 loads unconditionally, so the compiler's vmcnt waits stay exact: the stores of
+        // slice g wait for its loads only, those of g + 1 and g + 2 stay in flight.
+        int gl = 0, sl = 0, tl = slot;
+        auto issue = [&](u32x4 (&xa)[4], u32x4 (&xb)[4]) {
+            if (sl == 0) {
+                la.init(A, M, pitch, static_cast<int64_t>(tl / tiles_x) * 128);
+                lb.init(B, N, pitch, static_cast<int64_t>(tl % tiles_x) * 128);
+            }
+            la.load(sl, xa);
+            lb.load(sl, xb);
+            if (++gl < total && ++sl == n_slice) {
+                sl = 0;
+                tl += slots;
+            }
+        };
+        int gs = 0;  // store cursor
+        auto put = [&](const u32x4 (&xa)[4], const u32x4 (&xb)[4]) {
+            line_store(lds[gs & 1][0], xa);
+            line_store(lds[gs & 1][1], xb);
+            ++gs;
+            BESS_TICK_BARRIER(pw);  // slice stored; the consumers have released the other buffer
+        };
+        issue(va[0], vb[0]);
+        issue(va[1], vb[1]);
+        int g = 0;
+        for (; g + 3 <= total; g += 3) {
+            issue(va[2], vb[2]);
+            put(va[0], vb[0]);
+            issue(va[0], vb[0]);
+            put(va[1], vb[1]);
+            issue(va[1], vb[1]);
+            put(va[2], vb[2]);
+        }
+        if (g < total) {
+            issue(va[2], vb[2]);
+            put(va[0], vb[0]);
+        }
+        if (g + 1 < total) put(va[1], vb[1]);
+        __syncthreads();  // pairs with the consumers' barrier inside the last slice
+#ifdef BESS_PROBE_TICKS
+        if (blockIdx.x == 0 && threadIdx.x == 256) C[0] = static_cast<float>(pw);
+#endif
+        return;
+    }
+
+    // ---- consumers
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int l31 = lane & 31, lk = lane >> 5;
+    // byte offsets of this lane's fragments inside an image: [k step][hi | lo], row block i adds 32 rows
+    int off_a[2][2], off_b[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            off_a[ks][part] = slot_off(wm + l31, ks * 2 + lk + 4 * part);
+            off_b[ks][part] = slot_off(wn + l31, ks * 2 + lk + 4 * part);
+        }
+
+    f32x16 accm[2][2], accc[2][2];
+    auto zero = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    accm[i][j][r] = 0.f;
+                    accc[i][j][r] = 0.f;
+                }
+    };
+    zero();
+
+    h8 fa[2][2][2], fb[2][2][2];  // [register set][row block][hi | lo]
+#define BESS_RD(set, g, ks)                                                                          \
+    {                                                                                                \
+        const char* ia = lds[(g) & 1][0];                                                            \
+        const char* ib = lds[(g) & 1][1];                                                            \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
+            fa[set][i][0] = *reinterpret_cast<const h8*>(ia + off_a[ks][0] + i * 32 * ROW_B);        \
+            fa[set][i][1] = *reinterpret_cast<const h8*>(ia + off_a[ks][1] + i * 32 * ROW_B);        \
+            fb[set][i][0] = *reinterpret_cast<const h8*>(ib + off_b[ks][0] + i * 32 * ROW_B);        \
+            if (B_LO) fb[set][i][1] = *reinterpret_cast<const h8*>(ib + off_b[ks][1] + i * 32 * ROW_B); \
+        }                                                                                            \
+    }
+#define BESS_MM_MAIN(set)                                                                                   \
+    {                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)         \
+            accm[i][j] = mma16(fa[set][i][0], fb[set][j][0], accm[i][j]); \
+    }
+#define BESS_MM_CORR(set)                                                                                   \
+    {                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)         \
+            accc[i][j] = mma16(fa[set][i][1], fb[set][j][0], accc[i][j]); \
+        if (B_LO) {                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)     \
+                accc[i][j] = mma16(fa[set][i][0], fb[set][j][1], accc[i][j]); \
+        }                                                                                                   \
+    }
+
+    // Per slice: [12 MFMAs of k-step 0, the 8 fragment reads of k-step 1 slotted one per MFMA gap]
+    // barrier [12 MFMAs of k-step 1, with the reads of k-step 0 of the next slice].  A burst of
+    // reads between two MFMAs would leave the pipe idle while they issue; one per gap is hidden
+    // (profiles/ubench/mfma_f16.hip).  Every read has >= 4 MFMAs (128 cycles) before its first
+    // use and the barrier finds the slice already in registers.
+    constexpr int N_RD = B_LO ? 8 : 6, N_MM = B_LO ? 12 : 8;
+#define BESS_INTERLEAVE()                                                  \
+    {                                                                      \
+        _Pragma("unroll") for (int q = 0; q < N_RD; ++q) {                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             \
+        }                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, N_MM - N_RD, 0);       \
+    }
+    int s = 0, tile = slot;
+    __syncthreads();  // slice 0 stored
+    BESS_RD(0, 0, 0);
+    for (int g = 0; g < total; ++g) {
+        __builtin_amdgcn_sched_barrier(0);
+        BESS_RD(1, g, 1);
+        BESS_MM_MAIN(0);
+        BESS_MM_CORR(0);
+        BESS_INTERLEAVE();
+        __builtin_amdgcn_sched_barrier(0);
+        BESS_TICK_BARRIER(cw);  // slice g is in registers (buffer released); slice g + 1 is stored
+        __builtin_amdgcn_sched_barrier(0);
+        BESS_RD(0, g + 1, 0);  // after the last slice: a stale image, never used
+        BESS_MM_MAIN(1);
+        BESS_MM_CORR(1);
+        BESS_INTERLEAVE();
+        __builtin_amdgcn_sched_barrier(0);
+        if (++s == n_slice) {  // tile done: main + corr / 2048 -> C
+            const int64_t m0 = static_cast<int64_t>(tile / tiles_x) * 128 + wm;
+            const int64_t n0 = static_cast<int64_t>(tile % tiles_x) * 128 + wn;
+            // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+            float* c0 = C + (m0 + 4 * lk) * ldc + n0 + l31;
+            if (m0 + 64 <= M && n0 + 64 <= N) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            c0[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32] =
+                                accm[i][j][r] + accc[i][j][r] * (1.f / 2048.f);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
+                            if (m0 + 4 * lk + rr < M && n0 + l31 + j * 32 < N)
+                                c0[rr * ldc + j * 32] = accm[i][j][r] + accc[i][j][r] * (1.f / 2048.f);
+                        }
+            }
+            zero();
+            s = 0;
+            tile += slots;
+        }
+    }
+#ifdef BESS_PROBE_TICKS
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        C[1] = static_cast<float>(cw);
+        C[2] = static_cast<float>(__builtin_amdgcn_s_memtime() - t_start);
+        C[3] = static_cast<float>(total);
+    }
+#endif
+#undef BESS_RD
+#undef BESS_MM_MAIN
+#undef BESS_MM_CORR
+#undef BESS_INTERLEAVE
+}
+
+static bool split_disabled() {
+    static const bool off = [] {
+        const char* e = std::getenv("BESS_GEMM_FP32");
+        return e && e[0] && e[0] != '0';
+    }();
+    return off;
+}
+
+static int n_compute_units() {
+    static const int n = [] {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) return 256;
+        return cu;
+    }();
+    return n;
+}
+
+static int64_t split_pitch(int W) { return ceil_div(W, SK) * ROW_B; }
+constexpr int64_t SPLIT_CHUNK = 65536;  // candidate rows split per pass at most (128 MiB of lines at W = 512)
+
+// Workspace the split path wants for this shape; 0 = the shape is left to the fp32 kernels
+// (too few 128-tiles to occupy the chip, or the path is switched off).
+int64_t gemm_split_workspace(int64_t S, int64_t N, int W) {
+    if (split_disabled() || S < 1 || N < 1 || W < 1) return 0;
+    if (ceil_div(N, 128) * ceil_div(S, 128) < 256) return 0;
+    return (S + (N < SPLIT_CHUNK ? N : SPLIT_CHUNK)) * split_pitch(W);
+}
+
+// splits `a` (f32 rows; skipped when a.rows == 0) and `b` (table dtype) in one launch
+static int split_rows(const SplitSrc& a, char* dst_a, int dtype_b, const SplitSrc& b, char* dst_b, int W,
+                      hipStream_t st) {
+    const int n_blk = static_cast<int>(ceil_div(W, SK));
+    const int64_t blocks_a = ceil_div(a.rows * n_blk * 4, 256), blocks_b = ceil_div(b.rows * n_blk * 4, 256);
+    BESS_REQUIRE(blocks_a + blocks_b < (1ll << 31), "gemm_split: too many rows");
+    const unsigned grid = static_cast<unsigned>(blocks_a + blocks_b);
+    const auto al = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    const bool vec = W % 8 == 0 && a.ld % 8 == 0 && b.ld % 8 == 0 && al(a.base) && al(b.base);
+    const int ba = static_cast<int>(blocks_a);
+    if (dtype_b == BESS_F32) {
+        if (vec) k_split_rows<float, true><<<grid, 256, 0, st>>>(a, dst_a, ba, b, dst_b, W, n_blk);
+        else k_split_rows<float, false><<<grid, 256, 0, st>>>(a, dst_a, ba, b, dst_b, W, n_blk);
+    } else {
+        if (vec) k_split_rows<half_t, true><<<grid, 256, 0, st>>>(a, dst_a, ba, b, dst_b, W, n_blk);
+        else k_split_rows<half_t, false><<<grid, 256, 0, st>>>(a, dst_a, ba, b, dst_b, W, n_blk);
+    }
+    return check_launch("split_rows");
+}
+
+// out[q, j] = Q[q] . E[idx[j]] through the workspace (>= gemm_split_workspace bytes, 16-B aligned)
+int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const int32_t* idx, int64_t N, int W,
+                   float* out, int64_t ld, void* ws, int64_t ws_bytes, hipStream_t st) {
+    const int64_t pitch = split_pitch(W);
+    BESS_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 16 == 0, "gemm_split: workspace must be 16-B aligned");
+    int64_t chunk = (ws_bytes / pitch - S) / 128 * 128;  // candidate rows per pass
+    if (chunk >= N) chunk = N;
+    BESS_REQUIRE(chunk >= 128 || chunk == N, "gemm_split: workspace too small");
+    char* qa = static_cast<char*>(ws);
+    char* eb = qa + S * pitch;
+    const int n_slice = static_cast<int>(ceil_div(W, SK));
+    for (int64_t j0 = 0; j0 < N; j0 += chunk) {
+        const int64_t nc = N - j0 < chunk ? N - j0 : chunk;
+        // rows j0 .. j0 + nc: through the index if there is one, else consecutive rows of the table
+        const int64_t sz = dtype == BESS_F32 ? 4 : 2;
+        SplitSrc src{idx ? E : static_cast<const char*>(E) + j0 * W * sz, idx ? idx + j0 : nullptr, nc, W};
+        // the query rows ride along with the first chunk
+        if (int e = split_rows(SplitSrc{Q, nullptr, j0 == 0 ? S : 0, W}, qa, dtype, src, eb, W, st)) return e;
+        const int64_t tiles_x = ceil_div(nc, 128), tiles = tiles_x * ceil_div(S, 128);
+        BESS_REQUIRE(tiles < (1ll << 31), "gemm_split: too many tiles");
+        const int grid = static_cast<int>(tiles < n_compute_units() ? tiles : n_compute_units());
+        if (dtype == BESS_F32)
+            k_gemm_split_f16<true><<<grid, 512, 0, st>>>(qa, eb, S, nc, n_slice, out + j0, ld,
+                                                         static_cast<int>(tiles_x), static_cast<int>(tiles));
+        else
+            k_gemm_split_f16<false><<<grid, 512, 0, st>>>(qa, eb, S, nc, n_slice, out + j0, ld,
+                                                          static_cast<int>(tiles_x), static_cast<int>(tiles));
+        if (int e = check_launch("gemm_split_f16")) return e;
+    }
+    return BESS_OK;
+}
+
+}  // namespace bess

@@ -336,10 +336,16 @@ static int run_bwd_one(const bess_model_desc* d, RowSrc<TX> X, RowSrc<TY> Y, con
 
 using namespace bess;
 
-extern "C" int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* query,
-                                         int64_t n_query, const void* neg_base,
-                                         const int32_t* neg_idx, int64_t n_neg, float* out,
-                                         int64_t ld_out, void* stream) {
+extern "C" int64_t bess_neg_score_shared_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg) {
+    if (!d || check_desc(d) || n_query <= 0 || n_neg <= 0) return 0;
+    if (d->scorer == BESS_BOXE || d->scorer == BESS_AFFINE || reduce_of(d) != RED_DOT) return 0;
+    return gemm_split_workspace(n_query, n_neg, d->width);
+}
+
+extern "C" int bess_neg_score_shared_fwd_ws(const bess_model_desc* d, const float* query, int64_t n_query,
+                                            const void* neg_base, const int32_t* neg_idx, int64_t n_neg,
+                                            float* out, int64_t ld_out, void* workspace,
+                                            int64_t workspace_bytes, void* stream) {
     if (int e = check_desc(d)) return e;
     BESS_REQUIRE(n_query >= 0 && n_neg >= 0, "neg_score_shared_fwd: bad sizes");
     if (n_query == 0 || n_neg == 0) return BESS_OK;
@@ -353,15 +359,27 @@ extern "C" int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* 
         return affine_shared_fwd(d, query, n_query, static_cast<const float*>(neg_base), n_neg, out, ld_out,
                                  as_stream(stream));
     }
-    if (reduce_of(d) == RED_DOT)  // bilinear scorers: matrix cores
+    if (reduce_of(d) == RED_DOT) {  // bilinear scorers: matrix cores
+        const int64_t want = workspace ? gemm_split_workspace(n_query, n_neg, d->width) : 0;
+        if (want > 0 && workspace_bytes >= want)
+            return gemm_split_fwd(d->dtype, query, n_query, neg_base, neg_idx, n_neg, d->width, out, ld_out,
+                                  workspace, workspace_bytes, as_stream(stream));
         return gemm_dot_fwd(d->dtype, query, n_query, neg_base, neg_idx, n_neg, d->width, out, ld_out,
                             as_stream(stream));
+    }
     RowSrc<float> Q{query, nullptr, n_query};
     if (d->dtype == BESS_F32)
         return run_fwd<float>(d, Q, RowSrc<float>{static_cast<const float*>(neg_base), neg_idx, n_neg}, out,
                               ld_out, as_stream(stream));
     return run_fwd<half_t>(d, Q, RowSrc<half_t>{static_cast<const half_t*>(neg_base), neg_idx, n_neg}, out,
                            ld_out, as_stream(stream));
+}
+
+extern "C" int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* query,
+                                         int64_t n_query, const void* neg_base,
+                                         const int32_t* neg_idx, int64_t n_neg, float* out,
+                                         int64_t ld_out, void* stream) {
+    return bess_neg_score_shared_fwd_ws(d, query, n_query, neg_base, neg_idx, n_neg, out, ld_out, nullptr, 0, stream);
 }
 
 extern "C" int bess_neg_score_shared_bwd(const bess_model_desc* d, const float* query,

@@ -196,6 +196,22 @@ int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* query,
                               const int32_t* neg_idx, int64_t n_neg, float* out,
                               int64_t ld_out, void* stream);
 
+/* K4 with a scratch buffer.  For the bilinear scorers (DistMult, ComplEx) and shapes of at
+ * least 256 output tiles of 128 x 128, bess_neg_score_shared_workspace returns the bytes of
+ * device scratch (16-B aligned, contents irrelevant, free again when the call has run on
+ * `stream`) with which the product runs on the fp16 matrix cores at fp32 accuracy: operands
+ * are split into fp16 pairs carrying 22 significand bits, products accumulate in fp32
+ * (csrc/gemm_split.hip; operands must be finite and < 65504 in magnitude; BESS_GEMM_FP32=1
+ * in the environment switches the path off).  It returns 0 when the shape or the scorer does
+ * not use scratch.  With workspace == NULL or fewer bytes than asked for, the call is
+ * bess_neg_score_shared_fwd (exact fp32 MFMA). */
+int64_t bess_neg_score_shared_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg);
+int bess_neg_score_shared_fwd_ws(const bess_model_desc* d, const float* query,
+                                 int64_t n_query, const void* neg_base,
+                                 const int32_t* neg_idx, int64_t n_neg, float* out,
+                                 int64_t ld_out, void* workspace, int64_t workspace_bytes,
+                                 void* stream);
+
 /* backward of K4.  `out` is the forward result (needed for p = 2).
  * d_query [n_query, W] and d_neg [n_neg, W] (f32) are overwritten. */
 int bess_neg_score_shared_bwd(const bess_model_desc* d, const float* query,
