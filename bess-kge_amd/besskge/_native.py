@@ -30,7 +30,7 @@ _c_f32p = ctypes.POINTER(ctypes.c_float)
 _c_u8p = ctypes.POINTER(ctypes.c_uint8)
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
-_RETURNS_I64 = ("bess_neg_score_shared_workspace",)  # every other entry returns an int status
+_RETURNS_I64 = ("bess_neg_score_shared_workspace", "bess_neg_score_shared_bwd_workspace")  # every other entry returns an int status
 _i32 = ctypes.c_int32
 _f32 = ctypes.c_float
 
@@ -113,6 +113,8 @@ SIGNATURES = {
     "bess_neg_score_shared_workspace": [_MD, _i64, _i64],
     "bess_neg_score_shared_fwd_ws": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp],
     "bess_neg_score_shared_bwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
+    "bess_neg_score_shared_bwd_workspace": [_MD, _i64, _i64],
+    "bess_neg_score_shared_bwd_ws": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
     "bess_mask_scores": [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _vp],
     "bess_loss_fwd_bwd": [_LD, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
     "bess_scatter_add_rows": [_vp, _i32, _vp, _vp, _i64, _f32, _vp],
@@ -596,10 +598,14 @@ def neg_score_shared_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, out:
         neg, hat, inv = _affine_candidates(d, neg)
     dq = torch.empty((nq, query_width(d)), dtype=torch.float32, device=dev)
     dn = torch.empty((n_neg, d.width), dtype=torch.float32, device=dev)
+    lib = load()
+    ws_bytes = int(lib.bess_neg_score_shared_bwd_workspace(ctypes.byref(d), nq, n_neg))  # see neg_score_shared_fwd
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
     with torch.cuda.device(dev), _Timed("bess_neg_score_shared_bwd", dev):
-        rc = load().bess_neg_score_shared_bwd(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
+        rc = lib.bess_neg_score_shared_bwd_ws(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
                                               _idx(neg.idx, "negative idx"), n_neg, out.data_ptr(), n_neg,
-                                              d_out.data_ptr(), n_neg, dq.data_ptr(), dn.data_ptr(), _stream(dev))
+                                              d_out.data_ptr(), n_neg, dq.data_ptr(), dn.data_ptr(),
+                                              ws.data_ptr() if ws is not None else None, ws_bytes, _stream(dev))
     _check(rc, "bess_neg_score_shared_bwd")
     if hat is not None and (d.reserved[1] & 1):
         dn = normalize_rows_bwd(hat, inv, dn)

@@ -44,6 +44,10 @@ int gemm_dot_fwd(int dtype, const float* Q, int64_t S, const void* E, const int3
 int64_t gemm_split_workspace(int64_t S, int64_t N, int W);
 int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const int32_t* idx, int64_t N, int W,
                    float* out, int64_t ld, void* ws, int64_t ws_bytes, hipStream_t st);
+int64_t gemm_split_bwd_workspace(int64_t S, int64_t N, int W);
+int gemm_split_bwd(int dtype, const float* G, int64_t ldg, int64_t S, const float* Q, const void* E,
+                   const int32_t* idx, int64_t N, int W, float* dQ, float* dE, void* ws, int64_t ws_bytes,
+                   hipStream_t st);
 int gemm_dot_dq(int dtype, const float* G, int64_t ldg, int64_t S, const void* E, const int32_t* idx, int64_t N,
                 int W, float* dQ, hipStream_t st);
 int gemm_dot_de(const float* G, int64_t ldg, int64_t S, const float* Q, int64_t N, int W, float* dE,

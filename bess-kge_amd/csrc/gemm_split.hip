@@ -53,6 +53,10 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 constexpr int SK = 32;            // k slice held by one LDS image
 constexpr int ROW_B = 128;        // bytes per image row: 32 hi | 32 lo
 constexpr int IMG_B = 128 * ROW_B;
+#ifndef BESS_SPLIT_RING
+#define BESS_SPLIT_RING 3
+#endif
+constexpr int RING = BESS_SPLIT_RING;  // K slices a producer keeps in flight (registers)
 
 struct SplitSrc {
     const void* base;
@@ -108,6 +112,84 @@ __global__ __launch_bounds__(256) void k_split_rows(SplitSrc a, char* __restrict
                                  static_cast<int64_t>(blockIdx.x - blocks_a) * 256 + threadIdx.x);
 }
 
+// Pre-pass over 32 x 32 tiles of a row source [R rows (by index)][C columns], through LDS:
+//   PLAIN: image row r, k = columns   (line (r, bx)), as k_split_rows
+//   TRANS: image row c, k = rows      (line (c, by)): the transposed operand of a backward product
+// grid = (k blocks of the plain image, k blocks of the transposed image); blocks past the data
+// write zero lines (the k padding that makes the slice count a multiple of the k split).
+template <typename T, bool PLAIN, bool TRANS, bool VEC>
+__global__ __launch_bounds__(256) void k_split_tile32(SplitSrc src, int64_t C, char* __restrict__ dst_plain,
+                                                      int nblk_plain, char* __restrict__ dst_trans,
+                                                      int nblk_trans) {
+    __shared__ float tile[32][33];
+    const int t = threadIdx.x;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * 32, c0 = static_cast<int64_t>(blockIdx.x) * 32;
+    const T* base = static_cast<const T*>(src.base);
+    if (VEC) {  // C % 4 == 0, 16-B aligned rows: one 4-element load per thread covers the tile
+        const int64_t r = r0 + (t >> 3), c = c0 + (t & 7) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < src.rows && c < C) {
+            const int64_t rr = src.idx ? static_cast<int64_t>(src.idx[r]) : r;
+            VecLoad<T, 4>::load(base + rr * src.ld + c, v);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tile[t >> 3][(t & 7) * 4 + i] = v[i];
+    } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int64_t r = r0 + p * 8 + (t >> 5), c = c0 + (t & 31);
+            float v = 0.f;
+            if (r < src.rows && c < C) {
+                const int64_t rr = src.idx ? static_cast<int64_t>(src.idx[r]) : r;
+                v = static_cast<float>(base[rr * src.ld + c]);
+            }
+            tile[p * 8 + (t >> 5)][t & 31] = v;
+        }
+    }
+    __syncthreads();
+    // 8 threads write one 128-B line with one 16-B store each: pieces 0-3 = hi of k 8j .. 8j + 7,
+    // pieces 4-7 = lo of the same k (every thread computes both halves of its 8 numbers)
+    const int row = t >> 3, piece = t & 7, k0 = (piece & 3) * 8;
+    auto put = [&](const float (&x)[8], char* line) {
+        h8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const _Float16 hi = static_cast<_Float16>(x[i]);
+            const _Float16 lo = static_cast<_Float16>((x[i] - static_cast<float>(hi)) * 2048.f);
+            o[i] = piece < 4 ? hi : lo;
+        }
+        *reinterpret_cast<h8*>(line + piece * 16) = o;
+    };
+    if (PLAIN && r0 + row < src.rows) {
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = tile[row][k0 + i];
+        put(x, dst_plain + ((r0 + row) * nblk_plain + blockIdx.x) * ROW_B);
+    }
+    if (TRANS && c0 + row < C) {
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = tile[k0 + i][row];
+        put(x, dst_trans + ((c0 + row) * nblk_trans + blockIdx.y) * ROW_B);
+    }
+}
+
+// out[i] = part[0][i] + part[1][i] + ... (fixed order), 4 elements per thread
+__global__ __launch_bounds__(256) void k_sum_parts(const float* __restrict__ part, int64_t stride, int n_part,
+                                                   float* __restrict__ out, int64_t n4) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = reinterpret_cast<const float4*>(part)[i];
+    for (int p = 1; p < n_part; ++p) {
+        const float4 b = reinterpret_cast<const float4*>(part + p * stride)[i];
+        a.x += b.x;
+        a.y += b.y;
+        a.z += b.z;
+        a.w += b.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
+}
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // one producer thread's share of a slice: 16-B piece (t & 7) of the lines of rows p * 32 + (t >> 3)
@@ -161,15 +243,18 @@ __device__ __forceinline__ f32x16 mma16(h8 a, h8 b, f32x16 c) {
 
 // A, B: split images of M and N rows (n_slice lines each); C[m, n] = A[m] . B[n]
 template <bool B_LO>
+// Split K (the backward products have few output tiles and a long k): a "tile" index t stands for
+// output tile t / ksplit and the k range [t % ksplit, +1) * n_slice lines; part p of an output
+// tile goes to C + p * part_stride (summed in a fixed order by k_sum_parts: deterministic).
 __global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__ A, const char* __restrict__ B,
                                                         int64_t M, int64_t N, int n_slice,
                                                         float* __restrict__ C, int64_t ldc, int tiles_x,
-                                                        int n_tiles) {
+                                                        int n_tiles, int ksplit, int64_t part_stride) {
     __shared__ __attribute__((aligned(16))) char lds[2][2][IMG_B];  // [buffer][operand]
     const int slot = blockIdx.x, slots = gridDim.x;
     const int my_tiles = (n_tiles - slot + slots - 1) / slots;
     const int total = my_tiles * n_slice;  // (tile, slice) pairs of this workgroup, in order
-    const int64_t pitch = static_cast<int64_t>(n_slice) * ROW_B;
+    const int64_t pitch = static_cast<int64_t>(n_slice) * ksplit * ROW_B;
 
     unsigned long long pw = 0, cw = 0;  // BESS_PROBE_TICKS
     (void)pw;
@@ -178,17 +263,19 @@ __global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
     if (threadIdx.x >= 256) {  // ---- producers
-        u32x4 va[3][4], vb[3][4];  // register ring: slices g, g + 1, g + 2
+        u32x4 va[RING][4], vb[RING][4];  // register ring: slices g .. g + RING - 1
         LineLoader la, lb;
-        // load cursor: runs two slices ahead of the store cursor and stops on the last slice
+        // load cursor: runs RING - 1 slices ahead of the store cursor and stops on the last slice
         // (the surplus loads at the end re-read it and are never stored).  Every call issues the
         // same 8 loads unconditionally, so the compiler's vmcnt waits stay exact: the stores of
-        // slice g wait for its loads only, those of g + 1 and g + 2 stay in flight.
+        // slice g wait for its loads only, those of the later slices stay in flight.
         int gl = 0, sl = 0, tl = slot;
         auto issue = [&](u32x4 (&xa)[4], u32x4 (&xb)[4]) {
             if (sl == 0) {
-                la.init(A, M, pitch, static_cast<int64_t>(tl / tiles_x) * 128);
-                lb.init(B, N, pitch, static_cast<int64_t>(tl % tiles_x) * 128);
+                const int ot = tl / ksplit;
+                const int64_t k_off = static_cast<int64_t>(tl % ksplit) * n_slice * ROW_B;
+                la.init(A + k_off, M, pitch, static_cast<int64_t>(ot / tiles_x) * 128);
+                lb.init(B + k_off, N, pitch, static_cast<int64_t>(ot % tiles_x) * 128);
             }
             la.load(sl, xa);
             lb.load(sl, xb);
@@ -204,22 +291,19 @@ __global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__
             ++gs;
             BESS_TICK_BARRIER(pw);  // slice stored; the consumers have released the other buffer
         };
-        issue(va[0], vb[0]);
-        issue(va[1], vb[1]);
+#pragma unroll
+        for (int u = 0; u < RING - 1; ++u) issue(va[u], vb[u]);
         int g = 0;
-        for (; g + 3 <= total; g += 3) {
-            issue(va[2], vb[2]);
-            put(va[0], vb[0]);
-            issue(va[0], vb[0]);
-            put(va[1], vb[1]);
-            issue(va[1], vb[1]);
-            put(va[2], vb[2]);
+        for (; g + RING <= total; g += RING) {
+#pragma unroll
+            for (int u = 0; u < RING; ++u) {
+                issue(va[(u + RING - 1) % RING], vb[(u + RING - 1) % RING]);
+                put(va[u], vb[u]);
+            }
         }
-        if (g < total) {
-            issue(va[2], vb[2]);
-            put(va[0], vb[0]);
-        }
-        if (g + 1 < total) put(va[1], vb[1]);
+#pragma unroll
+        for (int u = 0; u < RING - 1; ++u)  // the last total % RING slices are already in the ring
+            if (g + u < total) put(va[u], vb[u]);
         __syncthreads();  // pairs with the consumers' barrier inside the last slice
 #ifdef BESS_PROBE_TICKS
         if (blockIdx.x == 0 && threadIdx.x == 256) C[0] = static_cast<float>(pw);
@@ -315,10 +399,11 @@ __global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__
         BESS_INTERLEAVE();
         __builtin_amdgcn_sched_barrier(0);
         if (++s == n_slice) {  // tile done: main + corr / 2048 -> C
-            const int64_t m0 = static_cast<int64_t>(tile / tiles_x) * 128 + wm;
-            const int64_t n0 = static_cast<int64_t>(tile % tiles_x) * 128 + wn;
+            const int ot = tile / ksplit;
+            const int64_t m0 = static_cast<int64_t>(ot / tiles_x) * 128 + wm;
+            const int64_t n0 = static_cast<int64_t>(ot % tiles_x) * 128 + wn;
             // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-            float* c0 = C + (m0 + 4 * lk) * ldc + n0 + l31;
+            float* c0 = C + (tile % ksplit) * part_stride + (m0 + 4 * lk) * ldc + n0 + l31;
             if (m0 + 64 <= M && n0 + 64 <= N) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -430,13 +515,115 @@ int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const in
         const int grid = static_cast<int>(tiles < n_compute_units() ? tiles : n_compute_units());
         if (dtype == BESS_F32)
             k_gemm_split_f16<true><<<grid, 512, 0, st>>>(qa, eb, S, nc, n_slice, out + j0, ld,
-                                                         static_cast<int>(tiles_x), static_cast<int>(tiles));
+                                                         static_cast<int>(tiles_x), static_cast<int>(tiles), 1, 0);
         else
             k_gemm_split_f16<false><<<grid, 512, 0, st>>>(qa, eb, S, nc, n_slice, out + j0, ld,
-                                                          static_cast<int>(tiles_x), static_cast<int>(tiles));
+                                                          static_cast<int>(tiles_x), static_cast<int>(tiles), 1, 0);
         if (int e = check_launch("gemm_split_f16")) return e;
     }
     return BESS_OK;
+}
+
+// ---- backward products -----------------------------------------------------------------
+//   dQ[q, w] = sum_j G[q, j] E[idx[j], w]     A = G (plain image),  B = E^T   k = j
+//   dE[j, w] = sum_q G[q, j] Q[q, w]          A = G^T,              B = Q^T   k = q
+// One pass over G writes both of its images.
+struct BwdPlan {
+    int ks;          // k split of a product with `tiles` output tiles and `k` reduction length
+    int nblk;        // k blocks per image row, a multiple of ks
+};
+static BwdPlan plan_k(int64_t tiles, int64_t k) {
+    const int blk = static_cast<int>(ceil_div(k, SK));
+    int ks = 1;
+    while (ks < 8 && tiles * ks < 192 && blk / (ks * 2) >= 8) ks *= 2;
+    return BwdPlan{ks, static_cast<int>(ceil_div(blk, ks)) * ks};
+}
+
+struct BwdLayout {
+    BwdPlan pq, pe;  // plans of the dQ and dE products
+    int64_t g_plain, g_trans, e_trans, q_trans, parts, total;
+};
+static bool bwd_layout(int64_t S, int64_t N, int W, BwdLayout& L) {
+    if (split_disabled() || S < 128 || N < 128 || W < 64 || W % 4) return false;
+    const int64_t tw = ceil_div(W, 128);
+    L.pq = plan_k(ceil_div(S, 128) * tw, N);
+    L.pe = plan_k(ceil_div(N, 128) * tw, S);
+    // worth it only when both products can occupy at least half of the chip
+    if (ceil_div(S, 128) * tw * L.pq.ks < 128 || ceil_div(N, 128) * tw * L.pe.ks < 128) return false;
+    L.g_plain = S * L.pq.nblk * ROW_B;
+    L.g_trans = N * L.pe.nblk * ROW_B;
+    L.e_trans = static_cast<int64_t>(W) * L.pq.nblk * ROW_B;
+    L.q_trans = static_cast<int64_t>(W) * L.pe.nblk * ROW_B;
+    const int64_t p1 = L.pq.ks > 1 ? L.pq.ks * S * W * 4 : 0, p2 = L.pe.ks > 1 ? L.pe.ks * N * W * 4 : 0;
+    L.parts = p1 > p2 ? p1 : p2;
+    L.total = L.g_plain + L.g_trans + L.e_trans + L.q_trans + L.parts;
+    return true;
+}
+
+int64_t gemm_split_bwd_workspace(int64_t S, int64_t N, int W) {
+    BwdLayout L;
+    return bwd_layout(S, N, W, L) ? L.total : 0;
+}
+
+static int product(const char* A, const char* B, int64_t M, int64_t N, const BwdPlan& p, float* C, int64_t ldc,
+                   float* parts, hipStream_t st) {
+    const int64_t tiles_x = ceil_div(N, 128), tiles = tiles_x * ceil_div(M, 128) * p.ks;
+    BESS_REQUIRE(tiles < (1ll << 31), "gemm_split: too many tiles");
+    const int grid = static_cast<int>(tiles < n_compute_units() ? tiles : n_compute_units());
+    float* dst = p.ks > 1 ? parts : C;
+    k_gemm_split_f16<true><<<grid, 512, 0, st>>>(A, B, M, N, p.nblk / p.ks, dst, ldc, static_cast<int>(tiles_x),
+                                                 static_cast<int>(tiles), p.ks, M * ldc);
+    if (int e = check_launch("gemm_split_f16")) return e;
+    if (p.ks > 1) {
+        const int64_t n4 = M * ldc / 4;
+        k_sum_parts<<<static_cast<unsigned>(ceil_div(n4, 256)), 256, 0, st>>>(parts, M * ldc, p.ks, C, n4);
+        return check_launch("sum_parts");
+    }
+    return BESS_OK;
+}
+
+// d_query [S, W] and d_neg [N, W] (both dense, leading dimension W) through the workspace
+int gemm_split_bwd(int dtype, const float* G, int64_t ldg, int64_t S, const float* Q, const void* E,
+                   const int32_t* idx, int64_t N, int W, float* dQ, float* dE, void* ws, int64_t ws_bytes,
+                   hipStream_t st) {
+    BwdLayout L;
+    BESS_REQUIRE(bwd_layout(S, N, W, L) && ws_bytes >= L.total, "gemm_split_bwd: workspace too small");
+    BESS_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 16 == 0, "gemm_split: workspace must be 16-B aligned");
+    char* gp = static_cast<char*>(ws);
+    char* gt = gp + L.g_plain;
+    char* et = gt + L.g_trans;
+    char* qt = et + L.e_trans;
+    float* parts = reinterpret_cast<float*>(qt + L.q_trans);
+    const auto al = [](const void* p, int64_t ld, int64_t sz) {
+        return reinterpret_cast<uintptr_t>(p) % 16 == 0 && ld * sz % 16 == 0;
+    };
+    // G [S, N]: plain image with k = j (nblk of dQ), transposed image with k = q (nblk of dE)
+    const dim3 gg(L.pq.nblk, L.pe.nblk);
+    const SplitSrc sg{G, nullptr, S, ldg};
+    if (N % 4 == 0 && al(G, ldg, 4))
+        k_split_tile32<float, true, true, true><<<gg, 256, 0, st>>>(sg, N, gp, L.pq.nblk, gt, L.pe.nblk);
+    else
+        k_split_tile32<float, true, true, false><<<gg, 256, 0, st>>>(sg, N, gp, L.pq.nblk, gt, L.pe.nblk);
+    // E rows [N (by index), W] -> E^T: image rows w, k = j       (W % 4 == 0 checked by bwd_layout)
+    const dim3 ge(static_cast<unsigned>(ceil_div(W, 32)), L.pq.nblk);
+    const SplitSrc se{E, idx, N, W};
+    if (dtype == BESS_F32) {
+        if (al(E, W, 4)) k_split_tile32<float, false, true, true><<<ge, 256, 0, st>>>(se, W, nullptr, 0, et, L.pq.nblk);
+        else k_split_tile32<float, false, true, false><<<ge, 256, 0, st>>>(se, W, nullptr, 0, et, L.pq.nblk);
+    } else {
+        if (al(E, W, 2) && W % 8 == 0)
+            k_split_tile32<half_t, false, true, true><<<ge, 256, 0, st>>>(se, W, nullptr, 0, et, L.pq.nblk);
+        else
+            k_split_tile32<half_t, false, true, false><<<ge, 256, 0, st>>>(se, W, nullptr, 0, et, L.pq.nblk);
+    }
+    // Q [S, W] -> Q^T: image rows w, k = q
+    const dim3 gq(static_cast<unsigned>(ceil_div(W, 32)), L.pe.nblk);
+    const SplitSrc sq{Q, nullptr, S, W};
+    if (al(Q, W, 4)) k_split_tile32<float, false, true, true><<<gq, 256, 0, st>>>(sq, W, nullptr, 0, qt, L.pe.nblk);
+    else k_split_tile32<float, false, true, false><<<gq, 256, 0, st>>>(sq, W, nullptr, 0, qt, L.pe.nblk);
+    if (int e = check_launch("split_tile32")) return e;
+    if (int e = product(gp, et, S, W, L.pq, dQ, W, parts, st)) return e;
+    return product(gt, qt, N, W, L.pe, dE, W, parts, st);
 }
 
 }  // namespace bess

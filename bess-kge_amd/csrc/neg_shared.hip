@@ -382,11 +382,27 @@ extern "C" int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* 
     return bess_neg_score_shared_fwd_ws(d, query, n_query, neg_base, neg_idx, n_neg, out, ld_out, nullptr, 0, stream);
 }
 
+extern "C" int64_t bess_neg_score_shared_bwd_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg) {
+    if (!d || check_desc(d) || n_query <= 0 || n_neg <= 0) return 0;
+    if (d->scorer == BESS_BOXE || d->scorer == BESS_AFFINE || reduce_of(d) != RED_DOT) return 0;
+    return gemm_split_bwd_workspace(n_query, n_neg, d->width);
+}
+
 extern "C" int bess_neg_score_shared_bwd(const bess_model_desc* d, const float* query,
                                          int64_t n_query, const void* neg_base,
                                          const int32_t* neg_idx, int64_t n_neg, const float* out,
                                          int64_t ld_out, const float* d_out, int64_t ld_dout,
                                          float* d_query, float* d_neg, void* stream) {
+    return bess_neg_score_shared_bwd_ws(d, query, n_query, neg_base, neg_idx, n_neg, out, ld_out, d_out, ld_dout,
+                                        d_query, d_neg, nullptr, 0, stream);
+}
+
+extern "C" int bess_neg_score_shared_bwd_ws(const bess_model_desc* d, const float* query,
+                                            int64_t n_query, const void* neg_base,
+                                            const int32_t* neg_idx, int64_t n_neg, const float* out,
+                                            int64_t ld_out, const float* d_out, int64_t ld_dout,
+                                            float* d_query, float* d_neg, void* workspace,
+                                            int64_t workspace_bytes, void* stream) {
     if (int e = check_desc(d)) return e;
     BESS_REQUIRE(n_query >= 0 && n_neg >= 0, "neg_score_shared_bwd: bad sizes");
     if (n_query == 0 || n_neg == 0) return BESS_OK;
@@ -404,6 +420,10 @@ extern "C" int bess_neg_score_shared_bwd(const bess_model_desc* d, const float* 
                                  ld_dout, d_query, d_neg, st);
     }
     if (reduce_of(d) == RED_DOT) {
+        const int64_t want = workspace ? gemm_split_bwd_workspace(n_query, n_neg, d->width) : 0;
+        if (want > 0 && workspace_bytes >= want)
+            return gemm_split_bwd(d->dtype, d_out, ld_dout, n_query, query, neg_base, neg_idx, n_neg, d->width,
+                                  d_query, d_neg, workspace, workspace_bytes, st);
         if (int e = gemm_dot_dq(d->dtype, d_out, ld_dout, n_query, neg_base, neg_idx, n_neg, d->width, d_query, st))
             return e;
         return gemm_dot_de(d_out, ld_dout, n_query, query, n_neg, d->width, d_neg, st);

@@ -221,6 +221,19 @@ int bess_neg_score_shared_bwd(const bess_model_desc* d, const float* query,
                               int64_t ld_dout, float* d_query, float* d_neg,
                               void* stream);
 
+/* backward of K4 with a scratch buffer, as bess_neg_score_shared_fwd_ws: the two products
+ * (d_query = d_out . E, d_neg = d_out^T . Q) on the fp16 matrix cores from split operands,
+ * k split over workgroups with the partial tiles summed in a fixed order (deterministic).
+ * bess_neg_score_shared_bwd_workspace returns the scratch bytes, 0 when the shape or the
+ * scorer does not use scratch. */
+int64_t bess_neg_score_shared_bwd_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg);
+int bess_neg_score_shared_bwd_ws(const bess_model_desc* d, const float* query,
+                                 int64_t n_query, const void* neg_base,
+                                 const int32_t* neg_idx, int64_t n_neg, const float* out,
+                                 int64_t ld_out, const float* d_out, int64_t ld_dout,
+                                 float* d_query, float* d_neg, void* workspace,
+                                 int64_t workspace_bytes, void* stream);
+
 /* K7 - mask / augment block of BessKGE.forward (bess.py:182-245), in place:
  *   neg[s, j] += BAD_NEGATIVE_SCORE  where
  *     j == diag_step * qpos(s)                       (diag_step > 0: augment)

@@ -35,7 +35,7 @@ def timeit(fn, reps=20, warm=3):
     return a.elapsed_time(b) / reps
 
 
-def run(name, dtype, M, W, S, N, use_idx=True, scale=0.1, check=True):
+def run(name, dtype, M, W, S, N, use_idx=True, scale=0.1, check=True, bwd=False):
     g = torch.Generator(device="cpu").manual_seed(0)
     table = (torch.randn(M, W, generator=g) * scale).to(dtype).to(dev)
     d = nat.make_desc(nat.DISTMULT, 0, table, W)
@@ -56,15 +56,27 @@ def run(name, dtype, M, W, S, N, use_idx=True, scale=0.1, check=True):
     flops = 2.0 * S * N * W
     print(f"{name:36s} S={S:6d} N={N:7d} W={W:4d} {str(dtype)[6:]:7s} {t*1e3:9.1f} us {flops/t/1e9:7.1f} TFLOP/s{err}",
           flush=True)
+    if bwd:
+        go = torch.randn(S, N, generator=g).to(dev)
+        dq, dn = nat.neg_score_shared_bwd(d, q, neg, out, go)
+        rows = (table[idx.long()] if use_idx else table[:N]).double()
+        sq = min(S, 512)
+        rq = go[:sq].double() @ rows
+        rn = go.double().T[:sq] @ q.double()
+        e1 = (dq[:sq].double() - rq).abs().max().item() / rq.abs().max().item()
+        e2 = (dn[:sq].double() - rn).abs().max().item() / rn.abs().max().item()
+        t = timeit(lambda: nat.neg_score_shared_bwd(d, q, neg, out, go))
+        print(f"{'  backward (d_query, d_neg)':36s} {'':34s} {t*1e3:9.1f} us {2*flops/t/1e9:7.1f} TFLOP/s"
+              f" max|err|/max|ref| d_query {e1:.2e} d_neg {e2:.2e}", flush=True)
 
 
 if __name__ == "__main__":
     print("BESS_GEMM_FP32 =", os.environ.get("BESS_GEMM_FP32", "<unset>"))
-    run("C2 ComplEx shared 4096x4096", torch.float32, 93_773, 512, 4096, 4096)
-    run("C5 DistMult shared 8192x4096", torch.float32, 1_000_000, 512, 8192, 4096)
-    run("ragged 4099 x 5001, W=500", torch.float32, 20_000, 500, 4099, 5001)
+    run("C2 ComplEx shared 4096x4096", torch.float32, 93_773, 512, 4096, 4096, bwd=True)
+    run("C5 DistMult shared 8192x4096", torch.float32, 1_000_000, 512, 8192, 4096, bwd=True)
+    run("ragged 4099 x 5001, W=500", torch.float32, 20_000, 500, 4099, 5001, bwd=True)
     run("tiny values (1e-4)", torch.float32, 20_000, 256, 2048, 4096, scale=1e-4)
     run("large values (100)", torch.float32, 20_000, 256, 2048, 4096, scale=100.0)
-    run("fp16 table 4096x4096 W=256", torch.float16, 312_576, 256, 4096, 4096)
+    run("fp16 table 4096x4096 W=256", torch.float16, 312_576, 256, 4096, 4096, bwd=True)
     run("YAGO3-10 all entities d=128", torch.float32, 123_182, 256, 5000, 123_182, use_idx=False)
     run("wikikg2-like all entities W=512", torch.float32, 1_000_000, 512, 4096, 1_000_000, use_idx=False, check=False)

@@ -47,7 +47,7 @@ int main() {
     char* eb = qa + S * n_slice * 128;
     hipEventRecord(a);
     for (int i = 0; i < reps; ++i)
-        bess::k_gemm_split_f16<true><<<256, 512>>>(qa, eb, S, N, n_slice, out, N, 32, 1024);
+        bess::k_gemm_split_f16<true><<<256, 512>>>(qa, eb, S, N, n_slice, out, N, 32, 1024, 1, 0);
     hipEventRecord(b);
     hipEventSynchronize(b);
     hipEventElapsedTime(&ms, a, b);

@@ -15,7 +15,7 @@ from conftest import REPO
 def header_functions():
     text = open(os.path.join(REPO, "include", "besskge_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(bess_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t)\s+(bess_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -28,6 +28,24 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert sorted(_native.SIGNATURES) == names, "ctypes binding and header disagree"
     assert lib.bess_version() == _native.ABI_VERSION == 1
+
+
+def test_workspace_query_needs_no_gpu():
+    """bess_neg_score_shared_workspace is host arithmetic: bilinear scorers with >= 256 output
+    tiles of 128 x 128 ask for (S + min(N, 65536)) lines of ceil(W / 32) * 128 bytes, the rest 0."""
+    from besskge import _native
+
+    lib = _native.load()
+    d = _native.ModelDesc()
+    d.scorer, d.norm_p, d.dtype, d.width, d.rel_width = _native.DISTMULT, 0, 0, 500, 500
+    if os.environ.get("BESS_GEMM_FP32", "0") not in ("", "0"):
+        assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4096, 4096) == 0
+        return
+    assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4096, 4096) == (4096 + 4096) * 16 * 128
+    assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4096, 1 << 20) == (4096 + 65536) * 16 * 128
+    assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 512, 768) == 0  # too few tiles
+    d.scorer, d.norm_p = _native.TRANSE, 1
+    assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4096, 4096) == 0  # not a dot product
 
 
 def test_struct_layouts_match_header():

@@ -680,3 +680,76 @@ def test_public_broadcast_helpers(dev, sharing):
         got = box.boxe_score(bumped.to(dev), rel[..., : 2 * d].reshape(S, 1, 2, d).to(dev),
                              rel[..., 2 * d: 4 * d].reshape(S, 1, 2, d).to(dev), rel[..., 4 * d:].to(dev))
         close(got, kge.boxe_score(name, p, bumped, rel), scale=2e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("S,N,W,use_idx,scale", [
+    (2048, 2048, 256, True, 0.1),      # exactly 256 tiles
+    (2051, 2309, 100, True, 1.0),      # ragged rows, columns and k (W not a multiple of 4)
+    (1700, 33000, 64, False, 3e-4),    # dense candidates (all-entities scoring), tiny values
+    (4099, 1100, 136, True, 50.0),     # W % 8 == 0 but not % 32, large values
+])
+def test_split_fp16_gemm_matches_float64_product(dev, dtype, S, N, W, use_idx, scale):
+    """csrc/gemm_split.hip: the bilinear shared-negative forward on the fp16 matrix cores must be
+    as close to the exact product as the fp32 MFMA kernel it replaces (both within 2e-6 of
+    max|out|; the reference tolerance is rtol 1e-4 / atol 1e-5), for every shape class the
+    dispatcher sends there; without a workspace the same entry point is the fp32 kernel."""
+    import ctypes
+
+    from besskge import _native as nat
+
+    g = torch.Generator().manual_seed(S + N + W)
+    M = max(N, 5000)
+    table = (torch.randn(M, W, generator=g) * scale).to(dtype).to(dev)
+    q = (torch.randn(S, W, generator=g) * scale).to(dev)
+    d = nat.make_desc(nat.DISTMULT, 0, table, W)
+    assert nat.load().bess_neg_score_shared_workspace(ctypes.byref(d), S, N) > 0, "shape must take the split path"
+    idx = torch.randint(M, (N,), generator=g, dtype=torch.int32).to(dev) if use_idx else None
+    neg = nat.RowSource(table, idx) if use_idx else nat.RowSource(table[:N].contiguous(), None)
+    got = nat.neg_score_shared_fwd(d, q, neg)
+    rows = table[idx.long()] if use_idx else table[:N]
+    exact = nat.load()  # the entry point without scratch = exact fp32 MFMA kernel
+    out32 = torch.empty((S, N), dtype=torch.float32, device=dev)
+    rc = exact.bess_neg_score_shared_fwd(ctypes.byref(d), q.data_ptr(), S, neg.base.data_ptr(),
+                                         idx.data_ptr() if use_idx else None, N, out32.data_ptr(), N, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    for lo in range(0, S, 1024):  # float64 reference in row blocks
+        ref = q[lo:lo + 1024].double() @ rows.double().T
+        bound = 2e-6 * float(ref.abs().max())
+        assert float((got[lo:lo + 1024].double() - ref).abs().max()) <= bound
+        assert float((out32[lo:lo + 1024].double() - ref).abs().max()) <= bound
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("S,N,W,scale", [
+    (4096, 4096, 256, 0.1),    # k split 4 / 4
+    (2051, 2309, 100, 1.0),    # ragged everything, W < 128
+    (1300, 9000, 384, 3e-3),   # different k splits for the two products
+])
+def test_split_fp16_gemm_backward_matches_float64_products(dev, dtype, S, N, W, scale):
+    """Backward of the bilinear shared-negative scores through csrc/gemm_split.hip (transposed split
+    images, k split with a fixed-order sum): d_query = G E and d_neg = G^T Q within 2e-6 of their
+    largest element, like the exact fp32 MFMA kernels they replace; and bit-identical when repeated."""
+    import ctypes
+
+    from besskge import _native as nat
+
+    g = torch.Generator().manual_seed(S * 3 + N + W)
+    M = 12000
+    table = (torch.randn(M, W, generator=g) * scale).to(dtype).to(dev)
+    q = (torch.randn(S, W, generator=g) * scale).to(dev)
+    go = torch.randn(S, N, generator=g).to(dev)
+    idx = torch.randint(M, (N,), generator=g, dtype=torch.int32).to(dev)
+    d = nat.make_desc(nat.DISTMULT, 0, table, W)
+    assert nat.load().bess_neg_score_shared_bwd_workspace(ctypes.byref(d), S, N) > 0, "shape must take the split path"
+    neg = nat.RowSource(table, idx)
+    out = torch.zeros(S, N, device=dev)  # unused by dot products
+    dq, dn = nat.neg_score_shared_bwd(d, q, neg, out, go)
+    dq2, dn2 = nat.neg_score_shared_bwd(d, q, neg, out, go)
+    assert torch.equal(dq, dq2) and torch.equal(dn, dn2)
+    rows = table[idx.long()].double()
+    rq = go.double() @ rows
+    rn = go.double().T @ q.double()
+    assert float((dq.double() - rq).abs().max()) <= 2e-6 * float(rq.abs().max())
+    assert float((dn.double() - rn).abs().max()) <= 2e-6 * float(rn.abs().max())
