@@ -564,12 +564,15 @@ def _affine_candidates(d: ModelDesc, neg: RowSource) -> Tuple[RowSource, torch.T
     return RowSource(hat), hat, inv
 
 
-def neg_score_shared_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource) -> torch.Tensor:
+def neg_score_shared_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, pad_ld: bool = False) -> torch.Tensor:
+    """Scores [nq, n_neg].  `pad_ld`: rows of the result are 16-B aligned (leading dimension rounded
+    up to 4 floats; the result is then a column slice of the buffer) - what `topk_update` streams fastest."""
     nq, n_neg = int(query.shape[0]), len(neg)
     dev = _neg_operands(d, query, neg, n_neg)
     if d.scorer == AFFINE:
         neg, _, _ = _affine_candidates(d, neg)
-    out = torch.empty((nq, n_neg), dtype=torch.float32, device=dev)
+    ld = (n_neg + 3) // 4 * 4 if pad_ld else n_neg
+    out = torch.empty((nq, ld), dtype=torch.float32, device=dev)
     lib = load()
     # scratch of the split-fp16 matrix-core path (0 for the other scorers / small shapes); from
     # torch's caching allocator, so it is stream-ordered and safe under graph capture
@@ -577,10 +580,10 @@ def neg_score_shared_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource) -> t
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
     with torch.cuda.device(dev), _Timed("bess_neg_score_shared_fwd", dev):
         rc = lib.bess_neg_score_shared_fwd_ws(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
-                                              _idx(neg.idx, "negative idx"), n_neg, out.data_ptr(), n_neg,
+                                              _idx(neg.idx, "negative idx"), n_neg, out.data_ptr(), ld,
                                               ws.data_ptr() if ws is not None else None, ws_bytes, _stream(dev))
     _check(rc, "bess_neg_score_shared_fwd")
-    return out
+    return out if ld == n_neg else out[:, :n_neg]
 
 
 def neg_score_shared_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, out: torch.Tensor,
@@ -823,9 +826,10 @@ def topk_update(scores: torch.Tensor, best_score: torch.Tensor, best_id: torch.T
     """Merge `scores` [rows, L] into the running (best_score, best_id) [rows, kk] lists in place."""
     dev = _same_device([("scores", scores), ("best_score", best_score), ("best_id", best_id), ("ids", ids),
                         ("mask", mask)])
-    _f32(scores, "scores")
+    if scores.dtype != torch.float32 or scores.dim() != 2 or (scores.shape[1] > 1 and scores.stride(1) != 1):
+        raise ValueError("topk_update: scores must be float32 [rows, L] with contiguous rows")
     _f32(best_score, "best_score")
-    if scores.dim() != 2 or best_score.dim() != 2 or best_score.shape[0] != scores.shape[0] \
+    if best_score.dim() != 2 or best_score.shape[0] != scores.shape[0] \
             or best_id.shape != best_score.shape or best_id.dtype != torch.int32 or not best_id.is_contiguous():
         raise ValueError("topk_update: best lists must be [rows, kk] (f32 scores, int32 ids)")
     R, L, kk = int(scores.shape[0]), int(scores.shape[1]), int(best_score.shape[1])
@@ -842,7 +846,8 @@ def topk_update(scores: torch.Tensor, best_score: torch.Tensor, best_id: torch.T
             raise ValueError("topk_update: mask must be a contiguous bool [1 | rows, L] tensor")
         mp, mr = mask.data_ptr(), int(mask.shape[0])
     with torch.cuda.device(dev), _Timed("bess_topk_update", dev):
-        rc = load().bess_topk_update(scores.data_ptr(), R, L, L, ip, ir, int(id_base), mp, mr,
+        ld = int(scores.stride(0)) if R > 1 else L
+        rc = load().bess_topk_update(scores.data_ptr(), R, L, max(ld, L), ip, ir, int(id_base), mp, mr,
                                      best_score.data_ptr(), best_id.data_ptr(), kk, _stream(dev))
     _check(rc, "bess_topk_update")
 

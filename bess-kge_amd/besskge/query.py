@@ -172,11 +172,13 @@ class TopKQueryBessKGE(_QueryModule):
             )
         return cache[dev]
 
+    #: bytes of the fp32 score tile [n_query, tile] between the scoring kernel and the top-k kernel
+    score_tile_bytes = 1 << 30
+
     def _tile(self, n_query: int) -> int:
-        # score tile [n_query, tile] of up to 1 GiB (few, large launches: writing and
-        # re-reading the tile costs 8 B per score, a few % of the scoring itself), at
-        # least the reference's window
-        return max(self.window_size, max(64, (256 << 20) // max(1, n_query)))
+        # few, large launches (writing and re-reading the tile costs 8 B per score), at least
+        # the reference's window
+        return max(self.window_size, max(64, (self.score_tile_bytes // 4) // max(1, n_query)))
 
     def forward_replicas(self, batches: List[_Batch]) -> List[Dict[str, Any]]:
         group = self._group()
@@ -197,7 +199,7 @@ class TopKQueryBessKGE(_QueryModule):
             if b.get("negative") is None:
                 for w0 in range(0, M, tile):
                     w1 = min(M, w0 + tile)
-                    sc = nat.neg_score_shared_fwd(desc, q, RowSource(table[w0:w1]))
+                    sc = nat.neg_score_shared_fwd(desc, q, RowSource(table[w0:w1]), pad_ld=True)
                     nat.topk_update(sc, bs, bi, id_base=w0)
             else:
                 if b.get("negative_mask") is None:
@@ -213,7 +215,7 @@ class TopKQueryBessKGE(_QueryModule):
                     for w0 in range(0, L, tile):
                         w1 = min(L, w0 + tile)
                         ids = cand[:, w0:w1].contiguous()
-                        sc = nat.neg_score_shared_fwd(desc, q, RowSource(table, ids.reshape(-1)))
+                        sc = nat.neg_score_shared_fwd(desc, q, RowSource(table, ids.reshape(-1)), pad_ld=True)
                         nat.topk_update(sc, bs, bi, ids=ids, mask=mask[:, w0:w1].contiguous())
                 else:
                     if cand.shape[0] != nq:

@@ -4,7 +4,7 @@
 // `gather_indices` of the reference's sliding-window loop (bess.py:771-822) and
 // the final `torch.topk` over the shards' lists (bess.py:889-894).
 //
-// One wavefront per query row.  The running list (kk <= 64 entries, sorted by
+// One workgroup (four wavefronts) per query row.  A wave's list (kk <= 64 entries, sorted by
 // descending score) lives in registers, entry j in lane j.  The window is
 // streamed 64 candidates at a time; a candidate enters only if it beats the
 // current kk-th score tau (`__ballot(x > tau)`), so after the first few chunks
@@ -17,71 +17,132 @@
 
 namespace bess {
 
+// WPR waves per query row (4 rows per workgroup, or 1 row whose four waves each stream a
+// contiguous quarter of the columns - more bytes in flight when there are few rows, at the price
+// of one list warm-up per wave).  With WPR = 4, wave 0 starts from the running list, waves 1-3 from
+// empty lists; at the end wave 0 examines the other three lists as three more chunks, in wave
+// order - quarters are in column order, so ties resolve exactly as in a single left-to-right pass.
+// VEC: rows are 16-B aligned (ld % 4 == 0), a lane loads 4 consecutive columns with one instruction.
+template <int WPR, bool VEC>
 __global__ __launch_bounds__(256) void k_topk_update(const float* __restrict__ scores, int64_t n_row,
                                                      int64_t n_col, int64_t ld, const int32_t* __restrict__ ids,
                                                      int64_t ids_rows, int32_t id_base,
                                                      const uint8_t* __restrict__ mask, int64_t mask_rows,
                                                      float* __restrict__ best_score,
                                                      int32_t* __restrict__ best_id, int kk) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = blockIdx.x * 4ll + (threadIdx.x >> 6);
-    if (row >= n_row) return;
+    __shared__ float l_s[3][64];
+    __shared__ int32_t l_i[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int part = WPR == 4 ? wave : 0;  // which quarter of the columns
+    const int64_t row = WPR == 4 ? static_cast<int64_t>(blockIdx.x) : blockIdx.x * 4ll + wave;
+    if (row >= n_row) return;  // WPR == 1 only (whole waves; no barrier on that path)
     float bs = -INFINITY;
     int32_t bi = 0;
-    if (lane < kk) {
+    if (part == 0 && lane < kk) {
         bs = best_score[row * kk + lane];
         bi = best_id[row * kk + lane];
     }
     float tau = __shfl(bs, kk - 1, 64);
+    // candidate (xv, iv) enters the list if it beats the kk-th entry
+    auto insert = [&](float xv, int32_t iv) {
+        // entries that stay ahead of the newcomer (>=: earlier entries win ties)
+        const int pos = __popcll(__ballot(lane < kk && bs >= xv));
+        const float up_s = __shfl_up(bs, 1, 64);
+        const int32_t up_i = __shfl_up(bi, 1, 64);
+        if (lane < kk) {
+            if (lane > pos) {
+                bs = up_s;
+                bi = up_i;
+            } else if (lane == pos) {
+                bs = xv;
+                bi = iv;
+            }
+        }
+        tau = __shfl(bs, kk - 1, 64);
+    };
+    // a chunk of 64 candidates (one per lane), examined in lane order
+    auto examine = [&](float x, int32_t xi) {
+        unsigned long long m = __ballot(x > tau);
+        while (m) {
+            const int l = __ffsll(static_cast<long long>(m)) - 1;
+            insert(__shfl(x, l, 64), __shfl(xi, l, 64));
+            m &= ~(1ull << l);
+            m &= __ballot(x > tau);
+        }
+    };
     const float* srow = scores + row * ld;
     const int32_t* irow = ids ? ids + (ids_rows == 1 ? 0 : row) * n_col : nullptr;
     const uint8_t* mrow = mask ? mask + (mask_rows == 1 ? 0 : row) * n_col : nullptr;
-    // U chunks of 64 candidates are loaded back to back (U independent loads in
-    // flight per lane: the row is streamed, not pointer-chased), then examined
-    constexpr int U = 8;
-    for (int64_t c0 = 0; c0 < n_col; c0 += 64 * U) {
-        float xs[U];
-        int32_t xis[U];
+    // U groups are loaded back to back (U independent loads in flight per lane: the row is
+    // streamed, not pointer-chased), then examined
+    constexpr int U = VEC ? 4 : 8, PER = VEC ? 4 : 1, STEP = 64 * U * PER;
+    const int64_t seg = WPR == 4 ? (n_col + 4 * STEP - 1) / (4 * STEP) * STEP : n_col;  // columns per wave
+    const int64_t c_begin = part * seg, c_end = min(n_col, c_begin + seg);
+    for (int64_t c0 = c_begin; c0 < c_end; c0 += STEP) {
+        float xs[U][PER];
+        int32_t xis[U][PER];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t j = c0 + 64 * u + lane;
-            xs[u] = -INFINITY;
-            xis[u] = 0;
-            if (j < n_col) {
-                xs[u] = srow[j];
-                if (mrow && mrow[j] == 0) xs[u] += BESS_BAD_NEGATIVE_SCORE;
-                xis[u] = irow ? irow[j] : id_base + static_cast<int32_t>(j);
+            const int64_t j = c0 + 64 * PER * u + lane * PER;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                xs[u][i] = -INFINITY;
+                xis[u][i] = 0;
+            }
+            if constexpr (VEC) {
+                if (j + 3 < c_end) {
+                    VecLoad<float, 4>::load(srow + j, xs[u]);
+                } else {  // the last, partial group of the row
+#pragma unroll
+                    for (int i = 0; i < PER; ++i)
+                        if (j + i < c_end) xs[u][i] = srow[j + i];
+                }
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    if (j + i < c_end) {
+                        if (mrow && mrow[j + i] == 0) xs[u][i] += BESS_BAD_NEGATIVE_SCORE;
+                        xis[u][i] = irow ? irow[j + i] : id_base + static_cast<int32_t>(j + i);
+                    }
+                }
+            } else if (j < c_end) {
+                xs[u][0] = srow[j];
+                if (mrow && mrow[j] == 0) xs[u][0] += BESS_BAD_NEGATIVE_SCORE;
+                xis[u][0] = irow ? irow[j] : id_base + static_cast<int32_t>(j);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float x = xs[u];
-            const int32_t xi = xis[u];
-            unsigned long long m = __ballot(x > tau);
-            while (m) {
-                const int l = __ffsll(static_cast<long long>(m)) - 1;
-                const float xv = __shfl(x, l, 64);
-                const int32_t iv = __shfl(xi, l, 64);
-                // entries that stay ahead of the newcomer (>=: earlier entries win ties)
-                const int pos = __popcll(__ballot(lane < kk && bs >= xv));
-                const float up_s = __shfl_up(bs, 1, 64);
-                const int32_t up_i = __shfl_up(bi, 1, 64);
-                if (lane < kk) {
-                    if (lane > pos) {
-                        bs = up_s;
-                        bi = up_i;
-                    } else if (lane == pos) {
-                        bs = xv;
-                        bi = iv;
+            if constexpr (!VEC) {
+                examine(xs[u][0], xis[u][0]);
+            } else {
+                // 256 candidates, column = 4 * lane + i: taken in column order (lowest lane first,
+                // then lowest component), so that equal scores keep their left-to-right order
+                unsigned long long any = __ballot(xs[u][0] > tau || xs[u][1] > tau || xs[u][2] > tau || xs[u][3] > tau);
+                while (any) {
+                    const int l = __ffsll(static_cast<long long>(any)) - 1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float xv = __shfl(xs[u][i], l, 64);
+                        if (xv > tau) insert(xv, __shfl(xis[u][i], l, 64));  // wave-uniform branch
                     }
+                    any &= ~(1ull << l);
+                    any &= __ballot(xs[u][0] > tau || xs[u][1] > tau || xs[u][2] > tau || xs[u][3] > tau);
                 }
-                tau = __shfl(bs, kk - 1, 64);
-                m &= ~(1ull << l);
-                m &= __ballot(x > tau);
             }
         }
     }
-    if (lane < kk) {
+    if (WPR == 4) {
+        if (wave > 0) {
+            l_s[wave - 1][lane] = lane < kk ? bs : -INFINITY;
+            l_i[wave - 1][lane] = bi;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) examine(l_s[w][lane], l_i[w][lane]);
+        }
+    }
+    if (part == 0 && lane < kk) {
         best_score[row * kk + lane] = bs;
         best_id[row * kk + lane] = bi;
     }
@@ -95,13 +156,28 @@ extern "C" int bess_topk_update(const float* scores, int64_t n_row, int64_t n_co
                                 const int32_t* ids, int64_t ids_rows, int32_t id_base, const uint8_t* mask,
                                 int64_t mask_rows, float* best_score, int32_t* best_id, int32_t kk,
                                 void* stream) {
-    BESS_REQUIRE(n_row >= 0 && n_col >= 0 && ld >= n_col, "topk_update: bad sizes");
+    BESS_REQUIRE(n_row >= 0 && n_row < (1ll << 31) && n_col >= 0 && ld >= n_col, "topk_update: bad sizes");
     BESS_REQUIRE(kk >= 1 && kk <= 64, "topk_update: list length %d not in [1, 64]", kk);
     if (n_row == 0 || n_col == 0) return BESS_OK;
     BESS_REQUIRE(scores && best_score && best_id, "topk_update: NULL pointer");
     BESS_REQUIRE(!ids || ids_rows == 1 || ids_rows == n_row, "topk_update: ids_rows must be 1 or n_row");
     BESS_REQUIRE(!mask || mask_rows == 1 || mask_rows == n_row, "topk_update: mask_rows must be 1 or n_row");
-    k_topk_update<<<static_cast<unsigned>(ceil_div(n_row, 4)), 256, 0, as_stream(stream)>>>(
-        scores, n_row, n_col, ld, ids, ids_rows, id_base, mask, mask_rows, best_score, best_id, kk);
+    // few rows: four waves per row keep enough loads in flight; many rows: one wave per row
+    // (measured crossover on 256 CUs, profiles/bench_topk.py)
+    const bool wide = n_row <= 6144;
+    const bool vec = ld % 4 == 0 && reinterpret_cast<uintptr_t>(scores) % 16 == 0;
+    const unsigned grid = static_cast<unsigned>(wide ? n_row : ceil_div(n_row, 4));
+    hipStream_t st = as_stream(stream);
+#define BESS_TOPK(WPR, VEC)                                                                                  \
+    k_topk_update<WPR, VEC><<<grid, 256, 0, st>>>(scores, n_row, n_col, ld, ids, ids_rows, id_base, mask,   \
+                                                  mask_rows, best_score, best_id, kk)
+    if (wide) {
+        if (vec) BESS_TOPK(4, true);
+        else BESS_TOPK(4, false);
+    } else {
+        if (vec) BESS_TOPK(1, true);
+        else BESS_TOPK(1, false);
+    }
+#undef BESS_TOPK
     return check_launch("topk_update");
 }

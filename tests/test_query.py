@@ -76,7 +76,8 @@ def test_metric_golden(dev, mode, winf, red):
 
 
 # ------------------------------------------------------- streaming top-k -----
-@pytest.mark.parametrize("rows,L,kk", [(1, 1, 1), (7, 50, 6), (130, 1000, 11), (5, 4097, 64), (33, 63, 20)])
+@pytest.mark.parametrize("rows,L,kk", [(1, 1, 1), (7, 50, 6), (130, 1000, 11), (5, 4097, 64), (33, 63, 20),
+                                       (6200, 1030, 11), (40, 9001, 33)])
 def test_topk_update_matches_torch(dev, rows, L, kk):
     from besskge import _native as nat
 
@@ -102,6 +103,34 @@ def test_topk_update_matches_torch(dev, rows, L, kk):
     torch.testing.assert_close(bs.cpu(), want.values)
     valid = want.values > -40000  # ids of the (tied) sentinel / masked tail are unspecified
     assert torch.equal(bi.cpu()[valid], torch.take_along_dim(cat_i, want.indices, dim=1)[valid])
+
+
+@pytest.mark.parametrize("rows,L,pad", [(9, 2051, True), (9, 2051, False), (6200, 700, True), (3, 5000, True)])
+def test_topk_update_ties_keep_column_order(dev, rows, L, pad):
+    """Equal scores keep their left-to-right (then earlier-window) order on every code path of the
+    kernel: 16-B loads (row-aligned, padded leading dimension) and scalar loads, four waves per
+    row and one.  torch.topk leaves the order of ties unspecified; a stable sort is the reference."""
+    from besskge import _native as nat
+
+    kk = 17
+    gen = torch.Generator().manual_seed(L + rows)
+    bs = torch.full((rows, kk), -50000.0, device=dev)
+    bi = torch.full((rows, kk), -1, dtype=torch.int32, device=dev)
+    cols = []
+    for w in range(2):
+        sc = torch.randint(0, 40, (rows, L), generator=gen).float()  # many ties
+        cols.append(sc)
+        if pad:
+            buf = torch.zeros(rows, (L + 3) // 4 * 4, device=dev)
+            buf[:, :L] = sc.to(dev)
+            view = buf[:, :L]
+        else:
+            view = sc.to(dev)
+        nat.topk_update(view, bs, bi, id_base=w * L)
+    allc = torch.cat(cols, dim=1)
+    order = torch.sort(allc, dim=1, descending=True, stable=True).indices[:, :kk]
+    assert torch.equal(bi.cpu().long(), order)
+    torch.testing.assert_close(bs.cpu(), torch.take_along_dim(allc, order, dim=1))
 
 
 # ------------------------------------------------------------- goldens ------
