@@ -46,7 +46,7 @@ K_TOTAL = 256
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def build(n_shard: int, rank: int, dev: torch.device, mode: str):
+def build(n_shard: int, rank: int, dev: torch.device, mode: str, distributed: bool):
     import besskge  # noqa: F401
     from besskge import runtime
     from besskge.bess import EmbeddingMovingBessKGE, ScoreMovingBessKGE
@@ -75,9 +75,9 @@ def build(n_shard: int, rank: int, dev: torch.device, mode: str):
     k_pair = K_TOTAL // n_shard
     ns = RandomShardedNegativeSampler(k_pair, sharding, 1234, "t", local_sampling=False, flat_negative_format=False)
     loss = LogSigmoidLoss(margin=12.0, negative_adversarial_sampling=True)
-    cls = EmbeddingMovingBessKGE if n_shard == 1 else ScoreMovingBessKGE
+    cls = ScoreMovingBessKGE if distributed else EmbeddingMovingBessKGE
     model = cls(negative_sampler=ns, score_fn=fn, loss_fn=loss)
-    group = SingleProcessGroup(1) if n_shard == 1 else DistributedGroup()
+    group = DistributedGroup() if distributed else SingleProcessGroup(1)
     model.entity_embedding = fn.entity_embedding
     for p in (fn.entity_embedding, fn.relation_embedding):
         p.requires_grad_(False)
@@ -209,17 +209,24 @@ def main() -> None:
     backend = os.environ.get("BESS_BENCH_BACKEND", "nccl")
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
-    if world > 1:
+    # BESS_BENCH_REHEARSE_DIST=1 at N = 1: the multi-GPU code path (ScoreMoving, DistributedGroup,
+    # pipelined begin / finish, RCCL collectives) on a one-rank process group - what can be checked
+    # of it on a 1-GPU box
+    distributed = world > 1 or os.environ.get("BESS_BENCH_REHEARSE_DIST", "0") == "1"
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        kw = {} if world > 1 else dict(rank=0, world_size=1)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, **kw)
         else:
-            dist.init_process_group(backend)
-    if args.mode == "train" and world > 1:
+            dist.init_process_group(backend, **kw)
+    if args.mode == "train" and distributed:
         raise SystemExit("--mode train is single-GPU (EmbeddingMoving) in this round")
 
     from besskge import _native as nat
 
-    model, sharding, k_pair = build(world, rank, dev, args.mode)
+    model, sharding, k_pair = build(world, rank, dev, args.mode, distributed)
     batches = make_batches(world, rank, sharding, k_pair, pool=8, dev=dev)
     lr = 1e-3
 
@@ -228,7 +235,7 @@ def main() -> None:
     # step i+1 overlap the gather+score kernel of step i.  Training steps
     # depend on each other (table updates) and stay on one stream.
     if args.streams <= 0:
-        args.streams = 1 if world == 1 else 2
+        args.streams = 2 if distributed else 1
     main_stream = torch.cuda.current_stream(dev)
     streams = [main_stream] if args.mode == "train" or args.streams == 1 else \
         [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
@@ -247,7 +254,7 @@ def main() -> None:
         pipelined: the row gathers and all-gathers of micro-batch i + 1 are issued before the
         scoring of micro-batch i, so that they sit in front of its score all-to-all in the
         in-order collective queue and run under its scoring kernel."""
-        if world == 1 or args.mode == "train":
+        if not distributed or args.mode == "train":
             for i in range(first, first + count):
                 step(i)
             return
@@ -264,7 +271,7 @@ def main() -> None:
                 ctx = nxt
 
     def fence() -> None:
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -281,7 +288,7 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = nat.stop_kernel_timing()
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -289,7 +296,7 @@ def main() -> None:
     # N = 1, score mode: also time the full training step (forward + backward +
     # sparse SGD, K9/K10) on the same workload, reported as an extra object
     train_extra = None
-    if world == 1 and args.mode == "score":
+    if not distributed and args.mode == "score":
         tsteps = max(5, min(args.steps, 30))
         for i in range(3):
             model.train_step_replicas([batches[i % len(batches)]], lr)
@@ -313,8 +320,8 @@ def main() -> None:
 
     # roofline of the dominant kernel (K5 forward): algorithmic bytes per launch
     W, sz = 2 * D, 4
-    rows = S * world * k_pair if world > 1 else S * k_pair  # rows gathered per launch on this GPU
-    nq = S * world if world > 1 else S
+    rows = S * world * k_pair  # rows gathered per launch on this GPU
+    nq = S * world
     algo_bytes = rows * (W * sz + 4 + 4) + nq * W * 4
     fwd = kernel_ms.get("bess_neg_score_pertriple_fwd", []) or kernel_ms.get("bess_neg_score_pertriple_fwd_dq", [])
     avg_ms = float(np.mean(fwd)) if fwd else float("nan")
@@ -344,7 +351,7 @@ def main() -> None:
             "config": {
                 "workload": f"ogbl-biokg-shaped ComplEx d=256 fp32 (W=512), {N_ENTITY_PER_SHARD:,} entities per shard, "
                             f"n_shard={world}, S=4096 positives x 256 per-triple negatives per GPU per step, "
-                            f"{'EmbeddingMoving' if world == 1 else 'ScoreMoving'}, mode={args.mode} "
+                            f"{'ScoreMoving' if distributed else 'EmbeddingMoving'}, mode={args.mode} "
                             "(gather+score+loss" + ("+backward+sparse SGD)" if args.mode == "train" else ")"),
                 "n_shard": world,
                 "shard_bs": S,
@@ -369,10 +376,10 @@ def main() -> None:
         line["kernel_avg_ms"] = extra
         if train_extra is not None:
             line["train_step"] = train_extra
-        if world == 1 and not args.no_cpu_baseline:
+        if not distributed and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -133,3 +133,22 @@ def test_distributed_device_sampler_own_rows(world):
         assert len(z[r].files) > 0
         for k in z[r].files:
             assert np.isfinite(z[r][k]).all()
+
+
+@pytest.mark.gpu
+def test_bench_distributed_path_over_rccl_single_rank():
+    """The multi-GPU leg of bench.py (ScoreMoving, DistributedGroup, pipelined begin / finish) on a
+    one-rank RCCL process group: every collective of the N > 1 path goes through RCCL with the
+    tensors the real run sends (dtypes, contiguity, side streams), which the gloo rehearsals cannot
+    show.  The line must be the same workload at nearly the single-process rate."""
+    import json
+
+    repo = os.path.dirname(HERE)
+    env = dict(os.environ, BESS_BENCH_REHEARSE_DIST="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29400 + os.getpid() % 500))
+    res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "10", "--warmup", "3",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and "ScoreMoving" in line["config"]["workload"]
+    assert line["value"] > 1e9 and line["roofline"]["frac"] > 0.3
