@@ -164,7 +164,14 @@ def sampler(out_dir: str) -> None:
 
 def main() -> None:
     mode, out_dir = sys.argv[1], sys.argv[2]
-    dist.init_process_group("gloo")
+    # gloo: several ranks share the box's one GPU (host-staged collectives); nccl (= RCCL): one rank
+    # per GPU - with a single GPU that is world_size 1, which still sends every collective through RCCL
+    backend = os.environ.get("BESS_DIST_BACKEND", "gloo")
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
     try:
         {"routing": routing, "bess": bess, "topk": topk, "sampler": sampler}[mode](out_dir)
         dist.barrier()

@@ -62,13 +62,15 @@ def _cases(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
-def test_distributed_bess_golden(world):
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo")])
+def test_distributed_bess_golden(world, backend):
+    """(1, nccl): the single-shard goldens through DistributedGroup over a one-rank RCCL group - the
+    forward and training-step collectives as RCCL sees them (the box has one GPU)."""
     from test_oracle import load_bess_case
 
     cases = _cases(world)
     assert cases
-    out = launch("bess", world, {"BESS_CASES": ",".join(cases)}, timeout=900)
+    out = launch("bess", world, {"BESS_CASES": ",".join(cases), "BESS_DIST_BACKEND": backend}, timeout=900)
     per_rank = [np.load(os.path.join(out, f"bess_{r}.npz")) for r in range(world)]
     for case in cases:
         c = load_bess_case(case)
@@ -95,15 +97,16 @@ def test_distributed_bess_golden(world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
-def test_distributed_queries_golden(world):
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo")])
+def test_distributed_queries_golden(world, backend):
     """TopKQueryBessKGE / AllScoresBESS, one process per shard, vs the reference's outputs."""
     from test_query import load_query_case, query_cases
 
     specs = [("topk", c) for c in query_cases("topk") if c.endswith(f"_n{world}")]
     specs += [("allscores", c) for c in query_cases("allscores") if c.endswith(f"_n{world}")]
     assert specs
-    out = launch("topk", world, {"BESS_CASES": ",".join(f"{f}:{c}" for f, c in specs)}, timeout=900)
+    out = launch("topk", world, {"BESS_CASES": ",".join(f"{f}:{c}" for f, c in specs), "BESS_DIST_BACKEND": backend},
+                 timeout=900)
     per_rank = [np.load(os.path.join(out, f"topk_{r}.npz")) for r in range(world)]
     for fix, case in specs:
         c = load_query_case(fix, case)
