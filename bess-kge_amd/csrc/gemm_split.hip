@@ -443,6 +443,161 @@ __global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__
 #undef BESS_INTERLEAVE
 }
 
+// ---- 256 x 128 tile, eight symmetric waves ------------------------------------------------
+// The 128 x 128 kernel above is bound by the operand lines it pulls from L2 (32 KiB per slice
+// of 1.05 MFLOP at 38-51 GB/s per CU).  A 256 x 128 tile needs 48 KiB for twice the flops.  Its
+// eight 64 x 64 wave tiles leave no room for loader waves at 256 VGPRs (two waves per SIMD), so
+// every wave does both jobs in one instruction stream: loads of slice g + 2 are issued into
+// registers before the MFMAs of slice g, slice g + 1 is written to LDS after them, one barrier
+// per slice.  Fragments are single-buffered (accumulators 128 + fragments 32 + two load stages
+// 48 VGPRs); the LDS latency of one wave is covered by the MFMAs of the other wave of its SIMD.
+// Images must be padded to whole tiles (256 / 128 rows; pad rows may hold anything - their
+// products are never stored), so a thread's six line pointers are one base plus constants.
+constexpr int W8_A = 256, W8_B = 128, W8_IMG = (W8_A + W8_B) * ROW_B;  // 48 KiB per buffer
+
+template <bool B_LO>
+__global__ __launch_bounds__(512) void k_gemm_split_w8(const char* __restrict__ A, const char* __restrict__ B,
+                                                       int64_t M, int64_t N, int n_slice,
+                                                       float* __restrict__ C, int64_t ldc, int tiles_x,
+                                                       int n_tiles, int ksplit, int64_t part_stride) {
+    extern __shared__ __attribute__((aligned(16))) char lds8[];  // [2][A rows 0-255 | B rows 0-127]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int slot = blockIdx.x, slots = gridDim.x;
+    const int my_tiles = (n_tiles - slot + slots - 1) / slots;
+    const int total = my_tiles * n_slice;
+    const int64_t pitch = static_cast<int64_t>(n_slice) * ksplit * ROW_B;
+
+    // loader role: piece (t & 7) of the lines of image rows (t >> 3) + 64 p, p = 0..3 (A) and 0..1 (B)
+    const int lrow = t >> 3, piece = t & 7;
+    const char *pa = A, *pb = B;
+    int gl = 0, sl = 0, tl = slot;  // load cursor, two slices ahead; stops on the last slice
+    auto issue = [&](u32x4 (&v)[6]) {
+        if (sl == 0) {
+            const int ot = tl / ksplit;
+            const int64_t k_off = static_cast<int64_t>(tl % ksplit) * n_slice * ROW_B + piece * 16;
+            pa = A + (static_cast<int64_t>(ot / tiles_x) * W8_A + lrow) * pitch + k_off;
+            pb = B + (static_cast<int64_t>(ot % tiles_x) * W8_B + lrow) * pitch + k_off;
+        }
+        const int64_t so = static_cast<int64_t>(sl) * ROW_B;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) v[p] = *reinterpret_cast<const u32x4*>(pa + p * 64 * pitch + so);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) v[4 + p] = *reinterpret_cast<const u32x4*>(pb + p * 64 * pitch + so);
+        if (++gl < total && ++sl == n_slice) {
+            sl = 0;
+            tl += slots;
+        }
+    };
+    auto put = [&](char* img, const u32x4 (&v)[6]) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(img + slot_off(p * 64 + lrow, piece)) = v[p];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            *reinterpret_cast<u32x4*>(img + W8_A * ROW_B + slot_off(p * 64 + lrow, piece)) = v[4 + p];
+    };
+
+    // MFMA role: wave tile 64 x 64 at (wm, wn) of the 256 x 128 tile
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int l31 = lane & 31, lk = lane >> 5;
+    int off_a[2][2], off_b[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            off_a[ks][part] = slot_off(wm + l31, ks * 2 + lk + 4 * part);
+            off_b[ks][part] = W8_A * ROW_B + slot_off(wn + l31, ks * 2 + lk + 4 * part);
+        }
+    f32x16 accm[2][2], accc[2][2];
+    auto zero = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    accm[i][j][r] = 0.f;
+                    accc[i][j][r] = 0.f;
+                }
+    };
+    zero();
+    auto kstep = [&](const char* img, int ks) {
+        h8 fa[2][2], fb[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa[i][0] = *reinterpret_cast<const h8*>(img + off_a[ks][0] + i * 32 * ROW_B);
+            fa[i][1] = *reinterpret_cast<const h8*>(img + off_a[ks][1] + i * 32 * ROW_B);
+            fb[i][0] = *reinterpret_cast<const h8*>(img + off_b[ks][0] + i * 32 * ROW_B);
+            if (B_LO) fb[i][1] = *reinterpret_cast<const h8*>(img + off_b[ks][1] + i * 32 * ROW_B);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) accm[i][j] = mma16(fa[i][0], fb[j][0], accm[i][j]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) accc[i][j] = mma16(fa[i][1], fb[j][0], accc[i][j]);
+        if (B_LO) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accc[i][j] = mma16(fa[i][0], fb[j][1], accc[i][j]);
+        }
+    };
+
+    u32x4 r0[6], r1[6];  // slices g (even) / g (odd) on their way to LDS
+    issue(r0);
+    issue(r1);
+    put(lds8, r0);
+    __syncthreads();
+    int s = 0, tile = slot;
+    // two slices per trip so that the register stages have fixed names
+    auto slice = [&](int g, u32x4 (&mine)[6], u32x4 (&next)[6]) {
+        issue(mine);  // slice g + 2 into the stage slice g has left
+        const char* img = lds8 + (g & 1) * W8_IMG;
+        kstep(img, 0);
+        kstep(img, 1);
+        put(lds8 + ((g + 1) & 1) * W8_IMG, next);  // slice g + 1 (after the last slice: a surplus copy)
+        __syncthreads();
+        if (++s == n_slice) {  // tile done: main + corr / 2048 -> C
+            const int ot = tile / ksplit;
+            const int64_t m0 = static_cast<int64_t>(ot / tiles_x) * W8_A + wm;
+            const int64_t n0 = static_cast<int64_t>(ot % tiles_x) * W8_B + wn;
+            float* c0 = C + (tile % ksplit) * part_stride + (m0 + 4 * lk) * ldc + n0 + l31;
+            if (m0 + 64 <= M && n0 + 64 <= N) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            c0[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32] =
+                                accm[i][j][r] + accc[i][j][r] * (1.f / 2048.f);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
+                            if (m0 + 4 * lk + rr < M && n0 + l31 + j * 32 < N)
+                                c0[rr * ldc + j * 32] = accm[i][j][r] + accc[i][j][r] * (1.f / 2048.f);
+                        }
+            }
+            zero();
+            s = 0;
+            tile += slots;
+        }
+    };
+    int g = 0;
+    for (; g + 2 <= total; g += 2) {
+        slice(g, r0, r1);
+        slice(g + 1, r1, r0);
+    }
+    if (g < total) slice(g, r0, r1);
+}
+
 static bool split_disabled() {
     static const bool off = [] {
         const char* e = std::getenv("BESS_GEMM_FP32");
@@ -461,6 +616,56 @@ static int n_compute_units() {
     return n;
 }
 
+// images are allocated with their rows rounded up to whole tiles of the 256 x 128 kernel
+static int64_t pad_a(int64_t rows) { return ceil_div(rows, W8_A) * W8_A; }
+static int64_t pad_b(int64_t rows) { return ceil_div(rows, W8_B) * W8_B; }
+
+static int tile_choice() {  // BESS_GEMM_TILE=128 keeps the producer / consumer kernel (A/B measurements)
+    static const int c = [] {
+        const char* e = std::getenv("BESS_GEMM_TILE");
+        return e ? std::atoi(e) : 0;
+    }();
+    return c;
+}
+
+// C[M, N] (+ k parts) = A . B^T from split images; picks the 256 x 128 kernel when the images are padded
+// to whole tiles (forward) and its tiles fill the chip: measured 3-8 % faster there, no more - the two
+// kernels meet the same wall (profiles/ubench/mfma_f16.hip: the clock the chip holds under MFMA + LDS load)
+static int launch_product(const char* A, const char* B, int64_t M, int64_t N, int n_slice, float* C, int64_t ldc,
+                          int ksplit, int64_t part_stride, bool b_lo, bool padded, hipStream_t st) {
+    const int cus = n_compute_units();
+    const int64_t tx = ceil_div(N, 128);
+    const int64_t t8 = tx * ceil_div(M, W8_A) * ksplit, t4 = tx * ceil_div(M, 128) * ksplit;
+    BESS_REQUIRE(t4 < (1ll << 31), "gemm_split: too many tiles");
+    const bool wide = padded && tile_choice() != 128 && (t8 >= cus || tile_choice() == 256);
+    if (wide) {
+        static const bool attr = [] {
+            const int bytes = 2 * W8_IMG;
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_split_w8<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_split_w8<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+        }();
+        BESS_REQUIRE(attr, "gemm_split: cannot reserve %d bytes of LDS", 2 * W8_IMG);
+        const int grid = static_cast<int>(t8 < cus ? t8 : cus);
+        if (b_lo)
+            k_gemm_split_w8<true><<<grid, 512, 2 * W8_IMG, st>>>(A, B, M, N, n_slice, C, ldc, static_cast<int>(tx),
+                                                                 static_cast<int>(t8), ksplit, part_stride);
+        else
+            k_gemm_split_w8<false><<<grid, 512, 2 * W8_IMG, st>>>(A, B, M, N, n_slice, C, ldc, static_cast<int>(tx),
+                                                                  static_cast<int>(t8), ksplit, part_stride);
+        return check_launch("gemm_split_w8");
+    }
+    const int grid = static_cast<int>(t4 < cus ? t4 : cus);
+    if (b_lo)
+        k_gemm_split_f16<true><<<grid, 512, 0, st>>>(A, B, M, N, n_slice, C, ldc, static_cast<int>(tx),
+                                                     static_cast<int>(t4), ksplit, part_stride);
+    else
+        k_gemm_split_f16<false><<<grid, 512, 0, st>>>(A, B, M, N, n_slice, C, ldc, static_cast<int>(tx),
+                                                      static_cast<int>(t4), ksplit, part_stride);
+    return check_launch("gemm_split_f16");
+}
+
 static int64_t split_pitch(int W) { return ceil_div(W, SK) * ROW_B; }
 constexpr int64_t SPLIT_CHUNK = 65536;  // candidate rows split per pass at most (128 MiB of lines at W = 512)
 
@@ -469,7 +674,7 @@ constexpr int64_t SPLIT_CHUNK = 65536;  // candidate rows split per pass at most
 int64_t gemm_split_workspace(int64_t S, int64_t N, int W) {
     if (split_disabled() || S < 1 || N < 1 || W < 1) return 0;
     if (ceil_div(N, 128) * ceil_div(S, 128) < 256) return 0;
-    return (S + (N < SPLIT_CHUNK ? N : SPLIT_CHUNK)) * split_pitch(W);
+    return (pad_a(S) + pad_b(N < SPLIT_CHUNK ? N : SPLIT_CHUNK)) * split_pitch(W);
 }
 
 // splits `a` (f32 rows; skipped when a.rows == 0) and `b` (table dtype) in one launch
@@ -497,11 +702,11 @@ int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const in
                    float* out, int64_t ld, void* ws, int64_t ws_bytes, hipStream_t st) {
     const int64_t pitch = split_pitch(W);
     BESS_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 16 == 0, "gemm_split: workspace must be 16-B aligned");
-    int64_t chunk = (ws_bytes / pitch - S) / 128 * 128;  // candidate rows per pass
+    int64_t chunk = (ws_bytes / pitch - pad_a(S)) / 128 * 128;  // candidate rows per pass
     if (chunk >= N) chunk = N;
-    BESS_REQUIRE(chunk >= 128 || chunk == N, "gemm_split: workspace too small");
+    BESS_REQUIRE(chunk >= 128, "gemm_split: workspace too small");
     char* qa = static_cast<char*>(ws);
-    char* eb = qa + S * pitch;
+    char* eb = qa + pad_a(S) * pitch;
     const int n_slice = static_cast<int>(ceil_div(W, SK));
     for (int64_t j0 = 0; j0 < N; j0 += chunk) {
         const int64_t nc = N - j0 < chunk ? N - j0 : chunk;
@@ -510,16 +715,7 @@ int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const in
         SplitSrc src{idx ? E : static_cast<const char*>(E) + j0 * W * sz, idx ? idx + j0 : nullptr, nc, W};
         // the query rows ride along with the first chunk
         if (int e = split_rows(SplitSrc{Q, nullptr, j0 == 0 ? S : 0, W}, qa, dtype, src, eb, W, st)) return e;
-        const int64_t tiles_x = ceil_div(nc, 128), tiles = tiles_x * ceil_div(S, 128);
-        BESS_REQUIRE(tiles < (1ll << 31), "gemm_split: too many tiles");
-        const int grid = static_cast<int>(tiles < n_compute_units() ? tiles : n_compute_units());
-        if (dtype == BESS_F32)
-            k_gemm_split_f16<true><<<grid, 512, 0, st>>>(qa, eb, S, nc, n_slice, out + j0, ld,
-                                                         static_cast<int>(tiles_x), static_cast<int>(tiles), 1, 0);
-        else
-            k_gemm_split_f16<false><<<grid, 512, 0, st>>>(qa, eb, S, nc, n_slice, out + j0, ld,
-                                                          static_cast<int>(tiles_x), static_cast<int>(tiles), 1, 0);
-        if (int e = check_launch("gemm_split_f16")) return e;
+        if (int e = launch_product(qa, eb, S, nc, n_slice, out + j0, ld, 1, 0, dtype == BESS_F32, true, st)) return e;
     }
     return BESS_OK;
 }
@@ -567,13 +763,8 @@ int64_t gemm_split_bwd_workspace(int64_t S, int64_t N, int W) {
 
 static int product(const char* A, const char* B, int64_t M, int64_t N, const BwdPlan& p, float* C, int64_t ldc,
                    float* parts, hipStream_t st) {
-    const int64_t tiles_x = ceil_div(N, 128), tiles = tiles_x * ceil_div(M, 128) * p.ks;
-    BESS_REQUIRE(tiles < (1ll << 31), "gemm_split: too many tiles");
-    const int grid = static_cast<int>(tiles < n_compute_units() ? tiles : n_compute_units());
     float* dst = p.ks > 1 ? parts : C;
-    k_gemm_split_f16<true><<<grid, 512, 0, st>>>(A, B, M, N, p.nblk / p.ks, dst, ldc, static_cast<int>(tiles_x),
-                                                 static_cast<int>(tiles), p.ks, M * ldc);
-    if (int e = check_launch("gemm_split_f16")) return e;
+    if (int e = launch_product(A, B, M, N, p.nblk / p.ks, dst, ldc, p.ks, M * ldc, true, false, st)) return e;
     if (p.ks > 1) {
         const int64_t n4 = M * ldc / 4;
         k_sum_parts<<<static_cast<unsigned>(ceil_div(n4, 256)), 256, 0, st>>>(parts, M * ldc, p.ks, C, n4);

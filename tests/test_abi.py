@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_workspace_query_needs_no_gpu():
     """bess_neg_score_shared_workspace is host arithmetic: bilinear scorers with >= 256 output
-    tiles of 128 x 128 ask for (S + min(N, 65536)) lines of ceil(W / 32) * 128 bytes, the rest 0."""
+    tiles of 128 x 128 ask for (S + min(N, 65536)) lines (rows rounded up to whole 256 / 128-row
+    tiles) of ceil(W / 32) * 128 bytes, the rest 0."""
     from besskge import _native
 
     lib = _native.load()
@@ -42,6 +43,7 @@ def test_workspace_query_needs_no_gpu():
         assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4096, 4096) == 0
         return
     assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4096, 4096) == (4096 + 4096) * 16 * 128
+    assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4000, 5000) == (4096 + 5120) * 16 * 128  # whole tiles
     assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4096, 1 << 20) == (4096 + 65536) * 16 * 128
     assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 512, 768) == 0  # too few tiles
     d.scorer, d.norm_p = _native.TRANSE, 1
