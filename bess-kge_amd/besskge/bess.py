@@ -387,19 +387,25 @@ class BessKGE(torch.nn.Module, ABC):
         s = state["s"]
         nat.apply_segments_opt(o, table, seg, gseg, s[0] if n_state > 0 else None, s[1] if n_state > 1 else None)
 
-    def _prefetch_segment_indices(self, steps: List[_ReplicaStep]) -> Dict[int, Any]:
-        """The inverted indices of per-triple negatives only depend on the sampled
-        indices: build them on a side stream while the forward kernels still run."""
-        seg_index: Dict[int, Any] = {}
-        dev = self.score_fn.relation_embedding.device
-        main = torch.cuda.current_stream(dev)
+    def _wants_segments(self, g: _NegGroup, st: _ReplicaStep) -> bool:
+        return not g.shared and g.neg.base is st.table and self.score_fn.supports_fused_segments
+
+    def _segment_index_on_side(self, g: _NegGroup, st: _ReplicaStep) -> Any:
+        dev = st.table.device
         side = self._aux_stream(dev)
-        side.wait_stream(main)
+        side.wait_stream(torch.cuda.current_stream(dev))  # the row ids are ready; nothing later is waited for
         with torch.cuda.stream(side):
-            for st in steps:
-                for g in st.groups:
-                    if not g.shared and g.neg.base is st.table and self.score_fn.supports_fused_segments:
-                        seg_index[id(g)] = nat.SegmentIndex(g.neg.idx, st.table.shape[0])
+            return nat.SegmentIndex(g.neg.idx, st.table.shape[0])
+
+    def _prefetch_segment_indices(self, steps: List[_ReplicaStep]) -> Dict[int, Any]:
+        """The inverted indices of per-triple negatives only depend on the sampled indices: they are
+        built on a side stream while the forward kernels run (`_run_groups_one` starts them before the
+        scoring kernel of their group is queued; groups scored elsewhere are started here)."""
+        seg_index: Dict[int, Any] = dict(getattr(self, "_seg_ahead", None) or {})
+        for st in steps:
+            for g in st.groups:
+                if self._wants_segments(g, st) and id(g) not in seg_index:
+                    seg_index[id(g)] = self._segment_index_on_side(g, st)
         return seg_index
 
     def _apply_updates(self, steps: List[_ReplicaStep], local_updates: List[List[Tuple[torch.Tensor, torch.Tensor]]],
@@ -473,6 +479,11 @@ class BessKGE(torch.nn.Module, ABC):
     # ------------------------------------------------------ group execution
     def _run_groups_one(self, g: _NegGroup, desc: nat.ModelDesc, st: Optional[_ReplicaStep] = None,
                         fuse: Optional[Dict[str, Any]] = None) -> torch.Tensor:
+        ahead = getattr(self, "_seg_ahead", None)
+        if ahead is not None and st is not None and self._wants_segments(g, st):
+            # training: the inverted index of the negatives only needs their row ids - start it on the
+            # side stream *before* the scoring kernel is queued, so that it runs under it
+            ahead[id(g)] = self._segment_index_on_side(g, st)
         if g.query is None:
             g.query, g.query_ctx = self.score_fn.query_fwd(g.side, g.ent, g.rel_idx)
         if g.shared:
@@ -695,10 +706,13 @@ class EmbeddingMovingBessKGE(BessKGE):
         n = group.n_shard
         W = self.entity_embedding_size
         self._train_fuse = [self._fusable(b) for b in batches]
+        self._seg_ahead = {}
         try:
             steps = self._score_replicas(batches)
+            seg_index = self._prefetch_segment_indices(steps)
         finally:
             self._train_fuse = None
+            self._seg_ahead = None
         desc = fn.kernel_desc()
         rel_table = fn.relation_embedding.data
         results = []
@@ -706,7 +720,6 @@ class EmbeddingMovingBessKGE(BessKGE):
         back: List[torch.Tensor] = []
         deferred: List[Tuple[torch.Tensor, _NegGroup, torch.Tensor]] = []
         local_updates: List[List[Tuple[torch.Tensor, torch.Tensor]]] = []
-        seg_index = self._prefetch_segment_indices(steps)
         for st, b in zip(steps, batches):
             out, d_pos, d_neg = self._finish(st, b, want_grad=True)
             results.append(out)
@@ -958,14 +971,16 @@ class ScoreMovingBessKGE(BessKGE):
         W = self.entity_embedding_size
         scheme = self.negative_sampler.corruption_scheme
         self._training_pass = True  # the backward needs the gathered embeddings, not finished queries
+        self._seg_ahead = {}
         try:
             steps = self._score_replicas(batches)
+            seg_index = self._prefetch_segment_indices(steps)
         finally:
             self._training_pass = False
+            self._seg_ahead = None
         desc = fn.kernel_desc()
         rel_table = fn.relation_embedding.data
         d_rel = torch.zeros(rel_table.shape, dtype=torch.float32, device=rel_table.device)
-        seg_index = self._prefetch_segment_indices(steps)
         results, d_scores, d_tails = [], [], []
         local_updates: List[List[Tuple[torch.Tensor, torch.Tensor]]] = []
         for st, b in zip(steps, batches):
