@@ -12,7 +12,7 @@ on a CUDA/HIP device or if the library is missing.
 
 import ctypes
 import pathlib
-from typing import Any, Optional, Sequence, Tuple
+from typing import Any, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -121,8 +121,9 @@ SIGNATURES = {
     "bess_sparse_sgd": [_i32, _i32, _vp, _vp, _vp, _i64, _f32, _vp],
     "bess_dense_sgd": [_i32, _vp, _vp, _i64, _f32, _vp],
     "bess_segment_index_workspace": [_i64, ctypes.POINTER(ctypes.c_size_t)],
-    "bess_build_segment_index": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
-    "bess_neg_pertriple_grad_segments": [_MD, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _vp],
+    "bess_build_segment_index": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, ctypes.c_size_t, _vp],
+    "bess_neg_pertriple_grad_segments": [_MD, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _f32,
+                                         _vp, _i64, _vp, _vp, _vp],
     "bess_apply_segments_sgd": [_i32, _i32, _vp, _vp, _vp, _i64, _vp, _f32, _vp],
     "bess_segment_sum_rows": [_i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "bess_topk_update": [_vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _i32, _vp],
@@ -691,12 +692,17 @@ def dense_sgd(table: torch.Tensor, grad: torch.Tensor, lr: float) -> None:
     _check(rc, "bess_dense_sgd")
 
 
+SEGMENT_CAP = 256  # BESS_SEGMENT_CAP of include/besskge_hip.h
+
+
 class SegmentIndex:
     """References grouped by destination row (see bess_build_segment_index)."""
 
-    __slots__ = ("refs", "seg_rows", "seg_offsets", "n_seg", "n_refs", "max_seg")
+    __slots__ = ("refs", "seg_rows", "seg_offsets", "n_seg", "n_refs", "max_seg", "long_segs", "long_cap", "long_count", "long_grad")
 
-    def __init__(self, idx: torch.Tensor, n_rows: int) -> None:
+    def __init__(self, idx: torch.Tensor, n_rows: int, width: int = 0) -> None:
+        """`width` (row width W of the table the gradients are for): lets the scratch of the long-row
+        tier be prepared with the index instead of at the first reduction."""
         dev = _dev(idx, "idx")
         ip = _idx(idx, "idx")
         n = int(idx.numel())
@@ -709,12 +715,21 @@ class SegmentIndex:
         self.n_seg = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.n_refs = n
         self.max_seg = min(n, int(n_rows))
+        # rows with more than SEGMENT_CAP references (padded candidate lists, hot entities): listed
+        # here, reduced by the whole device instead of one 16-lane group (include/besskge_hip.h)
+        self.long_cap = n // SEGMENT_CAP + 1
+        self.long_segs = torch.empty((self.long_cap + 1,), dtype=torch.int32, device=dev)
         bits = max(1, int(n_rows - 1).bit_length())
         with torch.cuda.device(dev), _Timed("bess_build_segment_index", dev):
             rc = load().bess_build_segment_index(ip, n, bits, self.refs.data_ptr(), self.seg_rows.data_ptr(),
-                                                 self.seg_offsets.data_ptr(), self.n_seg.data_ptr(), ws.data_ptr(),
+                                                 self.seg_offsets.data_ptr(), self.n_seg.data_ptr(),
+                                                 self.long_segs.data_ptr(), self.long_cap, ws.data_ptr(),
                                                  need.value, _stream(dev))
         _check(rc, "bess_build_segment_index")
+        # scratch of the long-row tier: zero before the first use, left zero / consistent by every use;
+        # zeroed here, i.e. on the stream that builds the index (off the critical path of a training step)
+        self.long_count = torch.zeros((self.long_cap,), dtype=torch.int32, device=dev)
+        self.long_grad = torch.zeros((self.long_cap, int(width)), dtype=torch.float32, device=dev) if width else None
 
 
 def neg_pertriple_grad_segments(d: ModelDesc, query: torch.Tensor, table: torch.Tensor, n_neg: int,
@@ -733,13 +748,21 @@ def neg_pertriple_grad_segments(d: ModelDesc, query: torch.Tensor, table: torch.
         raise ValueError("neg_pertriple_grad_segments: operand shapes do not match")
     fused = fused_sgd_lr is not None
     grad = None if fused else torch.empty((seg.max_seg, d.width), dtype=torch.float32, device=dev)
+    native = d.scorer <= COMPLEX  # the affine family reduces every row in one group (no long-row tier)
+    if native and (seg.long_grad is None or seg.long_grad.shape[1] != d.width):
+        seg.long_grad = torch.zeros((seg.long_cap, d.width), dtype=torch.float32, device=dev)
+    long_grad = seg.long_grad
     with torch.cuda.device(dev), _Timed("bess_neg_pertriple_grad_segments", dev):
         rc = load().bess_neg_pertriple_grad_segments(ctypes.byref(d), query.data_ptr(), nq, table.data_ptr(), n_neg,
                                                      d_out.data_ptr(), n_neg, seg.refs.data_ptr(),
                                                      seg.seg_rows.data_ptr(), seg.seg_offsets.data_ptr(),
                                                      seg.n_seg.data_ptr(), seg.max_seg,
                                                      0 if fused else grad.data_ptr(),
-                                                     float(fused_sgd_lr) if fused else 0.0, _stream(dev))
+                                                     float(fused_sgd_lr) if fused else 0.0,
+                                                     seg.long_segs.data_ptr() if native else None,
+                                                     seg.long_cap if native else 0,
+                                                     long_grad.data_ptr() if native else None,
+                                                     seg.long_count.data_ptr() if native else None, _stream(dev))
     _check(rc, "bess_neg_pertriple_grad_segments")
     return grad
 

@@ -395,7 +395,7 @@ class BessKGE(torch.nn.Module, ABC):
         side = self._aux_stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))  # the row ids are ready; nothing later is waited for
         with torch.cuda.stream(side):
-            return nat.SegmentIndex(g.neg.idx, st.table.shape[0])
+            return nat.SegmentIndex(g.neg.idx, st.table.shape[0], width=st.table.shape[1])
 
     def _prefetch_segment_indices(self, steps: List[_ReplicaStep]) -> Dict[int, Any]:
         """The inverted indices of per-triple negatives only depend on the sampled indices: they are

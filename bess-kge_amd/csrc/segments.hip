@@ -75,7 +75,84 @@ struct SegArgs {
     int W;
     int nch;
     float sign;
+    const int32_t* long_segs;    // optional: [0] = number of segments longer than SEG_CAP, [1..] = their ids
 };
+
+// A row that collects very many references (padded candidate lists, a hot entity) would keep one
+// 16-lane group busy for its whole length - 1 % of a million references on one row made the pass 30 x
+// slower.  Segments longer than SEG_CAP are therefore left out of the per-row pass and handled by the
+// whole grid: every group takes slices of SEG_CAP references, partial sums meet in a scratch row through
+// float atomics, a last small kernel applies / stores the row.  (Rows below the cap stay on the
+// atomic-free, bitwise reproducible path.)
+constexpr int SEG_CAP = BESS_SEGMENT_CAP;
+
+__global__ void k_find_long_segments(const int32_t* __restrict__ seg_offsets, const int32_t* __restrict__ n_seg,
+                                     int32_t* __restrict__ long_segs, int32_t capacity) {
+    const int n = *n_seg;
+    for (int s = blockIdx.x * 256 + threadIdx.x; s < n; s += 256 * gridDim.x) {
+        if (seg_offsets[s + 1] - seg_offsets[s] > SEG_CAP) {
+            const int li = atomicAdd(&long_segs[0], 1);
+            if (li < capacity) long_segs[1 + li] = s;
+        }
+    }
+}
+
+// acc += gradient contributions of references [r0, r1) (one destination row, held in `ev` for the
+// distance scorers) - lanes of a 16-lane group stride the row.
+// One reference = its query row (W floats) and one score gradient.  The references are visited two
+// at a time with the loads of the next one issued before the arithmetic of the current one, and their
+// ids are fetched two references ahead: before, every reference cost two dependent round trips (id,
+// then query row) in front of its FMAs.
+template <int VEC, int IT, int RED>
+__device__ __forceinline__ void seg_accumulate(const SegArgs& a, int g, const float (&ev)[IT][VEC], int r0, int r1,
+                                               float (&acc)[IT][VEC]) {
+    auto fetch = [&](int ref, float (&qv)[IT][VEC], float& go) {
+        const int q = ref / a.n_neg;
+        const int k = ref - q * a.n_neg;
+        go = a.sign * a.d_out[q * a.ld_dout + k];
+        const float* qp = a.query + static_cast<int64_t>(q) * a.W;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) load_chunk<float, VEC>(qp, g + 16 * it, a.nch, qv[it]);
+    };
+    auto accumulate = [&](const float (&qv)[IT][VEC], float go) {
+        if (RED == RED_L2) {
+            float ss = 0.f;
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const float dlt = qv[it][v] - ev[it][v];
+                    ss = fmaf(dlt, dlt, ss);
+                }
+            ss = row16_allreduce_sum(ss);
+            go = ss > 0.f ? go / sqrtf(ss) : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                if (RED == RED_DOT) acc[it][v] = fmaf(go, qv[it][v], acc[it][v]);
+                else if (RED == RED_L1) acc[it][v] -= go * sgnf(qv[it][v] - ev[it][v]);
+                else acc[it][v] = fmaf(-go, qv[it][v] - ev[it][v], acc[it][v]);
+            }
+    };
+    if (r0 >= r1) return;
+    const int last = r1 - 1;
+    float qa[IT][VEC], qb[IT][VEC], ga, gb;
+    int ref_b = a.refs[min(r0 + 1, last)];
+    fetch(a.refs[r0], qa, ga);
+    int r = r0;
+    for (; r + 2 <= r1; r += 2) {
+        const int ref_a2 = a.refs[min(r + 2, last)];
+        fetch(ref_b, qb, gb);
+        accumulate(qa, ga);
+        const int ref_b2 = a.refs[min(r + 3, last)];
+        fetch(ref_a2, qa, ga);  // past the end: the last reference again, not accumulated
+        accumulate(qb, gb);
+        ref_b = ref_b2;
+    }
+    if (r < r1) accumulate(qa, ga);
+}
 
 // grad_seg != NULL: write the per-row gradient.  grad_seg == NULL: apply SGD in
 // place, table[row] -= lr * grad (each row is owned by exactly one 16-lane
@@ -92,6 +169,7 @@ __global__ __launch_bounds__(256) void k_pertriple_grad_segments(SegArgs a, floa
     for (int64_t seg = group0; seg < n_seg; seg += n_group) {
         const int64_t row = a.seg_rows[seg];
         const int r0 = a.seg_offsets[seg], r1 = a.seg_offsets[seg + 1];
+        if (a.long_segs && r1 - r0 > SEG_CAP) continue;  // left to k_long_segments_*
         float ev[IT][VEC], acc[IT][VEC];
         // the row itself: needed inside the loop by the distance scorers, only for the final
         // read-modify-write by the dot-product scorers (loaded late there: 32 registers less in the loop)
@@ -106,57 +184,7 @@ __global__ __launch_bounds__(256) void k_pertriple_grad_segments(SegArgs a, floa
             }
             if (EV_EARLY) load_chunk<T, VEC>(table + row * a.W, c, a.nch, ev[it]);
         }
-        // One reference = its query row (W floats) and one score gradient.  The references of a row
-        // are visited two at a time with the loads of the next one issued before the arithmetic of
-        // the current one, and their ids are fetched two references ahead: before, every reference
-        // cost two dependent round trips (id, then query row) in front of its FMAs.
-        auto fetch = [&](int ref, float (&qv)[IT][VEC], float& go) {
-            const int q = ref / a.n_neg;
-            const int k = ref - q * a.n_neg;
-            go = a.sign * a.d_out[q * a.ld_dout + k];
-            const float* qp = a.query + static_cast<int64_t>(q) * a.W;
-#pragma unroll
-            for (int it = 0; it < IT; ++it) load_chunk<float, VEC>(qp, g + 16 * it, a.nch, qv[it]);
-        };
-        auto accumulate = [&](const float (&qv)[IT][VEC], float go) {
-            if (RED == RED_L2) {
-                float ss = 0.f;
-#pragma unroll
-                for (int it = 0; it < IT; ++it)
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        const float dlt = qv[it][v] - ev[it][v];
-                        ss = fmaf(dlt, dlt, ss);
-                    }
-                ss = row16_allreduce_sum(ss);
-                go = ss > 0.f ? go / sqrtf(ss) : 0.f;
-            }
-#pragma unroll
-            for (int it = 0; it < IT; ++it)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    if (RED == RED_DOT) acc[it][v] = fmaf(go, qv[it][v], acc[it][v]);
-                    else if (RED == RED_L1) acc[it][v] -= go * sgnf(qv[it][v] - ev[it][v]);
-                    else acc[it][v] = fmaf(-go, qv[it][v] - ev[it][v], acc[it][v]);
-                }
-        };
-        if (r0 < r1) {
-            const int last = r1 - 1;
-            float qa[IT][VEC], qb[IT][VEC], ga, gb;
-            int ref_b = a.refs[min(r0 + 1, last)];
-            fetch(a.refs[r0], qa, ga);
-            int r = r0;
-            for (; r + 2 <= r1; r += 2) {
-                const int ref_a2 = a.refs[min(r + 2, last)];
-                fetch(ref_b, qb, gb);
-                accumulate(qa, ga);
-                const int ref_b2 = a.refs[min(r + 3, last)];
-                fetch(ref_a2, qa, ga);  // past the end: the last reference again, not accumulated
-                accumulate(qb, gb);
-                ref_b = ref_b2;
-            }
-            if (r < r1) accumulate(qa, ga);
-        }
+        seg_accumulate<VEC, IT, RED>(a, g, ev, r0, r1, acc);
         if (!EV_EARLY && grad_seg == nullptr) {
 #pragma unroll
             for (int it = 0; it < IT; ++it) load_chunk<T, VEC>(table + row * a.W, g + 16 * it, a.nch, ev[it]);
@@ -180,6 +208,74 @@ __global__ __launch_bounds__(256) void k_pertriple_grad_segments(SegArgs a, floa
 #pragma unroll
                     for (int v = 0; v < VEC; ++v)
                         out[c * VEC + v] = static_cast<T>(ev[it][v] - lr * acc[it][v]);
+                }
+            }
+        }
+    }
+}
+
+// Long segments: all groups share the slices of SEG_CAP references of every long segment; partial sums
+// are added to long_grad[li, :] (all zero on entry).  The group that completes the last slice of a row
+// (a counter per row, never reset: it grows by `parts` per pass) reads the sum back, puts it where the
+// per-row pass would have (gradient row, or the fused SGD step) and leaves the scratch row zero again.
+template <typename T, int VEC, int IT, int RED>
+__global__ __launch_bounds__(256) void k_long_segments(SegArgs a, float* __restrict__ long_grad,
+                                                       int32_t* __restrict__ long_cnt, int32_t capacity,
+                                                       float* __restrict__ grad_seg, T* __restrict__ table_rw,
+                                                       float lr) {
+    const int lane = threadIdx.x & 63, g = lane & 15;
+    const int64_t group0 = (blockIdx.x * 256ll + threadIdx.x) >> 4;
+    const int64_t n_group = (gridDim.x * 256ll) >> 4;
+    const int n_long = min(a.long_segs[0], capacity);
+    const T* table = static_cast<const T*>(a.table);
+    for (int li = 0; li < n_long; ++li) {
+        const int seg = a.long_segs[1 + li];
+        const int64_t row = a.seg_rows[seg];
+        const int r0 = a.seg_offsets[seg], r1 = a.seg_offsets[seg + 1];
+        const int parts = (r1 - r0 + SEG_CAP - 1) / SEG_CAP;
+        if (group0 >= parts) continue;
+        float ev[IT][VEC];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) ev[it][v] = 0.f;
+            if (RED != RED_DOT || grad_seg == nullptr) load_chunk<T, VEC>(table + row * a.W, g + 16 * it, a.nch, ev[it]);
+        }
+        float* sum = long_grad + static_cast<int64_t>(li) * a.W;
+        for (int64_t p = group0; p < parts; p += n_group) {
+            float acc[IT][VEC];
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[it][v] = 0.f;
+            const int rb = r0 + static_cast<int>(p) * SEG_CAP;
+            seg_accumulate<VEC, IT, RED>(a, g, ev, rb, min(r1, rb + SEG_CAP), acc);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = g + 16 * it;
+                if (c < a.nch) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) atomicAdd(sum + c * VEC + v, acc[it][v]);
+                }
+            }
+            __threadfence();  // this group's adds are performed before its slice is counted
+            int old = 0;
+            if (g == 0) old = atomicAdd(long_cnt + li, 1);
+            old = __shfl(old, lane & 48, 64);  // from the first lane of the 16-lane group
+            if ((old + 1) % parts != 0) continue;
+            __threadfence();
+            // last slice of the row: every partial sum is in (device-scope loads: past the L1)
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = g + 16 * it;
+                if (c >= a.nch) continue;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    float* sp = sum + c * VEC + v;
+                    const float tot = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (grad_seg) grad_seg[static_cast<int64_t>(seg) * a.W + c * VEC + v] = tot;
+                    else table_rw[row * a.W + c * VEC + v] = static_cast<T>(ev[it][v] - lr * tot);
+                    __hip_atomic_store(sp, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -273,8 +369,17 @@ __global__ __launch_bounds__(256) void k_apply_segments_opt(OptArgs o, T* __rest
 
 template <typename T, int VEC, int IT>
 static void seg_by_red(int red, const SegArgs& a, float* grad_seg, void* table_rw, float lr, unsigned grid,
-                       hipStream_t st) {
+                       hipStream_t st, float* long_grad = nullptr, int32_t* long_cnt = nullptr, int32_t long_cap = 0) {
     T* rw = static_cast<T*>(table_rw);
+    if (long_grad) {  // the slices of the long segments, all groups together
+        if (red == RED_DOT)
+            k_long_segments<T, VEC, IT, RED_DOT><<<grid, 256, 0, st>>>(a, long_grad, long_cnt, long_cap, grad_seg, rw, lr);
+        else if (red == RED_L1)
+            k_long_segments<T, VEC, IT, RED_L1><<<grid, 256, 0, st>>>(a, long_grad, long_cnt, long_cap, grad_seg, rw, lr);
+        else
+            k_long_segments<T, VEC, IT, RED_L2><<<grid, 256, 0, st>>>(a, long_grad, long_cnt, long_cap, grad_seg, rw, lr);
+        return;
+    }
     if (red == RED_DOT) k_pertriple_grad_segments<T, VEC, IT, RED_DOT><<<grid, 256, 0, st>>>(a, grad_seg, rw, lr);
     else if (red == RED_L1) k_pertriple_grad_segments<T, VEC, IT, RED_L1><<<grid, 256, 0, st>>>(a, grad_seg, rw, lr);
     else k_pertriple_grad_segments<T, VEC, IT, RED_L2><<<grid, 256, 0, st>>>(a, grad_seg, rw, lr);
@@ -282,12 +387,12 @@ static void seg_by_red(int red, const SegArgs& a, float* grad_seg, void* table_r
 
 template <typename T, int VEC>
 static int seg_by_it(int it, int red, const SegArgs& a, float* grad_seg, void* rw, float lr, unsigned grid,
-                     hipStream_t st) {
-    if (it <= 1) seg_by_red<T, VEC, 1>(red, a, grad_seg, rw, lr, grid, st);
-    else if (it <= 2) seg_by_red<T, VEC, 2>(red, a, grad_seg, rw, lr, grid, st);
-    else if (it <= 4) seg_by_red<T, VEC, 4>(red, a, grad_seg, rw, lr, grid, st);
-    else if (it <= 8) seg_by_red<T, VEC, 8>(red, a, grad_seg, rw, lr, grid, st);
-    else if (it <= 16) seg_by_red<T, VEC, 16>(red, a, grad_seg, rw, lr, grid, st);
+                     hipStream_t st, float* long_grad = nullptr, int32_t* long_cnt = nullptr, int32_t long_cap = 0) {
+    if (it <= 1) seg_by_red<T, VEC, 1>(red, a, grad_seg, rw, lr, grid, st, long_grad, long_cnt, long_cap);
+    else if (it <= 2) seg_by_red<T, VEC, 2>(red, a, grad_seg, rw, lr, grid, st, long_grad, long_cnt, long_cap);
+    else if (it <= 4) seg_by_red<T, VEC, 4>(red, a, grad_seg, rw, lr, grid, st, long_grad, long_cnt, long_cap);
+    else if (it <= 8) seg_by_red<T, VEC, 8>(red, a, grad_seg, rw, lr, grid, st, long_grad, long_cnt, long_cap);
+    else if (it <= 16) seg_by_red<T, VEC, 16>(red, a, grad_seg, rw, lr, grid, st, long_grad, long_cnt, long_cap);
     else return fail(BESS_EUNSUPPORTED, "grad_segments: row of %d scalars too wide", a.W);
     return BESS_OK;
 }
@@ -309,8 +414,10 @@ extern "C" int bess_segment_index_workspace(int64_t n_refs, size_t* bytes) {
 
 extern "C" int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int32_t row_bits,
                                         int32_t* refs_sorted, int32_t* seg_rows, int32_t* seg_offsets,
-                                        int32_t* n_seg, void* workspace, size_t workspace_bytes,
-                                        void* stream) {
+                                        int32_t* n_seg, int32_t* long_segs, int64_t long_cap, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    BESS_REQUIRE(!long_segs || long_cap >= n_refs / SEG_CAP + 1, "build_segment_index: long_cap < n_refs / %d + 1",
+                 SEG_CAP);
     BESS_REQUIRE(n_refs > 0 && n_refs < (1ll << 31), "build_segment_index: n_refs out of range");
     BESS_REQUIRE(idx && refs_sorted && seg_rows && seg_offsets && n_seg && workspace, "build_segment_index: NULL pointer");
     BESS_REQUIRE(row_bits >= 1 && row_bits <= 31, "build_segment_index: row_bits out of range");
@@ -338,6 +445,12 @@ extern "C" int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int3
     e = hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, counts, seg_offsets, n, st);
     if (e != hipSuccess) return fail(static_cast<int>(e), "exclusive scan: %s", hipGetErrorString(e));
     k_close_offsets<<<1, 64, 0, st>>>(seg_offsets, n_seg, static_cast<int32_t>(n_refs));
+    if (long_segs) {
+        e = hipMemsetAsync(long_segs, 0, sizeof(int32_t), st);
+        if (e != hipSuccess) return fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
+        k_find_long_segments<<<static_cast<unsigned>(std::min<int64_t>(ceil_div(n_refs, 256), 1024)), 256, 0, st>>>(
+            seg_offsets, n_seg, long_segs, static_cast<int32_t>(long_cap));
+    }
     return check_launch("build_segment_index");
 }
 
@@ -346,8 +459,12 @@ extern "C" int bess_neg_pertriple_grad_segments(const bess_model_desc* d, const 
                                                 int64_t ld_dout, const int32_t* refs_sorted,
                                                 const int32_t* seg_rows, const int32_t* seg_offsets,
                                                 const int32_t* n_seg, int64_t max_seg, float* grad_seg,
-                                                float fused_sgd_lr, void* stream) {
+                                                float fused_sgd_lr, const int32_t* long_segs,
+                                                int64_t long_cap, float* long_grad, int32_t* long_count,
+                                                void* stream) {
     if (int e = check_desc(d)) return e;
+    BESS_REQUIRE(!long_segs || (long_grad && long_count && long_cap >= n_query * n_neg / SEG_CAP + 1),
+                 "grad_segments: long_segs needs long_grad, long_count and long_cap >= n_refs / %d + 1", SEG_CAP);
     BESS_REQUIRE(n_query > 0 && n_neg > 0 && n_query * n_neg < (1ll << 31), "grad_segments: bad sizes");
     BESS_REQUIRE(query && table && d_out && refs_sorted && seg_rows && seg_offsets && n_seg,
                  "grad_segments: NULL pointer");
@@ -382,7 +499,7 @@ extern "C" int bess_neg_pertriple_grad_segments(const bess_model_desc* d, const 
         const int cols = W - col0 < win ? W - col0 : win;
         char* tab = static_cast<char*>(table) + col0 * sz;
         SegArgs a{query + col0, tab, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg,
-                  static_cast<int>(n_neg), W, cols / vec, is_distance(d->scorer) ? -1.f : 1.f};
+                  static_cast<int>(n_neg), W, cols / vec, is_distance(d->scorer) ? -1.f : 1.f, long_segs};
         const int it = static_cast<int>(ceil_div(a.nch, 16));
         float* gs = grad_seg ? grad_seg + col0 : nullptr;
         int rc;
@@ -393,6 +510,23 @@ extern "C" int bess_neg_pertriple_grad_segments(const bess_model_desc* d, const 
             rc = (vec == 8) ? seg_by_it<half_t, 8>(it, red, a, gs, tab, fused_sgd_lr, grid, st)
                  : (vec == 2) ? seg_by_it<half_t, 2>(it, red, a, gs, tab, fused_sgd_lr, grid, st)
                               : seg_by_it<half_t, 1>(it, red, a, gs, tab, fused_sgd_lr, grid, st);
+        }
+        if (rc) return rc;
+    }
+    if (long_segs) {  // the rows left out above (usually none: one launch that finds nothing to do)
+        const int32_t cap = static_cast<int32_t>(long_cap);
+        SegArgs a{query, table, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg,
+                  static_cast<int>(n_neg), W, W / vec, is_distance(d->scorer) ? -1.f : 1.f, long_segs};
+        const int it = static_cast<int>(ceil_div(a.nch, 16));
+        const unsigned lgrid = 1024;  // 16 K groups share the slices
+        int rc;
+        if (d->dtype == BESS_F32) {
+            rc = (vec == 4) ? seg_by_it<float, 4>(it, red, a, grad_seg, table, fused_sgd_lr, lgrid, st, long_grad, long_count, cap)
+                            : seg_by_it<float, 1>(it, red, a, grad_seg, table, fused_sgd_lr, lgrid, st, long_grad, long_count, cap);
+        } else {
+            rc = (vec == 8) ? seg_by_it<half_t, 8>(it, red, a, grad_seg, table, fused_sgd_lr, lgrid, st, long_grad, long_count, cap)
+                 : (vec == 2) ? seg_by_it<half_t, 2>(it, red, a, grad_seg, table, fused_sgd_lr, lgrid, st, long_grad, long_count, cap)
+                              : seg_by_it<half_t, 1>(it, red, a, grad_seg, table, fused_sgd_lr, lgrid, st, long_grad, long_count, cap);
         }
         if (rc) return rc;
     }

@@ -302,11 +302,17 @@ int bess_sparse_sgd(int32_t dtype, int32_t width, void* table, const int32_t* id
  *   refs_sorted [n_refs] (reference ids ordered by row, ties in reference order),
  *   seg_rows [n_refs] (row of each segment), seg_offsets [n_refs + 1],
  *   n_seg [1] (device scalar: number of unique rows, read by the consumers so
- *   that no host synchronisation is needed). */
+ *   that no host synchronisation is needed);
+ *   long_segs (optional, int32 [long_cap + 1], long_cap >= n_refs / BESS_SEGMENT_CAP + 1):
+ *   [0] = number of segments with more than BESS_SEGMENT_CAP references, [1..] their ids
+ *   (any order) - rows that very many references point at (padded candidate lists, hot
+ *   entities), which bess_neg_pertriple_grad_segments spreads over the whole device. */
+#define BESS_SEGMENT_CAP 256
 int bess_segment_index_workspace(int64_t n_refs, size_t* bytes);
 int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int32_t row_bits,
                              int32_t* refs_sorted, int32_t* seg_rows,
-                             int32_t* seg_offsets, int32_t* n_seg, void* workspace,
+                             int32_t* seg_offsets, int32_t* n_seg, int32_t* long_segs,
+                             int64_t long_cap, void* workspace,
                              size_t workspace_bytes, void* stream);
 
 /* grad_seg[s, :] (f32 [max_seg, W], rows >= *n_seg untouched) = sum over the
@@ -315,14 +321,23 @@ int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int32_t row_bit
  * d_neg, summed per destination row; nothing of size [n_refs, W] is written.
  * With grad_seg == NULL the SGD step is fused: table[seg_rows[s]] -=
  * fused_sgd_lr * (that sum), each row read and written by its one owner (use
- * only when no later gradient computation still needs the old rows). */
+ * only when no later gradient computation still needs the old rows).
+ * long_segs / long_cap as filled by bess_build_segment_index, plus long_grad (f32
+ * [long_cap, W]) and long_count (int32 [long_cap]) - scratch that must be ALL ZERO before
+ * the first call and is left usable for the next one (sums are zeroed again, counters only
+ * grow) - or NULL / 0 / NULL / NULL: segments beyond BESS_SEGMENT_CAP references are then
+ * summed by all workgroups together (partial sums through float atomics into long_grad,
+ * the group that adds the last slice of a row writes it out) instead of by one 16-lane
+ * group each. */
 int bess_neg_pertriple_grad_segments(const bess_model_desc* d, const float* query,
                                      int64_t n_query, void* table, int64_t n_neg,
                                      const float* d_out, int64_t ld_dout,
                                      const int32_t* refs_sorted, const int32_t* seg_rows,
                                      const int32_t* seg_offsets, const int32_t* n_seg,
                                      int64_t max_seg, float* grad_seg,
-                                     float fused_sgd_lr, void* stream);
+                                     float fused_sgd_lr, const int32_t* long_segs,
+                                     int64_t long_cap, float* long_grad, int32_t* long_count,
+                                     void* stream);
 
 /* K10 on unique rows: table[seg_rows[s], :] -= lr * grad_seg[s, :], s < *n_seg
  * (plain read-modify-write: one rounding per row and step, also for f16). */

@@ -804,3 +804,39 @@ def test_split_gemm_training_step_under_graph_capture(dev):
     # the row updates go through float atomics (duplicate rows among heads / tails / negatives): order-dependent rounding
     torch.testing.assert_close(ent_e, ent_g, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(rel_e, rel_g, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,p", NATIVE_SCORERS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_grad_segments_with_rows_that_many_references_point_at(dev, name, p, dtype):
+    """Rows with more than BESS_SEGMENT_CAP references (padded candidate lists, hot entities) are
+    reduced by the whole device through partial sums; the result - gradient rows and the fused SGD
+    step - is that of the per-reference backward scattered by index_add, as for ordinary rows."""
+    from besskge import _native as nat
+    from besskge._native import RowSource
+
+    gen = torch.Generator().manual_seed(11)
+    M, d, S, N = 500, 24, 150, 40   # 6000 references
+    W, Wr = widths(name, d)
+    table = torch.randn(M, W, generator=gen).to(dtype).to(dev)
+    q = torch.randn(S, W, generator=gen).to(dev)
+    idx = torch.randint(M, (S * N,), generator=gen, dtype=torch.int32)
+    sel = torch.rand(S * N, generator=gen)
+    idx[sel < 0.25] = 3          # ~1500 references: 6 slices of 256
+    idx[(sel >= 0.25) & (sel < 0.31)] = 77   # ~360 references: 2 slices
+    idx = idx.to(dev)
+    go = (torch.randn(S, N, generator=gen) * 0.1).to(dev)
+    desc = nat.make_desc(dict(TransE=0, RotatE=1, DistMult=2, ComplEx=3)[name], max(p, 1), table, Wr)
+    _, dn = nat.neg_score_pertriple_bwd(desc, q, RowSource(table, idx), N, go)
+    seg = nat.SegmentIndex(idx, M)
+    n_seg = int(seg.n_seg.item())
+    assert int(seg.long_segs[0].item()) == 2
+    assert sorted(seg.seg_rows[seg.long_segs[1:3].long()].cpu().tolist()) == [3, 77]
+    uniq = torch.unique(idx.cpu().long())
+    want = torch.zeros(M, W, dtype=torch.float64).index_add_(0, idx.cpu().long(), dn.cpu().double())
+    g1 = nat.neg_pertriple_grad_segments(desc, q, table, N, go, seg)
+    close(g1[:n_seg], want[uniq].float(), rtol=1e-4, atol=1e-5, scale=2e-6)
+    t2 = table.clone()
+    nat.neg_pertriple_grad_segments(desc, q, t2, N, go, seg, fused_sgd_lr=0.5)
+    want_t = table.float().cpu() - 0.5 * want.float()
+    close(t2, want_t, rtol=2e-3 if dtype == torch.float16 else 1e-5, atol=4e-3 if dtype == torch.float16 else 1e-5)
