@@ -557,31 +557,15 @@ struct AffSegArgs {
     int d;
     int nch;
     int normalize;
+    const int32_t* long_segs;    // optional: rows with more than BESS_SEGMENT_CAP references (segments.hip)
 };
 
-template <typename T, int VEC, int IT, int NPART, int P>
-__global__ __launch_bounds__(256) void k_aff_grad_segments(AffSegArgs a, float* __restrict__ grad_seg, T* table_rw,
-                                                           float lr) {
-    const int lane = threadIdx.x & 63;
-    const int g = lane & 15;
-    const int n_seg = *a.n_seg;
-    const int64_t group0 = (blockIdx.x * 256ll + threadIdx.x) >> 4;
-    const int64_t n_group = (gridDim.x * 256ll) >> 4;
-    const T* table = static_cast<const T*>(a.table);
-    const int W = NPART * a.d;
-    for (int64_t seg = group0; seg < n_seg; seg += n_group) {
-        const int64_t row = a.seg_rows[seg];
-        const int r0 = a.seg_offsets[seg], r1 = a.seg_offsets[seg + 1];
-        float ev[NPART][IT][VEC], inv[NPART], dc[NPART][IT][VEC];
-        aff_load_row<T, VEC, IT, NPART>(table + row * W, g, a.d, a.nch, ev);
-        aff_inv_norm<VEC, IT, NPART>(ev, a.normalize, inv);
-#pragma unroll
-        for (int p = 0; p < NPART; ++p)
-#pragma unroll
-            for (int it = 0; it < IT; ++it)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) dc[p][it][v] = 0.f;
-        for (int r = r0; r < r1; ++r) {
+// dc += contributions of references [r0, r1) of one destination row (ev, inv: the row and its part norms)
+template <int VEC, int IT, int NPART, int P>
+__device__ __forceinline__ void aff_seg_accumulate(const AffSegArgs& a, int g, const float (&ev)[NPART][IT][VEC],
+                                                   const float (&inv)[NPART], int r0, int r1,
+                                                   float (&dc)[NPART][IT][VEC]) {
+    for (int r = r0; r < r1; ++r) {
             const int ref = a.refs[r];
             const int q = ref / a.n_neg;
             const int k = ref - q * a.n_neg;
@@ -610,6 +594,15 @@ __global__ __launch_bounds__(256) void k_aff_grad_segments(AffSegArgs a, float* 
                     for (int p = 0; p < NPART; ++p) dc[p][it][v] = fmaf(sc, qv[p][it][v], dc[p][it][v]);
                 }
         }
+}
+
+// summed d score / d c_p of a row -> gradient of the stored row (normalisation backward, once) -> output
+template <typename T, int VEC, int IT, int NPART>
+__device__ __forceinline__ void aff_seg_finish(const AffSegArgs& a, int g, const float (&ev)[NPART][IT][VEC],
+                                               const float (&inv)[NPART], const float (&dc)[NPART][IT][VEC],
+                                               int64_t seg, int64_t row, float* __restrict__ grad_seg, T* table_rw,
+                                               float lr) {
+    const int W = NPART * a.d;
 #pragma unroll
         for (int p = 0; p < NPART; ++p) {
             float dot = 0.f;
@@ -636,16 +629,115 @@ __global__ __launch_bounds__(256) void k_aff_grad_segments(AffSegArgs a, float* 
                 }
             }
         }
+}
+
+template <typename T, int VEC, int IT, int NPART, int P>
+__global__ __launch_bounds__(256) void k_aff_grad_segments(AffSegArgs a, float* __restrict__ grad_seg, T* table_rw,
+                                                           float lr) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane & 15;
+    const int n_seg = *a.n_seg;
+    const int64_t group0 = (blockIdx.x * 256ll + threadIdx.x) >> 4;
+    const int64_t n_group = (gridDim.x * 256ll) >> 4;
+    const T* table = static_cast<const T*>(a.table);
+    const int W = NPART * a.d;
+    for (int64_t seg = group0; seg < n_seg; seg += n_group) {
+        const int64_t row = a.seg_rows[seg];
+        const int r0 = a.seg_offsets[seg], r1 = a.seg_offsets[seg + 1];
+        if (a.long_segs && r1 - r0 > BESS_SEGMENT_CAP) continue;  // left to k_aff_long_segments
+        float ev[NPART][IT][VEC], inv[NPART], dc[NPART][IT][VEC];
+        aff_load_row<T, VEC, IT, NPART>(table + row * W, g, a.d, a.nch, ev);
+        aff_inv_norm<VEC, IT, NPART>(ev, a.normalize, inv);
+#pragma unroll
+        for (int p = 0; p < NPART; ++p)
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) dc[p][it][v] = 0.f;
+        aff_seg_accumulate<VEC, IT, NPART, P>(a, g, ev, inv, r0, r1, dc);
+        aff_seg_finish<T, VEC, IT, NPART>(a, g, ev, inv, dc, seg, row, grad_seg, table_rw, lr);
+    }
+}
+
+// Rows with more than BESS_SEGMENT_CAP references, as k_long_segments (segments.hip): slices of the
+// references are shared by all groups, the partial d score / d c_p meet in long_grad[li, :] through float
+// atomics, and the group that adds a row's last slice reads the sum back, applies the normalisation
+// backward, writes the row out and leaves the scratch row zero.
+template <typename T, int VEC, int IT, int NPART, int P>
+__global__ __launch_bounds__(256) void k_aff_long_segments(AffSegArgs a, float* __restrict__ long_grad,
+                                                           int32_t* __restrict__ long_cnt, int32_t capacity,
+                                                           float* __restrict__ grad_seg, T* table_rw, float lr) {
+    const int lane = threadIdx.x & 63, g = lane & 15;
+    const int64_t group0 = (blockIdx.x * 256ll + threadIdx.x) >> 4;
+    const int64_t n_group = (gridDim.x * 256ll) >> 4;
+    const int n_long = min(a.long_segs[0], capacity);
+    const T* table = static_cast<const T*>(a.table);
+    const int W = NPART * a.d;
+    for (int li = 0; li < n_long; ++li) {
+        const int seg = a.long_segs[1 + li];
+        const int64_t row = a.seg_rows[seg];
+        const int r0 = a.seg_offsets[seg], r1 = a.seg_offsets[seg + 1];
+        const int parts = (r1 - r0 + BESS_SEGMENT_CAP - 1) / BESS_SEGMENT_CAP;
+        if (group0 >= parts) continue;
+        float ev[NPART][IT][VEC], inv[NPART];
+        aff_load_row<T, VEC, IT, NPART>(table + row * W, g, a.d, a.nch, ev);
+        aff_inv_norm<VEC, IT, NPART>(ev, a.normalize, inv);
+        float* sum = long_grad + static_cast<int64_t>(li) * W;
+        for (int64_t pt = group0; pt < parts; pt += n_group) {
+            float dc[NPART][IT][VEC];
+#pragma unroll
+            for (int p = 0; p < NPART; ++p)
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) dc[p][it][v] = 0.f;
+            const int rb = r0 + static_cast<int>(pt) * BESS_SEGMENT_CAP;
+            aff_seg_accumulate<VEC, IT, NPART, P>(a, g, ev, inv, rb, min(r1, rb + BESS_SEGMENT_CAP), dc);
+#pragma unroll
+            for (int p = 0; p < NPART; ++p)
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    const int c = g + 16 * it;
+                    if (c < a.nch) {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) atomicAdd(sum + p * a.d + c * VEC + v, dc[p][it][v]);
+                    }
+                }
+            __threadfence();
+            int old = 0;
+            if (g == 0) old = atomicAdd(long_cnt + li, 1);
+            old = __shfl(old, lane & 48, 64);
+            if ((old + 1) % parts != 0) continue;
+            __threadfence();
+#pragma unroll
+            for (int p = 0; p < NPART; ++p)
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    const int c = g + 16 * it;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        dc[p][it][v] = 0.f;
+                        if (c < a.nch) {
+                            float* sp = sum + p * a.d + c * VEC + v;
+                            dc[p][it][v] = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(sp, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            aff_seg_finish<T, VEC, IT, NPART>(a, g, ev, inv, dc, seg, row, grad_seg, table_rw, lr);
+        }
     }
 }
 
 template <typename T, int VEC, int NPART>
 static int aff_seg_by_it(int it, int p, const AffSegArgs& a, float* grad_seg, void* rw, float lr, unsigned grid,
-                         hipStream_t st) {
+                         hipStream_t st, float* long_grad = nullptr, int32_t* long_cnt = nullptr, int32_t cap = 0) {
     T* t = static_cast<T*>(rw);
-#define BESS_AFS(ITV)                                                                               \
-    (p == 1 ? k_aff_grad_segments<T, VEC, ITV, NPART, 1><<<grid, 256, 0, st>>>(a, grad_seg, t, lr)   \
-            : k_aff_grad_segments<T, VEC, ITV, NPART, 2><<<grid, 256, 0, st>>>(a, grad_seg, t, lr))
+#define BESS_AFS(ITV)                                                                                              \
+    (long_grad ? (p == 1 ? k_aff_long_segments<T, VEC, ITV, NPART, 1><<<grid, 256, 0, st>>>(a, long_grad, long_cnt, cap, grad_seg, t, lr) \
+                         : k_aff_long_segments<T, VEC, ITV, NPART, 2><<<grid, 256, 0, st>>>(a, long_grad, long_cnt, cap, grad_seg, t, lr)) \
+               : (p == 1 ? k_aff_grad_segments<T, VEC, ITV, NPART, 1><<<grid, 256, 0, st>>>(a, grad_seg, t, lr)     \
+                         : k_aff_grad_segments<T, VEC, ITV, NPART, 2><<<grid, 256, 0, st>>>(a, grad_seg, t, lr)))
     if (it <= 1) BESS_AFS(1);
     else if (it <= 2) BESS_AFS(2);
     else if (it <= 4) BESS_AFS(4);
@@ -658,12 +750,13 @@ static int aff_seg_by_it(int it, int p, const AffSegArgs& a, float* grad_seg, vo
 int affine_grad_segments(const bess_model_desc* d, const float* query, void* table, int64_t n_neg,
                          const float* d_out, int64_t ld_dout, const int32_t* refs_sorted, const int32_t* seg_rows,
                          const int32_t* seg_offsets, const int32_t* n_seg, int64_t max_seg, float* grad_seg,
-                         float fused_sgd_lr, hipStream_t st) {
+                         float fused_sgd_lr, const int32_t* long_segs, int64_t long_cap, float* long_grad,
+                         int32_t* long_count, hipStream_t st) {
     const int n_part = d->reserved[0];
     const int dd = d->width / n_part;
     const int vec = (dd % 4 == 0) ? 4 : 1;
     AffSegArgs a{query, table, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg, static_cast<int>(n_neg),
-                 dd, dd / vec, d->reserved[1] & 1};
+                 dd, dd / vec, d->reserved[1] & 1, long_segs};
     const int it = static_cast<int>(ceil_div(a.nch, 16));
     const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(max_seg, 16), 256 * 16));
     int rc;
@@ -674,6 +767,16 @@ int affine_grad_segments(const bess_model_desc* d, const float* query, void* tab
     else rc = vec == 4 ? BESS_AFSD(half_t, 4) : BESS_AFSD(half_t, 1);
 #undef BESS_AFSD
     if (rc) return rc;
+    if (long_segs) {  // the rows left out above, by all groups together (usually none)
+        const int32_t cap = static_cast<int32_t>(long_cap);
+#define BESS_AFSL(T, V)                                                                                                  \
+    (n_part == 1 ? aff_seg_by_it<T, V, 1>(it, d->norm_p, a, grad_seg, table, fused_sgd_lr, 1024, st, long_grad, long_count, cap) \
+                 : aff_seg_by_it<T, V, 2>(it, d->norm_p, a, grad_seg, table, fused_sgd_lr, 1024, st, long_grad, long_count, cap))
+        if (d->dtype == BESS_F32) rc = vec == 4 ? BESS_AFSL(float, 4) : BESS_AFSL(float, 1);
+        else rc = vec == 4 ? BESS_AFSL(half_t, 4) : BESS_AFSL(half_t, 1);
+#undef BESS_AFSL
+        if (rc) return rc;
+    }
     return check_launch("neg_pertriple_grad_segments (affine)");
 }
 

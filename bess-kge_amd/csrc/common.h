@@ -65,7 +65,8 @@ int affine_query_bwd(const bess_model_desc* d, int32_t side, const void* ent_bas
 int affine_grad_segments(const bess_model_desc* d, const float* query, void* table, int64_t n_neg,
                          const float* d_out, int64_t ld_dout, const int32_t* refs_sorted, const int32_t* seg_rows,
                          const int32_t* seg_offsets, const int32_t* n_seg, int64_t max_seg, float* grad_seg,
-                         float fused_sgd_lr, hipStream_t st);
+                         float fused_sgd_lr, const int32_t* long_segs, int64_t long_cap, float* long_grad,
+                         int32_t* long_count, hipStream_t st);
 int affine_shared_fwd(const bess_model_desc* d, const float* query, int64_t S, const float* cand, int64_t N, float* out,
                       int64_t ld, hipStream_t st);
 int affine_shared_bwd(const bess_model_desc* d, const float* query, int64_t S, const float* cand, int64_t N,

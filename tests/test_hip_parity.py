@@ -840,3 +840,38 @@ def test_grad_segments_with_rows_that_many_references_point_at(dev, name, p, dty
     nat.neg_pertriple_grad_segments(desc, q, t2, N, go, seg, fused_sgd_lr=0.5)
     want_t = table.float().cpu() - 0.5 * want.float()
     close(t2, want_t, rtol=2e-3 if dtype == torch.float16 else 1e-5, atol=4e-3 if dtype == torch.float16 else 1e-5)
+
+
+@pytest.mark.parametrize("n_part,normalize,p", [(1, True, 1), (2, True, 2), (2, False, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_affine_grad_segments_with_rows_that_many_references_point_at(dev, n_part, normalize, p, dtype):
+    """The long-row tier of the affine family: slices summed through atomics, the normalisation
+    backward applied once to the total - same result as index_add of the per-reference backward."""
+    from besskge import _native as nat
+    from besskge._native import RowSource
+
+    gen = torch.Generator().manual_seed(13)
+    M, d, S, N = 400, 24, 150, 40
+    W = n_part * d
+    table = torch.randn(M, W, generator=gen).to(dtype).to(dev)
+    q = torch.randn(S, (n_part + 1) * d, generator=gen).to(dev)
+    idx = torch.randint(M, (S * N,), generator=gen, dtype=torch.int32)
+    sel = torch.rand(S * N, generator=gen)
+    idx[sel < 0.2] = 5
+    idx[(sel >= 0.2) & (sel < 0.27)] = 91
+    idx = idx.to(dev)
+    go = (torch.randn(S, N, generator=gen) * 0.1).to(dev)
+    desc = nat.make_desc(nat.AFFINE, p, table, d)
+    desc.reserved[0], desc.reserved[1] = n_part, int(normalize)
+    _, dn = nat.neg_score_pertriple_bwd(desc, q, RowSource(table, idx), N, go)
+    seg = nat.SegmentIndex(idx, M, width=W)
+    n_seg = int(seg.n_seg.item())
+    assert int(seg.long_segs[0].item()) == 2
+    uniq = torch.unique(idx.cpu().long())
+    want = torch.zeros(M, W, dtype=torch.float64).index_add_(0, idx.cpu().long(), dn.cpu().double())
+    g1 = nat.neg_pertriple_grad_segments(desc, q, table, N, go, seg)
+    close(g1[:n_seg], want[uniq].float(), rtol=1e-4, atol=1e-5, scale=4e-6)
+    t2 = table.clone()
+    nat.neg_pertriple_grad_segments(desc, q, t2, N, go, seg, fused_sgd_lr=0.5)  # second use of the scratch rows
+    tol = 4e-3 if dtype == torch.float16 else 1e-5
+    close(t2, table.float().cpu() - 0.5 * want.float(), rtol=tol, atol=tol, scale=4e-6)
