@@ -757,8 +757,8 @@ def test_split_fp16_gemm_backward_matches_float64_products(dev, dtype, S, N, W, 
 
 def test_split_gemm_training_step_under_graph_capture(dev):
     """A whole training step whose shared-negative products take the split-fp16 path (scratch from
-    torch's allocator, k-split backward): captured in a hipGraph and replayed it must give the losses of the eager run bit for bit and its
-    tables up to the rounding order of the atomic row updates."""
+    torch's allocator, k-split backward): captured in a hipGraph and replayed it must give the first loss of the eager run bit for bit, and the
+    later losses and the tables up to the rounding order of the atomic row updates."""
     import ctypes
 
     from besskge import _native as nat
@@ -800,7 +800,8 @@ def test_split_gemm_training_step_under_graph_capture(dev):
     l_e, ent_e, rel_e = run(False)
     l_g, ent_g, rel_g = run(True)
     assert torch.isfinite(l_e).all() and float(l_e[2]) < float(l_e[0])  # it trains
-    assert torch.equal(l_e, l_g)  # forward and loss: deterministic kernels only
+    assert torch.equal(l_e[0], l_g[0])  # forward and loss from identical tables: deterministic kernels only
+    torch.testing.assert_close(l_e, l_g, rtol=1e-6, atol=0)  # later steps see the rounding of the atomic updates
     # the row updates go through float atomics (duplicate rows among heads / tails / negatives): order-dependent rounding
     torch.testing.assert_close(ent_e, ent_g, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(rel_e, rel_g, rtol=1e-5, atol=1e-6)
