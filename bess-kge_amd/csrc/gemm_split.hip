@@ -746,6 +746,7 @@ static bool bwd_layout(int64_t S, int64_t N, int W, BwdLayout& L) {
     L.pe = plan_k(ceil_div(N, 128) * tw, S);
     // worth it only when both products can occupy at least half of the chip
     if (ceil_div(S, 128) * tw * L.pq.ks < 128 || ceil_div(N, 128) * tw * L.pe.ks < 128) return false;
+    if (L.pq.nblk > 65535 || L.pe.nblk > 65535) return false;  // k blocks ride on gridDim.y of the pre-pass
     L.g_plain = S * L.pq.nblk * ROW_B;
     L.g_trans = N * L.pe.nblk * ROW_B;
     L.e_trans = static_cast<int64_t>(W) * L.pq.nblk * ROW_B;
