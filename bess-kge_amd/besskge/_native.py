@@ -748,7 +748,7 @@ def neg_pertriple_grad_segments(d: ModelDesc, query: torch.Tensor, table: torch.
         raise ValueError("neg_pertriple_grad_segments: operand shapes do not match")
     fused = fused_sgd_lr is not None
     grad = None if fused else torch.empty((seg.max_seg, d.width), dtype=torch.float32, device=dev)
-    native = d.scorer <= COMPLEX or d.scorer == AFFINE  # scorers with a segmented reduction
+    native = True  # every scorer id has a segmented reduction with a long-row tier
     if native and (seg.long_grad is None or seg.long_grad.shape[1] != d.width):
         seg.long_grad = torch.zeros((seg.long_cap, d.width), dtype=torch.float32, device=dev)
     long_grad = seg.long_grad

@@ -837,6 +837,8 @@ class BoxE(_TorchQueryHooks, DistanceBasedScoreFunction):
 
     _scorer_id = nat.BOXE
 
+    supports_fused_segments = True  # csrc/boxe.hip: k_box_grad_segments
+
     def __init__(
         self,
         negative_sample_sharing: bool,

@@ -62,6 +62,11 @@ int affine_query_fwd(const bess_model_desc* d, int32_t side, const void* ent_bas
 int affine_query_bwd(const bess_model_desc* d, int32_t side, const void* ent_base, const int32_t* ent_idx,
                      const void* rel_table, const int32_t* rel_idx, int64_t n, const float* d_query, float* d_ent,
                      float* d_rel, hipStream_t st);
+int boxe_grad_segments(const bess_model_desc* d, const float* query, void* table, int64_t n_neg, const float* d_out,
+                       int64_t ld_dout, const int32_t* refs_sorted, const int32_t* seg_rows,
+                       const int32_t* seg_offsets, const int32_t* n_seg, int64_t max_seg, float* grad_seg,
+                       float fused_sgd_lr, const int32_t* long_segs, int64_t long_cap, float* long_grad,
+                       int32_t* long_count, hipStream_t st);
 int affine_grad_segments(const bess_model_desc* d, const float* query, void* table, int64_t n_neg,
                          const float* d_out, int64_t ld_dout, const int32_t* refs_sorted, const int32_t* seg_rows,
                          const int32_t* seg_offsets, const int32_t* n_seg, int64_t max_seg, float* grad_seg,

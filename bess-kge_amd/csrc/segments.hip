@@ -473,6 +473,10 @@ extern "C" int bess_neg_pertriple_grad_segments(const bess_model_desc* d, const 
         return affine_grad_segments(d, query, table, n_neg, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg,
                                     max_seg, grad_seg, fused_sgd_lr, long_segs, long_cap, long_grad, long_count,
                                     as_stream(stream));
+    if (d->scorer == BESS_BOXE)
+        return boxe_grad_segments(d, query, table, n_neg, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg,
+                                  max_seg, grad_seg, fused_sgd_lr, long_segs, long_cap, long_grad, long_count,
+                                  as_stream(stream));
     BESS_REQUIRE(d->scorer <= BESS_COMPLEX, "grad_segments: scorer %d has no segmented form", d->scorer);
     const int W = d->width;
     const int maxvec = d->dtype == BESS_F32 ? 4 : 8;

@@ -876,3 +876,41 @@ def test_affine_grad_segments_with_rows_that_many_references_point_at(dev, n_par
     nat.neg_pertriple_grad_segments(desc, q, t2, N, go, seg, fused_sgd_lr=0.5)  # second use of the scratch rows
     tol = 4e-3 if dtype == torch.float16 else 1e-5
     close(t2, table.float().cpu() - 0.5 * want.float(), rtol=tol, atol=tol, scale=4e-6)
+
+
+@pytest.mark.parametrize("tanh,per_dim,p", [(True, True, 1), (True, False, 2), (False, True, 2), (False, False, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_boxe_grad_segments_match_scatter_of_row_gradients(dev, tanh, per_dim, p, dtype):
+    """K9 of BoxE (csrc/boxe.hip k_box_grad_segments, incl. the long-row tier): the per-row sums of
+    d score / d e recomputed from the six query vectors equal index_add of the backward kernel's
+    per-reference gradients; the fused SGD step is the same update."""
+    from besskge import _native as nat
+    from besskge._native import RowSource
+
+    gen = torch.Generator().manual_seed(17)
+    for M, d, S, N, hot in ((300, 40, 33, 17, False), (400, 24, 150, 40, True), (64, 6, 9, 5, False)):
+        W = 2 * d
+        table = (torch.randn(M, W, generator=gen) * 0.7).to(dtype).to(dev)
+        q = torch.randn(S, 6 * d, generator=gen)
+        q[:, 2 * d:3 * d].abs_()   # half widths H_0, H_1 are positive
+        q[:, 5 * d:].abs_()
+        q = q.to(dev)
+        idx = torch.randint(M, (S * N,), generator=gen, dtype=torch.int32)
+        if hot:
+            idx[torch.rand(S * N, generator=gen) < 0.2] = 5
+        idx = idx.to(dev)
+        go = (torch.randn(S, N, generator=gen) * 0.1).to(dev)
+        desc = nat.make_desc(nat.BOXE, p, table, W)
+        desc.reserved[0] = int(tanh) | (int(per_dim) << 1)
+        _, dn = nat.neg_score_pertriple_bwd(desc, q, RowSource(table, idx), N, go)
+        seg = nat.SegmentIndex(idx, M, width=W)
+        n_seg = int(seg.n_seg.item())
+        assert int(seg.long_segs[0].item()) == (1 if hot else 0)
+        uniq = torch.unique(idx.cpu().long())
+        want = torch.zeros(M, W, dtype=torch.float64).index_add_(0, idx.cpu().long(), dn.cpu().double())
+        g1 = nat.neg_pertriple_grad_segments(desc, q, table, N, go, seg)
+        close(g1[:n_seg], want[uniq].float(), rtol=1e-4, atol=1e-5, scale=4e-6)
+        t2 = table.clone()
+        nat.neg_pertriple_grad_segments(desc, q, t2, N, go, seg, fused_sgd_lr=0.5)
+        tol = 4e-3 if dtype == torch.float16 else 1e-5
+        close(t2, table.float().cpu() - 0.5 * want.float(), rtol=tol, atol=tol, scale=4e-6)
