@@ -737,6 +737,7 @@ class ConvE(_TorchQueryHooks, MatrixDecompositionScoreFunction):
     tails can be corrupted (reference scoring.py:949-1146)."""
 
     _scorer_id = nat.DISTMULT  # candidates see a dot product over [embedding | bias] rows
+    supports_fused_segments = True  # ... so their K9 is the dot-product segmented reduction
 
     def __init__(
         self,
