@@ -129,7 +129,10 @@ SIGNATURES = {
     "bess_topk_update": [_vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _i32, _vp],
     "bess_ranks_from_scores": [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp],
     "bess_ranks_from_indices": [_vp, _vp, _i64, _i64, _i32, _vp, _vp],
-    "bess_apply_segments_opt": [ctypes.POINTER(OptDesc), _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "bess_apply_segments_opt": [ctypes.POINTER(OptDesc), _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
+    "bess_neg_pertriple_step_segments": [_MD, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
+                                         _vp, _i64, _vp, _vp, ctypes.POINTER(OptDesc), _vp, _vp, _vp, _vp, _vp],
+    "bess_map_extra_rows": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp],
     "bess_neg_pertriple_items": [_MD, _i64, _i64, ctypes.POINTER(ctypes.c_int32)],
     "bess_neg_score_pertriple_fwd_dq": [_MD, _LD, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
     "bess_normalize_rows": [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
@@ -732,6 +735,21 @@ class SegmentIndex:
         self.long_grad = torch.zeros((self.long_cap, int(width)), dtype=torch.float32, device=dev) if width else None
 
 
+class _IdentitySegments:
+    """Segments of a table whose every row is updated: row s is segment s."""
+
+    __slots__ = ("seg_rows", "n_seg", "max_seg")
+
+    def __init__(self, n_rows: int, device: torch.device) -> None:
+        self.seg_rows = torch.arange(n_rows, dtype=torch.int32, device=device)
+        self.n_seg = torch.full((1,), n_rows, dtype=torch.int32, device=device)
+        self.max_seg = n_rows
+
+
+def identity_segments(n_rows: int, device: torch.device) -> _IdentitySegments:
+    return _IdentitySegments(n_rows, device)
+
+
 def neg_pertriple_grad_segments(d: ModelDesc, query: torch.Tensor, table: torch.Tensor, n_neg: int,
                                 d_out: torch.Tensor, seg: SegmentIndex,
                                 fused_sgd_lr: Optional[float] = None) -> Optional[torch.Tensor]:
@@ -796,7 +814,9 @@ def segment_sum_rows(src: torch.Tensor, seg: SegmentIndex) -> torch.Tensor:
 
 
 def apply_segments_opt(o: OptDesc, table: torch.Tensor, seg: SegmentIndex, grad_seg: torch.Tensor,
-                       state1: Optional[torch.Tensor], state2: Optional[torch.Tensor]) -> None:
+                       state1: Optional[torch.Tensor], state2: Optional[torch.Tensor],
+                       keep: Optional[torch.Tensor] = None) -> None:
+    """`keep` (int32 [seg.max_seg]): update only the segments with a non-zero entry."""
     dev = _same_device([("table", table), ("grad_seg", grad_seg), ("state1", state1), ("state2", state2)])
     W = int(table.shape[1])
     _rows(table, "table", W)
@@ -812,8 +832,63 @@ def apply_segments_opt(o: OptDesc, table: torch.Tensor, seg: SegmentIndex, grad_
         rc = load().bess_apply_segments_opt(ctypes.byref(o), _dtype_code(table), W, table.data_ptr(),
                                             seg.seg_rows.data_ptr(), seg.n_seg.data_ptr(), seg.max_seg,
                                             grad_seg.data_ptr(), state1.data_ptr() if state1 is not None else 0,
-                                            state2.data_ptr() if state2 is not None else 0, _stream(dev))
+                                            state2.data_ptr() if state2 is not None else 0,
+                                            keep.data_ptr() if keep is not None else None, _stream(dev))
     _check(rc, "bess_apply_segments_opt")
+
+
+def map_extra_rows(seg: SegmentIndex, extra: SegmentIndex) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(extra_map [seg.max_seg], keep [extra.max_seg]) - see bess_neg_pertriple_step_segments."""
+    dev = _same_device([("seg_rows", seg.seg_rows), ("extra_rows", extra.seg_rows)])
+    xmap = torch.empty((seg.max_seg,), dtype=torch.int32, device=dev)
+    keep = torch.empty((extra.max_seg,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().bess_map_extra_rows(seg.seg_rows.data_ptr(), seg.n_seg.data_ptr(), seg.max_seg,
+                                        extra.seg_rows.data_ptr(), extra.n_seg.data_ptr(), extra.max_seg,
+                                        xmap.data_ptr(), keep.data_ptr(), _stream(dev))
+    _check(rc, "bess_map_extra_rows")
+    return xmap, keep
+
+
+def neg_pertriple_step_segments(d: ModelDesc, query: torch.Tensor, table: torch.Tensor, n_neg: int,
+                                d_out: torch.Tensor, seg: SegmentIndex, o: OptDesc,
+                                state1: Optional[torch.Tensor], state2: Optional[torch.Tensor],
+                                extra_map: Optional[torch.Tensor] = None,
+                                extra_sum: Optional[torch.Tensor] = None) -> None:
+    """K9 + K10 in one pass: optimiser `o` applied to the unique rows of `seg` with their summed
+    gradient (+ extra_sum[extra_map[s]]), in place (TransE / RotatE / DistMult / ComplEx)."""
+    dev = _same_device([("query", query), ("table", table), ("d_out", d_out), ("refs", seg.refs),
+                        ("state1", state1), ("state2", state2), ("extra_sum", extra_sum)])
+    _f32(query, "query")
+    _f32(d_out, "d_out")
+    _rows(table, "table", d.width)
+    nq = int(query.shape[0])
+    if _dtype_code(table) != d.dtype or tuple(query.shape) != (nq, query_width(d)) \
+            or tuple(d_out.shape) != (nq, n_neg) or seg.n_refs != nq * n_neg:
+        raise ValueError("neg_pertriple_step_segments: operand shapes do not match")
+    for st, nm in ((state1, "state1"), (state2, "state2")):
+        if st is not None:
+            _f32(st, nm)
+            if tuple(st.shape) != tuple(table.shape):
+                raise ValueError(f"neg_pertriple_step_segments: {nm} must have the shape of the table")
+    if (extra_map is None) != (extra_sum is None):
+        raise ValueError("neg_pertriple_step_segments: extra_map and extra_sum come together")
+    if extra_sum is not None:
+        _f32(extra_sum, "extra_sum")
+        if extra_sum.shape[1] != d.width or extra_map.dtype != torch.int32 or extra_map.numel() != seg.max_seg:
+            raise ValueError("neg_pertriple_step_segments: extra_map / extra_sum shapes")
+    if seg.long_grad is None or seg.long_grad.shape[1] != d.width:
+        seg.long_grad = torch.zeros((seg.long_cap, d.width), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _Timed("bess_neg_pertriple_step_segments", dev):
+        rc = load().bess_neg_pertriple_step_segments(
+            ctypes.byref(d), query.data_ptr(), nq, table.data_ptr(), n_neg, d_out.data_ptr(), n_neg,
+            seg.refs.data_ptr(), seg.seg_rows.data_ptr(), seg.seg_offsets.data_ptr(), seg.n_seg.data_ptr(),
+            seg.max_seg, seg.long_segs.data_ptr(), seg.long_cap, seg.long_grad.data_ptr(), seg.long_count.data_ptr(),
+            ctypes.byref(o), state1.data_ptr() if state1 is not None else None,
+            state2.data_ptr() if state2 is not None else None,
+            extra_map.data_ptr() if extra_map is not None else None,
+            extra_sum.data_ptr() if extra_sum is not None else None, _stream(dev))
+    _check(rc, "bess_neg_pertriple_step_segments")
 
 
 def ranks_from_scores(pos: torch.Tensor, cand: torch.Tensor, mode: int, worst_rank_infty: bool) -> torch.Tensor:

@@ -364,14 +364,8 @@ class BessKGE(torch.nn.Module, ABC):
             st["s"].append(torch.zeros(table.shape, dtype=torch.float32, device=table.device))
         return st
 
-    def _apply_optimizer(self, opt: Any, table: torch.Tensor, contributions: List[Tuple[torch.Tensor, torch.Tensor]]
-                         ) -> None:
-        """General K9 + K10: coalesce (row, gradient row) lists per unique row, then
-        one optimiser update per row.  `contributions` all index `table`."""
-        idx = torch.cat([i.reshape(-1) for i, _ in contributions]).contiguous()
-        grad = torch.cat([g for _, g in contributions], dim=0).contiguous()
-        seg = nat.SegmentIndex(idx, table.shape[0])
-        gseg = nat.segment_sum_rows(grad, seg)
+    def _opt_desc(self, opt: Any, table: torch.Tensor) -> Tuple[Any, Optional[torch.Tensor], Optional[torch.Tensor]]:
+        """(descriptor, state1, state2) of one optimiser step on `table` (advances its step count)."""
         if opt.kind == nat.OPT_SGD:
             n_state = 1 if opt.momentum != 0.0 else 0
         else:
@@ -385,7 +379,46 @@ class BessKGE(torch.nn.Module, ABC):
         o.eps = float(getattr(opt, "eps", 0.0))
         o.weight_decay = float(getattr(opt, "weight_decay", 0.0))
         s = state["s"]
-        nat.apply_segments_opt(o, table, seg, gseg, s[0] if n_state > 0 else None, s[1] if n_state > 1 else None)
+        return o, (s[0] if n_state > 0 else None), (s[1] if n_state > 1 else None)
+
+    def _apply_optimizer(self, opt: Any, table: torch.Tensor, contributions: List[Tuple[torch.Tensor, torch.Tensor]]
+                         ) -> None:
+        """General K9 + K10: coalesce (row, gradient row) lists per unique row, then
+        one optimiser update per row.  `contributions` all index `table`."""
+        idx = torch.cat([i.reshape(-1) for i, _ in contributions]).contiguous()
+        grad = torch.cat([g for _, g in contributions], dim=0).contiguous()
+        seg = nat.SegmentIndex(idx, table.shape[0])
+        gseg = nat.segment_sum_rows(grad, seg)
+        o, s1, s2 = self._opt_desc(opt, table)
+        nat.apply_segments_opt(o, table, seg, gseg, s1, s2)
+
+    def _apply_optimizer_dense(self, opt: Any, table: torch.Tensor, grad: torch.Tensor) -> None:
+        """Optimiser step on every row of a small replicated table (relation table, dense parameters):
+        the rows are their own segments - nothing to sort or sum."""
+        cache = self.__dict__.setdefault("_dense_segments", {})
+        key = (table.data_ptr(), int(table.shape[0]))
+        if key not in cache:
+            cache[key] = nat.identity_segments(int(table.shape[0]), table.device)
+        o, s1, s2 = self._opt_desc(opt, table)
+        nat.apply_segments_opt(o, table, cache[key], grad.contiguous(), s1, s2)
+
+    def _apply_optimizer_fused(self, opt: Any, desc: nat.ModelDesc, table: torch.Tensor, g: _NegGroup,
+                               go: torch.Tensor, seg: Any, extras: List[Tuple[torch.Tensor, torch.Tensor]]) -> None:
+        """K9 + K10 of a shard whose per-triple negatives form one group, for a stateful optimiser:
+        the big per-row reduction applies the optimiser itself (no [unique rows, W] gradient, no host
+        sync); the small lists (heads, tails, ...) are summed per unique row first and ride along, so
+        every touched row still gets one update with its total gradient."""
+        o, s1, s2 = self._opt_desc(opt, table)
+        xmap = xsum = xseg = keep = None
+        if extras:
+            idx = torch.cat([i.reshape(-1) for i, _ in extras]).contiguous()
+            grad = torch.cat([x for _, x in extras], dim=0).contiguous()
+            xseg = nat.SegmentIndex(idx, table.shape[0])
+            xsum = nat.segment_sum_rows(grad, xseg)
+            xmap, keep = nat.map_extra_rows(seg, xseg)
+        nat.neg_pertriple_step_segments(desc, g.query, table, g.n_per_query, go, seg, o, s1, s2, xmap, xsum)
+        if extras:  # rows of the small lists that no negative points at
+            nat.apply_segments_opt(o, table, xseg, xsum, s1, s2, keep=keep)
 
     def _wants_segments(self, g: _NegGroup, st: _ReplicaStep) -> bool:
         return not g.shared and g.neg.base is st.table and self.score_fn.supports_fused_segments
@@ -443,7 +476,13 @@ class BessKGE(torch.nn.Module, ABC):
                     nat.sparse_sgd(st.table, idx.contiguous(), g.contiguous(), lr)
         else:
             # non-linear optimisers need the *summed* gradient of every row first
+            native = desc.scorer <= nat.COMPLEX
             for st, upd in zip(steps, local_updates):
+                mine = [item for item in deferred if item[0] is st.table]
+                if native and len(mine) == 1:
+                    table, g, go = mine[0]
+                    self._apply_optimizer_fused(optimizer, desc, table, g, go, seg_index[id(g)], list(upd))
+                    continue
                 contrib = list(upd)
                 for table, g, go in deferred:
                     if table is st.table:
@@ -458,8 +497,7 @@ class BessKGE(torch.nn.Module, ABC):
         if plain:
             nat.dense_sgd(rel_table, d_rel, lr)
         else:
-            all_rows = torch.arange(rel_table.shape[0], dtype=torch.int32, device=rel_table.device)
-            self._apply_optimizer(optimizer, rel_table, [(all_rows, d_rel)])
+            self._apply_optimizer_dense(optimizer, rel_table, d_rel)
         # dense parameters of the scorer (ConvE's query network): replicated like the relation table
         dense_grads = self.score_fn.__dict__.pop("dense_grads", {})
         for p in self.score_fn.dense_parameters():
@@ -472,8 +510,7 @@ class BessKGE(torch.nn.Module, ABC):
             if plain:
                 nat.dense_sgd(as_table, g, lr)
             else:
-                rows = torch.arange(as_table.shape[0], dtype=torch.int32, device=as_table.device)
-                self._apply_optimizer(optimizer, as_table, [(rows, g)])
+                self._apply_optimizer_dense(optimizer, as_table, g)
 
 
     # ------------------------------------------------------ group execution

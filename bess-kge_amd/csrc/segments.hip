@@ -62,6 +62,48 @@ __global__ void k_close_offsets(int32_t* __restrict__ seg_offsets, const int32_t
     if (threadIdx.x == 0 && blockIdx.x == 0) seg_offsets[*n_seg] = n_refs;
 }
 
+// Row-sparse optimisers on the unique rows of a step ("lazy" semantics: state of
+// untouched rows is left alone, like torch.optim.SparseAdam / Adagrad on sparse
+// gradients).  state1/state2 are f32 [M, W] (momentum | sum of squares | exp_avg, exp_avg_sq).
+struct OptArgs {
+    int kind;
+    float lr, momentum, beta1, beta2, eps, weight_decay;
+    float bias1, bias2;  // 1 - beta^t for Adam
+};
+
+// one optimiser step on one scalar (p: parameter, g: summed gradient, s1 / s2: its state)
+__device__ __forceinline__ void opt_step(const OptArgs& o, float& p, float g, float& s1, float& s2) {
+    if (o.kind == BESS_OPT_SGD) {
+        g += o.weight_decay * p;
+        if (o.momentum != 0.f) {
+            s1 = o.momentum * s1 + g;
+            g = s1;
+        }
+        p -= o.lr * g;
+    } else if (o.kind == BESS_OPT_ADAGRAD) {
+        g += o.weight_decay * p;
+        s1 += g * g;
+        p -= o.lr * g / (sqrtf(s1) + o.eps);
+    } else {  // BESS_OPT_ADAM (decoupled weight decay when weight_decay != 0: AdamW)
+        p -= o.lr * o.weight_decay * p;
+        s1 = o.beta1 * s1 + (1.f - o.beta1) * g;
+        s2 = o.beta2 * s2 + (1.f - o.beta2) * g * g;
+        p -= o.lr * sqrtf(o.bias2) / o.bias1 * s1 / (sqrtf(s2) + o.eps);
+    }
+}
+
+// What the per-row pass does with the summed gradient of a row beyond "write it" / "plain SGD":
+// a stateful optimiser applied in the same pass (kind >= 0), with the other contributions to the
+// row (heads, tails, shared negatives ..., already summed per unique row in xsum) added first -
+// xmap[seg] is the row of xsum that belongs to segment seg, or -1.
+struct SegOpt {
+    OptArgs o;        // o.kind < 0: off
+    float* state1;
+    float* state2;
+    const int32_t* xmap;
+    const float* xsum;
+};
+
 struct SegArgs {
     const float* query;
     const void* table;
@@ -76,6 +118,7 @@ struct SegArgs {
     int nch;
     float sign;
     const int32_t* long_segs;    // optional: [0] = number of segments longer than SEG_CAP, [1..] = their ids
+    SegOpt opt;
 };
 
 // A row that collects very many references (padded candidate lists, a hot entity) would keep one
@@ -154,6 +197,65 @@ __device__ __forceinline__ void seg_accumulate(const SegArgs& a, int g, const fl
     if (r < r1) accumulate(qa, ga);
 }
 
+// The summed gradient `acc` of a row (value `ev`) goes out: as a gradient row, as the fused plain
+// SGD step, or through a stateful optimiser together with the row's other contributions.
+template <typename T, int VEC, int IT>
+__device__ __forceinline__ void seg_finish(const SegArgs& a, int g, int64_t seg, int64_t row,
+                                           const float (&ev)[IT][VEC], const float (&acc)[IT][VEC],
+                                           float* __restrict__ grad_seg, T* table_rw, float lr) {
+    if (a.opt.o.kind >= 0) {
+        // state rows are touched once per step: streamed past the caches (non-temporal), so that they do
+        // not evict the query slice the column window keeps in L2
+        const int x = a.opt.xmap ? a.opt.xmap[seg] : -1;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = g + 16 * it;
+            if (c >= a.nch) continue;
+            float xs[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) xs[v] = 0.f;
+            if (x >= 0) load_chunk<float, VEC>(a.opt.xsum + static_cast<int64_t>(x) * a.W, c, a.nch, xs);
+            typedef float fvec __attribute__((ext_vector_type(VEC)));
+            const int64_t at = row * a.W + c * VEC;
+            fvec s1v = 0.f, s2v = 0.f;
+            if (a.opt.state1) s1v = __builtin_nontemporal_load(reinterpret_cast<const fvec*>(a.opt.state1 + at));
+            if (a.opt.state2) s2v = __builtin_nontemporal_load(reinterpret_cast<const fvec*>(a.opt.state2 + at));
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float p = ev[it][v], s1 = s1v[v], s2 = s2v[v];
+                opt_step(a.opt.o, p, acc[it][v] + xs[v], s1, s2);
+                table_rw[at + v] = static_cast<T>(p);
+                s1v[v] = s1;
+                s2v[v] = s2;
+            }
+            if (a.opt.state1) __builtin_nontemporal_store(s1v, reinterpret_cast<fvec*>(a.opt.state1 + at));
+            if (a.opt.state2) __builtin_nontemporal_store(s2v, reinterpret_cast<fvec*>(a.opt.state2 + at));
+        }
+        return;
+    }
+    if (grad_seg) {
+        float* out = grad_seg + seg * a.W;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = g + 16 * it;
+            if (c < a.nch) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) out[c * VEC + v] = acc[it][v];
+            }
+        }
+    } else {
+        T* out = table_rw + row * a.W;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = g + 16 * it;
+            if (c < a.nch) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) out[c * VEC + v] = static_cast<T>(ev[it][v] - lr * acc[it][v]);
+            }
+        }
+    }
+}
+
 // grad_seg != NULL: write the per-row gradient.  grad_seg == NULL: apply SGD in
 // place, table[row] -= lr * grad (each row is owned by exactly one 16-lane
 // group, which read the old value before writing the new one).
@@ -189,28 +291,7 @@ __global__ __launch_bounds__(256) void k_pertriple_grad_segments(SegArgs a, floa
 #pragma unroll
             for (int it = 0; it < IT; ++it) load_chunk<T, VEC>(table + row * a.W, g + 16 * it, a.nch, ev[it]);
         }
-        if (grad_seg) {
-            float* out = grad_seg + seg * a.W;
-#pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                const int c = g + 16 * it;
-                if (c < a.nch) {
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) out[c * VEC + v] = acc[it][v];
-                }
-            }
-        } else {
-            T* out = table_rw + row * a.W;
-#pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                const int c = g + 16 * it;
-                if (c < a.nch) {
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v)
-                        out[c * VEC + v] = static_cast<T>(ev[it][v] - lr * acc[it][v]);
-                }
-            }
-        }
+        seg_finish<T, VEC, IT>(a, g, seg, row, ev, acc, grad_seg, table_rw, lr);
     }
 }
 
@@ -265,19 +346,21 @@ __global__ __launch_bounds__(256) void k_long_segments(SegArgs a, float* __restr
             if ((old + 1) % parts != 0) continue;
             __threadfence();
             // last slice of the row: every partial sum is in (device-scope loads: past the L1)
+            float tot[IT][VEC];
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 const int c = g + 16 * it;
-                if (c >= a.nch) continue;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
-                    float* sp = sum + c * VEC + v;
-                    const float tot = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (grad_seg) grad_seg[static_cast<int64_t>(seg) * a.W + c * VEC + v] = tot;
-                    else table_rw[row * a.W + c * VEC + v] = static_cast<T>(ev[it][v] - lr * tot);
-                    __hip_atomic_store(sp, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    tot[it][v] = 0.f;
+                    if (c < a.nch) {
+                        float* sp = sum + c * VEC + v;
+                        tot[it][v] = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(sp, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
+            seg_finish<T, VEC, IT>(a, g, seg, row, ev, tot, grad_seg, table_rw, lr);
         }
     }
 }
@@ -318,52 +401,49 @@ __global__ __launch_bounds__(256) void k_segment_sum_rows(const float* __restric
     }
 }
 
-// Row-sparse optimisers on the unique rows of a step ("lazy" semantics: state of
-// untouched rows is left alone, like torch.optim.SparseAdam / Adagrad on sparse
-// gradients).  state1/state2 are f32 [M, W] (momentum | sum of squares | exp_avg, exp_avg_sq).
-struct OptArgs {
-    int kind;
-    float lr, momentum, beta1, beta2, eps, weight_decay;
-    float bias1, bias2;  // 1 - beta^t for Adam
-};
-
+// keep (optional): only segments with keep[s] != 0 are updated
 template <typename T>
 __global__ __launch_bounds__(256) void k_apply_segments_opt(OptArgs o, T* __restrict__ table, int W,
                                                             const int32_t* __restrict__ seg_rows,
                                                             const int32_t* __restrict__ n_seg,
                                                             const float* __restrict__ grad_seg,
                                                             float* __restrict__ state1,
-                                                            float* __restrict__ state2) {
+                                                            float* __restrict__ state2,
+                                                            const int32_t* __restrict__ keep) {
     const int64_t total = static_cast<int64_t>(*n_seg) * W;
     for (int64_t t = blockIdx.x * 256ll + threadIdx.x; t < total; t += 256ll * gridDim.x) {
         const int64_t s = t / W;
+        if (keep && keep[s] == 0) continue;
         const int c = static_cast<int>(t - s * W);
         const int64_t at = static_cast<int64_t>(seg_rows[s]) * W + c;
         float p = static_cast<float>(table[at]);
-        float g = grad_seg[t];
-        if (o.kind == BESS_OPT_SGD) {
-            g += o.weight_decay * p;
-            if (o.momentum != 0.f) {
-                const float b = o.momentum * state1[at] + g;
-                state1[at] = b;
-                g = b;
-            }
-            p -= o.lr * g;
-        } else if (o.kind == BESS_OPT_ADAGRAD) {
-            g += o.weight_decay * p;
-            const float ss = state1[at] + g * g;
-            state1[at] = ss;
-            p -= o.lr * g / (sqrtf(ss) + o.eps);
-        } else {  // BESS_OPT_ADAM (decoupled weight decay when weight_decay != 0: AdamW)
-            p -= o.lr * o.weight_decay * p;
-            const float m = o.beta1 * state1[at] + (1.f - o.beta1) * g;
-            const float v = o.beta2 * state2[at] + (1.f - o.beta2) * g * g;
-            state1[at] = m;
-            state2[at] = v;
-            const float step = o.lr * sqrtf(o.bias2) / o.bias1;
-            p -= step * m / (sqrtf(v) + o.eps);
-        }
+        float s1 = state1 ? state1[at] : 0.f, s2 = state2 ? state2[at] : 0.f;
+        opt_step(o, p, grad_seg[t], s1, s2);
+        if (state1) state1[at] = s1;
+        if (state2) state2[at] = s2;
         table[at] = static_cast<T>(p);
+    }
+}
+
+// xmap[s] = x for every unique extra row x that is also a segment s of the big index (binary search in
+// its ascending seg_rows), keep[x] = 1 for the extra rows that are not (they get their own update)
+__global__ __launch_bounds__(256) void k_map_extra_rows(const int32_t* __restrict__ seg_rows,
+                                                        const int32_t* __restrict__ n_seg,
+                                                        const int32_t* __restrict__ xrows,
+                                                        const int32_t* __restrict__ n_x,
+                                                        int32_t* __restrict__ xmap, int32_t* __restrict__ keep) {
+    const int nx = *n_x, ns = *n_seg;
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < nx; x += 256 * gridDim.x) {
+        const int r = xrows[x];
+        int lo = 0, hi = ns;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (seg_rows[mid] < r) lo = mid + 1;
+            else hi = mid;
+        }
+        const bool found = lo < ns && seg_rows[lo] == r;
+        if (found) xmap[lo] = x;
+        keep[x] = found ? 0 : 1;
     }
 }
 
@@ -454,14 +534,12 @@ extern "C" int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int3
     return check_launch("build_segment_index");
 }
 
-extern "C" int bess_neg_pertriple_grad_segments(const bess_model_desc* d, const float* query, int64_t n_query,
-                                                void* table, int64_t n_neg, const float* d_out,
-                                                int64_t ld_dout, const int32_t* refs_sorted,
-                                                const int32_t* seg_rows, const int32_t* seg_offsets,
-                                                const int32_t* n_seg, int64_t max_seg, float* grad_seg,
-                                                float fused_sgd_lr, const int32_t* long_segs,
-                                                int64_t long_cap, float* long_grad, int32_t* long_count,
-                                                void* stream) {
+static int grad_segments_impl(const bess_model_desc* d, const float* query, int64_t n_query, void* table,
+                              int64_t n_neg, const float* d_out, int64_t ld_dout, const int32_t* refs_sorted,
+                              const int32_t* seg_rows, const int32_t* seg_offsets, const int32_t* n_seg,
+                              int64_t max_seg, float* grad_seg, float fused_sgd_lr, const int32_t* long_segs,
+                              int64_t long_cap, float* long_grad, int32_t* long_count, const SegOpt& opt,
+                              void* stream) {
     if (int e = check_desc(d)) return e;
     BESS_REQUIRE(!long_segs || (long_grad && long_count && long_cap >= n_query * n_neg / SEG_CAP + 1),
                  "grad_segments: long_segs needs long_grad, long_count and long_cap >= n_refs / %d + 1", SEG_CAP);
@@ -469,6 +547,8 @@ extern "C" int bess_neg_pertriple_grad_segments(const bess_model_desc* d, const 
     BESS_REQUIRE(query && table && d_out && refs_sorted && seg_rows && seg_offsets && n_seg,
                  "grad_segments: NULL pointer");
     BESS_REQUIRE(ld_dout >= n_neg && max_seg > 0, "grad_segments: bad leading dimension / max_seg");
+    BESS_REQUIRE(opt.o.kind < 0 || d->scorer <= BESS_COMPLEX,
+                 "step_segments: the fused optimiser step exists for TransE / RotatE / DistMult / ComplEx");
     if (d->scorer == BESS_AFFINE)
         return affine_grad_segments(d, query, table, n_neg, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg,
                                     max_seg, grad_seg, fused_sgd_lr, long_segs, long_cap, long_grad, long_count,
@@ -503,8 +583,12 @@ extern "C" int bess_neg_pertriple_grad_segments(const bess_model_desc* d, const 
     for (int col0 = 0; col0 < W; col0 += win) {
         const int cols = W - col0 < win ? W - col0 : win;
         char* tab = static_cast<char*>(table) + col0 * sz;
+        SegOpt wopt = opt;  // the window's columns of the state tables and of the extra gradients
+        if (wopt.state1) wopt.state1 += col0;
+        if (wopt.state2) wopt.state2 += col0;
+        if (wopt.xsum) wopt.xsum += col0;
         SegArgs a{query + col0, tab, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg,
-                  static_cast<int>(n_neg), W, cols / vec, is_distance(d->scorer) ? -1.f : 1.f, long_segs};
+                  static_cast<int>(n_neg), W, cols / vec, is_distance(d->scorer) ? -1.f : 1.f, long_segs, wopt};
         const int it = static_cast<int>(ceil_div(a.nch, 16));
         float* gs = grad_seg ? grad_seg + col0 : nullptr;
         int rc;
@@ -521,7 +605,7 @@ extern "C" int bess_neg_pertriple_grad_segments(const bess_model_desc* d, const 
     if (long_segs) {  // the rows left out above (usually none: one launch that finds nothing to do)
         const int32_t cap = static_cast<int32_t>(long_cap);
         SegArgs a{query, table, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg,
-                  static_cast<int>(n_neg), W, W / vec, is_distance(d->scorer) ? -1.f : 1.f, long_segs};
+                  static_cast<int>(n_neg), W, W / vec, is_distance(d->scorer) ? -1.f : 1.f, long_segs, opt};
         const int it = static_cast<int>(ceil_div(a.nch, 16));
         const unsigned lgrid = 1024;  // 16 K groups share the slices
         int rc;
@@ -536,6 +620,72 @@ extern "C" int bess_neg_pertriple_grad_segments(const bess_model_desc* d, const 
         if (rc) return rc;
     }
     return check_launch("neg_pertriple_grad_segments");
+}
+
+static OptArgs opt_args(const bess_opt_desc* o) {
+    OptArgs a{o->kind, o->lr, o->momentum, o->beta1, o->beta2, o->eps, o->weight_decay, 1.f, 1.f};
+    if (o->kind == BESS_OPT_ADAM) {
+        a.bias1 = 1.f - powf(o->beta1, static_cast<float>(o->step));
+        a.bias2 = 1.f - powf(o->beta2, static_cast<float>(o->step));
+    }
+    return a;
+}
+
+static int check_opt(const bess_opt_desc* o, const float* state1, const float* state2, const char* who) {
+    BESS_REQUIRE(o, "%s: NULL descriptor", who);
+    BESS_REQUIRE(o->kind >= BESS_OPT_SGD && o->kind <= BESS_OPT_ADAM, "%s: unknown optimiser %d", who, o->kind);
+    if (o->kind == BESS_OPT_SGD && o->momentum != 0.f) BESS_REQUIRE(state1, "%s: SGD with momentum needs state1", who);
+    if (o->kind == BESS_OPT_ADAGRAD) BESS_REQUIRE(state1, "%s: Adagrad needs state1", who);
+    if (o->kind == BESS_OPT_ADAM) {
+        BESS_REQUIRE(state1 && state2, "%s: Adam needs state1 and state2", who);
+        BESS_REQUIRE(o->step >= 1, "%s: Adam needs step >= 1", who);
+    }
+    return BESS_OK;
+}
+
+extern "C" int bess_neg_pertriple_grad_segments(const bess_model_desc* d, const float* query, int64_t n_query,
+                                                void* table, int64_t n_neg, const float* d_out,
+                                                int64_t ld_dout, const int32_t* refs_sorted,
+                                                const int32_t* seg_rows, const int32_t* seg_offsets,
+                                                const int32_t* n_seg, int64_t max_seg, float* grad_seg,
+                                                float fused_sgd_lr, const int32_t* long_segs,
+                                                int64_t long_cap, float* long_grad, int32_t* long_count,
+                                                void* stream) {
+    SegOpt off{};
+    off.o.kind = -1;
+    return grad_segments_impl(d, query, n_query, table, n_neg, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets,
+                              n_seg, max_seg, grad_seg, fused_sgd_lr, long_segs, long_cap, long_grad, long_count, off,
+                              stream);
+}
+
+extern "C" int bess_neg_pertriple_step_segments(const bess_model_desc* d, const float* query, int64_t n_query,
+                                                void* table, int64_t n_neg, const float* d_out,
+                                                int64_t ld_dout, const int32_t* refs_sorted,
+                                                const int32_t* seg_rows, const int32_t* seg_offsets,
+                                                const int32_t* n_seg, int64_t max_seg,
+                                                const int32_t* long_segs, int64_t long_cap, float* long_grad,
+                                                int32_t* long_count, const bess_opt_desc* o, float* state1,
+                                                float* state2, const int32_t* extra_map,
+                                                const float* extra_sum, void* stream) {
+    if (int e = check_opt(o, state1, state2, "step_segments")) return e;
+    BESS_REQUIRE(!extra_map == !extra_sum, "step_segments: extra_map and extra_sum come together");
+    SegOpt opt{opt_args(o), o->kind == BESS_OPT_SGD && o->momentum == 0.f ? nullptr : state1,
+               o->kind == BESS_OPT_ADAM ? state2 : nullptr, extra_map, extra_sum};
+    return grad_segments_impl(d, query, n_query, table, n_neg, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets,
+                              n_seg, max_seg, nullptr, 0.f, long_segs, long_cap, long_grad, long_count, opt, stream);
+}
+
+extern "C" int bess_map_extra_rows(const int32_t* seg_rows, const int32_t* n_seg, int64_t max_seg,
+                                   const int32_t* extra_rows, const int32_t* n_extra, int64_t max_extra,
+                                   int32_t* extra_map, int32_t* keep, void* stream) {
+    BESS_REQUIRE(seg_rows && n_seg && extra_rows && n_extra && extra_map && keep, "map_extra_rows: NULL pointer");
+    BESS_REQUIRE(max_seg > 0 && max_extra > 0, "map_extra_rows: bad sizes");
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemsetAsync(extra_map, 0xff, sizeof(int32_t) * max_seg, st);  // -1 everywhere
+    if (e != hipSuccess) return fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
+    k_map_extra_rows<<<static_cast<unsigned>(std::min<int64_t>(ceil_div(max_extra, 256), 1024)), 256, 0, st>>>(
+        seg_rows, n_seg, extra_rows, n_extra, extra_map, keep);
+    return check_launch("map_extra_rows");
 }
 
 extern "C" int bess_apply_segments_sgd(int32_t dtype, int32_t width, void* table, const int32_t* seg_rows,
@@ -566,29 +716,21 @@ extern "C" int bess_segment_sum_rows(int32_t width, const float* src, const int3
 
 extern "C" int bess_apply_segments_opt(const bess_opt_desc* o, int32_t dtype, int32_t width, void* table,
                                        const int32_t* seg_rows, const int32_t* n_seg, int64_t max_seg,
-                                       const float* grad_seg, float* state1, float* state2, void* stream) {
-    BESS_REQUIRE(o, "apply_segments_opt: NULL descriptor");
-    BESS_REQUIRE(o->kind >= BESS_OPT_SGD && o->kind <= BESS_OPT_ADAM, "apply_segments_opt: unknown optimiser %d", o->kind);
+                                       const float* grad_seg, float* state1, float* state2,
+                                       const int32_t* keep, void* stream) {
+    if (int e = check_opt(o, state1, state2, "apply_segments_opt")) return e;
     BESS_REQUIRE(dtype == BESS_F32 || dtype == BESS_F16, "apply_segments_opt: unknown dtype %d", dtype);
     BESS_REQUIRE(width > 0 && max_seg > 0, "apply_segments_opt: bad sizes");
     BESS_REQUIRE(table && seg_rows && n_seg && grad_seg, "apply_segments_opt: NULL pointer");
-    if (o->kind == BESS_OPT_SGD && o->momentum != 0.f) BESS_REQUIRE(state1, "SGD with momentum needs state1");
-    if (o->kind == BESS_OPT_ADAGRAD) BESS_REQUIRE(state1, "Adagrad needs state1");
-    if (o->kind == BESS_OPT_ADAM) {
-        BESS_REQUIRE(state1 && state2, "Adam needs state1 and state2");
-        BESS_REQUIRE(o->step >= 1, "Adam needs step >= 1");
-    }
-    OptArgs a{o->kind, o->lr, o->momentum, o->beta1, o->beta2, o->eps, o->weight_decay, 1.f, 1.f};
-    if (o->kind == BESS_OPT_ADAM) {
-        a.bias1 = 1.f - powf(o->beta1, static_cast<float>(o->step));
-        a.bias2 = 1.f - powf(o->beta2, static_cast<float>(o->step));
-    }
+    const OptArgs a = opt_args(o);
+    float* s1 = o->kind == BESS_OPT_SGD && o->momentum == 0.f ? nullptr : state1;
+    float* s2 = o->kind == BESS_OPT_ADAM ? state2 : nullptr;
     const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(max_seg * width, 256), 256 * 16));
     if (dtype == BESS_F32)
         k_apply_segments_opt<float><<<grid, 256, 0, as_stream(stream)>>>(a, static_cast<float*>(table), width,
-                                                                         seg_rows, n_seg, grad_seg, state1, state2);
+                                                                         seg_rows, n_seg, grad_seg, s1, s2, keep);
     else
         k_apply_segments_opt<half_t><<<grid, 256, 0, as_stream(stream)>>>(a, static_cast<half_t*>(table), width,
-                                                                          seg_rows, n_seg, grad_seg, state1, state2);
+                                                                          seg_rows, n_seg, grad_seg, s1, s2, keep);
     return check_launch("apply_segments_opt");
 }

@@ -357,11 +357,36 @@ int bess_segment_sum_rows(int32_t width, const float* src, const int32_t* refs_s
  * decay), Adagrad, Adam / AdamW with "lazy" semantics - only rows touched by
  * the step move (torch.optim.SparseAdam / sparse Adagrad); replaces the dense
  * poptorch.optim step of the notebooks, which cannot be afforded on a shard of
- * tens of GB.  state1 / state2 may be NULL when the optimiser has no such state. */
+ * tens of GB.  state1 / state2 may be NULL when the optimiser has no such state.
+ * keep (optional, int32 [max_seg]): only segments with keep[s] != 0 are updated. */
 int bess_apply_segments_opt(const bess_opt_desc* o, int32_t dtype, int32_t width,
                             void* table, const int32_t* seg_rows, const int32_t* n_seg,
                             int64_t max_seg, const float* grad_seg, float* state1,
-                            float* state2, void* stream);
+                            float* state2, const int32_t* keep, void* stream);
+
+/* K9 + K10 in one pass for the stateful optimisers (what bess_neg_pertriple_grad_segments
+ * with fused_sgd_lr is for plain SGD): the summed gradient of each unique row is consumed by
+ * the optimiser step where it is formed - no [n_seg, W] gradient is written or re-read.
+ * The other contributions to the same table (heads, tails, shared negatives ...) come as
+ * their own per-unique-row sums extra_sum [n_extra, W] with extra_map [max_seg]
+ * (bess_map_extra_rows: extra_map[s] = row of extra_sum that belongs to segment s, or -1),
+ * so that a row touched from both sides still gets ONE update with its total gradient;
+ * bess_map_extra_rows also returns keep [max_extra] = 1 for the extra rows that are no
+ * segment of the big index - update those with bess_apply_segments_opt(..., keep).
+ * TransE / RotatE / DistMult / ComplEx; long_* as in bess_neg_pertriple_grad_segments. */
+int bess_neg_pertriple_step_segments(const bess_model_desc* d, const float* query,
+                                     int64_t n_query, void* table, int64_t n_neg,
+                                     const float* d_out, int64_t ld_dout,
+                                     const int32_t* refs_sorted, const int32_t* seg_rows,
+                                     const int32_t* seg_offsets, const int32_t* n_seg,
+                                     int64_t max_seg, const int32_t* long_segs,
+                                     int64_t long_cap, float* long_grad, int32_t* long_count,
+                                     const bess_opt_desc* o, float* state1, float* state2,
+                                     const int32_t* extra_map, const float* extra_sum,
+                                     void* stream);
+int bess_map_extra_rows(const int32_t* seg_rows, const int32_t* n_seg, int64_t max_seg,
+                        const int32_t* extra_rows, const int32_t* n_extra, int64_t max_extra,
+                        int32_t* extra_map, int32_t* keep, void* stream);
 
 /* dense axpy on a replicated table: table -= lr * grad (relation table) */
 int bess_dense_sgd(int32_t dtype, void* table, const float* grad, int64_t n_elem,
