@@ -244,13 +244,17 @@ __device__ __forceinline__ void seg_finish(const SegArgs& a, int g, int64_t seg,
             }
         }
     } else {
+        // each row is written once per step: streamed past the caches, like the optimiser state
+        typedef T tvec __attribute__((ext_vector_type(VEC)));
         T* out = table_rw + row * a.W;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int c = g + 16 * it;
             if (c < a.nch) {
+                tvec o;
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) out[c * VEC + v] = static_cast<T>(ev[it][v] - lr * acc[it][v]);
+                for (int v = 0; v < VEC; ++v) o[v] = static_cast<T>(ev[it][v] - lr * acc[it][v]);
+                __builtin_nontemporal_store(o, reinterpret_cast<tvec*>(out + c * VEC));
             }
         }
     }
