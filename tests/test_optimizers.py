@@ -127,3 +127,66 @@ def test_training_step_with_optimizers(dev, opt_name, case):
         torch.testing.assert_close(got[solid], ref[solid], rtol=2e-3, atol=5e-5)
         untouched = (grad.reshape(-1, grad.shape[-1]) == 0).all(dim=-1)
         assert torch.equal(got.reshape(-1, grad.shape[-1])[untouched], before.reshape(-1, grad.shape[-1])[untouched])
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adagrad", "adam"])
+@pytest.mark.parametrize("scorer,p", [("ComplEx", 1), ("TransE", 1), ("RotatE", 2)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_fused_optimizer_step_in_the_segmented_reduction(dev, kind, scorer, p, dtype):
+    """bess_neg_pertriple_step_segments (K9 + K10 in one pass, extra contributions merged through
+    bess_map_extra_rows, rows only they touch through bess_apply_segments_opt(keep)) over three steps
+    equals: gradient rows of the plain segmented reduction + index_add of the extras, then the lazy
+    optimiser formulas on the unique touched rows.  One hot row exercises the long-row tier."""
+    from besskge import _native as nat
+
+    gen = torch.Generator().manual_seed(3)
+    M, d, S, N = 260, 24, 40, 30
+    W = 2 * d if scorer in ("ComplEx", "RotatE") else d
+    Wr = d if scorer == "RotatE" else W
+    table = torch.randn(M, W, generator=gen).to(dtype)
+    p_ref, p_dev = table.float(), table.to(dev)
+    hp = dict(lr=0.05, momentum=0.9, weight_decay=0.01, eps=1e-8 if kind == "adam" else 1e-10, beta1=0.9, beta2=0.99)
+    s_ref = [torch.zeros(M, W), torch.zeros(M, W)]
+    s_dev = [torch.zeros(M, W, device=dev), torch.zeros(M, W, device=dev)]
+    o = nat.OptDesc()
+    o.kind = dict(sgd=nat.OPT_SGD, adagrad=nat.OPT_ADAGRAD, adam=nat.OPT_ADAM)[kind]
+    o.lr, o.momentum, o.weight_decay, o.eps, o.beta1, o.beta2 = hp["lr"], hp["momentum"], hp["weight_decay"], hp["eps"], hp["beta1"], hp["beta2"]
+    desc = nat.make_desc(dict(TransE=0, RotatE=1, DistMult=2, ComplEx=3)[scorer], p, p_dev, Wr)
+    for step in range(1, 4):
+        q = torch.randn(S, W, generator=gen).to(dev)
+        go = (torch.randn(S, N, generator=gen) * 0.1).to(dev)
+        idx = torch.randint(M // 2, (S * N,), generator=gen, dtype=torch.int32)  # negatives: rows < M / 2 only
+        idx[torch.rand(S * N, generator=gen) < 0.3] = 9                         # one long row
+        xidx = torch.randint(M, (70,), generator=gen, dtype=torch.int32)          # extras: any row, duplicates
+        xgrad = torch.randn(70, W, generator=gen)
+        seg = nat.SegmentIndex(idx.to(dev), M, width=W)
+        assert int(seg.long_segs[0].item()) == 1
+        # reference: plain segmented gradient (tested elsewhere) + extras, lazy formulas on the union
+        gseg = nat.neg_pertriple_grad_segments(desc, q, p_dev, N, go, seg)
+        n = int(seg.n_seg.item())
+        total = torch.zeros(M, W, dtype=torch.float64)
+        total[seg.seg_rows[:n].cpu().long()] = gseg[:n].cpu().double()
+        total.index_add_(0, xidx.long(), xgrad.double())
+        rows = torch.unique(torch.cat([idx.long(), xidx.long()]))
+        p_ref = lazy_reference(kind, p_ref, rows, total[rows].float(), s_ref, hp, step)
+        if dtype == torch.float16:
+            p_ref = p_ref.half().float()
+        # device: fused step
+        xseg = nat.SegmentIndex(xidx.to(dev), M)
+        xsum = nat.segment_sum_rows(xgrad.to(dev), xseg)
+        xmap, keep = nat.map_extra_rows(seg, xseg)
+        nx = int(xseg.n_seg.item())
+        orphan = torch.tensor([int(r) not in set(seg.seg_rows[:n].cpu().tolist()) for r in xseg.seg_rows[:nx].cpu()])
+        assert torch.equal(keep[:nx].cpu().bool(), orphan) and bool(orphan.any()) and not bool(orphan.all())
+        o.step = step
+        s2 = s_dev[1] if kind == "adam" else None
+        before = p_dev.clone()
+        nat.neg_pertriple_step_segments(desc, q, p_dev, N, go, seg, o, s_dev[0], s2, xmap, xsum)
+        nat.apply_segments_opt(o, p_dev, xseg, xsum, s_dev[0], s2, keep=keep)
+        tol = dict(rtol=1e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=4e-3, atol=4e-3)
+        torch.testing.assert_close(p_dev.float().cpu(), p_ref, **tol)
+        if kind != "sgd" or hp["momentum"]:
+            torch.testing.assert_close(s_dev[0].cpu(), s_ref[0], rtol=1e-3, atol=1e-5)
+        untouched = torch.ones(M, dtype=torch.bool)
+        untouched[rows] = False
+        assert torch.equal(p_dev.cpu()[untouched], before.cpu()[untouched])  # lazy: untouched rows do not move
