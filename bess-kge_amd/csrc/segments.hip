@@ -52,6 +52,74 @@ static hipError_t cub_sizes(int64_t n, CubSizes* cs) {
     return hipSuccess;
 }
 
+// Small lists (heads, tails, shared negatives of a step: a few thousand references): the whole
+// index - stable sort by row, unique rows, offsets, long-row list - in ONE workgroup and one
+// launch.  The device-wide pipeline above is ~17 launches of 4-5 us each, which is all latency at
+// this size (and sits between backward and update of a step with a stateful optimiser).
+constexpr int SEG_CAP_FOR_SMALL = BESS_SEGMENT_CAP;
+constexpr int SMALL_T = 1024, SMALL_I = 15, SMALL_N = SMALL_T * SMALL_I;  // up to 15,360 references
+
+__global__ __launch_bounds__(SMALL_T) void k_small_segment_index(const int32_t* __restrict__ idx, int n,
+                                                                 int row_bits, int32_t* __restrict__ refs_sorted,
+                                                                 int32_t* __restrict__ seg_rows,
+                                                                 int32_t* __restrict__ seg_offsets,
+                                                                 int32_t* __restrict__ n_seg,
+                                                                 int32_t* __restrict__ long_segs, int32_t long_cap) {
+    typedef hipcub::BlockRadixSort<int32_t, SMALL_T, SMALL_I, int32_t> Sort;
+    typedef hipcub::BlockDiscontinuity<int32_t, SMALL_T> Disc;
+    typedef hipcub::BlockScan<int32_t, SMALL_T> Scan;
+    __shared__ union {
+        typename Sort::TempStorage sort;
+        typename Disc::TempStorage disc;
+        typename Scan::TempStorage scan;
+    } tmp;
+    __shared__ int32_t n_long;
+    const int t = threadIdx.x;
+    int32_t key[SMALL_I], val[SMALL_I];
+#pragma unroll
+    for (int i = 0; i < SMALL_I; ++i) {
+        const int at = t * SMALL_I + i;  // blocked arrangement; the tail sorts behind every real row
+        key[i] = at < n ? idx[at] : static_cast<int32_t>(1u << row_bits);  // row ids are < 2^row_bits
+        val[i] = at;
+    }
+    Sort(tmp.sort).Sort(key, val, 0, row_bits + 1);  // LSD radix sort: stable
+    __syncthreads();
+    int32_t head[SMALL_I];
+    Disc(tmp.disc).FlagHeads(head, key, hipcub::Inequality());  // first item of the block is a head
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SMALL_I; ++i)
+        if (t * SMALL_I + i >= n) head[i] = 0;
+    int32_t sid[SMALL_I], total = 0;
+    Scan(tmp.scan).ExclusiveSum(head, sid, total);
+#pragma unroll
+    for (int i = 0; i < SMALL_I; ++i) {
+        const int at = t * SMALL_I + i;
+        if (at < n) {
+            refs_sorted[at] = val[i];
+            if (head[i]) {
+                seg_rows[sid[i]] = key[i];
+                seg_offsets[sid[i]] = at;
+            }
+        }
+    }
+    if (t == 0) {
+        *n_seg = total;
+        seg_offsets[total] = n;
+        n_long = 0;
+    }
+    if (!long_segs) return;
+    __syncthreads();  // offsets written by this workgroup are visible to it
+    for (int s2 = t; s2 < total; s2 += SMALL_T) {
+        if (seg_offsets[s2 + 1] - seg_offsets[s2] > SEG_CAP_FOR_SMALL) {
+            const int li = atomicAdd(&n_long, 1);
+            if (li < long_cap) long_segs[1 + li] = s2;
+        }
+    }
+    __syncthreads();
+    if (t == 0) long_segs[0] = n_long;
+}
+
 __global__ __launch_bounds__(256) void k_iota(int32_t* __restrict__ out, int64_t n) {
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) out[i] = static_cast<int32_t>(i);
 }
@@ -510,6 +578,11 @@ extern "C" int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int3
     BESS_REQUIRE(workspace_bytes >= need, "build_segment_index: workspace of %zu bytes, need %zu", workspace_bytes, need);
     hipStream_t st = as_stream(stream);
     const int n = static_cast<int>(n_refs);
+    if (n_refs <= SMALL_N && row_bits <= 30) {
+        k_small_segment_index<<<1, SMALL_T, 0, st>>>(idx, n, row_bits, refs_sorted, seg_rows, seg_offsets, n_seg,
+                                                     long_segs, static_cast<int32_t>(long_cap));
+        return check_launch("build_segment_index (small)");
+    }
     char* ws = static_cast<char*>(workspace);
     const size_t blk = align_up(sizeof(int32_t) * static_cast<size_t>(n_refs));
     int32_t* keys_sorted = reinterpret_cast<int32_t*>(ws);
