@@ -688,6 +688,8 @@ def test_public_broadcast_helpers(dev, sharing):
     (2051, 2309, 100, True, 1.0),      # ragged rows, columns and k (W not a multiple of 4)
     (1700, 33000, 64, False, 3e-4),    # dense candidates (all-entities scoring), tiny values
     (4099, 1100, 136, True, 50.0),     # W % 8 == 0 but not % 32, large values
+    (130, 40000, 8, False, 1.0),       # a single K slice, fewer query rows than one 256-row tile
+    (2048, 2048, 8, True, 1.0),        # a single K slice through the 128 x 128 kernel
 ])
 def test_split_fp16_gemm_matches_float64_product(dev, dtype, S, N, W, use_idx, scale):
     """csrc/gemm_split.hip: the bilinear shared-negative forward on the fp16 matrix cores must be
