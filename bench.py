@@ -313,6 +313,18 @@ def main() -> None:
             "ms_per_step": 1e3 * dt / tsteps,
             "steps": tsteps,
         }
+        # the notebooks train with AdamW: same step with the row-sparse AdamW of besskge.runtime
+        from besskge import runtime as _rt
+
+        adamw = _rt.Adam(lr=1e-3, weight_decay=1e-2)
+        for i in range(3):
+            model.train_step_replicas([batches[i % len(batches)]], adamw)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(tsteps):
+            model.train_step_replicas([batches[i % len(batches)]], adamw)
+        torch.cuda.synchronize()
+        train_extra["adamw_ms_per_step"] = 1e3 * (time.perf_counter() - t1) / tsteps
 
     n_neg = K_TOTAL  # negatives per positive, over all shards
     scored_per_step = world * S * (1 + n_neg)
