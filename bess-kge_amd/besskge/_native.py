@@ -74,6 +74,7 @@ class OptDesc(ctypes.Structure):
         ("beta2", _f32),
         ("eps", _f32),
         ("weight_decay", _f32),
+        ("step_ptr", _i64),
     ]
 
 

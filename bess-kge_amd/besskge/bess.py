@@ -374,6 +374,13 @@ class BessKGE(torch.nn.Module, ABC):
         state["step"] += 1
         o = nat.OptDesc()
         o.kind, o.step, o.lr = opt.kind, state["step"], float(opt.lr)
+        if getattr(self, "_device_step", False) and opt.kind == nat.OPT_ADAM:
+            # hipGraph replay (runtime.Options.use_graphs): the launch is recorded once, so the step count of
+            # Adam's bias correction lives on the device and the increment is part of the recorded step
+            if "step_dev" not in state:
+                state["step_dev"] = torch.zeros((1,), dtype=torch.int32, device=table.device)
+            state["step_dev"].add_(1)
+            o.step_ptr = state["step_dev"].data_ptr()
         o.momentum = float(getattr(opt, "momentum", 0.0))
         o.beta1, o.beta2 = float(getattr(opt, "beta1", 0.9)), float(getattr(opt, "beta2", 0.999))
         o.eps = float(getattr(opt, "eps", 0.0))
@@ -488,6 +495,10 @@ class BessKGE(torch.nn.Module, ABC):
                     if table is st.table:
                         seg = seg_index[id(g)]
                         gseg = nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go, seg)
+                        if torch.cuda.is_current_stream_capturing():
+                            raise NotImplementedError(
+                                "use_graphs with a stateful optimiser needs the fused optimiser step (TransE / RotatE / "
+                                "DistMult / ComplEx / ConvE with one per-triple group per shard) or shared negatives")
                         n_rows = int(seg.n_seg.item())  # one host sync per step on this path
                         contrib.append((seg.seg_rows[:n_rows], gseg[:n_rows]))
                 self._apply_optimizer(optimizer, st.table, contrib)

@@ -42,11 +42,12 @@ class Options:
     #: are read-only).  Training steps depend on each other and stay in order.
     pipeline_streams: int = 2
     #: capture one micro-batch step (all kernels of forward / forward+backward+
-    #: plain-SGD update, single process) into a hipGraph and replay it: the
-    #: notebook-sized micro-batches (S = 512, K = 32) are launch-bound, a replay
-    #: costs one launch.  Inputs are copied into static buffers; not available
-    #: with torch.distributed groups or stateful optimisers (their per-step
-    #: scalars are kernel arguments).
+    #: update, single process) into a hipGraph and replay it: the notebook-sized
+    #: micro-batches (S = 512, K = 32) are launch-bound, a replay costs one
+    #: launch.  Inputs are copied into static buffers.  Stateful optimisers
+    #: work too (their state tables are updated in place by the recorded
+    #: kernels, Adam's step count is kept on the device; learning rate etc. are
+    #: recorded by value).  Not available with torch.distributed groups.
     use_graphs: bool = False
 
     def deviceIterations(self, n: int) -> "Options":  # noqa: N802 - poptorch spelling
@@ -167,8 +168,11 @@ class Runner:
     def _call_with_graphs(self, batch: Dict[str, torch.Tensor], iters: int) -> Dict[str, torch.Tensor]:
         if isinstance(self.group, DistributedGroup):
             raise NotImplementedError("use_graphs is for single-process replica groups")
-        if self.optimizer is not None and not getattr(self.optimizer, "is_plain_sgd", True):
-            raise NotImplementedError("use_graphs supports plain SGD (stateful optimisers pass per-step scalars)")
+        stateful = self.optimizer is not None and not getattr(self.optimizer, "is_plain_sgd", True)
+        if stateful:
+            # the optimiser state lives in device tables the recorded kernels update in place; Adam's step
+            # count moves to the device (BessKGE._opt_desc).  Hyper-parameters are recorded by value.
+            self.model._device_step = True
         n = self.group.n_shard
         sig = tuple((k, tuple(v.shape[1:]), v.dtype) for k, v in sorted(batch.items()))
         cache = self.__dict__.setdefault("_graphs", {})
@@ -195,6 +199,12 @@ class Runner:
             if snapshot is not None:
                 fn.entity_embedding.data.copy_(snapshot[0])
                 fn.relation_embedding.data.copy_(snapshot[1])
+                for st in getattr(self.model, "_optimizer_state", {}).values():  # the warm-up steps moved it
+                    st["step"] = 0
+                    for t in st["s"]:
+                        t.zero_()
+                    if "step_dev" in st:
+                        st["step_dev"].zero_()
             cache[sig] = (graph, static, outs)
         graph, static, outs = cache[sig]
         collected: List[List[Dict[str, Any]]] = []

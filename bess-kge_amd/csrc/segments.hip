@@ -136,8 +136,19 @@ __global__ void k_close_offsets(int32_t* __restrict__ seg_offsets, const int32_t
 struct OptArgs {
     int kind;
     float lr, momentum, beta1, beta2, eps, weight_decay;
-    float bias1, bias2;  // 1 - beta^t for Adam
+    float bias1, bias2;           // 1 - beta^t for Adam (from the host's step count)
+    const int32_t* step_ptr;      // optional: step count on the device, overrides bias1 / bias2
 };
+
+// bias corrections from the device-side step count, when there is one
+__device__ __forceinline__ OptArgs opt_resolve(OptArgs o) {
+    if (o.kind == BESS_OPT_ADAM && o.step_ptr) {
+        const float t = static_cast<float>(*o.step_ptr);
+        o.bias1 = 1.f - powf(o.beta1, t);
+        o.bias2 = 1.f - powf(o.beta2, t);
+    }
+    return o;
+}
 
 // one optimiser step on one scalar (p: parameter, g: summed gradient, s1 / s2: its state)
 __device__ __forceinline__ void opt_step(const OptArgs& o, float& p, float g, float& s1, float& s2) {
@@ -272,6 +283,7 @@ __device__ __forceinline__ void seg_finish(const SegArgs& a, int g, int64_t seg,
                                            const float (&ev)[IT][VEC], const float (&acc)[IT][VEC],
                                            float* __restrict__ grad_seg, T* table_rw, float lr) {
     if (a.opt.o.kind >= 0) {
+        const OptArgs oo = opt_resolve(a.opt.o);
         // state rows are touched once per step: streamed past the caches (non-temporal), so that they do
         // not evict the query slice the column window keeps in L2
         const int x = a.opt.xmap ? a.opt.xmap[seg] : -1;
@@ -291,7 +303,7 @@ __device__ __forceinline__ void seg_finish(const SegArgs& a, int g, int64_t seg,
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 float p = ev[it][v], s1 = s1v[v], s2 = s2v[v];
-                opt_step(a.opt.o, p, acc[it][v] + xs[v], s1, s2);
+                opt_step(oo, p, acc[it][v] + xs[v], s1, s2);
                 table_rw[at + v] = static_cast<T>(p);
                 s1v[v] = s1;
                 s2v[v] = s2;
@@ -482,6 +494,7 @@ __global__ __launch_bounds__(256) void k_apply_segments_opt(OptArgs o, T* __rest
                                                             float* __restrict__ state1,
                                                             float* __restrict__ state2,
                                                             const int32_t* __restrict__ keep) {
+    o = opt_resolve(o);
     const int64_t total = static_cast<int64_t>(*n_seg) * W;
     for (int64_t t = blockIdx.x * 256ll + threadIdx.x; t < total; t += 256ll * gridDim.x) {
         const int64_t s = t / W;
@@ -700,8 +713,9 @@ static int grad_segments_impl(const bess_model_desc* d, const float* query, int6
 }
 
 static OptArgs opt_args(const bess_opt_desc* o) {
-    OptArgs a{o->kind, o->lr, o->momentum, o->beta1, o->beta2, o->eps, o->weight_decay, 1.f, 1.f};
-    if (o->kind == BESS_OPT_ADAM) {
+    OptArgs a{o->kind, o->lr, o->momentum, o->beta1, o->beta2, o->eps, o->weight_decay, 1.f, 1.f,
+              reinterpret_cast<const int32_t*>(static_cast<uintptr_t>(o->step_ptr))};
+    if (o->kind == BESS_OPT_ADAM && !o->step_ptr) {
         a.bias1 = 1.f - powf(o->beta1, static_cast<float>(o->step));
         a.bias2 = 1.f - powf(o->beta2, static_cast<float>(o->step));
     }
@@ -715,7 +729,7 @@ static int check_opt(const bess_opt_desc* o, const float* state1, const float* s
     if (o->kind == BESS_OPT_ADAGRAD) BESS_REQUIRE(state1, "%s: Adagrad needs state1", who);
     if (o->kind == BESS_OPT_ADAM) {
         BESS_REQUIRE(state1 && state2, "%s: Adam needs state1 and state2", who);
-        BESS_REQUIRE(o->step >= 1, "%s: Adam needs step >= 1", who);
+        BESS_REQUIRE(o->step >= 1 || o->step_ptr, "%s: Adam needs step >= 1", who);
     }
     return BESS_OK;
 }

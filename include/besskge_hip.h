@@ -106,6 +106,8 @@ typedef struct bess_opt_desc {
     float beta2;
     float eps;
     float weight_decay;
+    int64_t step_ptr; /* 0, or a device `const int32_t*`: the step count is read there by the kernels
+                         instead of `step` (a hipGraph replays the same launch with a growing count) */
 } bess_opt_desc;
 
 typedef struct bess_loss_desc {

@@ -27,14 +27,17 @@ for S, K in ((512, 32), (512, 256), (4096, 256), (4096, 2048), (16384, 2048), (6
     batch = dict(head=rng.integers(N_ENT, size=(ITERS, 1, S)), relation=rng.integers(N_REL, size=(ITERS, 1, S)),
                  tail=rng.integers(N_ENT, size=(ITERS, 1, S)), negative=rng.integers(N_ENT, size=(ITERS, 1, 1, K)))
     batch = {k: torch.from_numpy(v.astype(np.int32)).to(dev) for k, v in batch.items()}
-    for train in (False, True):
+    for train in (False, True, "adamw"):  # "adamw": the notebook's optimiser (row-sparse AdamW here)
+        if train == "adamw" and S > 4096:
+            continue
         for graphs in ((False, True) if S <= 4096 else (False,)):
             torch.manual_seed(0)
             fn = TransE(True, 1, sharding, N_REL, D, [init_KGE_uniform], [init_KGE_uniform]).half()
             model = EmbeddingMovingBessKGE(negative_sampler=ns, score_fn=fn, augment_negative=True,
                                            loss_fn=SampledSoftmaxCrossEntropyLoss(n_entity=2_500_604))
             opts = runtime.Options(device_iterations=ITERS, use_graphs=graphs, pipeline_streams=1)
-            runner = runtime.training_model(model, opts, runtime.SGD(lr=1e-3), device=dev) if train else \
+            optim = runtime.Adam(lr=1e-3, weight_decay=1e-2) if train == "adamw" else runtime.SGD(lr=1e-3)
+            runner = runtime.training_model(model, opts, optim, device=dev) if train else \
                 runtime.inference_model(model, opts, device=dev)
             for _ in range(2):
                 runner(**batch)
@@ -46,5 +49,6 @@ for S, K in ((512, 32), (512, 256), (4096, 256), (4096, 2048), (16384, 2048), (6
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / (R * ITERS)
             n_neg = K + S  # augmentation adds the S tails of the micro-batch
-            print(f"S={S:6d} K={K:5d} {'train' if train else 'score'} graphs={'on ' if graphs else 'off'}: "
+            what = "adamw" if train == "adamw" else ("train" if train else "score")
+            print(f"S={S:6d} K={K:5d} {what} graphs={'on ' if graphs else 'off'}: "
                   f"{1e6*dt:9.1f} us/micro-batch  {S*(1+n_neg)/dt/1e9:8.2f} G triples/s", flush=True)

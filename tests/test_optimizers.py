@@ -190,3 +190,38 @@ def test_fused_optimizer_step_in_the_segmented_reduction(dev, kind, scorer, p, d
         untouched = torch.ones(M, dtype=torch.bool)
         untouched[rows] = False
         assert torch.equal(p_dev.cpu()[untouched], before.cpu()[untouched])  # lazy: untouched rows do not move
+
+
+@pytest.mark.parametrize("opt_name", ["adam", "sgdm", "adagrad"])
+@pytest.mark.parametrize("case", ["tr_EM_TransE1_t_flat_n1", "tr_EM_ComplEx0_h_pt_n1"])
+def test_graph_replay_with_stateful_optimizers(dev, opt_name, case):
+    """Options.use_graphs with Adagrad / SGD-momentum / Adam: four recorded-and-replayed steps move the
+    tables like four eager steps (Adam's bias correction follows the device-side step count)."""
+    from besskge import runtime
+    from test_hip_parity import build_model
+
+    c = load_bess_case(case)
+    n = c["meta"]["n_shard"]
+    keys = ("head", "relation", "tail", "negative", "negative_mask")
+    batch = {k: c["batch"][k].flatten(end_dim=1)[:n] for k in keys if k in c["batch"]}
+
+    def make():
+        if opt_name == "adam":
+            return runtime.Adam(lr=0.01, weight_decay=0.01)
+        if opt_name == "sgdm":
+            return runtime.SGD(lr=0.05, momentum=0.9)
+        return runtime.Adagrad(lr=0.1)
+
+    out = []
+    for graphs in (False, True):
+        model = build_model(c, dev)
+        runner = runtime.training_model(model, runtime.Options(device_iterations=1, use_graphs=graphs), make(),
+                                        device=dev)
+        losses = [runner(**batch)["loss"].float().cpu().clone() for _ in range(4)]
+        out.append((torch.stack(losses), model.score_fn.entity_embedding.detach().float().cpu().clone(),
+                    model.score_fn.relation_embedding.detach().float().cpu().clone()))
+    (l0, e0, r0), (l1, e1, r1) = out
+    assert float(l0[3].sum()) != float(l0[0].sum())  # the steps do change the model
+    torch.testing.assert_close(l1, l0, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(e1, e0, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(r1, r0, rtol=1e-4, atol=2e-5)
