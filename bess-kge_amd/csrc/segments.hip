@@ -57,8 +57,9 @@ static hipError_t cub_sizes(int64_t n, CubSizes* cs) {
 // launch.  The device-wide pipeline above is ~17 launches of 4-5 us each, which is all latency at
 // this size (and sits between backward and update of a step with a stateful optimiser).
 constexpr int SEG_CAP_FOR_SMALL = BESS_SEGMENT_CAP;
-constexpr int SMALL_T = 1024, SMALL_I = 15, SMALL_N = SMALL_T * SMALL_I;  // up to 15,360 references
+constexpr int SMALL_T = 1024, SMALL_N = SMALL_T * 15;  // up to 15,360 references (2, 4 or 15 per thread)
 
+template <int SMALL_I>
 __global__ __launch_bounds__(SMALL_T) void k_small_segment_index(const int32_t* __restrict__ idx, int n,
                                                                  int row_bits, int32_t* __restrict__ refs_sorted,
                                                                  int32_t* __restrict__ seg_rows,
@@ -83,6 +84,8 @@ __global__ __launch_bounds__(SMALL_T) void k_small_segment_index(const int32_t* 
         val[i] = at;
     }
     Sort(tmp.sort).Sort(key, val, 0, row_bits + 1);  // LSD radix sort: stable
+    constexpr int SMALL_CAP = SMALL_T * SMALL_I;
+    (void)SMALL_CAP;
     __syncthreads();
     int32_t head[SMALL_I];
     Disc(tmp.disc).FlagHeads(head, key, hipcub::Inequality());  // first item of the block is a head
@@ -592,8 +595,13 @@ extern "C" int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int3
     hipStream_t st = as_stream(stream);
     const int n = static_cast<int>(n_refs);
     if (n_refs <= SMALL_N && row_bits <= 30) {
-        k_small_segment_index<<<1, SMALL_T, 0, st>>>(idx, n, row_bits, refs_sorted, seg_rows, seg_offsets, n_seg,
-                                                     long_segs, static_cast<int32_t>(long_cap));
+        const int32_t lc = static_cast<int32_t>(long_cap);
+        if (n <= SMALL_T * 2)
+            k_small_segment_index<2><<<1, SMALL_T, 0, st>>>(idx, n, row_bits, refs_sorted, seg_rows, seg_offsets, n_seg, long_segs, lc);
+        else if (n <= SMALL_T * 4)
+            k_small_segment_index<4><<<1, SMALL_T, 0, st>>>(idx, n, row_bits, refs_sorted, seg_rows, seg_offsets, n_seg, long_segs, lc);
+        else
+            k_small_segment_index<15><<<1, SMALL_T, 0, st>>>(idx, n, row_bits, refs_sorted, seg_rows, seg_offsets, n_seg, long_segs, lc);
         return check_launch("build_segment_index (small)");
     }
     char* ws = static_cast<char*>(workspace);
