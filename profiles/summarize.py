@@ -51,6 +51,27 @@ json.dump({"neg_score_pertriple_fwd_bytes_per_launch": 2 * fetch * 1024 + write 
           open("profiles/pmc_traffic.json", "w"), indent=1)
 for name in ("score.json", "train.json", "score_hbm.json"):
     os.system(f"cp {src}/{name} {out}/bench_{name}")
+# index of the other logs kept for this round (each is the stdout of the script named in its first column)
+INDEX = [
+    ("bench_default.json", "python bench.py", "the driver's line: value, roofline, train_step (SGD and AdamW), cpu_baseline"),
+    ("microbench_final.log", "profiles/microbench.py", "every hot entry point on the BASELINE shapes (GB/s, TFLOP/s, T lane-ops/s)"),
+    ("bench_gemm_split.log", "profiles/bench_gemm_split.py", "split-fp16 matrix-core products: accuracy vs float64 and rate, forward + backward"),
+    ("bench_topk.log", "profiles/bench_topk.py", "top-k over all entities (YAGO3-10, wikikg2, biokg shapes)"),
+    ("bench_c4.log", "profiles/bench_c4.py", "BASELINE configs[3] regime through runtime.Runner, hipGraph replay, SGD and AdamW"),
+    ("bench_graphs.log", "profiles/bench_graphs.py", "hipGraph replay in the launch-bound regime (configs[0] shape)"),
+    ("bench_optim.log", "profiles/bench_optim.py", "training step of the bench workload per optimiser"),
+    ("bench_skew.log", "profiles/bench_skew.py", "segmented K9 when a share of all references points at one row"),
+    ("bench_sampler.log", "profiles/bench_sampler.py", "device-side samplers vs numpy"),
+    ("ubench_hbm_bw.log", "profiles/ubench/hbm_bw.hip", "what the memory system delivers: streaming and random-row reads"),
+    ("ubench_valu_rate.log", "profiles/ubench/valu_rate.hip", "VALU ceiling of the p-norm tile kernels (scalar and packed)"),
+    ("ubench_mfma_f32.log", "profiles/ubench/mfma_f32.hip", "fp32 MFMA inner loop ceiling"),
+    ("ubench_mfma_f16.log", "profiles/ubench/mfma_f16.hip", "fp16 MFMA consumer loop of the split GEMM: rate and clocks"),
+    ("ubench_l1_tile.log", "profiles/ubench/l1_tile.hip", "the steps that took the L1 tile kernel from 35 to 48 T lane-ops/s"),
+]
+lines.append("\n## Other logs of this round\n\n| file | produced by | what |\n|---|---|---|\n")
+for name, prod, what in INDEX:
+    if os.path.exists(f"{out}/{name}"):
+        lines.append(f"| `{name}` | `{prod}` | {what} |\n")
 open(f"{out}/SUMMARY.md", "w").write(
     f"# Round {tag} profiles (MI355X, ROCm 7.2, rocprofv3)\n\nRecipe: `profiles/run_profiles.sh {tag}` on the GPU box (gpurun),"
     f" then `python profiles/summarize.py {tag}`; the raw stats CSVs and the bench lines of the profiled runs are next to"
