@@ -62,6 +62,9 @@ INDEX = [
     ("bench_optim.log", "profiles/bench_optim.py", "training step of the bench workload per optimiser"),
     ("bench_skew.log", "profiles/bench_skew.py", "segmented K9 when a share of all references points at one row"),
     ("bench_sampler.log", "profiles/bench_sampler.py", "device-side samplers vs numpy"),
+    ("stress_long_rows.log", "profiles/stress_long_rows.py", "400 random skewed problems through the long-row tier of K9"),
+    ("stress_gemm_split.log", "profiles/stress_gemm_split.py", "80 random shapes through the split-fp16 products vs float64"),
+    ("stress_topk.log", "profiles/stress_topk.py", "150 random top-k problems (ties, masks, padded rows) vs a stable sort"),
     ("ubench_hbm_bw.log", "profiles/ubench/hbm_bw.hip", "what the memory system delivers: streaming and random-row reads"),
     ("ubench_valu_rate.log", "profiles/ubench/valu_rate.hip", "VALU ceiling of the p-norm tile kernels (scalar and packed)"),
     ("ubench_mfma_f32.log", "profiles/ubench/mfma_f32.hip", "fp32 MFMA inner loop ceiling"),
