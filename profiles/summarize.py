@@ -64,6 +64,7 @@ INDEX = [
     ("bench_sampler.log", "profiles/bench_sampler.py", "device-side samplers vs numpy"),
     ("stress_long_rows.log", "profiles/stress_long_rows.py", "400 random skewed problems through the long-row tier of K9"),
     ("stress_gemm_split.log", "profiles/stress_gemm_split.py", "80 random shapes through the split-fp16 products vs float64"),
+    ("stress_pertriple.log", "profiles/stress_pertriple.py", "150 random problems: dominant kernel and its backward vs torch float64"),
     ("stress_fused_forward.log", "profiles/stress_fused_forward.py", "160 random problems: fused training forward vs the two-pass path"),
     ("stress_topk.log", "profiles/stress_topk.py", "150 random top-k problems (ties, masks, padded rows) vs a stable sort"),
     ("ubench_hbm_bw.log", "profiles/ubench/hbm_bw.hip", "what the memory system delivers: streaming and random-row reads"),
