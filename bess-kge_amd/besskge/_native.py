@@ -17,7 +17,7 @@ from typing import Any, List, Optional, Sequence, Tuple
 import torch
 
 LIB_NAME = "libbesskge_hip.so"
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 TRANSE, ROTATE, DISTMULT, COMPLEX, AFFINE, BOXE = 0, 1, 2, 3, 4, 5
 F32, F16 = 0, 1
@@ -141,7 +141,18 @@ SIGNATURES = {
     "bess_sample_negatives": [_PG, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "bess_sample_bucket_indices": [_PG, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "bess_lookup_triples": [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
+    "bess_comm_unique_id": [_c_u8p],
+    "bess_comm_init_rank": [_i32, _i32, _c_u8p, ctypes.POINTER(_vp)],
+    "bess_comm_init_all": [_i32, _c_i32p, ctypes.POINTER(_vp)],
+    "bess_comm_destroy": [_vp],
+    "bess_comm_info": [_vp, _c_i32p, _c_i32p, _c_i32p],
+    "bess_alltoall": [_vp, _vp, _vp, _i64, _vp],
+    "bess_allgather": [_vp, _vp, _vp, _i64, _vp],
+    "bess_allreduce_sum_f32": [_vp, _vp, _vp, _i64, _vp],
+    "bess_pack_exchange": [_vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp],
 }
+COMM_ID_BYTES = 128
+ECOMM_BASE = 10000
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -226,7 +237,7 @@ def _check(rc: int, what: str) -> None:
     if rc != 0:
         buf = ctypes.create_string_buffer(512)
         load().bess_last_error(buf, 512)
-        kind = "invalid argument" if rc < 0 else f"hipError {rc}"
+        kind = "invalid argument" if rc < 0 else (f"ncclResult {rc - ECOMM_BASE}" if rc >= ECOMM_BASE else f"hipError {rc}")
         raise RuntimeError(f"besskge native call {what} failed ({kind}): {buf.value.decode()}")
 
 
@@ -1033,3 +1044,98 @@ def lookup_triples(triples: torch.Tensor, sample_idx: torch.Tensor, swap_tail: b
                                       ppp, int(swap_tail), ptr("head"), ptr("relation"), ptr("tail"),
                                       _stream(dev)), "lookup_triples")
     return out
+
+
+# --------------------------------------------------------------------------- #
+# collectives between shards (RCCL through the C ABI)
+def comm_unique_id() -> bytes:
+    """128 opaque bytes; made by one rank, handed to every rank's `Communicator`."""
+    buf = (ctypes.c_uint8 * COMM_ID_BYTES)()
+    _check(load().bess_comm_unique_id(buf), "bess_comm_unique_id")
+    return bytes(buf)
+
+
+class Communicator:
+    """`bess_comm*` of this rank (owns it: destroyed with the object).  Belongs to the HIP
+    device that is current when it is made; collectives run on PyTorch's current stream
+    of that device."""
+
+    def __init__(self, world: int, rank: int, unique_id: bytes, device: torch.device) -> None:
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError(f"unique id must be {COMM_ID_BYTES} bytes")
+        if device.type != "cuda":
+            raise RuntimeError("besskge: communicators live on HIP devices (there is no CPU fallback)")
+        self.world, self.rank, self.device = int(world), int(rank), device
+        self._h = _vp()
+        buf = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        with torch.cuda.device(device):
+            _check(load().bess_comm_init_rank(self.world, self.rank, buf, ctypes.byref(self._h)),
+                   "bess_comm_init_rank")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            torch.cuda.synchronize(self.device)
+            h, self._h = self._h, _vp()
+            _check(load().bess_comm_destroy(h), "bess_comm_destroy")
+
+    def __del__(self) -> None:  # pragma: no cover - interpreter shutdown order
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _buf(self, t: torch.Tensor, name: str) -> int:
+        if not t.is_cuda or t.device != self.device:
+            raise RuntimeError(f"besskge: `{name}` is on {t.device}, the communicator on {self.device}")
+        if not t.is_contiguous():
+            raise ValueError(f"`{name}` must be contiguous")
+        return t.data_ptr()
+
+    def all_to_all(self, send: torch.Tensor, recv: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """send [world, ...]: block p goes to rank p; returns recv (block p came from rank p)."""
+        if send.dim() < 1 or send.shape[0] != self.world:
+            raise ValueError(f"all_to_all: leading dim {tuple(send.shape)[:1]} != world {self.world}")
+        if recv is None:
+            recv = torch.empty_like(send)
+        elif recv.shape != send.shape or recv.dtype != send.dtype:
+            raise ValueError("all_to_all: recv does not match send")
+        per_peer = send[0].numel() * send.element_size()
+        with torch.cuda.device(self.device), _Timed("bess_alltoall", self.device):
+            rc = load().bess_alltoall(self._h, self._buf(send, "send"), self._buf(recv, "recv"), per_peer,
+                                      _stream(self.device))
+        _check(rc, "bess_alltoall")
+        return recv
+
+    def all_gather(self, send: torch.Tensor) -> torch.Tensor:
+        """recv [world, *send.shape] in rank order."""
+        recv = torch.empty((self.world, *send.shape), dtype=send.dtype, device=send.device)
+        with torch.cuda.device(self.device), _Timed("bess_allgather", self.device):
+            rc = load().bess_allgather(self._h, self._buf(send, "send"), self._buf(recv, "recv"),
+                                       send.numel() * send.element_size(), _stream(self.device))
+        _check(rc, "bess_allgather")
+        return recv
+
+    def all_reduce_sum_(self, x: torch.Tensor) -> torch.Tensor:
+        """In-place sum over ranks of a float32 tensor."""
+        _f32(x, "x")
+        with torch.cuda.device(self.device), _Timed("bess_allreduce_sum_f32", self.device):
+            p = self._buf(x, "x")
+            rc = load().bess_allreduce_sum_f32(self._h, p, p, x.numel(), _stream(self.device))
+        _check(rc, "bess_allreduce_sum_f32")
+        return x
+
+    def pack_exchange(self, table: torch.Tensor, idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """K1 + C1: idx [world, L] rows of `table` -> (send, recv), both [world, L, W]."""
+        W = int(table.shape[1])
+        _rows(table, "table", W)
+        if idx.dtype != torch.int32 or idx.dim() != 2 or idx.shape[0] != self.world or not idx.is_contiguous():
+            raise ValueError("pack_exchange: idx must be a contiguous int32 [world, L] tensor")
+        L = int(idx.shape[1])
+        send = torch.empty((self.world, L, W), dtype=table.dtype, device=table.device)
+        recv = torch.empty_like(send)
+        with torch.cuda.device(self.device), _Timed("bess_pack_exchange", self.device):
+            rc = load().bess_pack_exchange(self._h, _dtype_code(table), W, self._buf(table, "table"),
+                                           self._buf(idx, "idx"), L, send.data_ptr(), recv.data_ptr(),
+                                           _stream(self.device))
+        _check(rc, "bess_pack_exchange")
+        return send, recv

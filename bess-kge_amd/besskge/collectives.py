@@ -14,7 +14,13 @@ replica j, result block j came from replica j) and `all_gather_cross_replica`
   in the reference's tests, `tests/test_bess.py:123-127`); the collectives are
   device-side block transposes.
 
-Both operate on *lists* with one tensor per local replica, so the model code is
+* :class:`NativeGroup` - the same layout with the collectives issued through the
+  library's own RCCL entry points (`bess_alltoall`, `bess_allgather`,
+  `bess_allreduce_sum_f32`, `bess_pack_exchange`; include/besskge_hip.h) on the
+  stream the kernels run on: a step is one in-order queue, nothing waits on
+  c10d's separate collective stream, and the step can be hipGraph-captured.
+
+All operate on *lists* with one tensor per local replica, so the model code is
 written once.  The entity-shard gradient is never all-reduced (the reference
 removes that all-reduce with a PopART pattern,
 `custom_ops/remove_all_reduce_pattern.cpp:15-47`); only replicated parameters
@@ -130,3 +136,75 @@ class DistributedGroup(ReplicaGroup):
 
     def barrier(self) -> None:
         dist.barrier(group=self.pg)
+
+
+class NativeGroup(ReplicaGroup):
+    """One replica per process; collectives through the C ABI (`bess_comm_*`, RCCL) on
+    PyTorch's current HIP stream.
+
+    The 128-byte RCCL id is made by rank 0 and handed round through an existing
+    `torch.distributed` process group of any backend (used for nothing else but
+    `barrier()`), or passed in (`unique_id=`; `world` / `rank` then come from the
+    arguments, and torch.distributed is not needed at all).
+    """
+
+    def __init__(self, device: torch.device, process_group: Optional[dist.ProcessGroup] = None,
+                 unique_id: Optional[bytes] = None, world: Optional[int] = None,
+                 rank: Optional[int] = None) -> None:
+        from besskge import _native as nat
+
+        self.pg = process_group
+        if unique_id is None:
+            if not dist.is_initialized():
+                raise RuntimeError("NativeGroup needs torch.distributed (to hand the RCCL id round) or `unique_id=`")
+            world = dist.get_world_size(process_group)
+            rank = dist.get_rank(process_group)
+            box = [nat.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group else 0,
+                                       group=process_group, device=torch.device("cpu")
+                                       if dist.get_backend(process_group) == "gloo" else device)
+            unique_id = box[0]
+            self._has_dist = True
+        else:
+            if world is None or rank is None:
+                raise ValueError("NativeGroup(unique_id=...) also needs world= and rank=")
+            self._has_dist = dist.is_initialized()
+        self.n_shard = int(world)
+        self.rank = int(rank)
+        self.local_shards = [self.rank]
+        self.device = device
+        self.comm = nat.Communicator(self.n_shard, self.rank, unique_id, device)
+
+    def all_to_all(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        (x,) = xs
+        return [self.comm.all_to_all(x.contiguous())]
+
+    def all_gather(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        (x,) = xs
+        return [self.comm.all_gather(x.contiguous())]
+
+    def all_reduce_sum(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        (x,) = xs
+        if x.dtype != torch.float32:
+            y = self.comm.all_reduce_sum_(x.float().contiguous())
+            x.copy_(y)
+            return [x]
+        if not x.is_contiguous():
+            y = self.comm.all_reduce_sum_(x.contiguous())
+            x.copy_(y)
+            return [x]
+        return [self.comm.all_reduce_sum_(x)]
+
+    def pack_exchange(self, table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """K1 + C1 in one native call: rows `table[idx]` (idx [n_shard, L]) -> received [n_shard, L, W]."""
+        return self.comm.pack_exchange(table, idx)[1]
+
+    def barrier(self) -> None:
+        if self._has_dist:
+            torch.cuda.current_stream(self.device).synchronize()
+            dist.barrier(group=self.pg)
+        else:
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def close(self) -> None:
+        self.comm.close()

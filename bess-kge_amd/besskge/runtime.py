@@ -21,7 +21,9 @@ from typing import Any, Dict, List, Optional
 import torch
 
 from besskge.bess import BessKGE
-from besskge.collectives import DistributedGroup, ReplicaGroup, SingleProcessGroup
+from besskge.collectives import DistributedGroup, NativeGroup, ReplicaGroup, SingleProcessGroup
+
+_MULTI_PROCESS = (DistributedGroup, NativeGroup)
 
 _BATCH_KEYS = ("head", "relation", "tail", "negative", "triple_mask", "triple_weight", "negative_mask", "step")
 
@@ -47,7 +49,8 @@ class Options:
     #: launch.  Inputs are copied into static buffers.  Stateful optimisers
     #: work too (their state tables are updated in place by the recorded
     #: kernels, Adam's step count is kept on the device; learning rate etc. are
-    #: recorded by value).  Not available with torch.distributed groups.
+    #: recorded by value).  One process per GPU: with `NativeGroup` (collectives on
+    #: the kernels' stream, captured with them), not with c10d's `DistributedGroup`.
     use_graphs: bool = False
 
     def deviceIterations(self, n: int) -> "Options":  # noqa: N802 - poptorch spelling
@@ -167,7 +170,9 @@ class Runner:
 
     def _call_with_graphs(self, batch: Dict[str, torch.Tensor], iters: int) -> Dict[str, torch.Tensor]:
         if isinstance(self.group, DistributedGroup):
-            raise NotImplementedError("use_graphs is for single-process replica groups")
+            raise NotImplementedError(
+                "use_graphs needs the collectives on the kernels' own stream: SingleProcessGroup, or NativeGroup "
+                "(bess_comm_* / RCCL through the C ABI) for one process per GPU - not c10d's DistributedGroup")
         stateful = self.optimizer is not None and not getattr(self.optimizer, "is_plain_sgd", True)
         if stateful:
             # the optimiser state lives in device tables the recorded kernels update in place; Adam's step
@@ -184,8 +189,11 @@ class Runner:
                     slot[k].copy_(v[shard: shard + 1])
             fn = self.model.score_fn
             training = self.optimizer is not None
-            # the warm-up steps (index maps, allocator pools) and the capture must not train
-            snapshot = (fn.entity_embedding.data.clone(), fn.relation_embedding.data.clone()) if training else None
+            # The warm-up steps (index maps, allocator pools) and the capture must not train: everything a
+            # training step writes is saved here and put back afterwards - the tables, the optimiser state
+            # accumulated so far (a new input signature may turn up in the middle of a run: a last, shorter
+            # batch), and the scorer's dense parameters / buffers (ConvE's network and batch-norm statistics).
+            snapshot = self._training_snapshot() if training else None
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
@@ -197,14 +205,7 @@ class Runner:
             with torch.cuda.graph(graph):
                 outs = self._step(static)
             if snapshot is not None:
-                fn.entity_embedding.data.copy_(snapshot[0])
-                fn.relation_embedding.data.copy_(snapshot[1])
-                for st in getattr(self.model, "_optimizer_state", {}).values():  # the warm-up steps moved it
-                    st["step"] = 0
-                    for t in st["s"]:
-                        t.zero_()
-                    if "step_dev" in st:
-                        st["step_dev"].zero_()
+                self._restore_training_snapshot(snapshot)
             cache[sig] = (graph, static, outs)
         graph, static, outs = cache[sig]
         collected: List[List[Dict[str, Any]]] = []
@@ -221,6 +222,40 @@ class Runner:
                     step_out.append(o.clone())
             collected.append(step_out)
         return self._stack_outputs(collected)
+
+    def _training_snapshot(self) -> Dict[str, Any]:
+        fn = self.model.score_fn
+        snap: Dict[str, Any] = dict(
+            entity=fn.entity_embedding.data.clone(), relation=fn.relation_embedding.data.clone(),
+            dense=[(p, p.data.clone()) for p in fn.dense_parameters()],
+            buffers=[(b, b.clone()) for b in fn.buffers()], opt={})
+        for key, st in getattr(self.model, "_optimizer_state", {}).items():
+            snap["opt"][key] = dict(step=st["step"], s=[t.clone() for t in st["s"]],
+                                    step_dev=st["step_dev"].clone() if "step_dev" in st else None)
+        return snap
+
+    def _restore_training_snapshot(self, snap: Dict[str, Any]) -> None:
+        fn = self.model.score_fn
+        fn.entity_embedding.data.copy_(snap["entity"])
+        fn.relation_embedding.data.copy_(snap["relation"])
+        for p, v in snap["dense"]:
+            p.data.copy_(v)
+        for b, v in snap["buffers"]:
+            b.copy_(v)
+        for key, st in getattr(self.model, "_optimizer_state", {}).items():
+            old = snap["opt"].get(key)
+            # state tensors the warm-up created (or grew) go back to what they were: zero
+            st["step"] = old["step"] if old else 0
+            for i, t in enumerate(st["s"]):
+                if old and i < len(old["s"]):
+                    t.copy_(old["s"][i])
+                else:
+                    t.zero_()
+            if "step_dev" in st:
+                if old and old["step_dev"] is not None:
+                    st["step_dev"].copy_(old["step_dev"])
+                else:
+                    st["step_dev"].fill_(st["step"])
 
     def _split(self, batch: Dict[str, torch.Tensor], it: int) -> List[Dict[str, torch.Tensor]]:
         n = self.group.n_shard
@@ -256,7 +291,7 @@ class Runner:
         for st in streams:
             if st is not main:
                 st.wait_stream(main)
-        pipelined = (self.optimizer is None and isinstance(self.group, DistributedGroup) and iters > 1
+        pipelined = (self.optimizer is None and isinstance(self.group, _MULTI_PROCESS) and iters > 1
                      and hasattr(self.model, "forward_begin"))
         if pipelined:
             # one process per GPU: issue the gathers / all-gathers of micro-batch it + 1 before the
@@ -299,7 +334,7 @@ class Runner:
             for res in collected:
                 vals = [r[k] if r[k].dim() > 0 else r[k].reshape(1) for r in res]
                 x = torch.cat(vals, dim=0)
-                if self.options.gather_outputs and isinstance(self.group, DistributedGroup):
+                if self.options.gather_outputs and isinstance(self.group, _MULTI_PROCESS):
                     x = self.group.all_gather([x])[0].flatten(end_dim=1)
                 per_it.append(x)
             out[k] = torch.cat(per_it, dim=0)

@@ -141,17 +141,17 @@ class Sharding:
         )
 
     def save(self, out_file: Path) -> None:
-        """Write all fields to an .npz file."""
-        np.savez(out_file, **dataclasses.asdict(self))
+        """Write all fields to an .npz file (fields that are None are left out: the file
+        holds plain arrays only and loads without pickle)."""
+        np.savez(out_file, **{k: v for k, v in dataclasses.asdict(self).items() if v is not None})
 
     @classmethod
     def load(cls, path: Path) -> "Sharding":
         """Read a sharding written by :meth:`save`."""
-        fields = dict(np.load(path, allow_pickle=True))
+        fields = dict(np.load(path, allow_pickle=False))
         n_shard = int(fields.pop("n_shard"))
         for k in ("entity_type_counts", "entity_type_offsets"):
-            if k in fields and fields[k].dtype == object:
-                fields[k] = None
+            fields.setdefault(k, None)
         return cls(n_shard=n_shard, **fields)
 
 

@@ -10,12 +10,14 @@
  *
  * Conventions
  *   - every function returns int: 0 = ok, <0 = invalid argument (BESS_E*),
- *     >0 = hipError_t of the failing runtime call; bess_last_error() gives text;
+ *     >0 = hipError_t of the failing runtime call (BESS_ECOMM_BASE + ncclResult_t
+ *     for RCCL); bess_last_error() gives text;
  *   - no ownership transfer: every buffer is allocated by the caller (PyTorch)
  *     and passed as a raw device pointer; the library never allocates,
  *     synchronises or frees;
  *   - calls are asynchronous on the given hipStream_t (passed as void*);
- *   - no global mutable state; safe from one host thread per device;
+ *   - no global mutable state except communicators (bess_comm_*); safe from one
+ *     host thread per device;
  *   - index arrays are int32 (the dtype the samplers emit,
  *     batch_sampler.py:170-178); row offsets are computed in 64 bit, so a
  *     shard may exceed 4 GiB (config 5: 62.5 M rows x 2 KiB);
@@ -36,12 +38,14 @@
 extern "C" {
 #endif
 
-#define BESS_ABI_VERSION 1
+#define BESS_ABI_VERSION 2
 
-/* error codes (negative); positive return values are hipError_t */
+/* error codes (negative); positive return values are hipError_t, or
+ * BESS_ECOMM_BASE + ncclResult_t for a failing RCCL call */
 #define BESS_OK 0
 #define BESS_EINVAL -1       /* bad enum / size / null pointer            */
 #define BESS_EUNSUPPORTED -2 /* legal but not built (width/alignment...)  */
+#define BESS_ECOMM_BASE 10000
 
 /* scoring functions (reference besskge/scoring.py:258-462, 746-946) */
 #define BESS_TRANSE 0
@@ -459,6 +463,45 @@ int bess_sample_bucket_indices(const bess_pcg64_state* gen, const uint64_t* jump
 int bess_lookup_triples(const int32_t* triples, int64_t n_triple, const int64_t* sample_idx,
                         int64_t n_step, int64_t n1, int64_t n2, int64_t per_part, int32_t swap_tail,
                         int32_t* head, int32_t* relation, int32_t* tail, void* stream);
+
+/* ---- collectives between shards (RCCL over xGMI) -----------------------------
+ * Replace `poptorch_experimental_addons.collectives` (reference bess.py:14-19):
+ * `all_to_all_single_cross_replica` (call sites bess.py:346-350, 583-595),
+ * `all_gather_cross_replica` (bess.py:519-545) and PopTorch's implicit sum of the
+ * replicated parameters' gradients.  One process per GPU, rank == shard.  A communicator
+ * is the library's only global state; it is created and destroyed by the caller and
+ * belongs to the device that was current at bess_comm_init_rank.  Every collective is
+ * asynchronous on the given hipStream_t - pass the stream the kernels run on: a step is
+ * then ONE in-order queue of kernels and collectives, and can be captured into a hipGraph.
+ * Every rank must issue the same collectives in the same order.
+ *
+ * bess_comm_unique_id: 128 opaque bytes made by ONE rank and handed to all others by the
+ *   host (torch.distributed store, MPI, a file ...), then bess_comm_init_rank on every rank
+ *   (blocks until all `world` ranks have called it).
+ * bess_comm_init_all: all n communicators of a single-process job at once (dev_ids NULL:
+ *   devices 0..n-1); comms[i] is rank i. */
+#define BESS_COMM_ID_BYTES 128
+typedef struct bess_comm bess_comm;
+int bess_comm_unique_id(uint8_t* id);
+int bess_comm_init_rank(int32_t world, int32_t rank, const uint8_t* id, bess_comm** comm);
+int bess_comm_init_all(int32_t n, const int32_t* dev_ids, bess_comm** comms);
+int bess_comm_destroy(bess_comm* comm);
+int bess_comm_info(const bess_comm* comm, int32_t* world, int32_t* rank, int32_t* device);
+
+/* C1 / C4 / C5 / C8 - balanced all-to-all: block p (bytes_per_peer bytes) of `send` goes to
+ * rank p, block p of `recv` came from rank p (one grouped send / recv per peer: each
+ * block rides its own xGMI link).  send != recv. */
+int bess_alltoall(bess_comm* comm, const void* send, void* recv, int64_t bytes_per_peer, void* stream);
+/* C2 / C3 - all-gather: recv [world, bytes] in rank order. */
+int bess_allgather(bess_comm* comm, const void* send, void* recv, int64_t bytes, void* stream);
+/* C9 - sum over ranks of the replicated tables' gradients (in place when send == recv). */
+int bess_allreduce_sum_f32(bess_comm* comm, const float* send, float* recv, int64_t n, void* stream);
+/* K1 + C1 in one call (bess.py:332-350): rows table[idx[p * rows_per_peer + i]] are packed
+ * into send [world, rows_per_peer, width] and exchanged into recv (same shape: block p =
+ * the rows rank p packed for this rank).  Row size must be a multiple of 16 bytes. */
+int bess_pack_exchange(bess_comm* comm, int32_t dtype, int32_t width, const void* table,
+                       const int32_t* idx, int64_t rows_per_peer, void* send, void* recv,
+                       void* stream);
 
 #ifdef __cplusplus
 }

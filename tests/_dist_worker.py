@@ -23,28 +23,46 @@ for p in (os.path.join(REPO, "bess-kge_amd"), REPO, HERE):
         sys.path.insert(0, p)
 
 
-def routing(out_dir: str) -> None:
-    from besskge.collectives import DistributedGroup
+def make_group():
+    """DistributedGroup (c10d: gloo / nccl), or - BESS_DIST_BACKEND=native - NativeGroup: the library's
+    own RCCL entry points (bess_comm_*), the RCCL id handed round over a gloo process group."""
+    from besskge.collectives import DistributedGroup, NativeGroup
 
-    g = DistributedGroup()
+    if os.environ.get("BESS_DIST_BACKEND", "gloo") == "native":
+        return NativeGroup(torch.device("cuda", 0))
+    return DistributedGroup()
+
+
+def routing(out_dir: str) -> None:
+    g = make_group()
     n, r = g.n_shard, g.rank
+    native = os.environ.get("BESS_DIST_BACKEND", "gloo") == "native"
+    dev = torch.device("cuda", 0) if native else torch.device("cpu")
     # block j of rank r carries the value 100*r + j
-    x = torch.stack([torch.full((3, 2), 100.0 * r + j) for j in range(n)])
+    x = torch.stack([torch.full((3, 2), 100.0 * r + j) for j in range(n)]).to(dev)
     (a2a,) = g.all_to_all([x])
-    (ag,) = g.all_gather([torch.full((2,), float(r))])
-    (ar,) = g.all_reduce_sum([torch.full((4,), float(r + 1))])
-    ids = torch.arange(6, dtype=torch.int32).reshape(n, -1) + 10 * r if n in (2, 3, 6) else torch.zeros(n, 1, dtype=torch.int32)
-    (ag_i,) = g.all_gather([ids])
-    np.savez(os.path.join(out_dir, f"routing_{r}.npz"), a2a=a2a.numpy(), ag=ag.numpy(), ar=ar.numpy(), ag_i=ag_i.numpy())
+    (ag,) = g.all_gather([torch.full((2,), float(r), device=dev)])
+    (ar,) = g.all_reduce_sum([torch.full((4,), float(r + 1), device=dev)])
+    ids = torch.arange(6, dtype=torch.int32).reshape(n, -1) + 10 * r if n in (1, 2, 3, 6) else torch.zeros(n, 1, dtype=torch.int32)
+    (ag_i,) = g.all_gather([ids.to(dev)])
+    extra = {}
+    if native:
+        # K1 + C1 in one call: rank r packs rows 7 * j + r of its table for rank j; the table of rank r is 1000 r + row
+        table = (1000.0 * r + torch.arange(64, dtype=torch.float32, device=dev))[:, None].repeat(1, 8).half().contiguous()
+        idx = (7 * torch.arange(n, dtype=torch.int32, device=dev)[:, None] + r
+               + torch.zeros((1, 5), dtype=torch.int32, device=dev)).contiguous()
+        extra["packed"] = g.pack_exchange(table, idx).float().cpu().numpy()
+        torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f"routing_{r}.npz"), a2a=a2a.cpu().numpy(), ag=ag.cpu().numpy(),
+             ar=ar.cpu().numpy(), ag_i=ag_i.cpu().numpy(), **extra)
 
 
 def bess(out_dir: str) -> None:
     from besskge import runtime
-    from besskge.collectives import DistributedGroup
     from test_hip_parity import build_model
     from test_oracle import load_bess_case
 
-    g = DistributedGroup()
+    g = make_group()
     n, r = g.n_shard, g.rank
     dev = torch.device("cuda", 0)
     cases = [c for c in os.environ["BESS_CASES"].split(",") if c]
@@ -77,12 +95,11 @@ def topk(out_dir: str) -> None:
     """Distributed TopKQueryBessKGE / AllScoresBESS on golden cases (all ranks share the GPU)."""
     from besskge import runtime
     from besskge.bess import AllScoresBESS, TopKQueryBessKGE
-    from besskge.collectives import DistributedGroup
     from besskge.sharding import Sharding
     from test_hip_parity import make_scorer
     from test_query import candidate_sampler, load_query_case
 
-    g = DistributedGroup()
+    g = make_group()
     n, r = g.n_shard, g.rank
     dev = torch.device("cuda", 0)
     out = {}
@@ -170,6 +187,9 @@ def main() -> None:
     if backend == "nccl":
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    elif backend == "native":
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
     else:
         dist.init_process_group("gloo")
     try:

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert sorted(_native.SIGNATURES) == names, "ctypes binding and header disagree"
-    assert lib.bess_version() == _native.ABI_VERSION == 1
+    assert lib.bess_version() == _native.ABI_VERSION == 2
 
 
 def test_workspace_query_needs_no_gpu():
@@ -90,6 +90,39 @@ def test_invalid_arguments_return_error_codes():
     l = _native.LossDesc()
     l.kind = 7
     assert lib.bess_loss_fwd_bwd(ctypes.byref(l), 0, 0, 1, 1, 1, 0, 1, 0, 0, 0, 0, 1, 0) == -1
+
+
+def test_communicator_entry_points_reject_bad_arguments():
+    """The RCCL entry points of SURVEY 8(b) (bess_comm_*, bess_alltoall, bess_allgather,
+    bess_allreduce_sum_f32, bess_pack_exchange) are exported and validate before touching RCCL."""
+    from besskge import _native
+
+    lib = _native.load()
+    for name in ("bess_comm_unique_id", "bess_comm_init_rank", "bess_comm_init_all", "bess_comm_destroy",
+                 "bess_comm_info", "bess_alltoall", "bess_allgather", "bess_allreduce_sum_f32", "bess_pack_exchange"):
+        assert name in _native.SIGNATURES and hasattr(lib, name)
+    uid = _native.comm_unique_id()  # host-side: no device needed
+    assert len(uid) == _native.COMM_ID_BYTES == 128 and uid != _native.comm_unique_id()
+    h = ctypes.c_void_p()
+    buf = (ctypes.c_uint8 * 128).from_buffer_copy(uid)
+    assert lib.bess_comm_init_rank(2, 2, buf, ctypes.byref(h)) == -1 and "rank 2 of 2" in last_error(lib)
+    assert lib.bess_comm_init_rank(0, 0, buf, ctypes.byref(h)) == -1
+    assert lib.bess_comm_init_rank(1, 0, None, ctypes.byref(h)) == -1 and h.value is None
+    assert lib.bess_alltoall(None, 0, 0, 16, 0) == -1 and "NULL communicator" in last_error(lib)
+    assert lib.bess_allgather(None, 0, 0, 16, 0) == -1
+    assert lib.bess_allreduce_sum_f32(None, 0, 0, 4, 0) == -1
+    assert lib.bess_pack_exchange(None, 0, 8, 0, 0, 1, 0, 0, 0) == -1
+    assert lib.bess_comm_info(None, None, None, None) == -1
+    assert lib.bess_comm_destroy(None) == 0  # like free(NULL)
+
+
+def test_native_group_needs_a_hip_device():
+    from besskge import _native
+
+    import torch
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _native.Communicator(1, 0, _native.comm_unique_id(), torch.device("cpu"))
 
 
 def test_import_fails_loudly_without_the_library(tmp_path, monkeypatch):

@@ -55,6 +55,21 @@ def test_collectives_gloo(world):
                 assert np.array_equal(z["ag_i"][j], np.arange(6, dtype=np.int32).reshape(world, -1) + 10 * j)
 
 
+@pytest.mark.gpu
+def test_collectives_native_rccl_single_rank():
+    """The library's own RCCL entry points (bess_comm_init_rank, bess_alltoall, bess_allgather,
+    bess_allreduce_sum_f32, bess_pack_exchange) through NativeGroup on a one-rank communicator -
+    all a 1-GPU box can show of them; routing over several ranks is covered by the gloo cases
+    (same block layout by construction: block p <-> rank p)."""
+    out = launch("routing", 1, {"BESS_DIST_BACKEND": "native"})
+    z = np.load(os.path.join(out, "routing_0.npz"))
+    assert np.all(z["a2a"][0] == 0.0) and z["a2a"].shape == (1, 3, 2)
+    assert np.array_equal(z["ag"], np.zeros((1, 2), dtype=np.float32))
+    assert np.all(z["ar"] == 1.0)
+    assert np.array_equal(z["ag_i"][0], np.arange(6, dtype=np.int32).reshape(1, -1))
+    assert z["packed"].shape == (1, 5, 8) and np.all(z["packed"] == 0.0)  # row 7 * 0 + 0 of table 0
+
+
 def _cases(n):
     from test_oracle import bess_cases
 
@@ -62,10 +77,11 @@ def _cases(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo")])
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (1, "native"), (2, "gloo"), (4, "gloo")])
 def test_distributed_bess_golden(world, backend):
     """(1, nccl): the single-shard goldens through DistributedGroup over a one-rank RCCL group - the
-    forward and training-step collectives as RCCL sees them (the box has one GPU)."""
+    forward and training-step collectives as RCCL sees them (the box has one GPU); (1, native): the
+    same through NativeGroup, i.e. the library's own bess_comm_* / bess_alltoall ... entry points."""
     from test_oracle import load_bess_case
 
     cases = _cases(world)
@@ -97,7 +113,7 @@ def test_distributed_bess_golden(world, backend):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo")])
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (1, "native"), (2, "gloo"), (4, "gloo")])
 def test_distributed_queries_golden(world, backend):
     """TopKQueryBessKGE / AllScoresBESS, one process per shard, vs the reference's outputs."""
     from test_query import load_query_case, query_cases
@@ -117,7 +133,16 @@ def test_distributed_queries_golden(world, backend):
                 want_s = c["outs"]["topk_scores"][:, r].numpy().reshape(-1, m["k"])
                 want_i = c["outs"]["topk_global_id"][:, r].numpy().reshape(-1, m["k"])
                 np.testing.assert_allclose(z[f"{case}_scores"], want_s, rtol=1e-4, atol=1e-4)
-                assert (z[f"{case}_ids"] == want_i).mean() > 0.98
+                # ids are exact wherever the order is determined: a mismatch is only accepted inside a run of
+                # (numerically) equal scores, or in the last slot (which may tie with the first entry cut off)
+                tol = 1e-4 * np.maximum(1.0, np.abs(want_s))
+                tie = np.zeros_like(want_s, dtype=bool)
+                close = np.abs(np.diff(want_s, axis=1)) <= tol[:, 1:]
+                tie[:, 1:] |= close
+                tie[:, :-1] |= close
+                tie[:, -1] = True
+                bad = (z[f"{case}_ids"] != want_i) & ~tie
+                assert not bad.any(), f"{case}: {int(bad.sum())} top-k ids differ outside ties"
             else:
                 want = c["outs"]["scores"][:, :, r].numpy()  # [bps, n_step, shard_bs, n * ws]
                 got = z[f"{case}_scores"]  # [n_step, bps * shard_bs, n * ws]

@@ -225,3 +225,34 @@ def test_graph_replay_with_stateful_optimizers(dev, opt_name, case):
     torch.testing.assert_close(l1, l0, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(e1, e0, rtol=1e-4, atol=2e-5)
     torch.testing.assert_close(r1, r0, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("opt_name", ["adam", "sgdm"])
+def test_graph_capture_of_a_second_signature_keeps_training_state(dev, opt_name):
+    """A new input signature in the middle of a run (a last, shorter batch) is captured with
+    warm-up steps that must leave no trace: tables, accumulated optimiser state and Adam's step
+    count afterwards are those of the eager run."""
+    from besskge import runtime
+    from test_hip_parity import build_model
+
+    c = load_bess_case("tr_EM_TransE1_t_flat_n1")
+    keys = ("head", "relation", "tail", "negative")
+    full = {k: c["batch"][k].flatten(end_dim=1)[:1] for k in keys}
+    short = dict(full, negative=full["negative"][..., : full["negative"].shape[-1] // 2].contiguous())
+    assert short["negative"].shape != full["negative"].shape
+
+    def make():
+        return runtime.Adam(lr=0.01, weight_decay=0.01) if opt_name == "adam" else runtime.SGD(lr=0.05, momentum=0.9)
+
+    out = []
+    for graphs in (False, True):
+        model = build_model(c, dev)
+        runner = runtime.training_model(model, runtime.Options(device_iterations=1, use_graphs=graphs), make(),
+                                        device=dev)
+        losses = [runner(**b)["loss"].float().cpu().clone() for b in (full, full, full, short, short, full)]
+        out.append((torch.stack(losses), model.score_fn.entity_embedding.detach().float().cpu().clone(),
+                    model.score_fn.relation_embedding.detach().float().cpu().clone()))
+    (l0, e0, r0), (l1, e1, r1) = out
+    torch.testing.assert_close(l1, l0, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(e1, e0, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(r1, r0, rtol=1e-4, atol=2e-5)
