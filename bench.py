@@ -1,26 +1,42 @@
 #!/usr/bin/env python3
 """Benchmark of the BESS hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode score|train]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode score|train] [--comm auto|native|c10d]
 
 Metric (BASELINE.json): positive+negative triples scored per second, and the
-achieved HBM GB/s of the dominant (gather + score) kernel against the roofline.
+achieved GB/s of the dominant (gather + score) kernel against the roofline.
 
-Workload at N = 1 (BASELINE.json configs[1], "C2"): ogbl-biokg-shaped ComplEx,
-embedding_size 256 (W = Wr = 512, fp32, 2 KiB rows), 93,773 entities,
-51 relations, n_shard = 1; one step = one micro-batch of S = 4096 positive
-triples, each scored against its own K = 256 negative tails (per-triple
-negatives: the HBM-bound regime, one gathered row per scored triple) through
-`EmbeddingMovingBessKGE`, with the log-sigmoid loss: K1 gather (fused), K2-K6
-scoring, K8 loss.  `--mode train` adds backward + sparse SGD (K9/K10).
-Synthetic indices (uniform), default-initialised tables; the index tensors of a
-pool of distinct micro-batches are resident in HBM before the timed region.
+Headline workload (BASELINE.json configs[1], "C2"): ogbl-biokg-shaped ComplEx,
+embedding_size 256 (W = Wr = 512, fp32, 2 KiB rows), 93,773 entities per shard,
+51 relations; one step = one micro-batch of S = 4096 positive triples per GPU,
+each scored against its own K = 256 negative tails (per-triple negatives: the
+HBM-bound regime, one gathered row per scored triple), with the log-sigmoid
+loss: K1 gather (fused), K2-K6 scoring, K8 loss.  `--mode train` adds backward
++ sparse SGD (K9/K10).  N = 1: `EmbeddingMovingBessKGE`, n_shard = 1.  N > 1
+(one process per GPU): weak scaling with `ScoreMovingBessKGE` (queries
+all-gathered, scores returned by all-to-all: the scheme the reference recommends
+for per-triple negatives, docs/source/bess.rst:75-86), K = 256 / N per shard pair.
 
-N > 1 (one process per GPU, torch.distributed / RCCL): weak scaling - every GPU
-holds a 93,773-row shard and scores S = 4096 positives against 256 negatives
-spread over the N shards (K = 256 / N per shard pair) with
-`ScoreMovingBessKGE` (queries all-gathered, scores returned by all-to-all: the
-scheme the reference recommends for per-triple negatives, docs/source/bess.rst).
+Extra objects on the same JSON line:
+  roofline      dominant kernel of the headline leg.  The C2 table is 192 MB and
+                lives in the 256 MiB Infinity Cache: bound = "infinity-cache".
+  roofline_hbm  (N = 1) the same launch on an HBM-resident shard (4 M rows, 8.2 GB),
+                timed in this run with its own HIP events: the honest HBM figure.
+  c4            BASELINE.json configs[3] / north_star's scaling workload, at every N:
+                ogbl-wikikg2-shaped TransE d=256 **fp16**, 312,576 rows per shard,
+                n_shard = N, flat (shared) negatives, `augment_negative`,
+                sampled-softmax cross entropy, `EmbeddingMovingBessKGE`, full
+                **training** step (notebooks/3_wikikg2_fp16.ipynb:251-256,344,385-392),
+                swept over the micro-batch size S and negatives per shard pair K.
+  train_step    (N = 1) the headline workload as a full training step (SGD, AdamW,
+                eager and hipGraph replay).
+  cpu_baseline  (N = 1) the oracle (CPU restatement of the reference's torch path) on
+                the same S = 4096 x 256 micro-batch, on this box's host cores.
+
+Synthetic indices (uniform), default-initialised tables (the scorers' own
+constructors, allocating only this rank's shard, on the device); the index
+tensors of a pool of distinct micro-batches are resident in HBM before the
+timed region.
 """
 
 import argparse
@@ -38,54 +54,87 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-N_ENTITY_PER_SHARD = 93_773  # overridden by --entities-per-shard (out-of-cache variant)
+N_ENTITY_C2 = 93_773
+N_ENTITY_HBM = 4_000_000  # rows of the HBM-resident variant (8.2 GB of 2 KiB rows)
 N_REL = 51
 D = 256  # complex embedding size -> W = 512
 S = 4096
 K_TOTAL = 256
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0  # same guide: float4 copy / random-row gathers from HBM
+VALU_PEAK_TLOPS = 78.6     # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one op per lane per cycle
+
+C4_ROWS_PER_SHARD = 312_576  # ceil(2,500,604 / 8)
+C4_N_ENTITY = 2_500_604
+C4_N_REL = 535
+C4_D = 256
+C4_SWEEP = ((512, 32), (4096, 256), (4096, 2048))  # (S per GPU, K per shard pair); first = the notebook's point
 
 
-def build(n_shard: int, rank: int, dev: torch.device, mode: str, distributed: bool):
-    import besskge  # noqa: F401
-    from besskge import runtime
+# --------------------------------------------------------------------------- #
+def make_group(comm: str, world: int, rank: int, dev: torch.device, distributed: bool, backend: str):
+    """(group, name of the collective backend in use)."""
+    from besskge.collectives import DistributedGroup, NativeGroup, SingleProcessGroup
+
+    if not distributed:
+        return SingleProcessGroup(1), "none"
+    if comm == "c10d" or backend != "nccl":
+        return DistributedGroup(), f"c10d/{backend}"
+    # native: the library's own RCCL entry points on the kernels' stream.  A short self-check of the
+    # three collectives against their definition decides - on all ranks together - whether to use them.
+    ok, why, group = 1, "", None
+    try:
+        group = NativeGroup(dev)
+        x = (1000.0 * rank + torch.arange(world, dtype=torch.float32, device=dev))[:, None].repeat(1, 64).contiguous()
+        (y,) = group.all_to_all([x])
+        want = (1000.0 * torch.arange(world, dtype=torch.float32, device=dev) + rank)[:, None].repeat(1, 64)
+        (g,) = group.all_gather([torch.full((8,), float(rank), device=dev)])
+        (r,) = group.all_reduce_sum([torch.full((8,), float(rank + 1), device=dev)])
+        torch.cuda.synchronize()
+        if not torch.equal(y, want):
+            ok, why = 0, "all_to_all routing"
+        elif not torch.equal(g, torch.arange(world, dtype=torch.float32, device=dev)[:, None].repeat(1, 8)):
+            ok, why = 0, "all_gather order"
+        elif not torch.equal(r, torch.full((8,), world * (world + 1) / 2.0, device=dev)):
+            ok, why = 0, "all_reduce sum"
+    except Exception as e:  # noqa: BLE001 - any failure means "use c10d"
+        ok, why = 0, f"{type(e).__name__}: {e}"
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return group, "native (bess_comm_* / RCCL on the kernels' stream)"
+    if comm == "native":
+        raise SystemExit(f"--comm native: self-check failed on rank {rank}: {why or 'another rank failed'}")
+    if rank == 0:
+        print(f"bench: native collectives unavailable ({why or 'another rank failed'}); using c10d", file=sys.stderr)
+    return DistributedGroup(), f"c10d/{backend} (native self-check failed)"
+
+
+def build_c2(n_rows: int, n_shard: int, rank: int, dev: torch.device, group, distributed: bool):
+    """The headline model through the public constructors: only this rank's shard, on the device."""
     from besskge.bess import EmbeddingMovingBessKGE, ScoreMovingBessKGE
-    from besskge.collectives import DistributedGroup, SingleProcessGroup
-    from besskge.embedding import init_KGE_normal, initialize_entity_embedding
     from besskge.loss import LogSigmoidLoss
     from besskge.negative_sampler import RandomShardedNegativeSampler
     from besskge.scoring import ComplEx
     from besskge.sharding import Sharding
 
-    n_entity = N_ENTITY_PER_SHARD * n_shard
-    sharding = Sharding.create(n_entity, n_shard, seed=1234)
+    sharding = Sharding.create(n_rows * n_shard, n_shard, seed=1234)
     torch.manual_seed(rank)
-    # only this rank's slice is allocated, directly on the device
-    table = initialize_entity_embedding(sharding, [init_KGE_normal], [2 * D], device=dev, shards=[rank])
-    placeholder = torch.zeros(n_shard, sharding.max_entity_per_shard, 0)
-    fn = ComplEx.__new__(ComplEx)
-    torch.nn.Module.__init__(fn)
-    fn.negative_sample_sharing = False
-    fn.sharding = sharding
-    fn.embedding_size = D
-    fn.entity_embedding = table
-    torch.manual_seed(1)
-    fn.relation_embedding = torch.nn.Parameter(init_KGE_normal(torch.empty(N_REL, 2 * D, device=dev)))
-    del placeholder
+    fn = ComplEx(False, sharding, N_REL, D, device=dev, shards=[rank])
+    torch.manual_seed(1)  # the relation table is replicated: same values on every rank
+    torch.nn.init.normal_(fn.relation_embedding.data, std=1.0 / (2 * D))
     k_pair = K_TOTAL // n_shard
     ns = RandomShardedNegativeSampler(k_pair, sharding, 1234, "t", local_sampling=False, flat_negative_format=False)
     loss = LogSigmoidLoss(margin=12.0, negative_adversarial_sampling=True)
     cls = ScoreMovingBessKGE if distributed else EmbeddingMovingBessKGE
     model = cls(negative_sampler=ns, score_fn=fn, loss_fn=loss)
-    group = DistributedGroup() if distributed else SingleProcessGroup(1)
-    model.entity_embedding = fn.entity_embedding
     for p in (fn.entity_embedding, fn.relation_embedding):
         p.requires_grad_(False)
     model.attach(group, {rank: 0})
     return model, sharding, k_pair
 
 
-def make_batches(n_shard: int, rank: int, sharding, k_pair: int, pool: int, dev: torch.device):
+def make_batches_c2(n_shard: int, rank: int, sharding, k_pair: int, pool: int, dev: torch.device):
     """Index tensors of `pool` micro-batches for this rank, resident on the device.
     Layout of one replica's inputs (reference bess.py:142-156)."""
     rng = np.random.default_rng(1000 + rank)
@@ -116,69 +165,251 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(seconds: float = 12.0):
-    """The oracle (CPU restatement of the reference's torch path) on this box's
-    host cores, on a bounded sample of the same workload: S_cpu triples x
-    K_TOTAL per-triple negatives, ComplEx d=256, table of 93,773 rows."""
+def cpu_baseline(budget_s: float = 12.0):
+    """The oracle (CPU restatement of the reference's torch path) on this box's host cores, on the
+    SAME micro-batch shape as the GPU run: S = 4096 triples x 256 per-triple negatives, ComplEx
+    d=256, table of 93,773 rows.  Forward (gather + score + loss) and forward + autograd backward
+    (dense zero-filled table gradient + index_put: the reference's CPU training path) separately;
+    median over the passes that fit the time budget (at least 3 / 2)."""
     from oracle import kge
 
     cores = usable_cores()
     torch.set_num_threads(cores)
     gen = torch.Generator().manual_seed(0)
     W = 2 * D
-    n_ent = 93_773
-    table = (torch.randn(1, n_ent, W, generator=gen) / W)
+    table = (torch.randn(1, N_ENTITY_C2, W, generator=gen) / W)
     rel = torch.randn(N_REL, W, generator=gen) / W
-    s_cpu = 256
     spec = kge.StepSpec("ComplEx", 0, False, "t", False)
     rng = np.random.default_rng(0)
     batch = dict(
-        head=torch.from_numpy(rng.integers(n_ent, size=(1, 1, s_cpu))),
-        relation=torch.from_numpy(rng.integers(N_REL, size=(1, 1, s_cpu))),
-        tail=torch.from_numpy(rng.integers(n_ent, size=(1, 1, s_cpu))),
-        negative=torch.from_numpy(rng.integers(n_ent, size=(1, 1, s_cpu, K_TOTAL))),
+        head=torch.from_numpy(rng.integers(N_ENTITY_C2, size=(1, 1, S))),
+        relation=torch.from_numpy(rng.integers(N_REL, size=(1, 1, S))),
+        tail=torch.from_numpy(rng.integers(N_ENTITY_C2, size=(1, 1, S))),
+        negative=torch.from_numpy(rng.integers(N_ENTITY_C2, size=(1, 1, S, K_TOTAL))),
     )
     loss = dict(kind="logsigmoid", margin=12.0, adversarial=True, adversarial_scale=1.0)
-    with torch.no_grad():
-        kge.bess_step(spec, "EmbeddingMoving", table, rel, batch, loss)  # warm-up
-        t0 = time.perf_counter()
-        reps = 0
-        while time.perf_counter() - t0 < seconds:
+    scored = S * (1 + K_TOTAL)
+
+    def timed(fn, min_passes: int, budget: float):
+        fn()  # warm-up
+        ts, t_all = [], time.perf_counter()
+        while len(ts) < min_passes or (time.perf_counter() - t_all < budget and len(ts) < 20):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    def fwd():
+        with torch.no_grad():
             kge.bess_step(spec, "EmbeddingMoving", table, rel, batch, loss)
-            reps += 1
-        dt = time.perf_counter() - t0
-    # forward + backward (torch autograd: dense zero-filled table gradient + index_put, the
-    # reference's CPU training path), a few passes
+
     tg = table.clone().requires_grad_(True)
     rg = rel.clone().requires_grad_(True)
-    t1 = time.perf_counter()
-    reps_b = 0
-    while reps_b < 2 or time.perf_counter() - t1 < seconds / 2:
+
+    def fwd_bwd():
         tg.grad = rg.grad = None
         res = kge.bess_step(spec, "EmbeddingMoving", tg, rg, batch, loss)
         torch.stack(res["loss"]).sum().backward()
-        reps_b += 1
-    dt_b = time.perf_counter() - t1
+
+    tf = timed(fwd, 3, budget_s)
+    tb = timed(fwd_bwd, 2, budget_s)
     model = ""
     try:
         model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
     except (OSError, StopIteration):
         pass
     return dict(
-        value=reps * s_cpu * (1 + K_TOTAL) / dt,
+        value=scored / float(np.median(tf)),
         unit="triples/s",
         cores=cores,
         kind="port",
         cpu_model=model,
-        sample=f"{reps} passes of {s_cpu} triples x {K_TOTAL} per-triple negatives (forward: gather+score+loss), "
-               f"torch CPU fp32, {cores} threads, {dt:.1f} s",
-        train_value=reps_b * s_cpu * (1 + K_TOTAL) / dt_b,
-        train_sample=f"{reps_b} passes forward + autograd backward of the same sample, {dt_b:.1f} s",
+        sample=f"median of {len(tf)} passes over one full micro-batch ({S} triples x {K_TOTAL} per-triple negatives: "
+               f"gather+score+loss), torch CPU fp32, {cores} threads, {sum(tf):.1f} s",
+        train_value=scored / float(np.median(tb)),
+        train_sample=f"median of {len(tb)} passes forward + autograd backward of the same micro-batch, {sum(tb):.1f} s",
     )
 
 
+# --------------------------------------------------------------------------- #
+def kernel_roofline(kernel_ms, world: int, k_pair: int, mode: str):
+    """Algorithmic bytes of the dominant kernel (K5 forward) per launch and its measured rate."""
+    W, sz = 2 * D, 4
+    rows = S * world * k_pair  # rows gathered per launch on this GPU
+    nq = S * world
+    algo_bytes = rows * (W * sz + 4 + 4) + nq * W * 4
+    fwd = kernel_ms.get("bess_neg_score_pertriple_fwd", []) or kernel_ms.get("bess_neg_score_pertriple_fwd_dq", [])
+    avg_ms = float(np.mean(fwd)) if fwd else float("nan")
+    achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if fwd else float("nan")
+    return dict(
+        kernel="k_neg_pertriple_fwd (bess_neg_score_pertriple_fwd)" if mode == "score" else
+               "k_neg_pertriple_fwd<FUSE> + k_combine_dq (bess_neg_score_pertriple_fwd_dq)",
+        achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+        algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=avg_ms, launches_timed=len(fwd))
+
+
+def hbm_leg(dev: torch.device, steps: int, warmup: int):
+    """The headline launch on an HBM-resident shard: 4 M rows x 2 KiB = 8.2 GB (32x the Infinity
+    Cache), same S x K, n_shard = 1; the kernel is timed with HIP events on its stream."""
+    from besskge import _native as nat
+    from besskge.collectives import SingleProcessGroup
+
+    model, sharding, k_pair = build_c2(N_ENTITY_HBM, 1, 0, dev, SingleProcessGroup(1), False)
+    batches = make_batches_c2(1, 0, sharding, k_pair, pool=4, dev=dev)
+    with torch.no_grad():
+        for i in range(warmup):
+            model.forward_replicas([batches[i % len(batches)]])
+        torch.cuda.synchronize()
+        nat.start_kernel_timing(["bess_neg_score_pertriple_fwd"])
+        t0 = time.perf_counter()
+        for i in range(steps):
+            model.forward_replicas([batches[i % len(batches)]])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    out = kernel_roofline(nat.stop_kernel_timing(), 1, k_pair, "score")
+    out["bound"] = "hbm"
+    out["frac_of_achievable"] = out["achieved"] / HBM_ACHIEVABLE_GBS
+    out["achievable_note"] = f"{HBM_ACHIEVABLE_GBS:.0f} GB/s = what a plain copy / random-row gather reaches (MI355X_MICROARCH.md)"
+    out["traffic"] = None
+    out["workload"] = (f"same launch as the headline on a shard of {N_ENTITY_HBM:,} rows x 2 KiB = "
+                       f"{N_ENTITY_HBM * 2048 / 1e9:.1f} GB (HBM-resident)")
+    out["ms_per_step"] = 1e3 * dt / steps
+    out["value"] = S * (1 + K_TOTAL) * steps / dt
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, comm_name: str, steps: int):
+    """north_star's scaling workload: one shard of the 8-way wikikg2 setup per GPU (weak scaling:
+    312,576 rows per shard whatever N), TransE d=256 fp16, flat negatives, augmentation,
+    sampled-softmax CE, EmbeddingMoving, full training step (forward + backward + C8 + sparse SGD)."""
+    from besskge import runtime
+    from besskge.bess import EmbeddingMovingBessKGE
+    from besskge.collectives import DistributedGroup
+    from besskge.loss import SampledSoftmaxCrossEntropyLoss
+    from besskge.negative_sampler import RandomShardedNegativeSampler
+    from besskge.scoring import TransE
+    from besskge.sharding import Sharding
+
+    iters = 8
+    n = world
+    sharding = Sharding.create(C4_ROWS_PER_SHARD * n, n, seed=0)
+    points = []
+    for S_, K_ in C4_SWEEP:
+        ppp = S_ // n
+        if ppp * n != S_:
+            continue
+        rng = np.random.default_rng(100 + rank)
+        M = int(sharding.shard_counts[rank])
+        batch = dict(head=rng.integers(M, size=(iters, n, ppp)), relation=rng.integers(C4_N_REL, size=(iters, n, ppp)),
+                     tail=rng.integers(M, size=(iters, n, ppp)), negative=rng.integers(M, size=(iters, n, 1, K_)))
+        batch = {k: torch.from_numpy(v.astype(np.int32)).to(dev) for k, v in batch.items()}
+        n_neg = n * K_ + S_  # augmentation adds the S tails of the micro-batch
+        scored = world * S_ * (1 + n_neg)
+        point = dict(shard_bs=S_, negatives_per_shard_pair=K_, negatives_per_triple=n_neg)
+        variants = [("eager", False)]
+        if not isinstance(group, DistributedGroup):
+            variants.append(("graph", True))
+        for name, graphs in variants:
+            try:
+                torch.manual_seed(rank)
+                fn = TransE(True, 1, sharding, C4_N_REL, C4_D, device=dev, shards=[rank], dtype=torch.float16)
+                torch.manual_seed(1)
+                torch.nn.init.uniform_(fn.relation_embedding.data, -1.0 / C4_D, 1.0 / C4_D)
+                ns = RandomShardedNegativeSampler(K_, sharding, 0, "t", local_sampling=False, flat_negative_format=True)
+                model = EmbeddingMovingBessKGE(negative_sampler=ns, score_fn=fn, augment_negative=True,
+                                               loss_fn=SampledSoftmaxCrossEntropyLoss(n_entity=C4_N_ENTITY))
+                opts = runtime.Options(device_iterations=iters, use_graphs=graphs, pipeline_streams=1)
+                runner = runtime.training_model(model, opts, runtime.SGD(lr=1e-3), group=group, device=dev)
+                for _ in range(2):
+                    runner(**batch)
+                group.barrier()
+                torch.cuda.synchronize()
+                reps = max(1, steps // iters)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    runner(**batch)
+                group.barrier()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / (reps * iters)
+                if distributed:
+                    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    dt = float(t.item())
+                point[f"{name}_ms_per_step"] = 1e3 * dt
+                point[f"{name}_value"] = scored / dt
+            except Exception as e:  # noqa: BLE001 - a failing variant must not lose the line
+                point[f"{name}_error"] = f"{type(e).__name__}: {e}"[:300]
+            finally:
+                runner = model = fn = None
+                torch.cuda.empty_cache()
+        best = min((point[k] for k in ("eager_ms_per_step", "graph_ms_per_step") if k in point), default=None)
+        if best is not None:
+            point["ms_per_step"] = best
+            point["value"] = scored / (best * 1e-3)
+            # VALU work of the L1 distance matrix per GPU and step: forward |q - e| accumulate and the two
+            # backward products, S x N x W elements each (csrc/neg_shared.hip states the ops per element)
+            elems = S_ * n_neg * C4_D
+            point["valu"] = dict(bound="valu", elements_per_product=elems,
+                                 achieved=3 * elems / (best * 1e-3) / 1e12, unit="T element-updates/s (3 products/step)",
+                                 peak=VALU_PEAK_TLOPS, peak_unit="T lane-ops/s")
+        points.append(point)
+    return dict(
+        what="BASELINE configs[3] / north_star scaling workload: ogbl-wikikg2-shaped TransE d=256 fp16, "
+             f"{C4_ROWS_PER_SHARD:,} rows per shard, n_shard={n}, flat negatives K per shard pair, augment_negative, "
+             "sampled-softmax CE, EmbeddingMovingBessKGE, training step (fwd + bwd + C8 + sparse SGD); "
+             "value = whole-job positive+negative triples scored/s",
+        unit="triples/s", dtype="f16", scaling="weak", n_gpus=world, collectives=comm_name, sweep=points)
+
+
+def train_leg(model, batches, steps: int):
+    """The headline workload as a full training step, eager and under hipGraph replay."""
+    from besskge import runtime as _rt
+
+    def eager(optimizer, n):
+        for i in range(3):
+            model.train_step_replicas([batches[i % len(batches)]], optimizer)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n):
+            model.train_step_replicas([batches[i % len(batches)]], optimizer)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t1) / n
+
+    tsteps = max(5, min(steps, 30))
+    dt = eager(1e-3, tsteps)
+    out = {
+        "what": "same workload, full training step: gather+score+loss+backward+segmented scatter+sparse SGD",
+        "value": S * (1 + K_TOTAL) / dt,
+        "unit": "triples/s",
+        "ms_per_step": 1e3 * dt,
+        "steps": tsteps,
+    }
+    # the notebooks train with AdamW: same step with the row-sparse AdamW of besskge.runtime
+    out["adamw_ms_per_step"] = 1e3 * eager(_rt.Adam(lr=1e-3, weight_decay=1e-2), tsteps)
+    # hipGraph replay of the SGD step (one launch per step)
+    try:
+        iters = 8
+        stacked = {k: torch.cat([batches[i % len(batches)][k] for i in range(iters)], dim=0) for k in batches[0]}
+        runner = _rt.Runner(model, _rt.Options(device_iterations=iters, use_graphs=True), model.replica_group,
+                            stacked["head"].device, _rt.SGD(lr=1e-3))
+        for _ in range(2):
+            runner(**stacked)
+        torch.cuda.synchronize()
+        reps = max(1, tsteps // iters)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            runner(**stacked)
+        torch.cuda.synchronize()
+        out["graph_ms_per_step"] = 1e3 * (time.perf_counter() - t1) / (reps * iters)
+    except Exception as e:  # noqa: BLE001
+        out["graph_error"] = f"{type(e).__name__}: {e}"[:300]
+    return out
+
+
+# --------------------------------------------------------------------------- #
 def main() -> None:
-    global N_ENTITY_PER_SHARD
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -188,12 +419,14 @@ def main() -> None:
                     help="HIP streams the scoring steps alternate on (default: 1 at N=1 so that the per-launch "
                          "HIP-event timing of the dominant kernel is not blurred by overlap, 2 at N>1 to overlap "
                          "the exchange with scoring)")
+    ap.add_argument("--comm", choices=["auto", "native", "c10d"], default="auto",
+                    help="collectives at N > 1: the library's own RCCL entry points on the kernels' stream "
+                         "(native), torch.distributed (c10d), or native when its self-check passes (auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--entities-per-shard", type=int, default=N_ENTITY_PER_SHARD,
-                    help="rows per shard (default: the ogbl-biokg count; a 192 MB table sits in the "
-                         "256 MiB Infinity Cache - pass e.g. 4000000 for an HBM-resident 8 GB shard)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="headline leg only (no roofline_hbm / c4 / train_step)")
+    ap.add_argument("--entities-per-shard", type=int, default=N_ENTITY_C2,
+                    help="rows per shard of the headline leg (default: the ogbl-biokg count)")
     args = ap.parse_args()
-    N_ENTITY_PER_SHARD = args.entities_per_shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -209,7 +442,7 @@ def main() -> None:
     backend = os.environ.get("BESS_BENCH_BACKEND", "nccl")
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
-    # BESS_BENCH_REHEARSE_DIST=1 at N = 1: the multi-GPU code path (ScoreMoving, DistributedGroup,
+    # BESS_BENCH_REHEARSE_DIST=1 at N = 1: the multi-GPU code path (ScoreMoving, one process per GPU,
     # pipelined begin / finish, RCCL collectives) on a one-rank process group - what can be checked
     # of it on a 1-GPU box
     distributed = world > 1 or os.environ.get("BESS_BENCH_REHEARSE_DIST", "0") == "1"
@@ -221,13 +454,12 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=dev, **kw)
         else:
             dist.init_process_group(backend, **kw)
-    if args.mode == "train" and distributed:
-        raise SystemExit("--mode train is single-GPU (EmbeddingMoving) in this round")
 
     from besskge import _native as nat
 
-    model, sharding, k_pair = build(world, rank, dev, args.mode, distributed)
-    batches = make_batches(world, rank, sharding, k_pair, pool=8, dev=dev)
+    group, comm_name = make_group(args.comm, world, rank, dev, distributed, backend)
+    model, sharding, k_pair = build_c2(args.entities_per_shard, world, rank, dev, group, distributed)
+    batches = make_batches_c2(world, rank, sharding, k_pair, pool=8, dev=dev)
     lr = 1e-3
 
     # scoring micro-batches are independent (read-only tables): issue them
@@ -252,8 +484,7 @@ def main() -> None:
     def run_steps(first: int, count: int) -> None:
         """`count` scoring / training steps.  With more than one GPU the forward is software
         pipelined: the row gathers and all-gathers of micro-batch i + 1 are issued before the
-        scoring of micro-batch i, so that they sit in front of its score all-to-all in the
-        in-order collective queue and run under its scoring kernel."""
+        scoring of micro-batch i, so that they run under its scoring kernel (on the other stream)."""
         if not distributed or args.mode == "train":
             for i in range(first, first + count):
                 step(i)
@@ -293,58 +524,39 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # N = 1, score mode: also time the full training step (forward + backward +
-    # sparse SGD, K9/K10) on the same workload, reported as an extra object
-    train_extra = None
-    if not distributed and args.mode == "score":
-        tsteps = max(5, min(args.steps, 30))
-        for i in range(3):
-            model.train_step_replicas([batches[i % len(batches)]], lr)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(tsteps):
-            model.train_step_replicas([batches[i % len(batches)]], lr)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        train_extra = {
-            "what": "same workload, full training step: gather+score+loss+backward+segmented scatter+sparse SGD",
-            "value": S * (1 + K_TOTAL) * tsteps / dt,
-            "unit": "triples/s",
-            "ms_per_step": 1e3 * dt / tsteps,
-            "steps": tsteps,
-        }
-        # the notebooks train with AdamW: same step with the row-sparse AdamW of besskge.runtime
-        from besskge import runtime as _rt
-
-        adamw = _rt.Adam(lr=1e-3, weight_decay=1e-2)
-        for i in range(3):
-            model.train_step_replicas([batches[i % len(batches)]], adamw)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(tsteps):
-            model.train_step_replicas([batches[i % len(batches)]], adamw)
-        torch.cuda.synchronize()
-        train_extra["adamw_ms_per_step"] = 1e3 * (time.perf_counter() - t1) / tsteps
+    extra_legs = not args.no_extra_legs
+    train_extra = hbm = None
+    if not distributed and args.mode == "score" and extra_legs:
+        train_extra = train_leg(model, batches, args.steps)
+    del model
+    torch.cuda.empty_cache()
+    if not distributed and extra_legs and args.entities_per_shard == N_ENTITY_C2:
+        hbm = hbm_leg(dev, max(10, min(args.steps, 50)), 5)
+    c4 = c4_leg(world, rank, dev, group, distributed, comm_name, max(16, min(args.steps, 48))) if extra_legs else None
 
     n_neg = K_TOTAL  # negatives per positive, over all shards
     scored_per_step = world * S * (1 + n_neg)
     value = scored_per_step * args.steps / elapsed
 
-    # roofline of the dominant kernel (K5 forward): algorithmic bytes per launch
-    W, sz = 2 * D, 4
-    rows = S * world * k_pair  # rows gathered per launch on this GPU
-    nq = S * world
-    algo_bytes = rows * (W * sz + 4 + 4) + nq * W * 4
-    fwd = kernel_ms.get("bess_neg_score_pertriple_fwd", []) or kernel_ms.get("bess_neg_score_pertriple_fwd_dq", [])
-    avg_ms = float(np.mean(fwd)) if fwd else float("nan")
-    achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if fwd else float("nan")
-    traffic = None
-    pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("neg_score_pertriple_fwd_bytes_per_launch")
-        except Exception:
-            traffic = None
+    roof = kernel_roofline(kernel_ms, world, k_pair, args.mode)
+    table_mb = args.entities_per_shard * 2 * D * 4 / 1e6
+    in_cache = table_mb < 256 * 1.048576
+    roof["bound"] = "infinity-cache" if in_cache else "hbm"
+    roof["note"] = (f"the {table_mb:.0f} MB shard sits in the 256 MiB Infinity Cache: this rate is a cache figure priced "
+                    "against the 8 TB/s HBM spec; the HBM-resident figure of the same launch is `roofline_hbm`"
+                    if in_cache else "HBM-resident shard")
+    traffic, src = None, None
+    for cand in ("profiles/r02/pmc_traffic.json", "profiles/pmc_traffic.json"):
+        pmc = os.path.join(REPO, cand)
+        if os.path.exists(pmc):
+            try:
+                traffic, src = json.load(open(pmc)).get("neg_score_pertriple_fwd_bytes_per_launch"), cand
+                break
+            except Exception:  # noqa: BLE001
+                pass
+    roof["traffic"] = traffic
+    roof["traffic_source"] = (f"{src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of a separate run of this command "
+                              "(counters cannot be read inside the timed run)") if src else None
 
     if rank == 0:
         line = {
@@ -361,7 +573,7 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"ogbl-biokg-shaped ComplEx d=256 fp32 (W=512), {N_ENTITY_PER_SHARD:,} entities per shard, "
+                "workload": f"ogbl-biokg-shaped ComplEx d=256 fp32 (W=512), {args.entities_per_shard:,} entities per shard, "
                             f"n_shard={world}, S=4096 positives x 256 per-triple negatives per GPU per step, "
                             f"{'ScoreMoving' if distributed else 'EmbeddingMoving'}, mode={args.mode} "
                             "(gather+score+loss" + ("+backward+sparse SGD)" if args.mode == "train" else ")"),
@@ -369,23 +581,15 @@ def main() -> None:
                 "shard_bs": S,
                 "negatives_per_triple": n_neg,
                 "mode": args.mode,
+                "collectives": comm_name,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_neg_pertriple_fwd (bess_neg_score_pertriple_fwd)" if args.mode == "score" else
-                          "k_neg_pertriple_fwd<FUSE> + k_combine_dq (bess_neg_score_pertriple_fwd_dq)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "avg_launch_ms": avg_ms,
-                "launches_timed": len(fwd),
-            },
+            "roofline": roof,
         }
-        extra = {k: float(np.mean(v)) for k, v in kernel_ms.items() if v}
-        line["kernel_avg_ms"] = extra
+        line["kernel_avg_ms"] = {k: float(np.mean(v)) for k, v in kernel_ms.items() if v}
+        if hbm is not None:
+            line["roofline_hbm"] = hbm
+        if c4 is not None:
+            line["c4"] = c4
         if train_extra is not None:
             line["train_step"] = train_extra
         if not distributed and not args.no_cpu_baseline:
@@ -393,6 +597,8 @@ def main() -> None:
         print(json.dumps(line))
     if distributed:
         dist.barrier()
+        if hasattr(group, "close"):
+            group.close()
         dist.destroy_process_group()
 
 

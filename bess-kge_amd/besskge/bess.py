@@ -585,6 +585,9 @@ class EmbeddingMovingBessKGE(BessKGE):
         steps: List[_ReplicaStep] = []
         sends: List[torch.Tensor] = []
         exchange_negatives = n > 1 and not ns.local_sampling
+        # NativeGroup: gather into the send buffer + all-to-all behind one entry point (bess_pack_exchange)
+        packed_exchange = (hasattr(group, "pack_exchange")
+                           and (W * self.score_fn.entity_embedding.element_size()) % 16 == 0)
         for shard, b in zip(group.local_shards, batches):
             st = _ReplicaStep()
             st.table = self._local_table(shard)
@@ -600,12 +603,15 @@ class EmbeddingMovingBessKGE(BessKGE):
                 # K1: pack what leaves the shard, block j -> replica j
                 parts = [tail] + ([neg.flatten(start_dim=1)] if exchange_negatives else [])
                 st.send_idx = torch.cat(parts, dim=1).contiguous()  # [n, L]
-                sends.append(nat.gather_rows(st.table, st.send_idx.reshape(-1)).reshape(n, -1, W))
+                if packed_exchange:
+                    sends.append(group.pack_exchange(st.table, st.send_idx))  # K1 + C1, one native call
+                else:
+                    sends.append(nat.gather_rows(st.table, st.send_idx.reshape(-1)).reshape(n, -1, W))
             st.local_neg = neg  # type: ignore
             st.local_tail = tail  # type: ignore
             steps.append(st)
         if n > 1:
-            recvs = group.all_to_all(sends)  # C1
+            recvs = sends if packed_exchange else group.all_to_all(sends)  # C1
             for st, y in zip(steps, recvs):
                 st.recv = y.reshape(-1, W)
                 st.recv_rows = st.recv.shape[0]

@@ -60,11 +60,16 @@ def init_KGE_normal(
 
 
 # --------------------------------------------------------------------------- #
+#: rows filled per pass when a table is created directly in a narrower dtype (fp32 scratch of this many scalars)
+_INIT_CHUNK_SCALARS = 1 << 28
+
+
 def _from_initializers(
     lead_shape: Sequence[int],
     initializer: List[Callable[..., torch.Tensor]],
     row_size: Optional[List[int]],
     device: Optional[torch.device],
+    dtype: Optional[torch.dtype] = None,
 ) -> torch.Tensor:
     if not row_size:
         raise ValueError(
@@ -72,6 +77,20 @@ def _from_initializers(
         )
     if len(initializer) != len(row_size):
         raise ValueError("Different number of embedding splits and initializers provided")
+    if dtype is not None and dtype != torch.float32:
+        # the table is born in its final dtype (a 160 MB - 128 GB shard must not exist twice, once as
+        # fp32): rows are initialised in fp32 blocks and converted on the way in
+        W = int(sum(row_size))
+        out = torch.empty(size=(*lead_shape, W), dtype=dtype, device=device)
+        flat = out.view(-1, W)
+        step = max(1, _INIT_CHUNK_SCALARS // W)
+        for r0 in range(0, flat.shape[0], step):
+            r1 = min(flat.shape[0], r0 + step)
+            c0 = 0
+            for w, init in zip(row_size, initializer):
+                flat[r0:r1, c0:c0 + w] = init(torch.empty(size=(r1 - r0, w), dtype=torch.float32, device=device))
+                c0 += w
+        return out
     # one allocation; every initialiser fills its own column range.  The random
     # stream is consumed exactly as if the slices were created one after the
     # other and concatenated (reference embedding.py:173-188).
@@ -88,6 +107,7 @@ def initialize_entity_embedding(
     row_size: Optional[List[int]] = None,
     device: Optional[torch.device] = None,
     shards: Optional[Sequence[int]] = None,
+    dtype: Optional[torch.dtype] = None,
 ) -> torch.nn.Parameter:
     """Entity table `[n_shard, max_entity_per_shard, sum(row_size)]`.
 
@@ -99,6 +119,9 @@ def initialize_entity_embedding(
     :param row_size: widths of the pieces each row is made of.
     :param device: where to allocate (default: CPU, like the reference).
     :param shards: allocate only these shard slices (extension, see module doc).
+    :param dtype: create the table in this dtype (extension; default float32 like the reference,
+        to be narrowed with `.half()`).  With initialising functions the rows are drawn in fp32
+        blocks and converted while the table is filled, so no fp32 copy of the shard ever exists.
     """
     n, M = sharding.n_shard, sharding.max_entity_per_shard
     keep = None if shards is None else list(shards)
@@ -122,14 +145,14 @@ def initialize_entity_embedding(
             table = initializer[torch.from_numpy(ids)]
         else:
             raise ValueError("Table for initialization needs to be 2- or 3-dimensional")
-        table = table.to(dtype=torch.float32, device=device)
+        table = table.to(dtype=dtype or torch.float32, device=device)
         if row_size:
             assert (
                 sum(row_size) == table.shape[-1]
             ), "Initialization tensor and row_size provided are incompatible"
     else:
         n_alloc = n if keep is None else len(keep)
-        table = _from_initializers((n_alloc, M), initializer, row_size, device)
+        table = _from_initializers((n_alloc, M), initializer, row_size, device, dtype)
     return torch.nn.Parameter(table)
 
 
@@ -139,6 +162,7 @@ def initialize_relation_embedding(
     initializer: _Init,
     row_size: Optional[List[int]] = None,
     device: Optional[torch.device] = None,
+    dtype: Optional[torch.dtype] = None,
 ) -> torch.nn.Parameter:
     """Relation table `[n_relation_type (x2 with inverse relations), Wr]`.
 
@@ -147,14 +171,14 @@ def initialize_relation_embedding(
     if isinstance(initializer, torch.Tensor):
         if initializer.dim() != 2:
             raise ValueError("Table for initialization needs to be 2-dimensional")
-        table = initializer.to(dtype=torch.float32, device=device)
+        table = initializer.to(dtype=dtype or torch.float32, device=device)
         if row_size:
             assert (
                 sum(row_size) == table.shape[-1]
             ), "Initialization tensor and row_size provided are incompatible"
     else:
         n_rows = n_relation_type * (2 if inverse_relations else 1)
-        table = _from_initializers((n_rows,), initializer, row_size, device)
+        table = _from_initializers((n_rows,), initializer, row_size, device, dtype)
     return torch.nn.Parameter(table)
 
 

@@ -184,9 +184,9 @@ class Runner:
         if sig not in cache:
             static = [{k: torch.empty((1, *v.shape[1:]), dtype=v.dtype, device=self.device) for k, v in batch.items()}
                       for _ in self.group.local_shards]
-            for slot, shard in zip(static, self.group.local_shards):
-                for k, v in batch.items():
-                    slot[k].copy_(v[shard: shard + 1])
+            for slot, rep in zip(static, self._split(batch, 0)):
+                for k, v in rep.items():
+                    slot[k].copy_(v)
             fn = self.model.score_fn
             training = self.optimizer is not None
             # The warm-up steps (index maps, allocator pools) and the capture must not train: everything a
@@ -210,9 +210,9 @@ class Runner:
         graph, static, outs = cache[sig]
         collected: List[List[Dict[str, Any]]] = []
         for it in range(iters):
-            for slot, shard in zip(static, self.group.local_shards):
-                for k, v in batch.items():
-                    slot[k].copy_(v[it * n + shard: it * n + shard + 1], non_blocking=True)
+            for slot, rep in zip(static, self._split(batch, it)):
+                for k, v in rep.items():
+                    slot[k].copy_(v, non_blocking=True)
             graph.replay()
             step_out = []
             for o in outs:

@@ -40,7 +40,7 @@ over S rows; candidates are scored by the `csrc/boxe.hip` kernels.
 
 import struct
 from abc import ABC, abstractmethod
-from typing import Any, Callable, List, Tuple, Union
+from typing import Any, Callable, Dict, List, Optional, Tuple, Union
 
 import torch
 
@@ -59,6 +59,19 @@ from besskge.embedding import (
 from besskge.sharding import Sharding
 
 _Init = Union[torch.Tensor, List[Callable[..., torch.Tensor]]]
+
+
+def _placement(kw: Optional[Dict[str, Any]]) -> Dict[str, Any]:
+    """`device=`, `shards=`, `dtype=` of the scorer constructors (extension of the reference
+    signatures, keyword only): allocate just the shard slices this process hosts
+    (`[len(shards), M, W]`), directly on `device`, in `dtype` - so that a rank of a multi-GPU job
+    never materialises the whole `[n_shard, M, W]` table on the host (BASELINE config 5: 128 GB
+    per shard).  Defaults reproduce the reference: whole table, CPU, float32."""
+    kw = dict(kw or {})
+    out = dict(device=kw.pop("device", None), shards=kw.pop("shards", None), dtype=kw.pop("dtype", None))
+    if kw:
+        raise TypeError(f"unexpected keyword arguments {sorted(kw)}")
+    return out
 
 
 class BaseScoreFunction(torch.nn.Module, ABC):
@@ -214,13 +227,16 @@ class BaseScoreFunction(torch.nn.Module, ABC):
         entity_width: int,
         relation_width: int,
         what: str,
+        placement: Optional[Dict[str, Any]] = None,
     ) -> None:
         self.sharding = sharding
+        pl = _placement(placement)
         self.entity_embedding = initialize_entity_embedding(
-            sharding, entity_initializer, [entity_width]
+            sharding, entity_initializer, [entity_width], **pl
         )
         self.relation_embedding = initialize_relation_embedding(
-            n_relation_type, inverse_relations, relation_initializer, [relation_width]
+            n_relation_type, inverse_relations, relation_initializer, [relation_width],
+            device=pl["device"], dtype=pl["dtype"]
         )
         assert (
             self.entity_embedding.shape[-1] == entity_width
@@ -296,6 +312,7 @@ class TransE(DistanceBasedScoreFunction):
         entity_initializer: _Init = [init_KGE_uniform],
         relation_initializer: _Init = [init_KGE_uniform],
         inverse_relations: bool = False,
+        **placement: Any,
     ) -> None:
         super().__init__(negative_sample_sharing, scoring_norm)
         self._allocate(
@@ -303,6 +320,7 @@ class TransE(DistanceBasedScoreFunction):
             relation_initializer, embedding_size, embedding_size,
             "TransE requires `embedding_size` embedding parameters"
             " for each entity and relation",
+            placement=placement,
         )
         self.embedding_size = embedding_size
 
@@ -323,6 +341,7 @@ class RotatE(DistanceBasedScoreFunction):
         entity_initializer: _Init = [init_KGE_uniform],
         relation_initializer: _Init = [init_uniform_rotation],
         inverse_relations: bool = False,
+        **placement: Any,
     ) -> None:
         super().__init__(negative_sample_sharing, scoring_norm)
         self._allocate(
@@ -330,6 +349,7 @@ class RotatE(DistanceBasedScoreFunction):
             relation_initializer, 2 * embedding_size, embedding_size,
             "RotatE requires `2*embedding_size` embedding parameters for each entity"
             " and `embedding_size` embedding parameters for each relation",
+            placement=placement,
         )
         self.embedding_size = embedding_size
 
@@ -348,6 +368,7 @@ class DistMult(MatrixDecompositionScoreFunction):
         entity_initializer: _Init = [init_KGE_uniform],
         relation_initializer: _Init = [init_KGE_uniform],
         inverse_relations: bool = False,
+        **placement: Any,
     ) -> None:
         super().__init__(negative_sample_sharing)
         self._allocate(
@@ -355,6 +376,7 @@ class DistMult(MatrixDecompositionScoreFunction):
             relation_initializer, embedding_size, embedding_size,
             "DistMult requires `embedding_size` embedding parameters"
             " for each entity and relation",
+            placement=placement,
         )
         self.embedding_size = embedding_size
 
@@ -373,6 +395,7 @@ class ComplEx(MatrixDecompositionScoreFunction):
         entity_initializer: _Init = [init_KGE_normal],
         relation_initializer: _Init = [init_KGE_normal],
         inverse_relations: bool = False,
+        **placement: Any,
     ) -> None:
         super().__init__(negative_sample_sharing)
         self._allocate(
@@ -380,6 +403,7 @@ class ComplEx(MatrixDecompositionScoreFunction):
             relation_initializer, 2 * embedding_size, 2 * embedding_size,
             "ComplEx requires `2*embedding_size` embedding parameters"
             " for each entity and relation",
+            placement=placement,
         )
         self.embedding_size = embedding_size
 
@@ -547,16 +571,18 @@ class PairRE(_AffineScoreFunction):
         relation_initializer: _Init = [init_KGE_uniform],
         normalize_entities: bool = True,
         inverse_relations: bool = False,
+        **placement: Any,
     ) -> None:
         super().__init__(negative_sample_sharing, scoring_norm)
         self.sharding = sharding
         self.normalize = normalize_entities
         if isinstance(relation_initializer, list):
             relation_initializer = 2 * relation_initializer
-        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size])
+        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size], **_placement(placement))
         # [r_h | r_t]: projections of heads and tails
         self.relation_embedding = initialize_relation_embedding(
-            n_relation_type, inverse_relations, relation_initializer, [embedding_size, embedding_size])
+            n_relation_type, inverse_relations, relation_initializer, [embedding_size, embedding_size],
+            device=_placement(placement)["device"], dtype=_placement(placement)["dtype"])
         assert 2 * self.entity_embedding.shape[-1] == self.relation_embedding.shape[-1] == 2 * embedding_size, (
             "PairRE requires `embedding_size` embedding parameters for each entity"
             " and `2*embedding_size` embedding parameters for each relation")
@@ -594,16 +620,18 @@ class TripleRE(_AffineScoreFunction):
         normalize_entities: bool = True,
         u: float = 0.0,
         inverse_relations: bool = False,
+        **placement: Any,
     ) -> None:
         super().__init__(negative_sample_sharing, scoring_norm)
         self.sharding = sharding
         self.normalize = normalize_entities
         if isinstance(relation_initializer, list):
             relation_initializer = 3 * relation_initializer
-        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size])
+        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size], **_placement(placement))
         # [r_h | r_m | r_t]: head projection, translation, tail projection
         self.relation_embedding = initialize_relation_embedding(
-            n_relation_type, inverse_relations, relation_initializer, [embedding_size] * 3)
+            n_relation_type, inverse_relations, relation_initializer, [embedding_size] * 3,
+            device=_placement(placement)["device"], dtype=_placement(placement)["dtype"])
         assert 3 * self.entity_embedding.shape[-1] == self.relation_embedding.shape[-1] == 3 * embedding_size, (
             "TripleRE requires `embedding_size` embedding parameters for each entity"
             " and `3*embedding_size` embedding parameters for each relation")
@@ -650,6 +678,7 @@ class InterHT(_AffineScoreFunction):
         normalize_entities: bool = True,
         offset: float = 1.0,
         inverse_relations: bool = False,
+        **placement: Any,
     ) -> None:
         super().__init__(negative_sample_sharing, scoring_norm)
         self.sharding = sharding
@@ -657,9 +686,10 @@ class InterHT(_AffineScoreFunction):
         if isinstance(entity_initializer, list):
             entity_initializer = 2 * entity_initializer
         # [main | auxiliary]
-        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size] * 2)
+        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size] * 2, **_placement(placement))
         self.relation_embedding = initialize_relation_embedding(
-            n_relation_type, inverse_relations, relation_initializer, [embedding_size])
+            n_relation_type, inverse_relations, relation_initializer, [embedding_size],
+            device=_placement(placement)["device"], dtype=_placement(placement)["dtype"])
         assert self.entity_embedding.shape[-1] == 2 * self.relation_embedding.shape[-1] == 2 * embedding_size, (
             "InterHT requires `2*embedding_size` embedding parameters for each entity"
             " and `embedding_size` embedding parameters for each relation")
@@ -699,6 +729,7 @@ class TranS(_AffineScoreFunction):
         normalize_entities: bool = True,
         offset: float = 1.0,
         inverse_relations: bool = False,
+        **placement: Any,
     ) -> None:
         super().__init__(negative_sample_sharing, scoring_norm)
         self.sharding = sharding
@@ -706,12 +737,13 @@ class TranS(_AffineScoreFunction):
         if isinstance(entity_initializer, list):
             entity_initializer = 2 * entity_initializer
         # [main | tilde]
-        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size] * 2)
+        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size] * 2, **_placement(placement))
         if isinstance(relation_initializer, list):
             relation_initializer = 3 * relation_initializer
         # [r | r_bar | r_hat]
         self.relation_embedding = initialize_relation_embedding(
-            n_relation_type, inverse_relations, relation_initializer, [embedding_size] * 3)
+            n_relation_type, inverse_relations, relation_initializer, [embedding_size] * 3,
+            device=_placement(placement)["device"], dtype=_placement(placement)["dtype"])
         assert self.entity_embedding.shape[-1] / 2 == self.relation_embedding.shape[-1] / 3 == embedding_size, (
             "TranS requires `2*embedding_size` embedding parameters for each entity"
             " and `3*embedding_size` embedding parameters for each relation")
@@ -758,6 +790,7 @@ class ConvE(_TorchQueryHooks, MatrixDecompositionScoreFunction):
         feature_map_dropout: float = 0.2,
         hidden_dropout: float = 0.3,
         batch_normalization: bool = True,
+        **placement: Any,
     ) -> None:
         super().__init__(negative_sample_sharing)
         self.sharding = sharding
@@ -765,9 +798,10 @@ class ConvE(_TorchQueryHooks, MatrixDecompositionScoreFunction):
             raise ValueError("`embedding_size` needs to be equal to"
                              " `input_channels * embedding_width * embedding_height`")
         # [embedding | tail bias]
-        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size, 1])
+        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size, 1], **_placement(placement))
         self.relation_embedding = initialize_relation_embedding(
-            n_relation_type, inverse_relations, relation_initializer, [embedding_size])
+            n_relation_type, inverse_relations, relation_initializer, [embedding_size],
+            device=_placement(placement)["device"], dtype=_placement(placement)["dtype"])
         assert self.entity_embedding.shape[-1] - 1 == self.relation_embedding.shape[-1] == embedding_size, (
             "ConvE requires `embedding_size + 1` embedding parameters for each entity"
             " and `embedding_size` embedding parameters for each relation")
@@ -853,6 +887,7 @@ class BoxE(_TorchQueryHooks, DistanceBasedScoreFunction):
         dist_func_per_dim: bool = True,
         eps: float = 1e-6,
         inverse_relations: bool = False,
+        **placement: Any,
     ) -> None:
         super().__init__(negative_sample_sharing, scoring_norm)
         self.apply_tanh = apply_tanh
@@ -864,10 +899,11 @@ class BoxE(_TorchQueryHooks, DistanceBasedScoreFunction):
         if isinstance(relation_initializer, list):
             relation_initializer = 4 * [relation_initializer[0]] + 2 * [relation_initializer[1]]
         # [base | bump]
-        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size] * 2)
+        self.entity_embedding = initialize_entity_embedding(sharding, entity_initializer, [embedding_size] * 2, **_placement(placement))
         # [head centre | tail centre | head width | tail width | head size, tail size]
         self.relation_embedding = initialize_relation_embedding(
-            n_relation_type, inverse_relations, relation_initializer, [embedding_size] * 4 + [1, 1])
+            n_relation_type, inverse_relations, relation_initializer, [embedding_size] * 4 + [1, 1],
+            device=_placement(placement)["device"], dtype=_placement(placement)["dtype"])
         assert 2 * self.entity_embedding.shape[-1] == self.relation_embedding.shape[-1] - 2 == 4 * embedding_size, (
             "BoxE requires `2*embedding_size` embedding parameters for each entity"
             " and `4*embedding_size + 2` embedding parameters for each relation")

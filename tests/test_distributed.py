@@ -180,3 +180,8 @@ def test_bench_distributed_path_over_rccl_single_rank():
     line = json.loads(res.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and "ScoreMoving" in line["config"]["workload"]
     assert line["value"] > 1e9 and line["roofline"]["frac"] > 0.3
+    # the collectives went through the library's own RCCL entry points (self-check passed), and the
+    # C4 training leg ran on them too - eager and captured into a hipGraph together with its collectives
+    assert line["config"]["collectives"].startswith("native"), line["config"]["collectives"]
+    for pt in line["c4"]["sweep"]:
+        assert pt["value"] > 0 and "graph_ms_per_step" in pt, pt

@@ -116,3 +116,32 @@ def test_scorer_constructors_allocate_like_the_reference():
     assert fn.sharding is new and torch.equal(before, after)
     with pytest.raises(ValueError):
         TransE(True, 3, s, 5, 16)
+
+
+def test_scorer_constructors_place_only_the_hosted_shards():
+    """`device=`, `shards=`, `dtype=` of the scorer constructors (extension): a rank allocates just
+    its own slice, in its final dtype; defaults stay the reference's (whole table, fp32)."""
+    import besskge.embedding as emb
+    from besskge.scoring import ComplEx, TransE
+    from besskge.sharding import Sharding
+
+    sharding = Sharding.create(1000, 4, seed=0)
+    M = sharding.max_entity_per_shard
+    torch.manual_seed(0)
+    whole = TransE(True, 1, sharding, 7, 16)
+    assert whole.entity_embedding.shape == (4, M, 16) and whole.entity_embedding.dtype == torch.float32
+    fn = TransE(True, 1, sharding, 7, 16, shards=[2], dtype=torch.float16, device=torch.device("cpu"))
+    assert fn.entity_embedding.shape == (1, M, 16) and fn.entity_embedding.dtype == torch.float16
+    assert fn.relation_embedding.shape == (7, 16) and fn.relation_embedding.dtype == torch.float16
+    assert float(fn.entity_embedding.float().abs().max()) <= 1.0 / 16 + 1e-3  # init_KGE_uniform bound
+    # block-wise creation in the narrow dtype: several blocks cover every row
+    old = emb._INIT_CHUNK_SCALARS
+    emb._INIT_CHUNK_SCALARS = 100 * 32
+    try:
+        cx = ComplEx(False, sharding, 7, 16, shards=[0, 3], dtype=torch.float16)
+    finally:
+        emb._INIT_CHUNK_SCALARS = old
+    assert cx.entity_embedding.shape == (2, M, 32)
+    assert bool((cx.entity_embedding.float().abs().sum(-1) > 0).all())
+    with pytest.raises(TypeError, match="unexpected keyword"):
+        TransE(True, 1, sharding, 7, 16, bogus=1)
