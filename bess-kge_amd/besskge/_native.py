@@ -134,6 +134,8 @@ SIGNATURES = {
     "bess_neg_pertriple_step_segments": [_MD, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
                                          _vp, _i64, _vp, _vp, ctypes.POINTER(OptDesc), _vp, _vp, _vp, _vp, _vp],
     "bess_map_extra_rows": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp],
+    "bess_coalesced_update": [ctypes.POINTER(OptDesc), _i32, _i32, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_i64),
+                              _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "bess_neg_pertriple_items": [_MD, _i64, _i64, ctypes.POINTER(ctypes.c_int32)],
     "bess_neg_score_pertriple_fwd_dq": [_MD, _LD, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
     "bess_normalize_rows": [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
@@ -847,6 +849,47 @@ def apply_segments_opt(o: OptDesc, table: torch.Tensor, seg: SegmentIndex, grad_
                                             state2.data_ptr() if state2 is not None else 0,
                                             keep.data_ptr() if keep is not None else None, _stream(dev))
     _check(rc, "bess_apply_segments_opt")
+
+
+MAX_ROW_LISTS = 8  # BESS_MAX_ROW_LISTS
+
+
+def coalesced_update(o: Optional[OptDesc], table: torch.Tensor, seg: SegmentIndex, grads: Sequence[torch.Tensor],
+                     state1: Optional[torch.Tensor] = None, state2: Optional[torch.Tensor] = None,
+                     keep: Optional[torch.Tensor] = None, sum_only: bool = False) -> Optional[torch.Tensor]:
+    """K9 + K10 of the small lists in one pass: `seg` indexes the concatenation of the lists' row
+    ids, `grads[l]` is the f32 [n_l, W] gradient of list l.  Every unique row gets one update
+    (one rounding).  `sum_only`: return the per-unique-row sums [seg.max_seg, W] instead."""
+    dev = _same_device([("table", table), ("refs", seg.refs), ("state1", state1), ("state2", state2)]
+                       + [(f"grads[{i}]", g) for i, g in enumerate(grads)])
+    W = int(table.shape[1])
+    _rows(table, "table", W)
+    if not 1 <= len(grads) <= MAX_ROW_LISTS:
+        raise ValueError(f"coalesced_update: {len(grads)} lists (1 .. {MAX_ROW_LISTS})")
+    total = 0
+    for i, g in enumerate(grads):
+        _f32(g, f"grads[{i}]")
+        if g.dim() != 2 or g.shape[1] != W:
+            raise ValueError(f"coalesced_update: grads[{i}] must be [n, {W}]")
+        total += int(g.shape[0])
+    if total != seg.n_refs:
+        raise ValueError(f"coalesced_update: the lists hold {total} rows, the index {seg.n_refs} references")
+    for st, nm in ((state1, "state1"), (state2, "state2")):
+        if st is not None:
+            _f32(st, nm)
+            if tuple(st.shape) != tuple(table.shape):
+                raise ValueError(f"coalesced_update: {nm} must have the shape of the table")
+    ptrs = (_vp * len(grads))(*[g.data_ptr() for g in grads])
+    rows = (_i64 * len(grads))(*[int(g.shape[0]) for g in grads])
+    out = torch.empty((seg.max_seg, W), dtype=torch.float32, device=dev) if sum_only else None
+    with torch.cuda.device(dev), _Timed("bess_coalesced_update", dev):
+        rc = load().bess_coalesced_update(
+            ctypes.byref(o) if o is not None else None, _dtype_code(table), W, table.data_ptr(), len(grads), ptrs, rows,
+            seg.refs.data_ptr(), seg.seg_rows.data_ptr(), seg.seg_offsets.data_ptr(), seg.n_seg.data_ptr(), seg.max_seg,
+            state1.data_ptr() if state1 is not None else None, state2.data_ptr() if state2 is not None else None,
+            keep.data_ptr() if keep is not None else None, out.data_ptr() if out is not None else None, _stream(dev))
+    _check(rc, "bess_coalesced_update")
+    return out
 
 
 def map_extra_rows(seg: SegmentIndex, extra: SegmentIndex) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -55,6 +55,19 @@ def _i32(x: torch.Tensor) -> torch.Tensor:
     return x.contiguous()
 
 
+class _PlainSGD:
+    """`table -= lr * grad` as an optimiser object (what a bare learning rate means), for the code
+    paths that coalesce all contributions per unique row before the update."""
+
+    kind = nat.OPT_SGD
+    momentum = 0.0
+    weight_decay = 0.0
+    is_plain_sgd = True
+
+    def __init__(self, lr: float) -> None:
+        self.lr = float(lr)
+
+
 class _NegGroup:
     """One (queries, corrupted side, candidate rows) scoring problem."""
 
@@ -390,14 +403,16 @@ class BessKGE(torch.nn.Module, ABC):
 
     def _apply_optimizer(self, opt: Any, table: torch.Tensor, contributions: List[Tuple[torch.Tensor, torch.Tensor]]
                          ) -> None:
-        """General K9 + K10: coalesce (row, gradient row) lists per unique row, then
-        one optimiser update per row.  `contributions` all index `table`."""
+        """General K9 + K10: all (row, gradient row) lists of a table coalesced per unique row and one
+        optimiser update per row (`bess_coalesced_update`: the sums are formed straight from the lists, in
+        a fixed order; every touched row is written once).  `contributions` all index `table`."""
         idx = torch.cat([i.reshape(-1) for i, _ in contributions]).contiguous()
-        grad = torch.cat([g for _, g in contributions], dim=0).contiguous()
         seg = nat.SegmentIndex(idx, table.shape[0])
-        gseg = nat.segment_sum_rows(grad, seg)
         o, s1, s2 = self._opt_desc(opt, table)
-        nat.apply_segments_opt(o, table, seg, gseg, s1, s2)
+        grads = [g.contiguous() for _, g in contributions]
+        if len(grads) > nat.MAX_ROW_LISTS:
+            grads = [torch.cat(grads, dim=0)]
+        nat.coalesced_update(o, table, seg, grads, s1, s2)
 
     def _apply_optimizer_dense(self, opt: Any, table: torch.Tensor, grad: torch.Tensor) -> None:
         """Optimiser step on every row of a small replicated table (relation table, dense parameters):
@@ -419,9 +434,11 @@ class BessKGE(torch.nn.Module, ABC):
         xmap = xsum = xseg = keep = None
         if extras:
             idx = torch.cat([i.reshape(-1) for i, _ in extras]).contiguous()
-            grad = torch.cat([x for _, x in extras], dim=0).contiguous()
+            grads = [x.contiguous() for _, x in extras]
+            if len(grads) > nat.MAX_ROW_LISTS:
+                grads = [torch.cat(grads, dim=0)]
             xseg = nat.SegmentIndex(idx, table.shape[0])
-            xsum = nat.segment_sum_rows(grad, xseg)
+            xsum = nat.coalesced_update(None, table, xseg, grads, sum_only=True)
             xmap, keep = nat.map_extra_rows(seg, xseg)
         nat.neg_pertriple_step_segments(desc, g.query, table, g.n_per_query, go, seg, o, s1, s2, xmap, xsum)
         if extras:  # rows of the small lists that no negative points at
@@ -456,11 +473,17 @@ class BessKGE(torch.nn.Module, ABC):
         rel_table = self.score_fn.relation_embedding.data
         plain = not hasattr(optimizer, "kind") or optimizer.is_plain_sgd
         lr = float(optimizer.lr) if hasattr(optimizer, "lr") else float(optimizer)
+        # f16 shards: a packed-f16 atomic add rounds the row once per contribution.  Plain SGD on them
+        # therefore takes the coalescing path of the stateful optimisers: contributions summed per unique
+        # row in fp32, one read-modify-write (one rounding) per touched row and step.
+        plain_rows = plain and self.score_fn.entity_embedding.dtype == torch.float32
+        if plain and not plain_rows and not hasattr(optimizer, "kind"):
+            optimizer = _PlainSGD(lr)
         main = torch.cuda.current_stream(rel_table.device)
         side = self._aux_stream(rel_table.device)
         # K9 + K10.  Every gradient has been computed from the pre-update tables by now.
         main.wait_stream(side)
-        if plain:
+        if plain_rows:
             # per-triple negatives of the own shard: segmented reduction.  A shard with a
             # single such group gets the SGD step fused into the reduction; with two
             # ("ht") all row gradients are formed before the first row is changed.

@@ -488,6 +488,60 @@ __global__ __launch_bounds__(256) void k_segment_sum_rows(const float* __restric
     }
 }
 
+// K9 + K10 for the small lists of a step (heads, tails, shared negatives, rows returned by C8 ...):
+// the references of the lists' virtual concatenation are grouped by destination row
+// (bess_build_segment_index over the concatenated row ids); one wave per unique row sums its
+// contributions in reference order (fixed: bitwise reproducible) straight from the lists - no
+// concatenated gradient, no [unique rows, W] buffer - and applies the optimiser: every touched
+// row is read, updated and written ONCE (one rounding per step, also for f16 tables, where a
+// packed-f16 atomic would round per contribution).
+struct RowLists {
+    const float* grad[BESS_MAX_ROW_LISTS];
+    int32_t first[BESS_MAX_ROW_LISTS + 1];  // first[l] = references in lists 0 .. l-1
+    int n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_coalesced_update(OptArgs o, RowLists L, T* __restrict__ table, int W,
+                                                          const int32_t* __restrict__ refs,
+                                                          const int32_t* __restrict__ seg_rows,
+                                                          const int32_t* __restrict__ seg_offsets,
+                                                          const int32_t* __restrict__ n_seg,
+                                                          float* __restrict__ state1, float* __restrict__ state2,
+                                                          const int32_t* __restrict__ keep, float* __restrict__ sum_out) {
+    o = opt_resolve(o);
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (blockIdx.x * 256ll + threadIdx.x) >> 6;
+    const int64_t n_wave = (gridDim.x * 256ll) >> 6;
+    const int ns = *n_seg;
+    for (int64_t s = wave0; s < ns; s += n_wave) {
+        if (keep && keep[s] == 0) continue;
+        const int r0 = seg_offsets[s], r1 = seg_offsets[s + 1];
+        const int64_t row = seg_rows[s];
+        for (int c = lane; c < W; c += 64) {
+            float acc = 0.f;
+            for (int r = r0; r < r1; ++r) {
+                const int ref = refs[r];
+                int l = 0;
+#pragma unroll
+                for (int k = 1; k < BESS_MAX_ROW_LISTS; ++k) l += (k < L.n && ref >= L.first[k]) ? 1 : 0;
+                acc += L.grad[l][static_cast<int64_t>(ref - L.first[l]) * W + c];
+            }
+            if (sum_out) {
+                sum_out[s * W + c] = acc;
+                continue;
+            }
+            const int64_t at = row * W + c;
+            float p = static_cast<float>(table[at]);
+            float s1 = state1 ? state1[at] : 0.f, s2 = state2 ? state2[at] : 0.f;
+            opt_step(o, p, acc, s1, s2);
+            if (state1) state1[at] = s1;
+            if (state2) state2[at] = s2;
+            table[at] = static_cast<T>(p);
+        }
+    }
+}
+
 // keep (optional): only segments with keep[s] != 0 are updated
 template <typename T>
 __global__ __launch_bounds__(256) void k_apply_segments_opt(OptArgs o, T* __restrict__ table, int W,
@@ -832,4 +886,48 @@ extern "C" int bess_apply_segments_opt(const bess_opt_desc* o, int32_t dtype, in
         k_apply_segments_opt<half_t><<<grid, 256, 0, as_stream(stream)>>>(a, static_cast<half_t*>(table), width,
                                                                           seg_rows, n_seg, grad_seg, s1, s2, keep);
     return check_launch("apply_segments_opt");
+}
+
+extern "C" int bess_coalesced_update(const bess_opt_desc* o, int32_t dtype, int32_t width, void* table,
+                                     int32_t n_lists, const float* const* list_grad, const int64_t* list_rows,
+                                     const int32_t* refs_sorted, const int32_t* seg_rows,
+                                     const int32_t* seg_offsets, const int32_t* n_seg, int64_t max_seg,
+                                     float* state1, float* state2, const int32_t* keep, float* sum_out,
+                                     void* stream) {
+    if (!sum_out)
+        if (int e = check_opt(o, state1, state2, "coalesced_update")) return e;
+    BESS_REQUIRE(dtype == BESS_F32 || dtype == BESS_F16, "coalesced_update: unknown dtype %d", dtype);
+    BESS_REQUIRE(width > 0 && max_seg > 0, "coalesced_update: bad sizes");
+    BESS_REQUIRE(n_lists >= 1 && n_lists <= BESS_MAX_ROW_LISTS, "coalesced_update: %d lists (1 .. %d)", n_lists,
+                 BESS_MAX_ROW_LISTS);
+    BESS_REQUIRE((table || sum_out) && list_grad && list_rows && refs_sorted && seg_rows && seg_offsets && n_seg,
+                 "coalesced_update: NULL pointer");
+    RowLists L{};
+    L.n = n_lists;
+    int64_t total = 0;
+    for (int l = 0; l < n_lists; ++l) {
+        BESS_REQUIRE(list_rows[l] >= 0 && (list_rows[l] == 0 || list_grad[l]), "coalesced_update: list %d", l);
+        L.grad[l] = list_grad[l];
+        L.first[l] = static_cast<int32_t>(total);
+        total += list_rows[l];
+    }
+    BESS_REQUIRE(total > 0 && total < (1ll << 31), "coalesced_update: %lld references", static_cast<long long>(total));
+    for (int l = n_lists; l <= BESS_MAX_ROW_LISTS; ++l) L.first[l] = static_cast<int32_t>(total);
+    OptArgs a{};
+    float *s1 = nullptr, *s2 = nullptr;
+    if (!sum_out) {
+        a = opt_args(o);
+        s1 = o->kind == BESS_OPT_SGD && o->momentum == 0.f ? nullptr : state1;
+        s2 = o->kind == BESS_OPT_ADAM ? state2 : nullptr;
+    }
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(max_seg, 4), 256 * 16));
+    if (dtype == BESS_F32)
+        k_coalesced_update<float><<<grid, 256, 0, as_stream(stream)>>>(a, L, static_cast<float*>(table), width,
+                                                                       refs_sorted, seg_rows, seg_offsets, n_seg, s1,
+                                                                       s2, keep, sum_out);
+    else
+        k_coalesced_update<half_t><<<grid, 256, 0, as_stream(stream)>>>(a, L, static_cast<half_t*>(table), width,
+                                                                        refs_sorted, seg_rows, seg_offsets, n_seg, s1,
+                                                                        s2, keep, sum_out);
+    return check_launch("coalesced_update");
 }

@@ -373,6 +373,23 @@ int bess_apply_segments_opt(const bess_opt_desc* o, int32_t dtype, int32_t width
                             int64_t max_seg, const float* grad_seg, float* state1,
                             float* state2, const int32_t* keep, void* stream);
 
+/* K9 + K10 for the SMALL lists of a step (heads, tails, shared negatives, rows returned by the
+ * backward all-to-all ...; autograd index_put_(accumulate) + optimiser): the lists' row ids are
+ * concatenated and indexed by bess_build_segment_index; reference r of the concatenation is
+ * gradient row (r - first[l]) of list l.  Every unique row is summed in reference order (bitwise
+ * reproducible) straight from the n_lists gradient arrays list_grad[l] (f32 [list_rows[l], width])
+ * and updated in the same pass: one read, one optimiser step, ONE store per touched row - so an
+ * f16 table is rounded once per step (a packed-f16 atomic add rounds per contribution).
+ * keep as in bess_apply_segments_opt.  With sum_out (f32 [max_seg, width]) != NULL the per-row sums
+ * are written there instead and nothing is updated (o, table, state may then be NULL). */
+#define BESS_MAX_ROW_LISTS 8
+int bess_coalesced_update(const bess_opt_desc* o, int32_t dtype, int32_t width, void* table,
+                          int32_t n_lists, const float* const* list_grad, const int64_t* list_rows,
+                          const int32_t* refs_sorted, const int32_t* seg_rows,
+                          const int32_t* seg_offsets, const int32_t* n_seg, int64_t max_seg,
+                          float* state1, float* state2, const int32_t* keep, float* sum_out,
+                          void* stream);
+
 /* K9 + K10 in one pass for the stateful optimisers (what bess_neg_pertriple_grad_segments
  * with fused_sgd_lr is for plain SGD): the summed gradient of each unique row is consumed by
  * the optimiser step where it is formed - no [n_seg, W] gradient is written or re-read.

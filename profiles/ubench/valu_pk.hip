@@ -1,0 +1,117 @@
+// Issue-rate probe of the packed forms the fp16 L1 tile kernels are built from (gfx950):
+//   mode 0  forward:   m = v_pk_max_f16(q2, e2);  acc = v_dot2_f32_f16(m, {1,1}, acc)        2 ops / 2 elements
+//   mode 1  backward:  d = v_pk_add_f16(x2, -y2); t = v_pk_max_i16(v_pk_min_i16(d, 1), -1);
+//                      acc = v_dot2_i32_i16(t, c2, acc)                                       4 ops / 2 elements
+//   mode 2  backward, sign by bit transfer (ties -> +c): d; c ^ (d & 0x80008000); v_dot2_f32_f16   4 ops / 2 elements
+// with the LDS read mix of a 4 x 4 register tile (2 ds_read_b128 per 16 (i, j) pairs).
+//   hipcc -O3 --offload-arch=gfx950 valu_pk.hip -o valu_pk && ./valu_pk
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef short s2 __attribute__((ext_vector_type(2)));
+
+// single-instruction helpers: the compiler scalarises packed int16 min / max (v_cmp + v_cndmask per half)
+// and puts a canonicalising v_pk_max_f16 x, x in front of a packed float max of loaded bits
+__device__ __forceinline__ uint32_t pk_max_f16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_sub_f16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <int MODE, bool WITH_LDS>
+__global__ __launch_bounds__(256) void k_probe(float* out, int iters, float seed) {
+    __shared__ uint4 lds[2048];
+    for (int i = threadIdx.x; i < 2048; i += 256) lds[i] = make_uint4(i * 2654435761u, i * 40503u, i + 77u, i * 3u);
+    __syncthreads();
+    float facc[16];
+    int iacc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { facc[i] = 0.f; iacc[i] = 0; }
+    uint32_t a[4] = {0x3c003800u, 0x34003c00u, 0x38003400u, 0x3c003c00u}, b[4] = {0x35003900u, 0x3a003b00u, 0x33003100u, 0x3c003200u};
+    const h2 ones = {(_Float16)1.f, (_Float16)1.f};
+    uint32_t one2 = 0x00010001u, mone2 = 0xffffffffu;
+    asm volatile("" : "+v"(one2), "+v"(mone2));
+    for (int it = 0; it < iters; ++it) {
+        if (WITH_LDS) {
+            const uint4 x = lds[(threadIdx.x >> 4) + ((it & 15) << 4)];
+            const uint4 y = lds[(threadIdx.x & 15) + ((it & 15) << 4) + 256];
+            a[0] = x.x; a[1] = x.y; a[2] = x.z; a[3] = x.w;
+            b[0] = y.x; b[1] = y.y; b[2] = y.z; b[3] = y.w;
+        } else {
+            asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const h2 x = __builtin_bit_cast(h2, a[i]), y = __builtin_bit_cast(h2, b[j]);
+                (void)x; (void)y;
+                if (MODE == 0) {
+                    const uint32_t m = pk_max_f16(a[i], b[j]);
+                    facc[4 * i + j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, m), ones, facc[4 * i + j], false);
+                } else if (MODE == 1) {
+                    const uint32_t d = pk_sub_f16(a[i], b[j]);
+                    const uint32_t t = pk_max_i16(pk_min_i16(d, one2), mone2);
+                    iacc[4 * i + j] = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, t), __builtin_bit_cast(s2, b[(j + 1) & 3]), iacc[4 * i + j], false);
+                } else {
+                    const uint32_t d = pk_sub_f16(a[i], b[j]);
+                    const uint32_t sg = (d & 0x80008000u) ^ b[(j + 1) & 3];
+                    facc[4 * i + j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, sg), ones, facc[4 * i + j], false);
+                }
+            }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += facc[i] + (float)iacc[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int MODE, bool LDS>
+static void bench(float* out, const char* name, int ops_per_pair) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int iters = 20000;
+    for (int wg_per_cu : {1, 2, 4, 8}) {
+        const int blocks = 256 * wg_per_cu;
+        k_probe<MODE, LDS><<<blocks, 256>>>(out, iters, 0.5f);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        k_probe<MODE, LDS><<<blocks, 256>>>(out, iters, 0.5f);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double pairs = double(blocks) * 256 * iters * 16.0;  // packed (2-element) steps
+        printf("%-28s lds_mix=%d %d wave(s)/SIMD: %8.3f ms  %6.2f T elements/s  %6.2f T lane-ops/s\n", name, (int)LDS,
+               wg_per_cu, ms, 2.0 * pairs / ms / 1e9, ops_per_pair * pairs / ms / 1e9);
+    }
+}
+
+int main() {
+    float* out;
+    hipMalloc(&out, sizeof(float) * 256 * 256 * 64);
+    bench<0, false>(out, "fwd pk_max+dot2", 2);
+    bench<0, true>(out, "fwd pk_max+dot2", 2);
+    bench<1, false>(out, "bwd sub+min+max+sdot2", 4);
+    bench<1, true>(out, "bwd sub+min+max+sdot2", 4);
+    bench<2, false>(out, "bwd sub+and+xor+fdot2", 4);
+    bench<2, true>(out, "bwd sub+and+xor+fdot2", 4);
+    return 0;
+}

@@ -256,3 +256,52 @@ def test_graph_capture_of_a_second_signature_keeps_training_state(dev, opt_name)
     torch.testing.assert_close(l1, l0, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(e1, e0, rtol=1e-4, atol=2e-5)
     torch.testing.assert_close(r1, r0, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("kind", ["sgd", "adam"])
+def test_coalesced_update_of_several_lists(dev, kind, dtype):
+    """bess_coalesced_update: three (rows, gradient) lists with duplicates inside and across the lists are
+    summed per unique row in fp32 and the row is updated ONCE - for an f16 table the result is
+    fp16(row - lr * sum) exactly (a per-contribution atomic would round several times); `sum_only`
+    returns the per-row sums; `keep` masks rows out."""
+    from besskge import _native as nat
+
+    torch.manual_seed(3)
+    M, W = 300, 96
+    table = torch.randn(M, W).to(dtype)
+    lists = []
+    for n in (70, 1, 130):
+        idx = torch.randint(0, 40, (n,), dtype=torch.int32)  # heavy duplication
+        lists.append((idx, torch.randn(n, W)))
+    idx_all = torch.cat([i for i, _ in lists])
+    seg = nat.SegmentIndex(idx_all.to(dev), M)
+    grads = [g.to(dev) for _, g in lists]
+    sums = nat.coalesced_update(None, table.to(dev), seg, grads, sum_only=True)
+    n_seg = int(seg.n_seg.item())
+    rows = seg.seg_rows[:n_seg].cpu().long()
+    want_sum = torch.zeros(M, W, dtype=torch.float64)
+    want_sum.index_add_(0, idx_all.long(), torch.cat([g for _, g in lists]).double())
+    assert torch.equal(rows, torch.unique(idx_all.long()))
+    torch.testing.assert_close(sums[:n_seg].cpu().double(), want_sum[rows], rtol=1e-5, atol=1e-5)
+
+    o = nat.OptDesc()
+    hp = dict(lr=0.05, momentum=0.0, weight_decay=0.0, beta1=0.9, beta2=0.999, eps=1e-8)
+    o.kind, o.step, o.lr = (nat.OPT_SGD if kind == "sgd" else nat.OPT_ADAM), 1, hp["lr"]
+    o.beta1, o.beta2, o.eps = hp["beta1"], hp["beta2"], hp["eps"]
+    t_dev = table.to(dev).clone()
+    s1 = torch.zeros(M, W, device=dev) if kind == "adam" else None
+    s2 = torch.zeros(M, W, device=dev) if kind == "adam" else None
+    keep = torch.ones(seg.max_seg, dtype=torch.int32, device=dev)
+    keep[0] = 0  # the smallest touched row stays as it is
+    nat.coalesced_update(o, t_dev, seg, grads, s1, s2, keep=keep)
+    state = [torch.zeros(M, W), torch.zeros(M, W)]
+    ref = lazy_reference(kind, table.float(), rows[1:], sums[:n_seg].cpu()[1:], state, hp, 1)
+    got = t_dev.cpu()
+    if dtype == torch.float16:
+        assert torch.equal(got, ref.half())  # rounded once, from the fp32 result
+    else:
+        torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-6)
+    assert torch.equal(got[rows[0]], table[rows[0]])
+    with pytest.raises(ValueError, match="references"):
+        nat.coalesced_update(o, t_dev, seg, grads[:2], s1, s2)
