@@ -79,6 +79,21 @@ class OptDesc(ctypes.Structure):
 
 
 OPT_SGD, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
+FLAG_FP32_MATH = 1  # BESS_FLAG_FP32_MATH (ModelDesc.reserved[0] of the four native scorers)
+
+
+class KillDesc(ctypes.Structure):
+    """struct bess_kill_desc: K7 (mask / augment kill) applied with the scores"""
+
+    _fields_ = [
+        ("diag_step", _i32),
+        ("ht", _i32),
+        ("ppp", _i32),
+        ("reserved", _i32),
+        ("mask", _vp),
+        ("mask_rows", _i64),
+        ("mask_cols", _i64),
+    ]
 
 
 class Pcg64State(ctypes.Structure):
@@ -113,6 +128,7 @@ SIGNATURES = {
     "bess_neg_score_shared_fwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
     "bess_neg_score_shared_workspace": [_MD, _i64, _i64],
     "bess_neg_score_shared_fwd_ws": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp],
+    "bess_neg_score_shared_fwd_masked": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, ctypes.POINTER(KillDesc), _vp, _i64, _vp],
     "bess_neg_score_shared_bwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
     "bess_neg_score_shared_bwd_workspace": [_MD, _i64, _i64],
     "bess_neg_score_shared_bwd_ws": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
@@ -582,9 +598,12 @@ def _affine_candidates(d: ModelDesc, neg: RowSource) -> Tuple[RowSource, torch.T
     return RowSource(hat), hat, inv
 
 
-def neg_score_shared_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, pad_ld: bool = False) -> torch.Tensor:
+def neg_score_shared_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, pad_ld: bool = False,
+                         kill: Optional[Tuple[int, bool, int, Optional[torch.Tensor]]] = None) -> torch.Tensor:
     """Scores [nq, n_neg].  `pad_ld`: rows of the result are 16-B aligned (leading dimension rounded
-    up to 4 floats; the result is then a column slice of the buffer) - what `topk_update` streams fastest."""
+    up to 4 floats; the result is then a column slice of the buffer) - what `topk_update` streams fastest.
+    `kill` = (diag_step, ht, ppp, mask [rows, cols] bool | None): K7 applied with the scores
+    (`mask_scores` semantics; in the scoring kernel's epilogue where it has one)."""
     nq, n_neg = int(query.shape[0]), len(neg)
     dev = _neg_operands(d, query, neg, n_neg)
     if d.scorer == AFFINE:
@@ -596,10 +615,26 @@ def neg_score_shared_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, pad_
     # torch's caching allocator, so it is stream-ordered and safe under graph capture
     ws_bytes = int(lib.bess_neg_score_shared_workspace(ctypes.byref(d), nq, n_neg))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
+    kd = None
+    if kill is not None:
+        diag_step, ht, ppp, mask = kill
+        kd = KillDesc()
+        kd.diag_step, kd.ht, kd.ppp = int(diag_step), int(bool(ht)), int(ppp)
+        if mask is not None:
+            _same_device([("negative_mask", mask), ("query", query)])
+            if mask.dtype != torch.bool or mask.dim() != 2 or not mask.is_contiguous():
+                raise ValueError("negative_mask must be a contiguous 2-D bool tensor")
+            kd.mask, kd.mask_rows, kd.mask_cols = mask.data_ptr(), int(mask.shape[0]), int(mask.shape[1])
     with torch.cuda.device(dev), _Timed("bess_neg_score_shared_fwd", dev):
-        rc = lib.bess_neg_score_shared_fwd_ws(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
-                                              _idx(neg.idx, "negative idx"), n_neg, out.data_ptr(), ld,
-                                              ws.data_ptr() if ws is not None else None, ws_bytes, _stream(dev))
+        if kd is None:
+            rc = lib.bess_neg_score_shared_fwd_ws(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
+                                                  _idx(neg.idx, "negative idx"), n_neg, out.data_ptr(), ld,
+                                                  ws.data_ptr() if ws is not None else None, ws_bytes, _stream(dev))
+        else:
+            rc = lib.bess_neg_score_shared_fwd_masked(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
+                                                      _idx(neg.idx, "negative idx"), n_neg, out.data_ptr(), ld,
+                                                      ctypes.byref(kd), ws.data_ptr() if ws is not None else None,
+                                                      ws_bytes, _stream(dev))
     _check(rc, "bess_neg_score_shared_fwd")
     return out if ld == n_neg else out[:, :n_neg]
 

@@ -85,6 +85,7 @@ class _NegGroup:
         self.query_ctx: Any = None  # what the scorer's query_bwd needs
         self.out: Optional[torch.Tensor] = None
         self.dq: Optional[torch.Tensor] = None  # d loss / d query from the fused training forward
+        self.kill: Any = None  # K7 applied together with the scores (shared negatives, one group)
 
 
 class _ReplicaStep:
@@ -108,6 +109,7 @@ class _ReplicaStep:
         self.local_tail: torch.Tensor = None  # type: ignore
         self.positive_score: torch.Tensor = None  # type: ignore
         self.negative_score: torch.Tensor = None  # type: ignore
+        self.kill_applied = False  # the scoring call already applied K7 (mask / augment kill)
 
 
 class BessKGE(torch.nn.Module, ABC):
@@ -291,7 +293,11 @@ class BessKGE(torch.nn.Module, ABC):
             for k in ("head", "relation", "tail", "negative"):
                 if b[k].shape[0] != 1:
                     raise ValueError(f"`{k}` must have a leading replica dim of 1, got {tuple(b[k].shape)}")
-            squeezed.append({k: _i32(b[k].squeeze(0)) for k in ("head", "relation", "tail", "negative")})
+            sq: Dict[str, Any] = {k: _i32(b[k].squeeze(0)) for k in ("head", "relation", "tail", "negative")}
+            # forward / training step: K7 may be applied by the scoring call itself (`score_batch` keeps
+            # returning the unmasked scores, like the reference's)
+            sq["_kill_from"] = b
+            squeezed.append(sq)
         return self.score_batch_replicas(squeezed)
 
     def score_batch(
@@ -320,21 +326,10 @@ class BessKGE(torch.nn.Module, ABC):
         n, ppp = st.n, st.ppp
         flat_ht = ns.flat_negative_format and ns.corruption_scheme == "ht"
 
-        negative_mask = batch.get("negative_mask")
-        mask2d = None
-        if negative_mask is not None:
-            # (1, B', n_shard, L) -> [B', n_shard * L]   (bess.py:182-199)
-            mask2d = negative_mask.squeeze(0).flatten(start_dim=-2).to(device=dev, dtype=torch.bool).contiguous()
-            if mask2d.shape[0] not in (1, 2, pos.shape[0]):
-                raise ValueError(f"negative_mask has {mask2d.shape[0]} rows")
-            if mask2d.shape[0] == 2 and not flat_ht:
-                raise ValueError("a 2-row negative_mask needs flat 'ht' negatives")
-        if self.augment_negative:
-            # true head/tail sits at column step * (position of the triple among the queries)
-            step = 1 if ns.flat_negative_format else 1 + n * int(batch["negative"].shape[-1])
-            nat.mask_scores(neg, step, ns.corruption_scheme == "ht", ppp, mask2d)
-        elif mask2d is not None:
-            nat.mask_scores(neg, 0, False, ppp if flat_ht else 0, mask2d)
+        if not st.kill_applied:
+            kill = self._kill_spec(batch, n, ppp, int(pos.shape[0]), dev)
+            if kill is not None:
+                nat.mask_scores(neg, kill[0], kill[1], kill[2], kill[3])
 
         out: Dict[str, Any] = dict()
         ret_neg = neg
@@ -366,6 +361,29 @@ class BessKGE(torch.nn.Module, ABC):
                     out["ranks"] = ranks
                 out["metrics"] = self.evaluation.stacked_metrics_from_ranks(ranks, tm)
         return out, d_pos, d_neg
+
+    def _kill_spec(self, batch: _Batch, n: int, ppp: int, S: int, dev: torch.device
+                   ) -> Optional[Tuple[int, bool, int, Optional[torch.Tensor]]]:
+        """K7 of this micro-batch as (diag_step, ht, ppp, mask2d) - the arguments of
+        `bess_mask_scores` - or None (reference bess.py:182-245)."""
+        ns = self.negative_sampler
+        flat_ht = ns.flat_negative_format and ns.corruption_scheme == "ht"
+        negative_mask = batch.get("negative_mask")
+        mask2d = None
+        if negative_mask is not None:
+            # (1, B', n_shard, L) -> [B', n_shard * L]   (bess.py:182-199)
+            mask2d = negative_mask.squeeze(0).flatten(start_dim=-2).to(device=dev, dtype=torch.bool).contiguous()
+            if mask2d.shape[0] not in (1, 2, S):
+                raise ValueError(f"negative_mask has {mask2d.shape[0]} rows")
+            if mask2d.shape[0] == 2 and not flat_ht:
+                raise ValueError("a 2-row negative_mask needs flat 'ht' negatives")
+        if self.augment_negative:
+            # true head/tail sits at column step * (position of the triple among the queries)
+            step = 1 if ns.flat_negative_format else 1 + n * int(batch["negative"].shape[-1])
+            return step, ns.corruption_scheme == "ht", ppp, mask2d
+        if mask2d is not None:
+            return 0, False, ppp if flat_ht else 0, mask2d
+        return None
 
     # ------------------------------------------------------- optimiser step
     def _opt_state(self, table: torch.Tensor, n_state: int) -> Dict[str, Any]:
@@ -558,7 +576,7 @@ class BessKGE(torch.nn.Module, ABC):
         if g.query is None:
             g.query, g.query_ctx = self.score_fn.query_fwd(g.side, g.ent, g.rel_idx)
         if g.shared:
-            g.out = nat.neg_score_shared_fwd(desc, g.query, g.neg)
+            g.out = nat.neg_score_shared_fwd(desc, g.query, g.neg, kill=g.kill)
         elif fuse is not None and st is not None and g.neg.base is st.table:
             # training, nothing masked afterwards: scores and d loss / d query in one pass (the
             # backward then never re-reads the negative rows)
@@ -643,8 +661,12 @@ class EmbeddingMovingBessKGE(BessKGE):
         rel_table = fn.relation_embedding.data
         done: List[_ReplicaStep] = []
         fuse = getattr(self, "_train_fuse", None)
-        for st in steps:
+        for st, b in zip(steps, batches):
             self._build_groups(st, exchange_negatives)
+            src = b.get("_kill_from")
+            if src is not None and len(st.groups) == 1 and st.groups[0].shared:
+                st.groups[0].kill = self._kill_spec(src, st.n, st.ppp, st.n * st.ppp, st.table.device)
+                st.kill_applied = st.groups[0].kill is not None
             st.positive_score, st.triple_ctx = fn.triple_fwd(
                 RowSource(st.table, st.head_idx), st.tail, st.rel_idx)
             outs = self._run_groups(st, desc, fuse[len(done)] if fuse else None)

@@ -97,7 +97,14 @@ class BaseScoreFunction(torch.nn.Module, ABC):
         d.dtype = nat._dtype_code(self.relation_embedding)
         d.width = int(self.entity_embedding.shape[-1])
         d.rel_width = int(self.relation_embedding.shape[-1])
+        if 0 <= self._scorer_id <= nat.COMPLEX and getattr(self, "fp32_math", False):
+            d.reserved[0] = nat.FLAG_FP32_MATH
         return d
+
+    #: TransE / RotatE with p = 1 on fp16 tables score shared negatives with packed-fp16 kernels that
+    #: round the query to fp16 first (what the reference's fp16 mode does); True keeps the query in
+    #: fp32 and uses the fp32 kernels
+    fp32_math: bool = False
 
     def _table_dtype(self, x: torch.Tensor) -> torch.Tensor:
         dt = self.relation_embedding.dtype

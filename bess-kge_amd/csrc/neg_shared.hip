@@ -332,9 +332,41 @@ static int run_bwd_one(const bess_model_desc* d, RowSrc<TX> X, RowSrc<TY> Y, con
     return BESS_OK;
 }
 
+// packed-fp16 L1 path (l1_f16.hip): scorer / dtype / width fit, not switched off, 16-B aligned operands
+static bool use_l1_pk(const bess_model_desc* d, const void* query, const void* neg_base) {
+    return l1_pk_eligible(d) && !(d->reserved[0] & BESS_FLAG_FP32_MATH) &&
+           reinterpret_cast<uintptr_t>(query) % 16 == 0 && reinterpret_cast<uintptr_t>(neg_base) % 16 == 0;
+}
+
 }  // namespace bess
 
 using namespace bess;
+
+extern "C" int bess_neg_score_shared_fwd_masked(const bess_model_desc* d, const float* query, int64_t n_query,
+                                                const void* neg_base, const int32_t* neg_idx, int64_t n_neg,
+                                                float* out, int64_t ld_out, const bess_kill_desc* kill,
+                                                void* workspace, int64_t workspace_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    if (kill && d->scorer <= BESS_COMPLEX && n_query > 0 && n_neg > 0 && query && neg_base && out &&
+        ld_out >= n_neg && use_l1_pk(d, query, neg_base)) {
+        BESS_REQUIRE(kill->diag_step >= 0, "neg_score_shared_fwd_masked: negative diag_step");
+        if (kill->mask) {
+            BESS_REQUIRE(kill->mask_cols > 0 && kill->mask_cols <= n_neg, "neg_score_shared_fwd_masked: mask_cols");
+            BESS_REQUIRE(kill->mask_rows == 1 || kill->mask_rows == 2 || kill->mask_rows == n_query,
+                         "neg_score_shared_fwd_masked: mask_rows %lld not 1, 2 or n_query", (long long)kill->mask_rows);
+        }
+        if (kill->ht || (kill->mask && kill->mask_rows == 2))
+            BESS_REQUIRE(kill->ppp >= 2 && (kill->ppp % 2) == 0 && (n_query % kill->ppp) == 0,
+                         "neg_score_shared_fwd_masked: 'ht' needs an even block size dividing n_query");
+        return l1_pk_fwd(d, query, n_query, neg_base, neg_idx, n_neg, out, ld_out, kill, as_stream(stream));
+    }
+    if (int e = bess_neg_score_shared_fwd_ws(d, query, n_query, neg_base, neg_idx, n_neg, out, ld_out, workspace,
+                                             workspace_bytes, stream))
+        return e;
+    if (!kill || n_query == 0 || n_neg == 0) return BESS_OK;
+    return bess_mask_scores(out, n_query, n_neg, ld_out, kill->diag_step, kill->ht, kill->ppp, kill->mask,
+                            kill->mask_rows, kill->mask_cols, stream);
+}
 
 extern "C" int64_t bess_neg_score_shared_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg) {
     if (!d || check_desc(d) || n_query <= 0 || n_neg <= 0) return 0;
@@ -367,6 +399,8 @@ extern "C" int bess_neg_score_shared_fwd_ws(const bess_model_desc* d, const floa
         return gemm_dot_fwd(d->dtype, query, n_query, neg_base, neg_idx, n_neg, d->width, out, ld_out,
                             as_stream(stream));
     }
+    if (use_l1_pk(d, query, neg_base))
+        return l1_pk_fwd(d, query, n_query, neg_base, neg_idx, n_neg, out, ld_out, nullptr, as_stream(stream));
     RowSrc<float> Q{query, nullptr, n_query};
     if (d->dtype == BESS_F32)
         return run_fwd<float>(d, Q, RowSrc<float>{static_cast<const float*>(neg_base), neg_idx, n_neg}, out,
@@ -384,6 +418,8 @@ extern "C" int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* 
 
 extern "C" int64_t bess_neg_score_shared_bwd_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg) {
     if (!d || check_desc(d) || n_query <= 0 || n_neg <= 0) return 0;
+    if (d->scorer <= BESS_COMPLEX && l1_pk_eligible(d) && !(d->reserved[0] & BESS_FLAG_FP32_MATH))
+        return l1_pk_bwd_workspace(n_query, n_neg);
     if (d->scorer == BESS_BOXE || d->scorer == BESS_AFFINE || reduce_of(d) != RED_DOT) return 0;
     return gemm_split_bwd_workspace(n_query, n_neg, d->width);
 }
@@ -428,6 +464,9 @@ extern "C" int bess_neg_score_shared_bwd_ws(const bess_model_desc* d, const floa
             return e;
         return gemm_dot_de(d_out, ld_dout, n_query, query, n_neg, d->width, d_neg, st);
     }
+    if (workspace && workspace_bytes >= l1_pk_bwd_workspace(n_query, n_neg) && use_l1_pk(d, query, neg_base) &&
+        reinterpret_cast<uintptr_t>(workspace) % 4 == 0)
+        return l1_pk_bwd(d, query, n_query, neg_base, neg_idx, n_neg, d_out, ld_dout, d_query, d_neg, workspace, st);
     RowSrc<float> Q{query, nullptr, n_query};
     if (d->dtype == BESS_F32) {
         RowSrc<float> E{static_cast<const float*>(neg_base), neg_idx, n_neg};

@@ -87,6 +87,9 @@ extern "C" {
 /* value added to the score of a masked negative (reference bess.py:31) */
 #define BESS_BAD_NEGATIVE_SCORE (-50000.0f)
 
+/* bess_model_desc.reserved[0] of TransE / RotatE / DistMult / ComplEx: flags */
+#define BESS_FLAG_FP32_MATH 1 /* never use the packed-fp16 forms of the shared-negative kernels */
+
 typedef struct bess_model_desc {
     int32_t scorer;    /* BESS_TRANSE ...                                  */
     int32_t norm_p;    /* 1 or 2 (TransE / RotatE), ignored otherwise      */
@@ -204,6 +207,34 @@ int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* query,
                               int64_t n_query, const void* neg_base,
                               const int32_t* neg_idx, int64_t n_neg, float* out,
                               int64_t ld_out, void* stream);
+
+/* TransE / RotatE with p = 1 on f16 tables and W % 32 == 0 (BASELINE configs[3]) take packed-fp16
+ * forms of K4 (csrc/l1_f16.hip) unless desc.reserved[0] has BESS_FLAG_FP32_MATH: as in the
+ * reference's fp16 mode (`model.half()`: the query `h + r` is an fp16 tensor) the query is rounded
+ * to fp16 (nearest even) when it meets the fp16 candidates; the sum over W is then exact-or-fp32
+ * (sum |q - e| = 2 sum max(q, e) - sum q - sum e).  The backward (through the _ws entry point:
+ * 4 * (n_query + n_neg) bytes of scratch) evaluates sgn(q - e) exactly, sgn(0) = 0, with the score
+ * gradients quantised to int16 per output row (absolute error max|d_out row| / 65534) and exact
+ * int32 accumulation: bitwise reproducible. */
+
+/* K4 + K7 in one call: bess_neg_score_shared_fwd_ws followed by bess_mask_scores(out, n_query,
+ * n_neg, ld_out, kill->diag_step, kill->ht, kill->ppp, kill->mask, kill->mask_rows,
+ * kill->mask_cols); the packed-fp16 L1 kernel applies the kill in its epilogue (one pass over
+ * the scores less).  kill == NULL: no masking. */
+typedef struct bess_kill_desc {
+    int32_t diag_step; /* > 0: augmentation, the true head / tail sits at column diag_step * qpos(s) */
+    int32_t ht;
+    int32_t ppp;
+    int32_t reserved;
+    const uint8_t* mask; /* [mask_rows, mask_cols] or NULL */
+    int64_t mask_rows;
+    int64_t mask_cols;
+} bess_kill_desc;
+int bess_neg_score_shared_fwd_masked(const bess_model_desc* d, const float* query,
+                                     int64_t n_query, const void* neg_base,
+                                     const int32_t* neg_idx, int64_t n_neg, float* out,
+                                     int64_t ld_out, const bess_kill_desc* kill, void* workspace,
+                                     int64_t workspace_bytes, void* stream);
 
 /* K4 with a scratch buffer.  For the bilinear scorers (DistMult, ComplEx) and shapes of at
  * least 256 output tiles of 128 x 128, bess_neg_score_shared_workspace returns the bytes of

@@ -138,6 +138,25 @@ def query(scorer: str, side: str, ent: torch.Tensor, rel: torch.Tensor) -> torch
     raise ValueError(scorer)
 
 
+# fp16 mode of the reference (`model.half()`, notebooks/3_wikikg2_fp16.ipynb:300-392): every tensor of the
+# scoring path is fp16, so the query `h + r` / `rot(h, r)` that meets the candidates in
+# `pea.distance_matrix` (scoring.py:194-197) has been rounded to fp16.  The oracle works on fp32 tensors
+# holding fp16-representable table values; inside `half_queries()` it also rounds that query (straight-through
+# for the gradient: rounding has derivative 1 almost everywhere), which is what the packed-fp16 L1 kernels of
+# the product do for TransE / RotatE with p = 1 and shared negatives.  Everything after the rounding stays
+# fp32 here (the reference would go on in fp16 with IPU stochastic rounding: no bit-exact equivalent).
+_HALF_QUERY = [False]
+
+
+class half_queries:
+    def __enter__(self) -> None:
+        self.old = _HALF_QUERY[0]
+        _HALF_QUERY[0] = True
+
+    def __exit__(self, *exc) -> None:
+        _HALF_QUERY[0] = self.old
+
+
 def _reduce(scorer: str, p: int, q: torch.Tensor, cand: torch.Tensor) -> torch.Tensor:
     """q [..., W] against cand [..., W] (broadcast) -> [...]"""
     if _is_distance(scorer):
@@ -239,6 +258,8 @@ def score_candidates(scorer: str, p: int, sharing: bool, side: str, ent: torch.T
         return -torch.norm(delta, p=p, dim=-1)
     q = query(scorer, side, ent, rel_table[rid.long()])  # [S, W]
     if sharing:
+        if _HALF_QUERY[0] and _is_distance(scorer) and p == 1:
+            q = q + (q.half().float() - q).detach()
         flat = cand.reshape(-1, cand.shape[-1])
         return _reduce(scorer, p, q[:, None, :], flat[None, :, :])
     return _reduce(scorer, p, q[:, None, :], cand)
