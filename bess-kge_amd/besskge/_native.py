@@ -123,6 +123,9 @@ SIGNATURES = {
     "bess_score_triple_bwd": [_MD, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "bess_query_fwd": [_MD, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "bess_query_bwd": [_MD, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "bess_query_triple_fwd": [_MD, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "bess_query_triple_bwd": [_MD, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "bess_sparse_sgd_lists": [_i32, _i32, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64), _f32, _vp],
     "bess_neg_score_pertriple_fwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
     "bess_neg_score_pertriple_bwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
     "bess_neg_score_shared_fwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
@@ -417,6 +420,42 @@ def score_triple_bwd(d: ModelDesc, head: RowSource, tail: RowSource, rel_table: 
             _idx(tail.idx, "tail_idx"), rel_table.data_ptr(), rel_idx.data_ptr(), n, d_out.data_ptr(),
             dh.data_ptr(), dt.data_ptr(), d_rel_table.data_ptr(), _stream(dev))
     _check(rc, "bess_score_triple_bwd")
+    return dh, dt
+
+
+def query_triple_fwd(d: ModelDesc, side: int, head: RowSource, tail: RowSource, rel_table: torch.Tensor,
+                     rel_idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(query [n, W], positive score [n]) in one launch."""
+    dev, n = _triple_operands(d, head, tail, rel_table, rel_idx)
+    q = torch.empty((n, d.width), dtype=torch.float32, device=dev)
+    out = torch.empty((n,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().bess_query_triple_fwd(
+            ctypes.byref(d), side, head.base.data_ptr(), _idx(head.idx, "head_idx"), tail.base.data_ptr(),
+            _idx(tail.idx, "tail_idx"), rel_table.data_ptr(), rel_idx.data_ptr(), n, q.data_ptr(), out.data_ptr(),
+            _stream(dev))
+    _check(rc, "bess_query_triple_fwd")
+    return q, out
+
+
+def query_triple_bwd(d: ModelDesc, side: int, head: RowSource, tail: RowSource, rel_table: torch.Tensor,
+                     rel_idx: torch.Tensor, d_out: torch.Tensor, d_query: torch.Tensor, d_rel_table: torch.Tensor
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(d_head [n, W], d_tail [n, W]) of positive score and query together; accumulates into d_rel_table."""
+    dev, n = _triple_operands(d, head, tail, rel_table, rel_idx)
+    _same_device([("d_out", d_out), ("d_query", d_query), ("d_rel_table", d_rel_table), ("x", head.base)])
+    for t, nm in ((d_out, "d_out"), (d_query, "d_query"), (d_rel_table, "d_rel_table")):
+        _f32(t, nm)
+    if d_out.numel() != n or tuple(d_query.shape) != (n, d.width) or tuple(d_rel_table.shape) != tuple(rel_table.shape):
+        raise ValueError("query_triple_bwd: gradient shapes do not match")
+    dh = torch.empty((n, d.width), dtype=torch.float32, device=dev)
+    dt = torch.empty((n, d.width), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().bess_query_triple_bwd(
+            ctypes.byref(d), side, head.base.data_ptr(), _idx(head.idx, "head_idx"), tail.base.data_ptr(),
+            _idx(tail.idx, "tail_idx"), rel_table.data_ptr(), rel_idx.data_ptr(), n, d_out.data_ptr(),
+            d_query.data_ptr(), dh.data_ptr(), dt.data_ptr(), d_rel_table.data_ptr(), _stream(dev))
+    _check(rc, "bess_query_triple_bwd")
     return dh, dt
 
 
@@ -734,6 +773,26 @@ def sparse_sgd(table: torch.Tensor, idx: torch.Tensor, grad: torch.Tensor, lr: f
     _check(rc, "bess_sparse_sgd")
 
 
+def sparse_sgd_lists(table: torch.Tensor, lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], lr: float) -> None:
+    """`sparse_sgd` for several (row ids, gradient rows) lists in one launch."""
+    if not 1 <= len(lists) <= MAX_ROW_LISTS:
+        raise ValueError(f"sparse_sgd_lists: {len(lists)} lists (1 .. {MAX_ROW_LISTS})")
+    dev = _same_device([("table", table)] + [(f"idx[{i}]", x) for i, (x, _) in enumerate(lists)]
+                       + [(f"grad[{i}]", g) for i, (_, g) in enumerate(lists)])
+    W = int(table.shape[1])
+    _rows(table, "table", W)
+    for i, (x, g) in enumerate(lists):
+        _f32(g, f"grad[{i}]")
+        _rows(g, f"grad[{i}]", W)
+        _idx(x, f"idx[{i}]", int(g.shape[0]))
+    ip = (_vp * len(lists))(*[x.data_ptr() for x, _ in lists])
+    gp = (_vp * len(lists))(*[g.data_ptr() for _, g in lists])
+    rows = (_i64 * len(lists))(*[int(g.shape[0]) for _, g in lists])
+    with torch.cuda.device(dev), _Timed("bess_sparse_sgd_lists", dev):
+        rc = load().bess_sparse_sgd_lists(_dtype_code(table), W, table.data_ptr(), len(lists), ip, gp, rows, lr, _stream(dev))
+    _check(rc, "bess_sparse_sgd_lists")
+
+
 def dense_sgd(table: torch.Tensor, grad: torch.Tensor, lr: float) -> None:
     dev = _same_device([("table", table), ("grad", grad)])
     _f32(grad, "grad")
@@ -752,9 +811,13 @@ class SegmentIndex:
 
     __slots__ = ("refs", "seg_rows", "seg_offsets", "n_seg", "n_refs", "max_seg", "long_segs", "long_cap", "long_count", "long_grad")
 
-    def __init__(self, idx: torch.Tensor, n_rows: int, width: int = 0) -> None:
+    def __init__(self, idx: torch.Tensor, n_rows: int, width: int = 0,
+                 scratch: Optional[dict] = None) -> None:
         """`width` (row width W of the table the gradients are for): lets the scratch of the long-row
-        tier be prepared with the index instead of at the first reduction."""
+        tier be prepared with the index instead of at the first reduction.  `scratch` (a dict the
+        caller keeps, e.g. one per model): the zero-initialised scratch of the long-row tier is taken
+        from / left in it instead of being allocated and zeroed per index (every use leaves it zero;
+        share it only between steps that run one after the other on the same stream)."""
         dev = _dev(idx, "idx")
         ip = _idx(idx, "idx")
         n = int(idx.numel())
@@ -764,7 +827,7 @@ class SegmentIndex:
         self.refs = torch.empty((n,), dtype=torch.int32, device=dev)
         self.seg_rows = torch.empty((n,), dtype=torch.int32, device=dev)
         self.seg_offsets = torch.empty((n + 1,), dtype=torch.int32, device=dev)
-        self.n_seg = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.n_seg = torch.empty((1,), dtype=torch.int32, device=dev)  # always written by the build
         self.n_refs = n
         self.max_seg = min(n, int(n_rows))
         # rows with more than SEGMENT_CAP references (padded candidate lists, hot entities): listed
@@ -780,8 +843,17 @@ class SegmentIndex:
         _check(rc, "bess_build_segment_index")
         # scratch of the long-row tier: zero before the first use, left zero / consistent by every use;
         # zeroed here, i.e. on the stream that builds the index (off the critical path of a training step)
-        self.long_count = torch.zeros((self.long_cap,), dtype=torch.int32, device=dev)
-        self.long_grad = torch.zeros((self.long_cap, int(width)), dtype=torch.float32, device=dev) if width else None
+        if scratch is not None:
+            key = (dev, "long", int(width))
+            have = scratch.get(key)
+            if have is None or have[0].shape[0] < self.long_cap:
+                have = (torch.zeros((self.long_cap,), dtype=torch.int32, device=dev),
+                        torch.zeros((self.long_cap, int(width)), dtype=torch.float32, device=dev) if width else None)
+                scratch[key] = have
+            self.long_count, self.long_grad = have
+        else:
+            self.long_count = torch.zeros((self.long_cap,), dtype=torch.int32, device=dev)
+            self.long_grad = torch.zeros((self.long_cap, int(width)), dtype=torch.float32, device=dev) if width else None
 
 
 class _IdentitySegments:

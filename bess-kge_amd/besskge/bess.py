@@ -110,6 +110,7 @@ class _ReplicaStep:
         self.positive_score: torch.Tensor = None  # type: ignore
         self.negative_score: torch.Tensor = None  # type: ignore
         self.kill_applied = False  # the scoring call already applied K7 (mask / augment kill)
+        self.fused_qt = False  # query + positive score came out of one launch (so will their backwards)
 
 
 class BessKGE(torch.nn.Module, ABC):
@@ -470,7 +471,8 @@ class BessKGE(torch.nn.Module, ABC):
         side = self._aux_stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))  # the row ids are ready; nothing later is waited for
         with torch.cuda.stream(side):
-            return nat.SegmentIndex(g.neg.idx, st.table.shape[0], width=st.table.shape[1])
+            return nat.SegmentIndex(g.neg.idx, st.table.shape[0], width=st.table.shape[1],
+                                    scratch=self.__dict__.setdefault("_seg_scratch", {}))
 
     def _prefetch_segment_indices(self, steps: List[_ReplicaStep]) -> Dict[int, Any]:
         """The inverted indices of per-triple negatives only depend on the sampled indices: they are
@@ -518,10 +520,11 @@ class BessKGE(torch.nn.Module, ABC):
                                                              seg_index[id(g)]) for table, g, go in items]
                     for (table, g, _), gseg in zip(items, grads):
                         nat.apply_segments_sgd(table, seg_index[id(g)], gseg, lr)
-            # everything else: sparse atomic SGD on the shard (duplicates accumulate)
+            # everything else: sparse atomic SGD on the shard (duplicates accumulate), one launch per shard
             for st, upd in zip(steps, local_updates):
-                for idx, g in upd:
-                    nat.sparse_sgd(st.table, idx.contiguous(), g.contiguous(), lr)
+                lists = [(idx.contiguous(), g.contiguous()) for idx, g in upd]
+                for i in range(0, len(lists), nat.MAX_ROW_LISTS):
+                    nat.sparse_sgd_lists(st.table, lists[i: i + nat.MAX_ROW_LISTS], lr)
         else:
             # non-linear optimisers need the *summed* gradient of every row first
             native = desc.scorer <= nat.COMPLEX
@@ -667,8 +670,16 @@ class EmbeddingMovingBessKGE(BessKGE):
             if src is not None and len(st.groups) == 1 and st.groups[0].shared:
                 st.groups[0].kill = self._kill_spec(src, st.n, st.ppp, st.n * st.ppp, st.table.device)
                 st.kill_applied = st.groups[0].kill is not None
-            st.positive_score, st.triple_ctx = fn.triple_fwd(
-                RowSource(st.table, st.head_idx), st.tail, st.rel_idx)
+            g0 = st.groups[0]
+            st.fused_qt = (len(st.groups) == 1 and g0.sel is None and fn.supports_fused_query_triple
+                           and st.tail.base.dtype == st.table.dtype)
+            if st.fused_qt:
+                # K2 + K3 + K6: the query of the one negative-scoring problem and the positive scores, one launch
+                g0.query, st.positive_score = fn.query_triple_fwd(g0.side, RowSource(st.table, st.head_idx), st.tail,
+                                                                  st.rel_idx)
+            else:
+                st.positive_score, st.triple_ctx = fn.triple_fwd(
+                    RowSource(st.table, st.head_idx), st.tail, st.rel_idx)
             outs = self._run_groups(st, desc, fuse[len(done)] if fuse else None)
             done.append(st)
             if len(outs) == 1:
@@ -836,11 +847,12 @@ class EmbeddingMovingBessKGE(BessKGE):
                 else:  # pragma: no cover
                     raise RuntimeError("gradient for an unknown row space")
 
-            # K3': positive scores
-            dh, dt = fn.triple_bwd(RowSource(st.table, st.head_idx), st.tail, st.rel_idx, st.triple_ctx, d_pos,
-                                   d_rel)
-            sink(RowSource(st.table, st.head_idx), dh)
-            sink(st.tail, dt)
+            # K3': positive scores (with the one group's K6' when query and score came out of one launch)
+            if not st.fused_qt:
+                dh, dt = fn.triple_bwd(RowSource(st.table, st.head_idx), st.tail, st.rel_idx, st.triple_ctx, d_pos,
+                                       d_rel)
+                sink(RowSource(st.table, st.head_idx), dh)
+                sink(st.tail, dt)
             # K4'/K5' + K6': negative scores
             if len(st.groups) == 1:
                 d_outs = [d_neg]
@@ -866,8 +878,14 @@ class EmbeddingMovingBessKGE(BessKGE):
                 else:
                     dq, dn = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go)
                     sink(g.neg, dn)
-                dx = fn.query_bwd(g.side, g.ent, g.rel_idx, g.query_ctx, dq, d_rel)
-                sink(g.ent, dx)
+                if st.fused_qt:
+                    dh, dt = fn.query_triple_bwd(g.side, RowSource(st.table, st.head_idx), st.tail, st.rel_idx, d_pos,
+                                                 dq, d_rel)
+                    sink(RowSource(st.table, st.head_idx), dh)
+                    sink(st.tail, dt)
+                else:
+                    dx = fn.query_bwd(g.side, g.ent, g.rel_idx, g.query_ctx, dq, d_rel)
+                    sink(g.ent, dx)
             if n > 1:
                 if st.ext_src is not None:  # rows appended for augmentation -> their origin
                     sink(st.ext_src, d_recv[st.recv_rows:].contiguous())

@@ -80,6 +80,8 @@ class SingleProcessGroup(ReplicaGroup):
         return [stacked for _ in range(self.n_shard)]
 
     def all_reduce_sum(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        if len(xs) == 1:
+            return [xs[0]]
         total = xs[0].clone()
         for x in xs[1:]:
             total += x

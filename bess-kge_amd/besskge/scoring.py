@@ -117,6 +117,21 @@ class BaseScoreFunction(torch.nn.Module, ABC):
     #: the training forward can accumulate d loss / d query next to the scores
     #: (`bess_neg_score_pertriple_fwd_dq`)
     supports_fused_forward = True
+    #: query_fwd + triple_fwd, and their backwards, also exist as ONE launch each
+    #: (`bess_query_triple_fwd / _bwd`: TransE / RotatE / DistMult / ComplEx)
+    supports_fused_query_triple = True
+
+    def query_triple_fwd(self, side: int, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor
+                         ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(query matrix of the side's negative-scoring problem, positive scores) of the same triples."""
+        return nat.query_triple_fwd(self.kernel_desc(), side, head, tail, self.relation_embedding.data, rel_idx)
+
+    def query_triple_bwd(self, side: int, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor,
+                         d_pos: torch.Tensor, dq: torch.Tensor, d_rel: torch.Tensor
+                         ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(d_head rows, d_tail rows) of positive score + query together; relation gradient added to `d_rel`."""
+        return nat.query_triple_bwd(self.kernel_desc(), side, head, tail, self.relation_embedding.data, rel_idx,
+                                    d_pos, dq, d_rel)
 
     def dense_parameters(self) -> List[torch.nn.Parameter]:
         """Parameters besides the two embedding tables (ConvE's network); replicated like the
@@ -429,6 +444,7 @@ class _TorchQueryHooks:
 
     supports_fused_segments = False
     supports_fused_forward = False
+    supports_fused_query_triple = False
 
     def _query_torch(self, side: int, rows: torch.Tensor, rel: torch.Tensor, rel_idx: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError

@@ -500,6 +500,8 @@ __global__ __launch_bounds__(256) void k_box_long_segments(BoxSegArgs a, float* 
             if (g == 0) old = atomicAdd(long_cnt + li, 1);
             old = __shfl(old, lane & 48, 64);
             if ((old + 1) % parts != 0) continue;
+            // the last arriver puts the counter back to zero: the scratch can serve the next launch as it is
+            if (g == 0) __hip_atomic_store(long_cnt + li, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __threadfence();
 #pragma unroll
             for (int p = 0; p < 2; ++p)

@@ -31,10 +31,7 @@ struct TripleArgs {
 
 // ------------------------------------------------------------------ forward
 template <typename T, int SCORER>
-__global__ __launch_bounds__(256) void k_score_triple_fwd(TripleArgs a, float* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
-    if (s >= a.n) return;
+__device__ __forceinline__ void triple_fwd_body(const TripleArgs& a, int64_t s, int lane, float* __restrict__ out) {
     const T* h = row_ptr(static_cast<const T*>(a.head_base), a.head_idx, s, a.W);
     const T* t = row_ptr(static_cast<const T*>(a.tail_base), a.tail_idx, s, a.W);
     const T* r = static_cast<const T*>(a.rel_table) + static_cast<int64_t>(a.rel_idx[s]) * a.Wr;
@@ -75,6 +72,14 @@ __global__ __launch_bounds__(256) void k_score_triple_fwd(TripleArgs a, float* _
     if (lane == 0) out[s] = acc;
 }
 
+template <typename T, int SCORER>
+__global__ __launch_bounds__(256) void k_score_triple_fwd(TripleArgs a, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (s >= a.n) return;
+    triple_fwd_body<T, SCORER>(a, s, lane, out);
+}
+
 struct QueryArgs {
     const void* ent_base;
     const int32_t* ent_idx;
@@ -87,10 +92,7 @@ struct QueryArgs {
 };
 
 template <typename T, int SCORER>
-__global__ __launch_bounds__(256) void k_query_fwd(QueryArgs a, float* __restrict__ query) {
-    const int lane = threadIdx.x & 63;
-    const int64_t q = blockIdx.x * 4ll + (threadIdx.x >> 6);
-    if (q >= a.n) return;
+__device__ __forceinline__ void query_fwd_body(const QueryArgs& a, int64_t q, int lane, float* __restrict__ query) {
     const T* x = row_ptr(static_cast<const T*>(a.ent_base), a.ent_idx, q, a.W);
     const T* r = static_cast<const T*>(a.rel_table) + static_cast<int64_t>(a.rel_idx[q]) * a.Wr;
     float* o = query + q * a.W;
@@ -121,16 +123,37 @@ __global__ __launch_bounds__(256) void k_query_fwd(QueryArgs a, float* __restric
     }
 }
 
-// ----------------------------------------------------------------- backward
 template <typename T, int SCORER>
-__global__ __launch_bounds__(256) void k_score_triple_bwd(TripleArgs a,
-                                                          const float* __restrict__ d_out,
-                                                          float* __restrict__ d_head,
-                                                          float* __restrict__ d_tail,
-                                                          float* __restrict__ d_rel) {
+__global__ __launch_bounds__(256) void k_query_fwd(QueryArgs a, float* __restrict__ query) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (q >= a.n) return;
+    query_fwd_body<T, SCORER>(a, q, lane, query);
+}
+
+// K2 + K3 + K6 of one replica's micro-batch in one launch: the positive score of every triple and the query
+// row in front of its negatives (the same wave reads h, r, t once from HBM; the second use hits L1 / L2)
+template <typename T, int SCORER>
+__global__ __launch_bounds__(256) void k_query_triple_fwd(TripleArgs a, QueryArgs qa, float* __restrict__ query,
+                                                          float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
     if (s >= a.n) return;
+    query_fwd_body<T, SCORER>(qa, s, lane, query);
+    triple_fwd_body<T, SCORER>(a, s, lane, out);
+}
+
+// ----------------------------------------------------------------- backward
+template <bool ACCUM>
+__device__ __forceinline__ void put(float* p, float v) {
+    if (ACCUM) *p += v;
+    else *p = v;
+}
+
+template <typename T, int SCORER>
+__device__ __forceinline__ void triple_bwd_body(const TripleArgs& a, int64_t s, int lane,
+                                                const float* __restrict__ d_out, float* __restrict__ d_head,
+                                                float* __restrict__ d_tail, float* __restrict__ d_rel) {
     const T* h = row_ptr(static_cast<const T*>(a.head_base), a.head_idx, s, a.W);
     const T* t = row_ptr(static_cast<const T*>(a.tail_base), a.tail_idx, s, a.W);
     const int64_t rid = a.rel_idx[s];
@@ -211,12 +234,23 @@ __global__ __launch_bounds__(256) void k_score_triple_bwd(TripleArgs a,
 }
 
 template <typename T, int SCORER>
-__global__ __launch_bounds__(256) void k_query_bwd(QueryArgs a, const float* __restrict__ d_query,
-                                                   float* __restrict__ d_ent,
-                                                   float* __restrict__ d_rel) {
+__global__ __launch_bounds__(256) void k_score_triple_bwd(TripleArgs a,
+                                                          const float* __restrict__ d_out,
+                                                          float* __restrict__ d_head,
+                                                          float* __restrict__ d_tail,
+                                                          float* __restrict__ d_rel) {
     const int lane = threadIdx.x & 63;
-    const int64_t q = blockIdx.x * 4ll + (threadIdx.x >> 6);
-    if (q >= a.n) return;
+    const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (s >= a.n) return;
+    triple_bwd_body<T, SCORER>(a, s, lane, d_out, d_head, d_tail, d_rel);
+}
+
+// ACCUM: d_ent already holds this lane's contribution of the positive score (written by the same lane
+// just before: same element -> lane mapping in both bodies); add instead of overwrite
+template <typename T, int SCORER, bool ACCUM>
+__device__ __forceinline__ void query_bwd_body(const QueryArgs& a, int64_t q, int lane,
+                                               const float* __restrict__ d_query, float* __restrict__ d_ent,
+                                               float* __restrict__ d_rel) {
     const T* x = row_ptr(static_cast<const T*>(a.ent_base), a.ent_idx, q, a.W);
     const int64_t rid = a.rel_idx[q];
     const T* r = static_cast<const T*>(a.rel_table) + rid * a.Wr;
@@ -227,13 +261,13 @@ __global__ __launch_bounds__(256) void k_query_bwd(QueryArgs a, const float* __r
     if (SCORER == BESS_TRANSE) {
         for (int e = lane; e < a.W; e += 64) {
             const float g = dq[e];
-            dx[e] = g;
+            put<ACCUM>(dx + e, g);
             if (g != 0.f) unsafeAtomicAdd(dr + e, tail ? g : -g);
         }
     } else if (SCORER == BESS_DISTMULT) {
         for (int e = lane; e < a.W; e += 64) {
             const float g = dq[e];
-            dx[e] = g * to_f32(r[e]);
+            put<ACCUM>(dx + e, g * to_f32(r[e]));
             unsafeAtomicAdd(dr + e, g * to_f32(x[e]));
         }
     } else {
@@ -245,20 +279,45 @@ __global__ __launch_bounds__(256) void k_query_bwd(QueryArgs a, const float* __r
                 const float sg = tail ? 1.f : -1.f;
                 const float ph = sg * to_f32(r[e]);
                 const float c = cosf(ph), sn = sinf(ph);
-                dx[e] = gr * c + gi * sn;
-                dx[d + e] = -gr * sn + gi * c;
+                put<ACCUM>(dx + e, gr * c + gi * sn);
+                put<ACCUM>(dx + d + e, -gr * sn + gi * c);
                 const float dph = gr * (-xr * sn - xi * c) + gi * (xr * c - xi * sn);
                 unsafeAtomicAdd(dr + e, sg * dph);
             } else {
                 const float sg = tail ? 1.f : -1.f;  // conj r for heads
                 const float rr = to_f32(r[e]), ri = sg * to_f32(r[d + e]);
-                dx[e] = gr * rr + gi * ri;
-                dx[d + e] = -gr * ri + gi * rr;
+                put<ACCUM>(dx + e, gr * rr + gi * ri);
+                put<ACCUM>(dx + d + e, -gr * ri + gi * rr);
                 unsafeAtomicAdd(dr + e, gr * xr + gi * xi);
                 unsafeAtomicAdd(dr + d + e, sg * (-gr * xi + gi * xr));
             }
         }
     }
+}
+
+template <typename T, int SCORER>
+__global__ __launch_bounds__(256) void k_query_bwd(QueryArgs a, const float* __restrict__ d_query,
+                                                   float* __restrict__ d_ent,
+                                                   float* __restrict__ d_rel) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (q >= a.n) return;
+    query_bwd_body<T, SCORER, false>(a, q, lane, d_query, d_ent, d_rel);
+}
+
+// K3' + K6' in one launch: gradients of the positive score w.r.t. head / tail rows and of the query w.r.t. the
+// entity it was built from, summed where both hit the same row (the query of a tail-corruption step is built
+// from the head: d_head = d pos / d h + d query / d h), relation gradients accumulated once
+template <typename T, int SCORER>
+__global__ __launch_bounds__(256) void k_query_triple_bwd(TripleArgs a, QueryArgs qa, const float* __restrict__ d_out,
+                                                          const float* __restrict__ d_query,
+                                                          float* __restrict__ d_head, float* __restrict__ d_tail,
+                                                          float* __restrict__ d_rel) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (s >= a.n) return;
+    triple_bwd_body<T, SCORER>(a, s, lane, d_out, d_head, d_tail, d_rel);
+    query_bwd_body<T, SCORER, true>(qa, s, lane, d_query, qa.side == BESS_CORRUPT_TAIL ? d_head : d_tail, d_rel);
 }
 
 template <template <typename, int> class Launcher, typename... Args>
@@ -300,6 +359,20 @@ template <typename T, int SC>
 struct LQueryBwd {
     static void run(QueryArgs a, const float* dq, float* dx, float* dr, hipStream_t st) {
         k_query_bwd<T, SC><<<ceil_div(a.n, 4), 256, 0, st>>>(a, dq, dx, dr);
+    }
+};
+
+template <typename T, int SC>
+struct LQueryTripleFwd {
+    static void run(TripleArgs a, QueryArgs qa, float* q, float* out, hipStream_t st) {
+        k_query_triple_fwd<T, SC><<<ceil_div(a.n, 4), 256, 0, st>>>(a, qa, q, out);
+    }
+};
+template <typename T, int SC>
+struct LQueryTripleBwd {
+    static void run(TripleArgs a, QueryArgs qa, const float* d_out, const float* dq, float* dh, float* dt, float* dr,
+                    hipStream_t st) {
+        k_query_triple_bwd<T, SC><<<ceil_div(a.n, 4), 256, 0, st>>>(a, qa, d_out, dq, dh, dt, dr);
     }
 };
 
@@ -386,4 +459,43 @@ extern "C" int bess_query_bwd(const bess_model_desc* d, int32_t side, const void
     BESS_REQUIRE(d_query && d_ent && d_rel_table, "query_bwd: NULL pointer");
     dispatch<LQueryBwd>(d, a, d_query, d_ent, d_rel_table, as_stream(stream));
     return check_launch("query_bwd");
+}
+
+extern "C" int bess_query_triple_fwd(const bess_model_desc* d, int32_t side, const void* head_base,
+                                     const int32_t* head_idx, const void* tail_base, const int32_t* tail_idx,
+                                     const void* rel_table, const int32_t* rel_idx, int64_t n_triple, float* query,
+                                     float* out, void* stream) {
+    TripleArgs a;
+    if (int e = triple_args(d, head_base, head_idx, tail_base, tail_idx, rel_table, rel_idx, n_triple, &a))
+        return e;
+    BESS_REQUIRE(d->scorer <= BESS_COMPLEX, "query_triple_fwd: TransE / RotatE / DistMult / ComplEx only");
+    QueryArgs qa;
+    const bool tail = side == BESS_CORRUPT_TAIL;
+    if (int e = query_args(d, side, tail ? head_base : tail_base, tail ? head_idx : tail_idx, rel_table, rel_idx,
+                           n_triple, &qa))
+        return e;
+    if (n_triple == 0) return BESS_OK;
+    BESS_REQUIRE(query && out, "query_triple_fwd: NULL out");
+    dispatch<LQueryTripleFwd>(d, a, qa, query, out, as_stream(stream));
+    return check_launch("query_triple_fwd");
+}
+
+extern "C" int bess_query_triple_bwd(const bess_model_desc* d, int32_t side, const void* head_base,
+                                     const int32_t* head_idx, const void* tail_base, const int32_t* tail_idx,
+                                     const void* rel_table, const int32_t* rel_idx, int64_t n_triple,
+                                     const float* d_out, const float* d_query, float* d_head, float* d_tail,
+                                     float* d_rel_table, void* stream) {
+    TripleArgs a;
+    if (int e = triple_args(d, head_base, head_idx, tail_base, tail_idx, rel_table, rel_idx, n_triple, &a))
+        return e;
+    BESS_REQUIRE(d->scorer <= BESS_COMPLEX, "query_triple_bwd: TransE / RotatE / DistMult / ComplEx only");
+    QueryArgs qa;
+    const bool tail = side == BESS_CORRUPT_TAIL;
+    if (int e = query_args(d, side, tail ? head_base : tail_base, tail ? head_idx : tail_idx, rel_table, rel_idx,
+                           n_triple, &qa))
+        return e;
+    if (n_triple == 0) return BESS_OK;
+    BESS_REQUIRE(d_out && d_query && d_head && d_tail && d_rel_table, "query_triple_bwd: NULL pointer");
+    dispatch<LQueryTripleBwd>(d, a, qa, d_out, d_query, d_head, d_tail, d_rel_table, as_stream(stream));
+    return check_launch("query_triple_bwd");
 }

@@ -108,6 +108,35 @@ __global__ __launch_bounds__(256) void k_scatter_add_rows_f16(__half2* __restric
     }
 }
 
+// K9 + K10 (atomic form) for several (row ids, gradient rows) lists in one launch
+struct SgdLists {
+    const int32_t* idx[BESS_MAX_ROW_LISTS];
+    const float* grad[BESS_MAX_ROW_LISTS];
+    int64_t first[BESS_MAX_ROW_LISTS + 1];  // first[l] = rows in lists 0 .. l-1
+    int n;
+};
+template <bool F16>
+__global__ __launch_bounds__(256) void k_scatter_add_lists(void* __restrict__ dst, int width, SgdLists L, float scale) {
+    const int wv = F16 ? width / 2 : width;  // values a thread handles per row position: 1 float or 2 halves
+    const int64_t total = L.first[L.n] * wv;
+    for (int64_t t = blockIdx.x * 256ll + threadIdx.x; t < total; t += 256ll * gridDim.x) {
+        const int64_t i = t / wv;
+        const int c = static_cast<int>(t - i * wv);
+        int l = 0;
+#pragma unroll
+        for (int k = 1; k < BESS_MAX_ROW_LISTS; ++k) l += (k < L.n && i >= L.first[k]) ? 1 : 0;
+        const int64_t r = i - L.first[l];
+        const int64_t row = L.idx[l][r];
+        if (F16) {
+            const float2 v = reinterpret_cast<const float2*>(L.grad[l])[r * wv + c];
+            unsafeAtomicAdd(static_cast<__half2*>(dst) + row * wv + c, __floats2half2_rn(scale * v.x, scale * v.y));
+        } else {
+            const float v = scale * L.grad[l][r * wv + c];
+            if (v != 0.f) unsafeAtomicAdd(static_cast<float*>(dst) + row * wv + c, v);
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_dense_axpy(T* __restrict__ table,
                                                     const float* __restrict__ grad, int64_t n,
@@ -202,4 +231,32 @@ extern "C" int bess_dense_sgd(int32_t dtype, void* table, const float* grad, int
         k_dense_axpy<half_t><<<grid_for(n_elem), 256, 0, as_stream(stream)>>>(
             static_cast<half_t*>(table), grad, n_elem, -lr);
     return check_launch("dense_sgd");
+}
+
+extern "C" int bess_sparse_sgd_lists(int32_t dtype, int32_t width, void* table, int32_t n_lists,
+                                     const int32_t* const* list_idx, const float* const* list_grad,
+                                     const int64_t* list_rows, float lr, void* stream) {
+    BESS_REQUIRE(dtype == BESS_F32 || dtype == BESS_F16, "sparse_sgd_lists: unknown dtype %d", dtype);
+    BESS_REQUIRE(width > 0 && n_lists >= 1 && n_lists <= BESS_MAX_ROW_LISTS, "sparse_sgd_lists: bad sizes");
+    BESS_REQUIRE(table && list_idx && list_grad && list_rows, "sparse_sgd_lists: NULL pointer");
+    if (dtype == BESS_F16 && width % 2) return fail(BESS_EUNSUPPORTED, "sparse_sgd_lists f16 needs an even width");
+    SgdLists L{};
+    L.n = n_lists;
+    int64_t total = 0;
+    for (int l = 0; l < n_lists; ++l) {
+        BESS_REQUIRE(list_rows[l] >= 0 && (list_rows[l] == 0 || (list_idx[l] && list_grad[l])), "sparse_sgd_lists: list %d",
+                     l);
+        L.idx[l] = list_idx[l];
+        L.grad[l] = list_grad[l];
+        L.first[l] = total;
+        total += list_rows[l];
+    }
+    for (int l = n_lists; l <= BESS_MAX_ROW_LISTS; ++l) L.first[l] = total;
+    if (total == 0) return BESS_OK;
+    hipStream_t st = as_stream(stream);
+    if (dtype == BESS_F32)
+        k_scatter_add_lists<false><<<grid_for(total * width), 256, 0, st>>>(table, width, L, -lr);
+    else
+        k_scatter_add_lists<true><<<grid_for(total * (width / 2)), 256, 0, st>>>(table, width, L, -lr);
+    return check_launch("sparse_sgd_lists");
 }

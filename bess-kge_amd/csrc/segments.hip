@@ -128,9 +128,13 @@ __global__ __launch_bounds__(256) void k_iota(int32_t* __restrict__ out, int64_t
 }
 
 // seg_offsets[n_seg] = n_refs (close the last segment); ExclusiveSum wrote only n entries
+// (and start the list of long segments that k_find_long_segments fills next at zero entries)
 __global__ void k_close_offsets(int32_t* __restrict__ seg_offsets, const int32_t* __restrict__ n_seg,
-                                int32_t n_refs) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) seg_offsets[*n_seg] = n_refs;
+                                int32_t n_refs, int32_t* __restrict__ long_segs) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        seg_offsets[*n_seg] = n_refs;
+        if (long_segs) long_segs[0] = 0;
+    }
 }
 
 // Row-sparse optimisers on the unique rows of a step ("lazy" semantics: state of
@@ -431,6 +435,8 @@ __global__ __launch_bounds__(256) void k_long_segments(SegArgs a, float* __restr
             if (g == 0) old = atomicAdd(long_cnt + li, 1);
             old = __shfl(old, lane & 48, 64);  // from the first lane of the 16-lane group
             if ((old + 1) % parts != 0) continue;
+            // the last arriver puts the counter back to zero: the scratch can serve the next launch as it is
+            if (g == 0) __hip_atomic_store(long_cnt + li, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __threadfence();
             // last slice of the row: every partial sum is in (device-scope loads: past the L1)
             float tot[IT][VEC];
@@ -676,10 +682,8 @@ extern "C" int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int3
     // counts beyond n_seg are undefined but never read: offsets are consumed up to n_seg only
     e = hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, counts, seg_offsets, n, st);
     if (e != hipSuccess) return fail(static_cast<int>(e), "exclusive scan: %s", hipGetErrorString(e));
-    k_close_offsets<<<1, 64, 0, st>>>(seg_offsets, n_seg, static_cast<int32_t>(n_refs));
+    k_close_offsets<<<1, 64, 0, st>>>(seg_offsets, n_seg, static_cast<int32_t>(n_refs), long_segs);
     if (long_segs) {
-        e = hipMemsetAsync(long_segs, 0, sizeof(int32_t), st);
-        if (e != hipSuccess) return fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
         k_find_long_segments<<<static_cast<unsigned>(std::min<int64_t>(ceil_div(n_refs, 256), 1024)), 256, 0, st>>>(
             seg_offsets, n_seg, long_segs, static_cast<int32_t>(long_cap));
     }

@@ -84,6 +84,9 @@ extern "C" {
 #define BESS_LOSS_MARGIN 1
 #define BESS_LOSS_SSCE 2
 
+/* most (row ids, gradient rows) lists one multi-list update call takes */
+#define BESS_MAX_ROW_LISTS 8
+
 /* value added to the score of a masked negative (reference bess.py:31) */
 #define BESS_BAD_NEGATIVE_SCORE (-50000.0f)
 
@@ -179,6 +182,22 @@ int bess_query_bwd(const bess_model_desc* d, int32_t side, const void* ent_base,
                    const int32_t* rel_idx, int64_t n_query, const float* d_query,
                    float* d_ent, float* d_rel_table, void* stream);
 
+/* K2 + K3 + K6 in one launch (TransE / RotatE / DistMult / ComplEx): bess_score_triple_fwd (out
+ * [n_triple]) and bess_query_fwd (query [n_triple, W]) of the same triples - the query is built
+ * from the head rows when side == BESS_CORRUPT_TAIL, from the tail rows otherwise - and their
+ * backward: bess_score_triple_bwd + bess_query_bwd, the two gradients that land on the same
+ * entity row (the one the query was built from) summed: d_head / d_tail [n_triple, W] f32
+ * overwritten, d_rel_table accumulated. */
+int bess_query_triple_fwd(const bess_model_desc* d, int32_t side, const void* head_base,
+                          const int32_t* head_idx, const void* tail_base, const int32_t* tail_idx,
+                          const void* rel_table, const int32_t* rel_idx, int64_t n_triple,
+                          float* query, float* out, void* stream);
+int bess_query_triple_bwd(const bess_model_desc* d, int32_t side, const void* head_base,
+                          const int32_t* head_idx, const void* tail_base, const int32_t* tail_idx,
+                          const void* rel_table, const int32_t* rel_idx, int64_t n_triple,
+                          const float* d_out, const float* d_query, float* d_head, float* d_tail,
+                          float* d_rel_table, void* stream);
+
 /* K5 - per-triple negatives, `reduce_embedding(q[:,None] o N)` (scoring.py:199,254):
  *   out[q*ld_out + k] = score(query[q], neg_base[neg_idx[q*n_neg + k]]),  k < n_neg
  * HBM-bound: one gathered row per scored triple, read straight from the shard.
@@ -214,8 +233,8 @@ int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* query,
  * to fp16 (nearest even) when it meets the fp16 candidates; the sum over W is then exact-or-fp32
  * (sum |q - e| = 2 sum max(q, e) - sum q - sum e).  The backward (through the _ws entry point:
  * 4 * (n_query + n_neg) bytes of scratch) evaluates sgn(q - e) exactly, sgn(0) = 0, with the score
- * gradients quantised to int16 per output row (absolute error max|d_out row| / 65534) and exact
- * int32 accumulation: bitwise reproducible. */
+ * gradients quantised to int16 per output row (unit = max|d_out row| / 32767, rounding remainders
+ * diffused along the row so that its sum is kept) and exact int32 accumulation: bitwise reproducible. */
 
 /* K4 + K7 in one call: bess_neg_score_shared_fwd_ws followed by bess_mask_scores(out, n_query,
  * n_neg, ld_out, kill->diag_step, kill->ht, kill->ppp, kill->mask, kill->mask_rows,
@@ -332,6 +351,12 @@ int bess_scatter_add_rows(float* dst, int32_t width, const int32_t* idx,
 int bess_sparse_sgd(int32_t dtype, int32_t width, void* table, const int32_t* idx,
                     const float* grad, int64_t n, float lr, void* stream);
 
+/* bess_sparse_sgd for up to BESS_MAX_ROW_LISTS (row ids, gradient rows) lists in ONE launch
+ * (heads, tails, shared negatives ... of a step): list l has list_rows[l] rows. */
+int bess_sparse_sgd_lists(int32_t dtype, int32_t width, void* table, int32_t n_lists,
+                          const int32_t* const* list_idx, const float* const* list_grad,
+                          const int64_t* list_rows, float lr, void* stream);
+
 /* K9 without atomics (n_shard == 1, per-triple negatives read straight from
  * the shard): group the n_refs references idx[i] by destination row with a
  * stable radix sort (bitwise reproducible sums), reduce each group on chip,
@@ -364,8 +389,9 @@ int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int32_t row_bit
  * only when no later gradient computation still needs the old rows).
  * long_segs / long_cap as filled by bess_build_segment_index, plus long_grad (f32
  * [long_cap, W]) and long_count (int32 [long_cap]) - scratch that must be ALL ZERO before
- * the first call and is left usable for the next one (sums are zeroed again, counters only
- * grow) - or NULL / 0 / NULL / NULL: segments beyond BESS_SEGMENT_CAP references are then
+ * the first call and is left ALL ZERO by every call (the group that finishes a row zeroes its
+ * sums and its counter), so one allocation serves every later step, whatever its index -
+ * or NULL / 0 / NULL / NULL: segments beyond BESS_SEGMENT_CAP references are then
  * summed by all workgroups together (partial sums through float atomics into long_grad,
  * the group that adds the last slice of a row writes it out) instead of by one 16-lane
  * group each. */
@@ -413,7 +439,6 @@ int bess_apply_segments_opt(const bess_opt_desc* o, int32_t dtype, int32_t width
  * f16 table is rounded once per step (a packed-f16 atomic add rounds per contribution).
  * keep as in bess_apply_segments_opt.  With sum_out (f32 [max_seg, width]) != NULL the per-row sums
  * are written there instead and nothing is updated (o, table, state may then be NULL). */
-#define BESS_MAX_ROW_LISTS 8
 int bess_coalesced_update(const bess_opt_desc* o, int32_t dtype, int32_t width, void* table,
                           int32_t n_lists, const float* const* list_grad, const int64_t* list_rows,
                           const int32_t* refs_sorted, const int32_t* seg_rows,

@@ -40,10 +40,12 @@ def desc(scorer, p, table, W, Wr):
     return nat.make_desc(SC[scorer], p, table, Wr)
 
 
-def run(name, scorer, p, dtype, M, W, Wr, S, N, shared):
+def run(name, scorer, p, dtype, M, W, Wr, S, N, shared, fp32_math=False):
     g = torch.Generator(device="cpu").manual_seed(0)
     table = (torch.randn(M, W, generator=g) * 0.1).to(dtype).to(dev)
     d = desc(scorer, p, table, W, Wr)
+    if fp32_math:
+        d.reserved[0] = nat.FLAG_FP32_MATH
     q = torch.randn(S, W, device=dev)
     sz = table.element_size()
     if shared:
@@ -55,8 +57,11 @@ def run(name, scorer, p, dtype, M, W, Wr, S, N, shared):
         t_b = timeit(lambda: nat.neg_score_shared_bwd(d, q, neg, out, go))
         ops = (2 if nat.reduce_of(d) == 0 else 3) * S * N * W if hasattr(nat, "reduce_of") else 2 * S * N * W
         flops = 2.0 * S * N * W
+        extra = ""
+        if scorer in ("TransE", "RotatE"):  # VALU kernels: elements per second (one element = one (q, j, w))
+            extra = f" | {S*N*W/t_f/1e9:6.1f} / {2*S*N*W/t_b/1e9:6.1f} T elements/s fwd / bwd (2 products)"
         print(f"{name:34s} shared  S={S:5d} N={N:5d} W={W:4d} {str(dtype)[6:]:7s} fwd {t_f*1e3:8.1f} us "
-              f"{flops/t_f/1e9:7.1f} TFLOP/s(2SNW) | bwd {t_b*1e3:8.1f} us {2*flops/t_b/1e9:7.1f} TFLOP/s(4SNW)")
+              f"{flops/t_f/1e9:7.1f} TFLOP/s(2SNW) | bwd {t_b*1e3:8.1f} us {2*flops/t_b/1e9:7.1f} TFLOP/s(4SNW){extra}")
     else:
         idx = torch.randint(M, (S * N,), dtype=torch.int32, device=dev)
         neg = RowSource(table, idx)
@@ -87,6 +92,9 @@ CASES = [
     ("C5 DistMult shared 8192x4096", "DistMult", 0, torch.float32, 1_000_000, 512, 512, 8192, 4096, True),
     ("C4 TransE f16 L1 shared 4096x4096", "TransE", 1, torch.float16, 312_576, 256, 256, 4096, 4096, True),
     ("C4 TransE f16 L1 shared 512x768", "TransE", 1, torch.float16, 312_576, 256, 256, 512, 768, True),
+    ("C4 TransE f16 L1 shared 4096x4352", "TransE", 1, torch.float16, 312_576, 256, 256, 4096, 4352, True),
+    ("C4 fp32-math L1 shared 4096x4096", "TransE", 1, torch.float16, 312_576, 256, 256, 4096, 4096, True, True),
+    ("C4 fp32-math L1 shared 512x768", "TransE", 1, torch.float16, 312_576, 256, 256, 512, 768, True, True),
     ("C3 RotatE L1 shared 4096x4096", "RotatE", 1, torch.float32, 61_591, 400, 200, 4096, 4096, True),
     ("C1 TransE L2 shared 512x64", "TransE", 2, torch.float32, 10_000, 128, 128, 512, 64, True),
 ]
