@@ -58,10 +58,6 @@ bool l1_pk_eligible(const bess_model_desc* d);
 int l1_pk_fwd(const bess_model_desc* d, const float* query, int64_t n_query, const void* neg_base,
               const int32_t* neg_idx, int64_t n_neg, float* out, int64_t ld_out, const bess_kill_desc* kill,
               hipStream_t st);
-int64_t l1_pk_bwd_workspace(int64_t n_query, int64_t n_neg);
-int l1_pk_bwd(const bess_model_desc* d, const float* query, int64_t n_query, const void* neg_base,
-              const int32_t* neg_idx, int64_t n_neg, const float* d_out, int64_t ld_dout, float* d_query,
-              float* d_neg, void* workspace, hipStream_t st);
 
 // affine-in-the-candidate distance scorers (affine.hip)
 int affine_pertriple(const bess_model_desc* d, bool fwd, const float* query, int64_t n_query, const void* neg_base,

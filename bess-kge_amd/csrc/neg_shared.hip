@@ -163,7 +163,10 @@ __global__ __launch_bounds__(256) void k_neg_shared_fwd(RowSrc<float> Q, RowSrc<
 //   L1 : coef = sign*g       f' = sgn(x - y)
 //   L2 : coef = g / out      f' = x - y        (out = -dist; 0 where dist == 0)
 // g = d_out[a*sa + b*sb], out likewise with (oa, ob) strides.
-template <typename TX, typename TY, int RED, bool VEC4>
+// ROUND16: f32 operands (the query matrix) are rounded to fp16 (nearest even) as they are loaded - the
+// backward of the packed-fp16 forward (l1_f16.hip), whose scores are a function of the rounded query;
+// differences of fp16 values are exact in fp32, so sgn(x - y) (0 at a tie) is exact.
+template <typename TX, typename TY, int RED, bool VEC4, bool ROUND16 = false>
 __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY> Y, int W,
                                                         float sign, const float* __restrict__ d_out,
                                                         int64_t sa, int64_t sb,
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
             const int w = w0 + tx * 4 + j;
             acc[i][j] = 0.f;
             xv[i][j] = (a < X.n && w < W) ? to_f32(X.row(a, W)[w]) : 0.f;
+            if (ROUND16) xv[i][j] = static_cast<float>(static_cast<_Float16>(xv[i][j]));
             if (RED == RED_L1) xv[i][j] *= SGN_PRESCALE;
         }
     }
@@ -230,6 +234,10 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) yv[i] = (ycol + i < W) ? to_f32(rp[ycol + i]) : 0.f;
+        }
+        if (ROUND16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yv[i] = static_cast<float>(static_cast<_Float16>(yv[i]));
         }
         if (RED == RED_L1) {
 #pragma unroll
@@ -303,7 +311,7 @@ static int run_fwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<T> E, float
 template <typename TX, typename TY>
 static int run_bwd_one(const bess_model_desc* d, RowSrc<TX> X, RowSrc<TY> Y, const float* d_out,
                        int64_t sa, int64_t sb, const float* out, int64_t oa, int64_t ob, float* dX,
-                       hipStream_t st) {
+                       hipStream_t st, bool round16 = false) {
     const int64_t tiles = ceil_div(d->width, TN) * ceil_div(X.n, TM);
     // split the reduction over Y until ~4 workgroups per CU are in flight
     int64_t split = 1;
@@ -323,6 +331,11 @@ static int run_bwd_one(const bess_model_desc* d, RowSrc<TX> X, RowSrc<TY> Y, con
                                                                        oa, ob, dX, chunk)                       \
           : k_neg_shared_bwd<TX, TY, RED, false><<<grid, 256, 0, st>>>(X, Y, d->width, sign, d_out, sa, sb,     \
                                                                         out, oa, ob, dX, chunk))
+    if (round16 && vec4 && reduce_of(d) == RED_L1) {
+        k_neg_shared_bwd<TX, TY, RED_L1, true, true><<<grid, 256, 0, st>>>(X, Y, d->width, sign, d_out, sa, sb, out, oa,
+                                                                        ob, dX, chunk);
+        return BESS_OK;
+    }
     switch (reduce_of(d)) {
         case RED_DOT: BESS_BWD(RED_DOT); break;
         case RED_L1: BESS_BWD(RED_L1); break;
@@ -418,8 +431,6 @@ extern "C" int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* 
 
 extern "C" int64_t bess_neg_score_shared_bwd_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg) {
     if (!d || check_desc(d) || n_query <= 0 || n_neg <= 0) return 0;
-    if (d->scorer <= BESS_COMPLEX && l1_pk_eligible(d) && !(d->reserved[0] & BESS_FLAG_FP32_MATH))
-        return l1_pk_bwd_workspace(n_query, n_neg);
     if (d->scorer == BESS_BOXE || d->scorer == BESS_AFFINE || reduce_of(d) != RED_DOT) return 0;
     return gemm_split_bwd_workspace(n_query, n_neg, d->width);
 }
@@ -464,9 +475,8 @@ extern "C" int bess_neg_score_shared_bwd_ws(const bess_model_desc* d, const floa
             return e;
         return gemm_dot_de(d_out, ld_dout, n_query, query, n_neg, d->width, d_neg, st);
     }
-    if (workspace && workspace_bytes >= l1_pk_bwd_workspace(n_query, n_neg) && use_l1_pk(d, query, neg_base) &&
-        reinterpret_cast<uintptr_t>(workspace) % 4 == 0)
-        return l1_pk_bwd(d, query, n_query, neg_base, neg_idx, n_neg, d_out, ld_dout, d_query, d_neg, workspace, st);
+    // the packed-fp16 forward scores the query rounded to fp16: differentiate that function
+    const bool r16 = use_l1_pk(d, query, neg_base);
     RowSrc<float> Q{query, nullptr, n_query};
     if (d->dtype == BESS_F32) {
         RowSrc<float> E{static_cast<const float*>(neg_base), neg_idx, n_neg};
@@ -474,8 +484,8 @@ extern "C" int bess_neg_score_shared_bwd_ws(const bess_model_desc* d, const floa
         if (int e = run_bwd_one<float, float>(d, E, Q, d_out, 1, ld_dout, out, 1, ld_out, d_neg, st)) return e;
     } else {
         RowSrc<half_t> E{static_cast<const half_t*>(neg_base), neg_idx, n_neg};
-        if (int e = run_bwd_one<float, half_t>(d, Q, E, d_out, ld_dout, 1, out, ld_out, 1, d_query, st)) return e;
-        if (int e = run_bwd_one<half_t, float>(d, E, Q, d_out, 1, ld_dout, out, 1, ld_out, d_neg, st)) return e;
+        if (int e = run_bwd_one<float, half_t>(d, Q, E, d_out, ld_dout, 1, out, ld_out, 1, d_query, st, r16)) return e;
+        if (int e = run_bwd_one<half_t, float>(d, E, Q, d_out, 1, ld_dout, out, 1, ld_out, d_neg, st, r16)) return e;
     }
     return check_launch("neg_score_shared_bwd");
 }

@@ -231,10 +231,8 @@ int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* query,
  * forms of K4 (csrc/l1_f16.hip) unless desc.reserved[0] has BESS_FLAG_FP32_MATH: as in the
  * reference's fp16 mode (`model.half()`: the query `h + r` is an fp16 tensor) the query is rounded
  * to fp16 (nearest even) when it meets the fp16 candidates; the sum over W is then exact-or-fp32
- * (sum |q - e| = 2 sum max(q, e) - sum q - sum e).  The backward (through the _ws entry point:
- * 4 * (n_query + n_neg) bytes of scratch) evaluates sgn(q - e) exactly, sgn(0) = 0, with the score
- * gradients quantised to int16 per output row (unit = max|d_out row| / 32767, rounding remainders
- * diffused along the row so that its sum is kept) and exact int32 accumulation: bitwise reproducible. */
+ * (sum |q - e| = 2 sum max(q, e) - sum q - sum e).  bess_neg_score_shared_bwd(_ws) then
+ * differentiates that function: sgn(fp16(q) - e), exact, 0 at a tie. */
 
 /* K4 + K7 in one call: bess_neg_score_shared_fwd_ws followed by bess_mask_scores(out, n_query,
  * n_neg, ld_out, kill->diag_step, kill->ht, kill->ppp, kill->mask, kill->mask_rows,

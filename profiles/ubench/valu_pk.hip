@@ -104,9 +104,71 @@ static void bench(float* out, const char* name, int ops_per_pair) {
     }
 }
 
+// one instruction at a time: 16 independent chains per lane, 8 waves per SIMD
+template <int OP>
+__global__ __launch_bounds__(256) void k_single(float* out, int iters) {
+    uint32_t a[16];
+    float f[16];
+    int ii[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a[i] = 0x3c003800u + i * 257u + threadIdx.x; f[i] = i; ii[i] = i; }
+    uint32_t b = 0x35003900u + threadIdx.x, c2 = 0x00010001u;
+    asm volatile("" : "+v"(b), "+v"(c2));
+    const h2 ones = {(_Float16)1.f, (_Float16)1.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (OP == 0) a[i] = pk_max_f16(a[i], b);
+            else if (OP == 1) a[i] = pk_sub_f16(a[i], b);
+            else if (OP == 2) a[i] = pk_min_i16(a[i], b);
+            else if (OP == 3) f[i] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a[i]), ones, f[i], false);
+            else if (OP == 4) ii[i] = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, a[i]), __builtin_bit_cast(s2, b), ii[i], false);
+            else if (OP == 5) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[i]) : "v"(b));
+            else if (OP == 6) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c2));
+            else if (OP == 7) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            else if (OP == 8) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            else if (OP == 9) asm volatile("v_max_f16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            else if (OP == 10) asm volatile("v_sad_u16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c2));
+            else if (OP == 11) asm volatile("v_sad_u8 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c2));
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += f[i] + (float)ii[i] + (float)a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int OP>
+static void single(float* out, const char* name) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int iters = 20000, blocks = 256 * 8;
+    k_single<OP><<<blocks, 256>>>(out, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k_single<OP><<<blocks, 256>>>(out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%-22s %8.3f ms  %6.2f T lane-instructions/s\n", name, ms, double(blocks) * 256 * iters * 16.0 / ms / 1e9);
+}
+
 int main() {
     float* out;
     hipMalloc(&out, sizeof(float) * 256 * 256 * 64);
+    single<5>(out, "v_add_f32");
+    single<7>(out, "v_xor_b32");
+    single<0>(out, "v_pk_max_f16");
+    single<1>(out, "v_pk_add_f16");
+    single<2>(out, "v_pk_min_i16");
+    single<8>(out, "v_pk_add_u16");
+    single<6>(out, "v_pk_fma_f16");
+    single<3>(out, "v_dot2c_f32_f16");
+    single<4>(out, "v_dot2c_i32_i16");
+    single<9>(out, "v_max_f16");
+    single<10>(out, "v_sad_u16");
+    single<11>(out, "v_sad_u8");
     bench<0, false>(out, "fwd pk_max+dot2", 2);
     bench<0, true>(out, "fwd pk_max+dot2", 2);
     bench<1, false>(out, "bwd sub+min+max+sdot2", 4);

@@ -15,6 +15,8 @@ all replicas in lock-step on the one GPU) and compares scores, loss and one
 sparse-SGD step with the CPU oracle's autograd.
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -84,6 +86,8 @@ def run_config(dev, scorer, p, d, dtype, n_shard, n_entity, n_rel, n_triple, sha
     # fp16 tables, TransE / RotatE with p = 1, shared negatives: the packed-fp16 kernels round the query to
     # fp16 before it meets the candidates (the reference's fp16 mode); the oracle does the same
     half_query = dtype == torch.float16 and scorer in ("TransE", "RotatE") and p == 1 and sharing and W % 32 == 0
+    if os.environ.get("BESS_TEST_FP32_MATH", "0") == "1":  # same configs with the packed-fp16 kernels switched off
+        fn.fp32_math, half_query = True, False
     import contextlib
     with (kge.half_queries() if half_query else contextlib.nullcontext()):
         want = kge.bess_step(spec, model, t0, r0, {k: batch[k][0] for k in keys}, lkw)
@@ -124,7 +128,10 @@ def run_config(dev, scorer, p, d, dtype, n_shard, n_entity, n_rel, n_triple, sha
             mag = want_ent.abs().clamp(min=2.0 ** -14)
             ulp = torch.exp2(torch.floor(torch.log2(mag)) - 10)
             err = (got_ent - want_ent).abs()
-            bad = err > ulp * 1.001
+            # (where row and update nearly cancel, the fp32 difference of the two gradients - the reference's own
+            # tolerance, rtol 1e-4 - is not small against the ulp of the tiny result: allow for it explicitly)
+            slack = lr * (1e-4 * t0.grad.abs() + 2e-5)
+            bad = err > ulp * 1.001 + slack
             assert not bool(bad.any()), (int(bad.sum()), float((err / ulp).max()))
             assert float((err > 0).float().mean()) < 0.02  # and almost all of them are exactly that value
             untouched = t0.grad.abs().sum(-1) == 0

@@ -6,10 +6,7 @@ precision.  Checked here in float64 on fp16-rounded inputs:
 
   forward   out[q, j] = -sum_w |fp16(Q[q, w]) - E[j, w]|                  (tolerance: fp32 accumulation)
   backward  dQ[a, w] = -sum_b g[a, b] sgn(fp16(Q[a, w]) - E[b, w]),  sgn(0) = 0
-            dE[b, w] = +sum_a g[a, b] sgn(fp16(Q[a, w]) - E[b, w])
-            with g quantised to int16 per output row (unit = max|g row| / 32767, rounding remainders
-            diffused along the row): |error| <= n_terms * unit, relative L2 error of the gradients
-            <= 2e-4; exact when g is a multiple of the unit; bitwise reproducible.
+            dE[b, w] = +sum_a g[a, b] sgn(fp16(Q[a, w]) - E[b, w])         (fp32 coefficients and sums)
 """
 
 import numpy as np
@@ -110,7 +107,9 @@ def exact_backward(Q, E, idx, g):
 
 @pytest.mark.parametrize("S,N,W,scale,ties", [(64, 64, 32, 1.0, False), (70, 130, 96, 1.0, True),
                                              (200, 1100, 256, 0.01, False), (512, 96, 64, 1.0, True)])
-def test_backward_sign_is_exact_and_coefficients_are_int16(dev, S, N, W, scale, ties):
+def test_backward_differentiates_the_rounded_query_function(dev, S, N, W, scale, ties):
+    """The backward of the packed forward (fp32 kernel, query rounded to fp16 as it is loaded):
+    sgn(fp16(q) - e) exactly, 0 at ties; fp32 coefficients and accumulation."""
     from besskge import _native as nat
 
     Q, E, idx = problem(S, N, W, 400, scale, 2, ties=ties)
@@ -123,40 +122,14 @@ def test_backward_sign_is_exact_and_coefficients_are_int16(dev, S, N, W, scale, 
     want_q, want_e = exact_backward(Q, E, idx, g)
     if ties:
         assert float((Q.half()[:, None, :] == E[idx.long()][None, :, :]).float().mean()) > 1e-3
-    # quantisation bound: with the diffused remainder every coefficient is off by less than one unit
-    bound_q = N * g.abs().max(1).values[:, None].double() / 32767
-    bound_e = S * g.abs().max(0).values[:, None].double() / 32767
-    err_q, err_e = (dq.cpu().double() - want_q).abs(), (dn.cpu().double() - want_e).abs()
-    assert bool((err_q <= bound_q + 1e-9).all()) and bool((err_e <= bound_e + 1e-9).all())
-    # ... and in practice far below it
-    assert float(err_q.mean()) < 0.05 * float(bound_q.mean()) + 1e-9
-    assert float(err_e.mean()) < 0.05 * float(bound_e.mean()) + 1e-9
-    assert float((err_q.pow(2).sum() / want_q.pow(2).sum()).sqrt()) < 2e-4
-    assert float((err_e.pow(2).sum() / want_e.pow(2).sum()).sqrt()) < 2e-4
-    # bitwise reproducible (the split reduction meets in integer atomics)
-    dq2, dn2 = nat.neg_score_shared_bwd(d, Q.to(dev), src, out, g.to(dev))
-    assert torch.equal(dq, dq2) and torch.equal(dn, dn2)
-
-
-def test_backward_is_exact_for_representable_coefficients(dev):
-    """Coefficients that are multiples of (row maximum) / 32767 AND of (column maximum) / 32767 are not
-    changed by the quantisation: the result is the exact sum, ties included."""
-    from besskge import _native as nat
-
-    S, N, W = 96, 160, 64
-    Q, E, idx = problem(S, N, W, 200, 1.0, 7, ties=True)
-    gen = torch.Generator().manual_seed(8)
-    k = torch.randint(-32767, 32768, (S, N), generator=gen)
-    k[:, 0] = 32767  # every row and every column holds the maximum once
-    k[0, :] = 32767
-    g = (k.double() / 32767 * 0.125).float()
-    d = desc(nat, W)
-    src = nat.RowSource(E.to(dev), idx.to(dev))
-    out = nat.neg_score_shared_fwd(d, Q.to(dev), src)
-    dq, dn = nat.neg_score_shared_bwd(d, Q.to(dev), src, out, g.to(dev))
-    want_q, want_e = exact_backward(Q, E, idx, g)
-    torch.testing.assert_close(dq.cpu().double(), want_q, rtol=2e-6, atol=1e-6)
-    torch.testing.assert_close(dn.cpu().double(), want_e, rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(dq.cpu().double(), want_q, rtol=1e-5, atol=1e-6 * float(g.sum(1).max()))
+    torch.testing.assert_close(dn.cpu().double(), want_e, rtol=1e-5, atol=1e-6 * float(g.sum(0).max()))
+    # with the fp32-math switch the query is NOT rounded: signs follow q, not fp16(q)
+    d32 = desc(nat, W, fp32_math=True)
+    dq32, _ = nat.neg_score_shared_bwd(d32, Q.to(dev), src, nat.neg_score_shared_fwd(d32, Q.to(dev), src), g.to(dev))
+    sg32 = torch.sign(Q.double()[:, None, :] - E[idx.long()].double()[None, :, :])
+    torch.testing.assert_close(dq32.cpu().double(), -(g.double()[:, :, None] * sg32).sum(1), rtol=1e-5,
+                               atol=1e-6 * float(g.sum(1).max()))
 
 
 def test_transe_fp16_step_against_the_fp16_query_oracle(dev):
@@ -202,7 +175,7 @@ def test_transe_fp16_step_against_the_fp16_query_oracle(dev):
     want_ent = (ent - lr * t0.grad).half().float()
     ulp = torch.exp2(torch.floor(torch.log2(want_ent.abs().clamp(min=2.0 ** -14))) - 10)
     err = (got - want_ent).abs()
-    # int16 coefficients: a gradient element may be off by (sum of row maxima) / 65534 - far below one
-    # fp16 ulp of the O(1) table values here, so at most a rounding boundary is crossed now and then
-    assert bool((err <= ulp * 1.001).all()), float((err / ulp).max())
+    # the two fp32 gradients differ in their last bits: at most a rounding boundary is crossed now and then
+    slack = lr * (1e-4 * t0.grad.abs() + 2e-5)  # fp32 difference of the two gradients, where row and update cancel
+    assert bool((err <= ulp * 1.001 + slack).all()), float((err / ulp).max())
     assert float((err > 0).float().mean()) < 0.02
