@@ -420,18 +420,71 @@ class BessKGE(torch.nn.Module, ABC):
         s = state["s"]
         return o, (s[0] if n_state > 0 else None), (s[1] if n_state > 1 else None)
 
-    def _apply_optimizer(self, opt: Any, table: torch.Tensor, contributions: List[Tuple[torch.Tensor, torch.Tensor]]
-                         ) -> None:
+    def _apply_optimizer(self, opt: Any, table: torch.Tensor, contributions: List[Tuple[torch.Tensor, torch.Tensor]],
+                         ahead: Optional[Tuple[List[torch.Tensor], Any]] = None) -> None:
         """General K9 + K10: all (row, gradient row) lists of a table coalesced per unique row and one
         optimiser update per row (`bess_coalesced_update`: the sums are formed straight from the lists, in
-        a fixed order; every touched row is written once).  `contributions` all index `table`."""
-        idx = torch.cat([i.reshape(-1) for i, _ in contributions]).contiguous()
-        seg = nat.SegmentIndex(idx, table.shape[0])
+        a fixed order; every touched row is written once).  `contributions` all index `table`.
+        `ahead`: (row-id lists, their SegmentIndex) built earlier on the side stream (`_small_index_ahead`);
+        used when the lists turned out to be exactly those."""
+        ids = [i.reshape(-1) for i, _ in contributions]
+        seg = None
+        if ahead is not None and len(ahead[0]) == len(ids) and all(
+                a.data_ptr() == b.data_ptr() and a.numel() == b.numel() for a, b in zip(ahead[0], ids)):
+            seg = ahead[1]
+        if seg is None:
+            seg = nat.SegmentIndex(torch.cat(ids).contiguous(), table.shape[0])
         o, s1, s2 = self._opt_desc(opt, table)
         grads = [g.contiguous() for _, g in contributions]
         if len(grads) > nat.MAX_ROW_LISTS:
             grads = [torch.cat(grads, dim=0)]
         nat.coalesced_update(o, table, seg, grads, s1, s2)
+
+    def _small_index_ahead(self, steps: List[_ReplicaStep], optimizer: Any) -> Dict[int, Any]:
+        """The index of a shard's small lists (heads, tails, shared negatives, rows returned by C8) only needs
+        their row ids, which are inputs of the step: when the update will coalesce them (f16 shard or a
+        stateful optimiser, no per-triple group reduced by the segmented K9), it is built here - on the side
+        stream, right behind the forward kernels - instead of on the critical path after the backward.  The
+        lists are named in the order the backward will hand them over (`_apply_optimizer` checks that)."""
+        plain = not hasattr(optimizer, "kind") or optimizer.is_plain_sgd
+        if plain and self.score_fn.entity_embedding.dtype == torch.float32:
+            return {}
+        fn = self.score_fn
+        out: Dict[int, Any] = {}
+        for st in steps:
+            plan: List[torch.Tensor] = []
+            ok = True
+
+            def add(src: RowSource) -> None:
+                if src.base is st.table and src.idx is not None:
+                    plan.append(src.idx.reshape(-1))
+
+            head = RowSource(st.table, st.head_idx)
+            if not st.fused_qt:
+                add(head)
+                add(st.tail)
+            for g in st.groups:
+                if not g.shared and g.neg.base is st.table and fn.supports_fused_segments:
+                    ok = False  # reduced by the segmented K9: the small lists ride along there
+                    break
+                add(g.neg)
+                if st.fused_qt:
+                    add(head)
+                    add(st.tail)
+                else:
+                    add(g.ent)
+            if not ok or not plan:
+                continue
+            if st.n > 1:
+                if st.ext_src is not None:
+                    add(st.ext_src)
+                plan.append(st.send_idx.reshape(-1))
+            dev = st.table.device
+            side = self._aux_stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                out[id(st)] = (plan, nat.SegmentIndex(torch.cat(plan).contiguous(), st.table.shape[0]))
+        return out
 
     def _apply_optimizer_dense(self, opt: Any, table: torch.Tensor, grad: torch.Tensor) -> None:
         """Optimiser step on every row of a small replicated table (relation table, dense parameters):
@@ -545,7 +598,8 @@ class BessKGE(torch.nn.Module, ABC):
                                 "DistMult / ComplEx / ConvE with one per-triple group per shard) or shared negatives")
                         n_rows = int(seg.n_seg.item())  # one host sync per step on this path
                         contrib.append((seg.seg_rows[:n_rows], gseg[:n_rows]))
-                self._apply_optimizer(optimizer, st.table, contrib)
+                self._apply_optimizer(optimizer, st.table, contrib,
+                                      (getattr(self, "_small_ahead", None) or {}).get(id(st)))
         # C9: replicated relation table
         # (single process: d_rel already holds the sum over the local replicas)
         (d_rel,) = group.all_reduce_sum([d_rel]) if len(group.local_shards) == 1 else (d_rel,)
@@ -823,6 +877,7 @@ class EmbeddingMovingBessKGE(BessKGE):
         finally:
             self._train_fuse = None
             self._seg_ahead = None
+        self._small_ahead = self._small_index_ahead(steps, optimizer)
         desc = fn.kernel_desc()
         rel_table = fn.relation_embedding.data
         results = []
@@ -895,7 +950,10 @@ class EmbeddingMovingBessKGE(BessKGE):
             returned = group.all_to_all(back)  # C8
             for st, upd, g in zip(steps, local_updates, returned):
                 upd.append((st.send_idx.reshape(-1), g.reshape(-1, W)))
-        self._apply_updates(steps, local_updates, deferred, seg_index, optimizer, desc, d_rel)
+        try:
+            self._apply_updates(steps, local_updates, deferred, seg_index, optimizer, desc, d_rel)
+        finally:
+            self._small_ahead = None
         return results
 
     def train_step(self, optimizer: Any, **batch: torch.Tensor) -> Dict[str, Any]:

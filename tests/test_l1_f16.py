@@ -176,6 +176,6 @@ def test_transe_fp16_step_against_the_fp16_query_oracle(dev):
     ulp = torch.exp2(torch.floor(torch.log2(want_ent.abs().clamp(min=2.0 ** -14))) - 10)
     err = (got - want_ent).abs()
     # the two fp32 gradients differ in their last bits: at most a rounding boundary is crossed now and then
-    slack = lr * (1e-4 * t0.grad.abs() + 2e-5)  # fp32 difference of the two gradients, where row and update cancel
+    slack = 1e-4 * want_ent.abs() + 2e-5  # the fp32 tables' tolerance (where row and update cancel, the gradients' fp32 difference shows)
     assert bool((err <= ulp * 1.001 + slack).all()), float((err / ulp).max())
     assert float((err > 0).float().mean()) < 0.02
