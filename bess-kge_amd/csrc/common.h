@@ -37,8 +37,9 @@ inline int reduce_of(const bess_model_desc* d) {
 }
 
 // fp32 MFMA GEMMs of the bilinear scorers (gemm_mfma.hip)
+// (run_if: optional device word; the kernels return at once while it is 0 - the conditional fallback of the split path)
 int gemm_dot_fwd(int dtype, const float* Q, int64_t S, const void* E, const int32_t* idx, int64_t N, int W,
-                 float* out, int64_t ld, hipStream_t st);
+                 float* out, int64_t ld, hipStream_t st, const int32_t* run_if = nullptr);
 // split-fp16 MFMA variant of gemm_dot_fwd (gemm_split.hip): workspace it wants for a shape
 // (0 = leave the shape to the fp32 kernels) and the product through that workspace
 int64_t gemm_split_workspace(int64_t S, int64_t N, int W);
@@ -49,9 +50,9 @@ int gemm_split_bwd(int dtype, const float* G, int64_t ldg, int64_t S, const floa
                    const int32_t* idx, int64_t N, int W, float* dQ, float* dE, void* ws, int64_t ws_bytes,
                    hipStream_t st);
 int gemm_dot_dq(int dtype, const float* G, int64_t ldg, int64_t S, const void* E, const int32_t* idx, int64_t N,
-                int W, float* dQ, hipStream_t st);
+                int W, float* dQ, hipStream_t st, const int32_t* run_if = nullptr);
 int gemm_dot_de(const float* G, int64_t ldg, int64_t S, const float* Q, int64_t N, int W, float* dE,
-                hipStream_t st);
+                hipStream_t st, const int32_t* run_if = nullptr);
 
 // packed-fp16 L1 distance matrix and its backward products (l1_f16.hip): TransE / RotatE, p = 1, f16 tables
 bool l1_pk_eligible(const bess_model_desc* d);

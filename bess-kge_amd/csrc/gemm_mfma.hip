@@ -41,6 +41,7 @@ struct GemmOperand {
     const int32_t* idx;  // optional row index
     int64_t rows;        // number of rows (M|N for ROWS_MN, K for ROWS_K)
     int64_t ld;          // elements between consecutive rows
+    const int32_t* run_if;  // optional gate (device word): the kernel returns at once while it is 0
 };
 
 // registers holding one thread's share of a TILE x 32 slice: TILE/32 x float4
@@ -193,6 +194,7 @@ __device__ __forceinline__ void stage_store(float* img, const Stage<TILE>& st) {
 template <typename TA, bool A_ROWS_K, typename TB, bool B_ROWS_K, int TILE, bool FAST>
 __global__ __launch_bounds__(256) void k_gemm_f32_mfma(GemmOperand A, GemmOperand B, int64_t M, int64_t N,
                                                        int64_t K, float* __restrict__ C, int64_t ldc) {
+    if (A.run_if && *A.run_if == 0) return;  // fallback launch of the split-fp16 path that is not needed
     constexpr int GT = TILE;
     constexpr int WT = TILE / 2;   // per-wave tile edge (64 or 32)
     constexpr int MT = WT / 32;    // 32x32 MFMA tiles per wave and dimension
@@ -310,6 +312,7 @@ template <typename TA, bool A_ROWS_K, typename TB, bool B_ROWS_K>
 __global__ __launch_bounds__(512) void k_gemm_f32_mfma_ws(GemmOperand A, GemmOperand B, int64_t M, int64_t N,
                                                           int64_t K, float* __restrict__ C, int64_t ldc,
                                                           int tiles_x, int n_tiles) {
+    if (A.run_if && *A.run_if == 0) return;
     constexpr int TILE = 128, WT = 64, MT = 2;
     constexpr int LD_T = TILE + 1, LD_D = TILE + 4;
     constexpr int LDA = A_ROWS_K ? LD_D : LD_T;
@@ -442,27 +445,27 @@ static int launch(const GemmOperand& A, const GemmOperand& B, int64_t M, int64_t
 
 // out[q, j] = Q[q] . E[idx[j]]
 int gemm_dot_fwd(int dtype, const float* Q, int64_t S, const void* E, const int32_t* idx, int64_t N, int W,
-                 float* out, int64_t ld, hipStream_t st) {
-    GemmOperand A{Q, nullptr, S, W};
-    GemmOperand B{E, idx, N, W};
+                 float* out, int64_t ld, hipStream_t st, const int32_t* run_if) {
+    GemmOperand A{Q, nullptr, S, W, run_if};
+    GemmOperand B{E, idx, N, W, nullptr};
     if (dtype == BESS_F32) return launch<float, false, float, false>(A, B, S, N, W, out, ld, st);
     return launch<float, false, half_t, false>(A, B, S, N, W, out, ld, st);
 }
 
 // dQ[q, w] = sum_j G[q, j] E[idx[j], w]
 int gemm_dot_dq(int dtype, const float* G, int64_t ldg, int64_t S, const void* E, const int32_t* idx, int64_t N,
-                int W, float* dQ, hipStream_t st) {
-    GemmOperand A{G, nullptr, S, ldg};
-    GemmOperand B{E, idx, N, W};
+                int W, float* dQ, hipStream_t st, const int32_t* run_if) {
+    GemmOperand A{G, nullptr, S, ldg, run_if};
+    GemmOperand B{E, idx, N, W, nullptr};
     if (dtype == BESS_F32) return launch<float, false, float, true>(A, B, S, W, N, dQ, W, st);
     return launch<float, false, half_t, true>(A, B, S, W, N, dQ, W, st);
 }
 
 // dE[j, w] = sum_q G[q, j] Q[q, w]
 int gemm_dot_de(const float* G, int64_t ldg, int64_t S, const float* Q, int64_t N, int W, float* dE,
-                hipStream_t st) {
-    GemmOperand A{G, nullptr, S, ldg};  // rows are k = q, contiguous along m = j
-    GemmOperand B{Q, nullptr, S, W};    // rows are k = q, contiguous along n = w
+                hipStream_t st, const int32_t* run_if) {
+    GemmOperand A{G, nullptr, S, ldg, run_if};  // rows are k = q, contiguous along m = j
+    GemmOperand B{Q, nullptr, S, W, nullptr};   // rows are k = q, contiguous along n = w
     return launch<float, true, float, true>(A, B, N, W, S, dE, W, st);
 }
 

@@ -21,7 +21,10 @@
 // tolerance (rtol 1e-4 / atol 1e-5, test_bess.py:245-246) is untouched; the cost is 3 fp16
 // MFMAs per 16 k instead of 8 fp32 MFMAs of twice their length.  fp16 tables have lo == 0
 // exactly: 2 MFMAs.  Operands must be finite and |x| < 65504 (fp16 range; KGE embeddings are
-// O(1)); BESS_GEMM_FP32=1 in the environment keeps the exact fp32 MFMA kernel instead.
+// O(1)): the pre-pass raises a flag in the workspace when it meets an element that is not, the
+// split kernels then return at once and the exact fp32 MFMA kernels - queued behind them, gated on
+// the same flag - compute the product (no host synchronisation); desc.reserved[0] &
+// BESS_FLAG_FP32_MATH keeps the fp32 kernels from the start.
 //
 // Two kernels, with a caller-provided workspace between them:
 //   k_split_rows   gathers the rows (by index), splits them and writes, per row and per block
@@ -40,8 +43,6 @@
 //               8 ds_read_b128, 12 MFMAs.  The barrier that releases a slice sits between its
 //               two k steps (after both have been read into registers), so the fragment reads of
 //               the next slice are issued under the MFMAs of this one.
-#include <cstdlib>
-
 #include "common.h"
 
 namespace bess {
@@ -63,7 +64,11 @@ struct SplitSrc {
     const int32_t* idx;  // optional row index
     int64_t rows;
     int64_t ld;
+    int32_t* range_flag;  // set to 1 when an element cannot be split: not finite, or |x| >= 65504 (fp16 range)
 };
+
+// an element the split cannot represent (hi would be inf / nan): the product then falls back to the fp32 kernels
+__device__ __forceinline__ bool unsplittable(float x) { return !(fabsf(x) < 65504.f); }
 
 // 16-B slot `c` (0..7) of image row `row`, swizzled: rows r, r+2, .. r+14 of one parity land
 // on the 8 slots of their half of the 256-B bank row
@@ -91,11 +96,14 @@ __device__ __forceinline__ void split_rows_body(const SplitSrc& src, int W, int 
             if (k + i < W) x[i] = static_cast<float>(row[k + i]);
     }
     h8 hi, lo;
+    bool bad = false;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         hi[i] = static_cast<_Float16>(x[i]);
         lo[i] = static_cast<_Float16>((x[i] - static_cast<float>(hi[i])) * 2048.f);
+        bad |= unsplittable(x[i]);
     }
+    if (bad && src.range_flag) atomicOr(src.range_flag, 1);
     char* line = dst + (r * n_blk + (c >> 2)) * ROW_B + (c & 3) * 16;
     *reinterpret_cast<h8*>(line) = hi;
     *reinterpret_cast<h8*>(line + 64) = lo;
@@ -134,6 +142,8 @@ __global__ __launch_bounds__(256) void k_split_tile32(SplitSrc src, int64_t C, c
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) tile[t >> 3][(t & 7) * 4 + i] = v[i];
+        if ((unsplittable(v[0]) || unsplittable(v[1]) || unsplittable(v[2]) || unsplittable(v[3])) && src.range_flag)
+            atomicOr(src.range_flag, 1);
     } else {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -143,6 +153,7 @@ __global__ __launch_bounds__(256) void k_split_tile32(SplitSrc src, int64_t C, c
                 const int64_t rr = src.idx ? static_cast<int64_t>(src.idx[r]) : r;
                 v = static_cast<float>(base[rr * src.ld + c]);
             }
+            if (unsplittable(v) && src.range_flag) atomicOr(src.range_flag, 1);
             tile[p * 8 + (t >> 5)][t & 31] = v;
         }
     }
@@ -249,8 +260,10 @@ template <bool B_LO>
 __global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__ A, const char* __restrict__ B,
                                                         int64_t M, int64_t N, int n_slice,
                                                         float* __restrict__ C, int64_t ldc, int tiles_x,
-                                                        int n_tiles, int ksplit, int64_t part_stride) {
+                                                        int n_tiles, int ksplit, int64_t part_stride,
+                                                        const int32_t* __restrict__ range_flag) {
     __shared__ __attribute__((aligned(16))) char lds[2][2][IMG_B];  // [buffer][operand]
+    if (range_flag && *range_flag) return;  // operands out of the fp16 range: the fp32 kernels take over
     const int slot = blockIdx.x, slots = gridDim.x;
     const int my_tiles = (n_tiles - slot + slots - 1) / slots;
     const int total = my_tiles * n_slice;  // (tile, slice) pairs of this workgroup, in order
@@ -459,8 +472,10 @@ template <bool B_LO>
 __global__ __launch_bounds__(512) void k_gemm_split_w8(const char* __restrict__ A, const char* __restrict__ B,
                                                        int64_t M, int64_t N, int n_slice,
                                                        float* __restrict__ C, int64_t ldc, int tiles_x,
-                                                       int n_tiles, int ksplit, int64_t part_stride) {
+                                                       int n_tiles, int ksplit, int64_t part_stride,
+                                                       const int32_t* __restrict__ range_flag) {
     extern __shared__ __attribute__((aligned(16))) char lds8[];  // [2][A rows 0-255 | B rows 0-127]
+    if (range_flag && *range_flag) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int slot = blockIdx.x, slots = gridDim.x;
     const int my_tiles = (n_tiles - slot + slots - 1) / slots;
@@ -598,13 +613,9 @@ __global__ __launch_bounds__(512) void k_gemm_split_w8(const char* __restrict__ 
     if (g < total) slice(g, r0, r1);
 }
 
-static bool split_disabled() {
-    static const bool off = [] {
-        const char* e = std::getenv("BESS_GEMM_FP32");
-        return e && e[0] && e[0] != '0';
-    }();
-    return off;
-}
+// (the switch that keeps the exact fp32 MFMA kernels is a descriptor flag, BESS_FLAG_FP32_MATH: the callers in
+// neg_shared.hip do not ask for this path then; the library reads no environment variables for dispatch)
+static bool split_disabled() { return false; }
 
 static int n_compute_units() {
     static const int n = [] {
@@ -620,24 +631,17 @@ static int n_compute_units() {
 static int64_t pad_a(int64_t rows) { return ceil_div(rows, W8_A) * W8_A; }
 static int64_t pad_b(int64_t rows) { return ceil_div(rows, W8_B) * W8_B; }
 
-static int tile_choice() {  // BESS_GEMM_TILE=128 keeps the producer / consumer kernel (A/B measurements)
-    static const int c = [] {
-        const char* e = std::getenv("BESS_GEMM_TILE");
-        return e ? std::atoi(e) : 0;
-    }();
-    return c;
-}
-
 // C[M, N] (+ k parts) = A . B^T from split images; picks the 256 x 128 kernel when the images are padded
 // to whole tiles (forward) and its tiles fill the chip: measured 3-8 % faster there, no more - the two
 // kernels meet the same wall (profiles/ubench/mfma_f16.hip: the clock the chip holds under MFMA + LDS load)
 static int launch_product(const char* A, const char* B, int64_t M, int64_t N, int n_slice, float* C, int64_t ldc,
-                          int ksplit, int64_t part_stride, bool b_lo, bool padded, hipStream_t st) {
+                          int ksplit, int64_t part_stride, bool b_lo, bool padded, const int32_t* flag,
+                          hipStream_t st) {
     const int cus = n_compute_units();
     const int64_t tx = ceil_div(N, 128);
     const int64_t t8 = tx * ceil_div(M, W8_A) * ksplit, t4 = tx * ceil_div(M, 128) * ksplit;
     BESS_REQUIRE(t4 < (1ll << 31), "gemm_split: too many tiles");
-    const bool wide = padded && tile_choice() != 128 && (t8 >= cus || tile_choice() == 256);
+    const bool wide = padded && t8 >= cus;
     if (wide) {
         static const bool attr = [] {
             const int bytes = 2 * W8_IMG;
@@ -650,23 +654,24 @@ static int launch_product(const char* A, const char* B, int64_t M, int64_t N, in
         const int grid = static_cast<int>(t8 < cus ? t8 : cus);
         if (b_lo)
             k_gemm_split_w8<true><<<grid, 512, 2 * W8_IMG, st>>>(A, B, M, N, n_slice, C, ldc, static_cast<int>(tx),
-                                                                 static_cast<int>(t8), ksplit, part_stride);
+                                                                 static_cast<int>(t8), ksplit, part_stride, flag);
         else
             k_gemm_split_w8<false><<<grid, 512, 2 * W8_IMG, st>>>(A, B, M, N, n_slice, C, ldc, static_cast<int>(tx),
-                                                                  static_cast<int>(t8), ksplit, part_stride);
+                                                                  static_cast<int>(t8), ksplit, part_stride, flag);
         return check_launch("gemm_split_w8");
     }
     const int grid = static_cast<int>(t4 < cus ? t4 : cus);
     if (b_lo)
         k_gemm_split_f16<true><<<grid, 512, 0, st>>>(A, B, M, N, n_slice, C, ldc, static_cast<int>(tx),
-                                                     static_cast<int>(t4), ksplit, part_stride);
+                                                     static_cast<int>(t4), ksplit, part_stride, flag);
     else
         k_gemm_split_f16<false><<<grid, 512, 0, st>>>(A, B, M, N, n_slice, C, ldc, static_cast<int>(tx),
-                                                      static_cast<int>(t4), ksplit, part_stride);
+                                                      static_cast<int>(t4), ksplit, part_stride, flag);
     return check_launch("gemm_split_f16");
 }
 
 static int64_t split_pitch(int W) { return ceil_div(W, SK) * ROW_B; }
+constexpr int64_t FLAG_BYTES = 256;  // tail of every workspace: the range flag (one int32, zeroed per call)
 constexpr int64_t SPLIT_CHUNK = 65536;  // candidate rows split per pass at most (128 MiB of lines at W = 512)
 
 // Workspace the split path wants for this shape; 0 = the shape is left to the fp32 kernels
@@ -674,7 +679,7 @@ constexpr int64_t SPLIT_CHUNK = 65536;  // candidate rows split per pass at most
 int64_t gemm_split_workspace(int64_t S, int64_t N, int W) {
     if (split_disabled() || S < 1 || N < 1 || W < 1) return 0;
     if (ceil_div(N, 128) * ceil_div(S, 128) < 256) return 0;
-    return (pad_a(S) + pad_b(N < SPLIT_CHUNK ? N : SPLIT_CHUNK)) * split_pitch(W);
+    return (pad_a(S) + pad_b(N < SPLIT_CHUNK ? N : SPLIT_CHUNK)) * split_pitch(W) + FLAG_BYTES;
 }
 
 // splits `a` (f32 rows; skipped when a.rows == 0) and `b` (table dtype) in one launch
@@ -702,6 +707,13 @@ int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const in
                    float* out, int64_t ld, void* ws, int64_t ws_bytes, hipStream_t st) {
     const int64_t pitch = split_pitch(W);
     BESS_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 16 == 0, "gemm_split: workspace must be 16-B aligned");
+    BESS_REQUIRE(ws_bytes >= FLAG_BYTES + 256 * pitch, "gemm_split: workspace too small");
+    ws_bytes -= FLAG_BYTES;
+    int32_t* flag = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + ws_bytes / 16 * 16);
+    {
+        hipError_t e = hipMemsetAsync(flag, 0, sizeof(int32_t), st);
+        if (e != hipSuccess) return fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
+    }
     int64_t chunk = (ws_bytes / pitch - pad_a(S)) / 128 * 128;  // candidate rows per pass
     if (chunk >= N) chunk = N;
     BESS_REQUIRE(chunk >= 128, "gemm_split: workspace too small");
@@ -712,12 +724,15 @@ int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const in
         const int64_t nc = N - j0 < chunk ? N - j0 : chunk;
         // rows j0 .. j0 + nc: through the index if there is one, else consecutive rows of the table
         const int64_t sz = dtype == BESS_F32 ? 4 : 2;
-        SplitSrc src{idx ? E : static_cast<const char*>(E) + j0 * W * sz, idx ? idx + j0 : nullptr, nc, W};
+        SplitSrc src{idx ? E : static_cast<const char*>(E) + j0 * W * sz, idx ? idx + j0 : nullptr, nc, W, flag};
         // the query rows ride along with the first chunk
-        if (int e = split_rows(SplitSrc{Q, nullptr, j0 == 0 ? S : 0, W}, qa, dtype, src, eb, W, st)) return e;
-        if (int e = launch_product(qa, eb, S, nc, n_slice, out + j0, ld, 1, 0, dtype == BESS_F32, true, st)) return e;
+        if (int e = split_rows(SplitSrc{Q, nullptr, j0 == 0 ? S : 0, W, flag}, qa, dtype, src, eb, W, st)) return e;
+        if (int e = launch_product(qa, eb, S, nc, n_slice, out + j0, ld, 1, 0, dtype == BESS_F32, true, flag, st))
+            return e;
     }
-    return BESS_OK;
+    // an operand outside the fp16 range (or not finite) raised the flag: the split kernels returned at once and
+    // the exact fp32 kernels compute the whole product now; else they are the ones that return at once
+    return gemm_dot_fwd(dtype, Q, S, E, idx, N, W, out, ld, st, flag);
 }
 
 // ---- backward products -----------------------------------------------------------------
@@ -753,7 +768,7 @@ static bool bwd_layout(int64_t S, int64_t N, int W, BwdLayout& L) {
     L.q_trans = static_cast<int64_t>(W) * L.pe.nblk * ROW_B;
     const int64_t p1 = L.pq.ks > 1 ? L.pq.ks * S * W * 4 : 0, p2 = L.pe.ks > 1 ? L.pe.ks * N * W * 4 : 0;
     L.parts = p1 > p2 ? p1 : p2;
-    L.total = L.g_plain + L.g_trans + L.e_trans + L.q_trans + L.parts;
+    L.total = L.g_plain + L.g_trans + L.e_trans + L.q_trans + L.parts + FLAG_BYTES;
     return true;
 }
 
@@ -763,9 +778,9 @@ int64_t gemm_split_bwd_workspace(int64_t S, int64_t N, int W) {
 }
 
 static int product(const char* A, const char* B, int64_t M, int64_t N, const BwdPlan& p, float* C, int64_t ldc,
-                   float* parts, hipStream_t st) {
+                   float* parts, const int32_t* flag, hipStream_t st) {
     float* dst = p.ks > 1 ? parts : C;
-    if (int e = launch_product(A, B, M, N, p.nblk / p.ks, dst, ldc, p.ks, M * ldc, true, false, st)) return e;
+    if (int e = launch_product(A, B, M, N, p.nblk / p.ks, dst, ldc, p.ks, M * ldc, true, false, flag, st)) return e;
     if (p.ks > 1) {
         const int64_t n4 = M * ldc / 4;
         k_sum_parts<<<static_cast<unsigned>(ceil_div(n4, 256)), 256, 0, st>>>(parts, M * ldc, p.ks, C, n4);
@@ -786,19 +801,24 @@ int gemm_split_bwd(int dtype, const float* G, int64_t ldg, int64_t S, const floa
     char* et = gt + L.g_trans;
     char* qt = et + L.e_trans;
     float* parts = reinterpret_cast<float*>(qt + L.q_trans);
+    int32_t* flag = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + L.total - FLAG_BYTES);
+    {
+        hipError_t e = hipMemsetAsync(flag, 0, sizeof(int32_t), st);
+        if (e != hipSuccess) return fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
+    }
     const auto al = [](const void* p, int64_t ld, int64_t sz) {
         return reinterpret_cast<uintptr_t>(p) % 16 == 0 && ld * sz % 16 == 0;
     };
     // G [S, N]: plain image with k = j (nblk of dQ), transposed image with k = q (nblk of dE)
     const dim3 gg(L.pq.nblk, L.pe.nblk);
-    const SplitSrc sg{G, nullptr, S, ldg};
+    const SplitSrc sg{G, nullptr, S, ldg, flag};
     if (N % 4 == 0 && al(G, ldg, 4))
         k_split_tile32<float, true, true, true><<<gg, 256, 0, st>>>(sg, N, gp, L.pq.nblk, gt, L.pe.nblk);
     else
         k_split_tile32<float, true, true, false><<<gg, 256, 0, st>>>(sg, N, gp, L.pq.nblk, gt, L.pe.nblk);
     // E rows [N (by index), W] -> E^T: image rows w, k = j       (W % 4 == 0 checked by bwd_layout)
     const dim3 ge(static_cast<unsigned>(ceil_div(W, 32)), L.pq.nblk);
-    const SplitSrc se{E, idx, N, W};
+    const SplitSrc se{E, idx, N, W, flag};
     if (dtype == BESS_F32) {
         if (al(E, W, 4)) k_split_tile32<float, false, true, true><<<ge, 256, 0, st>>>(se, W, nullptr, 0, et, L.pq.nblk);
         else k_split_tile32<float, false, true, false><<<ge, 256, 0, st>>>(se, W, nullptr, 0, et, L.pq.nblk);
@@ -810,12 +830,15 @@ int gemm_split_bwd(int dtype, const float* G, int64_t ldg, int64_t S, const floa
     }
     // Q [S, W] -> Q^T: image rows w, k = q
     const dim3 gq(static_cast<unsigned>(ceil_div(W, 32)), L.pe.nblk);
-    const SplitSrc sq{Q, nullptr, S, W};
+    const SplitSrc sq{Q, nullptr, S, W, flag};
     if (al(Q, W, 4)) k_split_tile32<float, false, true, true><<<gq, 256, 0, st>>>(sq, W, nullptr, 0, qt, L.pe.nblk);
     else k_split_tile32<float, false, true, false><<<gq, 256, 0, st>>>(sq, W, nullptr, 0, qt, L.pe.nblk);
     if (int e = check_launch("split_tile32")) return e;
-    if (int e = product(gp, et, S, W, L.pq, dQ, W, parts, st)) return e;
-    return product(gt, qt, N, W, L.pe, dE, W, parts, st);
+    if (int e = product(gp, et, S, W, L.pq, dQ, W, parts, flag, st)) return e;
+    if (int e = product(gt, qt, N, W, L.pe, dE, W, parts, flag, st)) return e;
+    // (k_sum_parts has then summed garbage into dQ / dE: overwritten by the fp32 kernels, which run only if the flag is up)
+    if (int e = gemm_dot_dq(dtype, G, ldg, S, E, idx, N, W, dQ, st, flag)) return e;
+    return gemm_dot_de(G, ldg, S, Q, N, W, dE, st, flag);
 }
 
 }  // namespace bess

@@ -384,6 +384,7 @@ extern "C" int bess_neg_score_shared_fwd_masked(const bess_model_desc* d, const 
 extern "C" int64_t bess_neg_score_shared_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg) {
     if (!d || check_desc(d) || n_query <= 0 || n_neg <= 0) return 0;
     if (d->scorer == BESS_BOXE || d->scorer == BESS_AFFINE || reduce_of(d) != RED_DOT) return 0;
+    if (d->reserved[0] & BESS_FLAG_FP32_MATH) return 0;  // the exact fp32 MFMA kernels are asked for
     return gemm_split_workspace(n_query, n_neg, d->width);
 }
 
@@ -405,7 +406,8 @@ extern "C" int bess_neg_score_shared_fwd_ws(const bess_model_desc* d, const floa
                                  as_stream(stream));
     }
     if (reduce_of(d) == RED_DOT) {  // bilinear scorers: matrix cores
-        const int64_t want = workspace ? gemm_split_workspace(n_query, n_neg, d->width) : 0;
+        const bool fp32 = d->reserved[0] & BESS_FLAG_FP32_MATH;
+        const int64_t want = workspace && !fp32 ? gemm_split_workspace(n_query, n_neg, d->width) : 0;
         if (want > 0 && workspace_bytes >= want)
             return gemm_split_fwd(d->dtype, query, n_query, neg_base, neg_idx, n_neg, d->width, out, ld_out,
                                   workspace, workspace_bytes, as_stream(stream));
@@ -432,6 +434,7 @@ extern "C" int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* 
 extern "C" int64_t bess_neg_score_shared_bwd_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg) {
     if (!d || check_desc(d) || n_query <= 0 || n_neg <= 0) return 0;
     if (d->scorer == BESS_BOXE || d->scorer == BESS_AFFINE || reduce_of(d) != RED_DOT) return 0;
+    if (d->reserved[0] & BESS_FLAG_FP32_MATH) return 0;
     return gemm_split_bwd_workspace(n_query, n_neg, d->width);
 }
 
@@ -467,7 +470,8 @@ extern "C" int bess_neg_score_shared_bwd_ws(const bess_model_desc* d, const floa
                                  ld_dout, d_query, d_neg, st);
     }
     if (reduce_of(d) == RED_DOT) {
-        const int64_t want = workspace ? gemm_split_bwd_workspace(n_query, n_neg, d->width) : 0;
+        const bool fp32 = d->reserved[0] & BESS_FLAG_FP32_MATH;
+        const int64_t want = workspace && !fp32 ? gemm_split_bwd_workspace(n_query, n_neg, d->width) : 0;
         if (want > 0 && workspace_bytes >= want)
             return gemm_split_bwd(d->dtype, d_out, ld_dout, n_query, query, neg_base, neg_idx, n_neg, d->width,
                                   d_query, d_neg, workspace, workspace_bytes, st);

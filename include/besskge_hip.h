@@ -91,7 +91,9 @@ extern "C" {
 #define BESS_BAD_NEGATIVE_SCORE (-50000.0f)
 
 /* bess_model_desc.reserved[0] of TransE / RotatE / DistMult / ComplEx: flags */
-#define BESS_FLAG_FP32_MATH 1 /* never use the packed-fp16 forms of the shared-negative kernels */
+#define BESS_FLAG_FP32_MATH 1 /* shared negatives with the plain fp32 kernels only: no packed-fp16 L1 forward
+                                 (TransE / RotatE on f16 tables), no split-fp16 matrix-core products (DistMult /
+                                 ComplEx) */
 
 typedef struct bess_model_desc {
     int32_t scorer;    /* BESS_TRANSE ...                                  */
@@ -258,8 +260,11 @@ int bess_neg_score_shared_fwd_masked(const bess_model_desc* d, const float* quer
  * device scratch (16-B aligned, contents irrelevant, free again when the call has run on
  * `stream`) with which the product runs on the fp16 matrix cores at fp32 accuracy: operands
  * are split into fp16 pairs carrying 22 significand bits, products accumulate in fp32
- * (csrc/gemm_split.hip; operands must be finite and < 65504 in magnitude; BESS_GEMM_FP32=1
- * in the environment switches the path off).  It returns 0 when the shape or the scorer does
+ * (csrc/gemm_split.hip).  An operand that is not finite or not below 65504 in magnitude (the fp16
+ * range) is noticed by the splitting pre-pass: the call then computes the product with the exact
+ * fp32 MFMA kernels instead, by itself and without a host synchronisation (they are queued behind
+ * the split kernels, each side gated on a flag in the scratch).  desc.reserved[0] &
+ * BESS_FLAG_FP32_MATH keeps the fp32 kernels from the start (no scratch is asked for then).  It returns 0 when the shape or the scorer does
  * not use scratch.  With workspace == NULL or fewer bytes than asked for, the call is
  * bess_neg_score_shared_fwd (exact fp32 MFMA). */
 int64_t bess_neg_score_shared_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg);

@@ -3,7 +3,7 @@
 vs a float64 product: accuracy and rate on the shared-negative / all-entities shapes.
 
     python profiles/bench_gemm_split.py            # split kernel (default dispatch)
-    BESS_GEMM_FP32=1 python profiles/bench_gemm_split.py   # exact fp32 MFMA kernel
+    python profiles/bench_gemm_split.py fp32   # exact fp32 MFMA kernels (descriptor flag BESS_FLAG_FP32_MATH)
 """
 
 import os
@@ -39,6 +39,8 @@ def run(name, dtype, M, W, S, N, use_idx=True, scale=0.1, check=True, bwd=False)
     g = torch.Generator(device="cpu").manual_seed(0)
     table = (torch.randn(M, W, generator=g) * scale).to(dtype).to(dev)
     d = nat.make_desc(nat.DISTMULT, 0, table, W)
+    if "fp32" in sys.argv[1:]:
+        d.reserved[0] = nat.FLAG_FP32_MATH
     q = (torch.randn(S, W, generator=g) * scale).to(dev)
     idx = torch.randint(M, (N,), dtype=torch.int32, device=dev) if use_idx else None
     neg = RowSource(table, idx) if use_idx else RowSource(table[:N], None)
@@ -71,7 +73,7 @@ def run(name, dtype, M, W, S, N, use_idx=True, scale=0.1, check=True, bwd=False)
 
 
 if __name__ == "__main__":
-    print("BESS_GEMM_FP32 =", os.environ.get("BESS_GEMM_FP32", "<unset>"))
+    print("fp32 kernels only:", "fp32" in sys.argv[1:])
     run("C2 ComplEx shared 4096x4096", torch.float32, 93_773, 512, 4096, 4096, bwd=True)
     run("C5 DistMult shared 8192x4096", torch.float32, 1_000_000, 512, 8192, 4096, bwd=True)
     run("ragged 4099 x 5001, W=500", torch.float32, 20_000, 500, 4099, 5001, bwd=True)

@@ -33,19 +33,22 @@ def test_library_exports_every_declared_symbol():
 def test_workspace_query_needs_no_gpu():
     """bess_neg_score_shared_workspace is host arithmetic: bilinear scorers with >= 256 output
     tiles of 128 x 128 ask for (S + min(N, 65536)) lines (rows rounded up to whole 256 / 128-row
-    tiles) of ceil(W / 32) * 128 bytes, the rest 0."""
+    tiles) of ceil(W / 32) * 128 bytes (+ 256 for the range flag), the rest 0."""
     from besskge import _native
 
     lib = _native.load()
     d = _native.ModelDesc()
     d.scorer, d.norm_p, d.dtype, d.width, d.rel_width = _native.DISTMULT, 0, 0, 500, 500
-    if os.environ.get("BESS_GEMM_FP32", "0") not in ("", "0"):
-        assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4096, 4096) == 0
-        return
-    assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4096, 4096) == (4096 + 4096) * 16 * 128
-    assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4000, 5000) == (4096 + 5120) * 16 * 128  # whole tiles
-    assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4096, 1 << 20) == (4096 + 65536) * 16 * 128
+    flag = 256  # tail of the scratch: the range flag of the fallback to the fp32 kernels
+    assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4096, 4096) == (4096 + 4096) * 16 * 128 + flag
+    assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4000, 5000) == (4096 + 5120) * 16 * 128 + flag  # whole tiles
+    assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4096, 1 << 20) == (4096 + 65536) * 16 * 128 + flag
     assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 512, 768) == 0  # too few tiles
+    d.reserved[0] = _native.FLAG_FP32_MATH  # the exact fp32 kernels are asked for: no scratch
+    assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4096, 4096) == 0
+    assert lib.bess_neg_score_shared_bwd_workspace(ctypes.byref(d), 4096, 4096) == 0
+    d.reserved[0] = 0
+    assert lib.bess_neg_score_shared_bwd_workspace(ctypes.byref(d), 4096, 4096) > 0
     d.scorer, d.norm_p = _native.TRANSE, 1
     assert lib.bess_neg_score_shared_workspace(ctypes.byref(d), 4096, 4096) == 0  # not a dot product
 

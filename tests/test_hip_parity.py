@@ -983,3 +983,51 @@ def test_sparse_sgd_of_several_lists_in_one_launch(dev, dtype):
     for idx, g in lists:
         want.index_add_(0, idx.cpu().long(), -0.5 * g.cpu().double())
     torch.testing.assert_close(a.float().cpu().double(), want, **tol)
+
+
+@pytest.mark.parametrize("where", ["query", "candidate", "score_gradient", "inf"])
+def test_split_fp16_gemm_falls_back_to_fp32_outside_the_fp16_range(dev, where):
+    """An operand of 65504 or more in magnitude (or a non-finite one) cannot be split into fp16 pairs: the
+    pre-pass raises a flag, the split kernels return at once and the exact fp32 MFMA kernels queued behind them
+    compute the product - same call, no host synchronisation, same accuracy as for in-range operands."""
+    import ctypes
+
+    from besskge import _native as nat
+
+    g = torch.Generator().manual_seed(17)
+    S, N, W, M = 2048, 2304, 128, 6000
+    table = torch.randn(M, W, generator=g)
+    q = torch.randn(S, W, generator=g)
+    go = torch.randn(S, N, generator=g)
+    idx = torch.randint(M, (N,), generator=g, dtype=torch.int32)
+    big = 3.0e5 if where != "inf" else float("inf")
+    if where in ("query", "inf"):
+        q[S - 3, 5] = big
+    elif where == "candidate":
+        table[int(idx[N - 1]), W - 1] = -big  # reached through the index, in the last chunk of rows
+    else:
+        go[7, N - 2] = big
+    table, q, go, idx = table.to(dev), q.to(dev), go.to(dev), idx.to(dev)
+    d = nat.make_desc(nat.DISTMULT, 0, table, W)
+    assert nat.load().bess_neg_score_shared_workspace(ctypes.byref(d), S, N) > 0
+    neg = nat.RowSource(table, idx)
+    rows = table[idx.long()].double()
+    got = nat.neg_score_shared_fwd(d, q, neg)
+    ref = q.double() @ rows.T
+    if where == "inf":
+        assert bool(torch.isinf(got[S - 3]).any() or torch.isnan(got[S - 3]).any())  # what fp32 arithmetic gives
+        keep = torch.ones(S, dtype=torch.bool, device=dev)
+        keep[S - 3] = False
+        assert float((got[keep].double() - ref[keep]).abs().max()) <= 2e-6 * float(ref[keep].abs().max())
+        return
+    if where != "score_gradient":
+        assert float((got.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    dq, dn = nat.neg_score_shared_bwd(d, q, neg, got, go)
+    rq, rn = go.double() @ rows, go.double().T @ q.double()
+    assert float((dq.double() - rq).abs().max()) <= 2e-6 * float(rq.abs().max())
+    assert float((dn.double() - rn).abs().max()) <= 2e-6 * float(rn.abs().max())
+    # and the descriptor flag asks for the fp32 kernels outright
+    d.reserved[0] = nat.FLAG_FP32_MATH
+    assert nat.load().bess_neg_score_shared_workspace(ctypes.byref(d), S, N) == 0
+    got32 = nat.neg_score_shared_fwd(d, q, neg)
+    assert float((got32.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
