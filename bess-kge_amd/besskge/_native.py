@@ -162,6 +162,7 @@ SIGNATURES = {
     "bess_sample_negatives": [_PG, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "bess_sample_bucket_indices": [_PG, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "bess_lookup_triples": [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
+    "bess_gather_candidate_lists": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp],
     "bess_comm_unique_id": [_c_u8p],
     "bess_comm_init_rank": [_i32, _i32, _c_u8p, ctypes.POINTER(_vp)],
     "bess_comm_init_all": [_i32, _c_i32p, ctypes.POINTER(_vp)],
@@ -1194,6 +1195,42 @@ def lookup_triples(triples: torch.Tensor, sample_idx: torch.Tensor, swap_tail: b
                                       ppp, int(swap_tail), ptr("head"), ptr("relation"), ptr("tail"),
                                       _stream(dev)), "lookup_triples")
     return out
+
+
+def gather_candidate_lists(table_h: torch.Tensor, mask_h: Optional[torch.Tensor], lookup: torch.Tensor,
+                           table_t: Optional[torch.Tensor] = None, mask_t: Optional[torch.Tensor] = None,
+                           per_part: int = 1, half: int = 1, mask_gather_layout: bool = False,
+                           want_mask: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Fixed candidate lists of the sampled triples, laid out for the exchange (see
+    bess_gather_candidate_lists): tables int32 [n_list, n_neg_shard, L] (+ bool masks), lookup int64
+    [n_step, n_shard, T] -> (entities int32 [n_step, n_neg_shard, n_shard, T, L], mask bool | None)."""
+    dev = _same_device([("table_h", table_h), ("mask_h", mask_h), ("lookup", lookup), ("table_t", table_t),
+                        ("mask_t", mask_t)])
+    for t, nm in ((table_h, "table_h"), (table_t, "table_t")):
+        if t is not None and (t.dtype != torch.int32 or t.dim() != 3 or not t.is_contiguous()):
+            raise ValueError(f"`{nm}` must be a contiguous int32 [n_list, n_neg_shard, L] tensor")
+    for t, nm in ((mask_h, "mask_h"), (mask_t, "mask_t")):
+        if t is not None and (t.dtype != torch.bool or tuple(t.shape) != tuple(table_h.shape) or not t.is_contiguous()):
+            raise ValueError(f"`{nm}` must be a contiguous bool tensor of the tables' shape")
+    if table_t is not None and tuple(table_t.shape) != tuple(table_h.shape):
+        raise ValueError("the two candidate tables must have the same shape")
+    if lookup.dtype != torch.int64 or lookup.dim() != 3 or not lookup.is_contiguous():
+        raise ValueError("`lookup` must be a contiguous int64 [n_step, n_shard, T] tensor")
+    n_list, n_neg_shard, L = (int(x) for x in table_h.shape)
+    n_step, n_shard, T = (int(x) for x in lookup.shape)
+    ent = torch.empty((n_step, n_neg_shard, n_shard, T, L), dtype=torch.int32, device=dev)
+    msk = None
+    if want_mask and mask_h is not None:
+        shape = (n_step, n_neg_shard, n_shard, T, L) if mask_gather_layout else (n_step, n_shard, T, n_neg_shard, L)
+        msk = torch.empty(shape, dtype=torch.bool, device=dev)
+    with torch.cuda.device(dev), _Timed("bess_gather_candidate_lists", dev):
+        rc = load().bess_gather_candidate_lists(
+            table_h.data_ptr(), table_t.data_ptr() if table_t is not None else None,
+            mask_h.data_ptr() if mask_h is not None else None, mask_t.data_ptr() if mask_t is not None else None,
+            n_list, lookup.data_ptr(), n_step, n_shard, T, int(per_part), int(half), n_neg_shard, L,
+            int(bool(mask_gather_layout)), ent.data_ptr(), msk.data_ptr() if msk is not None else None, _stream(dev))
+    _check(rc, "bess_gather_candidate_lists")
+    return ent, msk
 
 
 # --------------------------------------------------------------------------- #

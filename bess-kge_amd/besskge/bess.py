@@ -787,24 +787,33 @@ class EmbeddingMovingBessKGE(BessKGE):
 
         # Augmentation concatenates the positives of the corrupted side with the
         # negatives (bess.py:369-393, 430-448): both must be addressable in one
-        # row space.  Tails and exchanged negatives share the receive buffer;
-        # heads live in the shard, so a copy of the S head rows is appended to
-        # the receive buffer when heads are corrupted on several shards.
+        # row space.  Tails live in the receive buffer, heads in the shard; the
+        # negatives in the receive buffer (exchanged) or in the shard (local
+        # sampling, bess.py:340-347).  Where a group's positives and negatives sit in
+        # different spaces, a copy of the shard-side rows is appended to the receive
+        # buffer: the S head rows when heads are corrupted against exchanged
+        # negatives, the local negatives when tails are corrupted against them.
         pos_of = {nat.CORRUPT_HEAD: head_src, nat.CORRUPT_TAIL: tail_src}
+        base_of = {nat.CORRUPT_HEAD: neg_base, nat.CORRUPT_TAIL: neg_base}
+        rows_of = {nat.CORRUPT_HEAD: neg_idx2d, nat.CORRUPT_TAIL: neg_idx2d}
         if self.augment_negative and n > 1:
             if neg_base is st.recv and scheme in ("h", "ht"):
                 st.recv = torch.cat([st.recv, nat.gather_rows(st.table, st.head_idx)], dim=0)
                 st.ext_src = head_src
-                neg_base = st.recv
                 tail_src = st.tail = RowSource(st.recv, tail_src.idx)
                 ext_idx = st.recv_rows + torch.arange(S, dtype=torch.int32, device=dev)
                 pos_of[nat.CORRUPT_HEAD] = RowSource(st.recv, ext_idx)
                 pos_of[nat.CORRUPT_TAIL] = tail_src
+                base_of = {nat.CORRUPT_HEAD: st.recv, nat.CORRUPT_TAIL: st.recv}
             elif neg_base is st.table and scheme in ("t", "ht"):
-                raise NotImplementedError(
-                    "augment_negative with local_sampling on several shards"
-                    " (tails received, negatives local) is not supported"
-                )
+                local_rows = neg_idx2d.reshape(-1).contiguous()
+                st.recv = torch.cat([st.recv, nat.gather_rows(st.table, local_rows)], dim=0)
+                st.ext_src = RowSource(st.table, local_rows)
+                tail_src = st.tail = RowSource(st.recv, tail_src.idx)
+                pos_of[nat.CORRUPT_TAIL] = tail_src
+                base_of[nat.CORRUPT_TAIL] = st.recv
+                rows_of[nat.CORRUPT_TAIL] = (st.recv_rows + torch.arange(local_rows.numel(), dtype=torch.int32, device=dev)
+                                             ).reshape(neg_idx2d.shape)
 
         def make(side: int, sel: Optional[torch.Tensor], rows2d: torch.Tensor) -> _NegGroup:
             """rows2d: [Bg, nK] candidate rows for this group's queries."""
@@ -817,7 +826,7 @@ class EmbeddingMovingBessKGE(BessKGE):
                 rel = rel[sel].contiguous()
             Q = len(ent_src)
             Bg = int(rows2d.shape[0])
-            base = neg_base
+            base = base_of[side]
             if self.augment_negative:
                 # positives of the group become extra candidates (bess.py:369-393, 430-448)
                 assert pos_src.base is base
@@ -830,21 +839,21 @@ class EmbeddingMovingBessKGE(BessKGE):
             return _NegGroup(side, sel, ent_src, rel, RowSource(base, rows2d.reshape(-1).contiguous()),
                              False, int(rows2d.shape[1]))
 
+        rows_hd, rows_tl = rows_of[nat.CORRUPT_HEAD], rows_of[nat.CORRUPT_TAIL]
         if scheme == "h":
-            st.groups = [make(nat.CORRUPT_HEAD, None, neg_idx2d)]
+            st.groups = [make(nat.CORRUPT_HEAD, None, rows_hd)]
         elif scheme == "t":
-            st.groups = [make(nat.CORRUPT_TAIL, None, neg_idx2d)]
+            st.groups = [make(nat.CORRUPT_TAIL, None, rows_tl)]
         elif scheme == "ht":
             cut = ppp // 2
             slot = torch.arange(S, device=dev).reshape(n, ppp)
             sel_h = slot[:, :cut].reshape(-1)
             sel_t = slot[:, cut:].reshape(-1)
             if ns.flat_negative_format:
-                rows_h, rows_t = neg_idx2d[0:1], neg_idx2d[1:2]
+                rows_h, rows_t = rows_hd[0:1], rows_tl[1:2]
             else:
-                per = neg_idx2d.reshape(n, ppp, nK)
-                rows_h = per[:, :cut].reshape(-1, nK)
-                rows_t = per[:, cut:].reshape(-1, nK)
+                rows_h = rows_hd.reshape(n, ppp, nK)[:, :cut].reshape(-1, nK)
+                rows_t = rows_tl.reshape(n, ppp, nK)[:, cut:].reshape(-1, nK)
             st.groups = [make(nat.CORRUPT_HEAD, sel_h, rows_h), make(nat.CORRUPT_TAIL, sel_t, rows_t)]
         else:
             raise ValueError(f"corruption scheme {scheme!r} not supported")

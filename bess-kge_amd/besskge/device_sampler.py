@@ -14,8 +14,12 @@ host sampler's generators, so the two can be interleaved.
 
 Supported: `RandomShardedBatchSampler`, `RigidShardedBatchSampler`;
 `RandomShardedNegativeSampler`, `TypeBasedShardedNegativeSampler`,
-`PlaceholderNegativeSampler`.  `TripleBasedShardedNegativeSampler` (fixed
-candidate lists) has no random stream and stays on the host.
+`PlaceholderNegativeSampler`, and `TripleBasedShardedNegativeSampler`: its
+fixed candidate lists (sharded, sorted and padded once by the host class,
+reference `negative_sampler.py:385-540`) are kept in HBM and every step's
+look-up + layout for the exchange (`negative_sampler.py:422-477`) is one kernel
+(`bess_gather_candidate_lists`) - the sampler the wikikg2 validation against
+500 candidates per triple uses (`notebooks/3_wikikg2_fp16.ipynb:962-995`).
 
 `shards=range(r, r + 1)` makes rank `r` of a one-process-per-GPU job produce
 only its own slice `[:, r]` of every tensor (each rank jumps to its part of
@@ -33,6 +37,7 @@ from besskge.batch_sampler import RandomShardedBatchSampler, RigidShardedBatchSa
 from besskge.negative_sampler import (
     PlaceholderNegativeSampler,
     RandomShardedNegativeSampler,
+    TripleBasedShardedNegativeSampler,
     TypeBasedShardedNegativeSampler,
 )
 
@@ -135,9 +140,9 @@ class DeviceBatchSampler:
         ns = bs.negative_sampler
         if type(bs) not in (RandomShardedBatchSampler, RigidShardedBatchSampler):
             raise TypeError(f"no device twin for {type(bs).__name__}")
-        if type(ns) not in (RandomShardedNegativeSampler, TypeBasedShardedNegativeSampler, PlaceholderNegativeSampler):
-            raise TypeError(f"no device twin for {type(ns).__name__} (its candidates are fixed lists: keep it on "
-                            "the host)")
+        if type(ns) not in (RandomShardedNegativeSampler, TypeBasedShardedNegativeSampler, PlaceholderNegativeSampler,
+                            TripleBasedShardedNegativeSampler):
+            raise TypeError(f"no device twin for {type(ns).__name__}")
         self.host = bs
         self.device = torch.device(device)
         n = bs.n_shard
@@ -165,7 +170,23 @@ class DeviceBatchSampler:
             self._triple_mask = put(bs.triple_mask, torch.bool)
         if bs.hrt_freq_weighting:
             self._hrt_weights = put(bs.hrt_weights, torch.float64)
-        if not isinstance(ns, PlaceholderNegativeSampler):
+        if isinstance(ns, TripleBasedShardedNegativeSampler):
+            # candidate lists, already grouped by owning shard and padded to a common length by the host class
+            if ns.corruption_scheme in ("h", "t"):
+                self._cand = [put(ns.padded_negatives, torch.int32)]
+                self._cand_mask = [put(ns.mask, torch.bool)]
+                self._cand_sort = [put(ns.sort_neg_idx, torch.int32)] if ns.return_sort_idx else None
+            elif ns.flat_negative_format:  # one list per side: row 0 = heads, row 1 = tails
+                self._cand = [put(np.concatenate([ns.padded_negatives_h, ns.padded_negatives_t], axis=0), torch.int32)]
+                self._cand_mask = [put(np.concatenate([ns.mask_h, ns.mask_t], axis=0), torch.bool)]
+                self._cand_sort = [put(ns.sort_neg_h_idx, torch.int32), put(ns.sort_neg_t_idx, torch.int32)] \
+                    if ns.return_sort_idx else None
+            else:
+                self._cand = [put(ns.padded_negatives_h, torch.int32), put(ns.padded_negatives_t, torch.int32)]
+                self._cand_mask = [put(ns.mask_h, torch.bool), put(ns.mask_t, torch.bool)]
+                self._cand_sort = [put(ns.sort_neg_h_idx, torch.int32), put(ns.sort_neg_t_idx, torch.int32)] \
+                    if ns.return_sort_idx else None
+        elif not isinstance(ns, PlaceholderNegativeSampler):
             self._shard_counts = put(ns.shard_counts, torch.int32)
         if isinstance(ns, TypeBasedShardedNegativeSampler):
             self._triple_types = put(ns.triple_types, torch.int32)
@@ -211,6 +232,8 @@ class DeviceBatchSampler:
         ns = self.host.negative_sampler
         if isinstance(ns, PlaceholderNegativeSampler):
             return {}
+        if isinstance(ns, TripleBasedShardedNegativeSampler):
+            return self._candidate_lists(sample_idx)
         n = self.n_shard
         n_step = int(sample_idx.shape[0])
         if ns.flat_negative_format:
@@ -239,6 +262,45 @@ class DeviceBatchSampler:
         self._neg_stream.skip32(n_step * n * n * B * ns.n_negative)
         return dict(negative_entities=out)
 
+    def _candidate_lists(self, sample_idx: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """`TripleBasedShardedNegativeSampler.__call__` on the device (reference negative_sampler.py:422-477)."""
+        ns = self.host.negative_sampler
+        n_step, n = int(sample_idx.shape[0]), self.n_shard
+        per_part = int(sample_idx.shape[-1])
+        half = per_part // 2
+        flat = ns.flat_negative_format
+        dev = self.device
+        out: Dict[str, torch.Tensor] = {}
+        if ns.corruption_scheme in ("h", "t"):
+            lookup = torch.zeros((n_step, n, 1), dtype=torch.int64, device=dev) if flat \
+                else sample_idx.reshape(n_step, n, -1).contiguous()
+            ent, mask = nat.gather_candidate_lists(self._cand[0], self._cand_mask[0], lookup,
+                                                   mask_gather_layout=ns.mask_on_gather)
+            if ns.return_sort_idx:
+                full = torch.zeros_like(sample_idx) if flat else sample_idx
+                sort = self._cand_sort[0][full]
+        elif flat:
+            lookup = torch.tensor([0, 1], dtype=torch.int64, device=dev).expand(n_step, n, 2).contiguous()
+            ent, mask = nat.gather_candidate_lists(self._cand[0], self._cand_mask[0], lookup,
+                                                   mask_gather_layout=ns.mask_on_gather)
+            if ns.return_sort_idx:
+                zh = torch.zeros((*sample_idx.shape[:-1], half), dtype=torch.int64, device=dev)
+                zt = torch.zeros((*sample_idx.shape[:-1], per_part - half), dtype=torch.int64, device=dev)
+                sort = torch.cat([self._cand_sort[0][zh], self._cand_sort[1][zt]], dim=-2)
+        else:
+            lookup = sample_idx.reshape(n_step, n, -1).contiguous()
+            ent, mask = nat.gather_candidate_lists(self._cand[0], self._cand_mask[0], lookup, self._cand[1],
+                                                   self._cand_mask[1], per_part=per_part, half=half,
+                                                   mask_gather_layout=ns.mask_on_gather)
+            if ns.return_sort_idx:
+                sort = torch.cat([self._cand_sort[0][sample_idx[..., :half]], self._cand_sort[1][sample_idx[..., half:]]],
+                                 dim=-2)
+        out["negative_entities"] = ent
+        out["negative_mask"] = mask
+        if ns.return_sort_idx:
+            out["negative_sort_idx"] = sort.reshape(n_step, n, -1, sort.shape[-1]).contiguous()
+        return out
+
     def sample(self, idx: Optional[List[int]] = None) -> Dict[str, torch.Tensor]:
         """The tensors `host_sampler[idx]` would return, on the device
         (restricted to `shards` along axis 1).  `idx` is only used by the rigid
@@ -255,6 +317,7 @@ class DeviceBatchSampler:
         drawn = self._sample_negatives(sample_idx)
         if "negative_entities" in drawn:
             batch["negative"] = drawn.pop("negative_entities")
+        batch.update(drawn)  # negative_mask / negative_sort_idx of the triple-based sampler
         if bs.hrt_freq_weighting:
             w = self._hrt_weights[sample_idx]
             w = w.reshape(w.shape[0], w.shape[1], -1)
@@ -263,5 +326,9 @@ class DeviceBatchSampler:
         if bs.return_triple_idx:
             batch["triple_idx"] = sample_idx
         if (lo, hi) != (0, self.n_shard):
-            batch = {k: (v if k == "negative" else v[:, lo:hi].contiguous()) for k, v in batch.items()}
+            # (the random samplers have drawn only the slice of "negative" already; the candidate lists of the
+            # triple-based sampler come whole: axis 1 is the gathering shard of the entities, and the scoring -
+            # or, with mask_on_gather, the gathering - shard of the mask)
+            whole = isinstance(bs.negative_sampler, TripleBasedShardedNegativeSampler)
+            batch = {k: (v if (k == "negative" and not whole) else v[:, lo:hi].contiguous()) for k, v in batch.items()}
         return batch

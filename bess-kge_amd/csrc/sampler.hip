@@ -189,6 +189,44 @@ __global__ __launch_bounds__(256) void k_lookup_triples(const int32_t* __restric
 
 static inline U128 u128(const uint64_t* p) { return U128{p[0], p[1]}; }
 
+// `TripleBasedShardedNegativeSampler.__call__` (reference negative_sampler.py:422-477): the candidate lists
+// are fixed tables padded per shard ([n_list, n_shard, L], made once on the host and kept in HBM); a step
+// looks the list of every sampled triple up and lays entities and padding mask out for the exchange:
+//   ent [step, shard_neg, shard, T, L]       = table(t)[lookup[step, shard, t], shard_neg, :]   ("gather" layout)
+//   msk gather layout as ent, or score layout [step, shard, T, shard_neg, L]
+// T = (mid, triple) folded; with two tables ("ht": heads corrupted in the first `half` triples of every
+// block of `per_part`, tails in the rest) table(t) = t % per_part < half ? table_h : table_t.
+// One thread per 4 consecutive list entries (L is padded by the caller's tables, any L works).
+__global__ __launch_bounds__(256) void k_gather_candidate_lists(const int32_t* __restrict__ tab_h,
+                                                                const int32_t* __restrict__ tab_t,
+                                                                const uint8_t* __restrict__ msk_h,
+                                                                const uint8_t* __restrict__ msk_t,
+                                                                const int64_t* __restrict__ lookup, int64_t n_step,
+                                                                int64_t n_shard, int64_t T, int64_t per_part,
+                                                                int64_t half, int64_t n_neg_shard, int64_t L,
+                                                                int32_t mask_gather_layout,
+                                                                int32_t* __restrict__ ent, uint8_t* __restrict__ msk) {
+    const int64_t total = n_step * n_neg_shard * n_shard * T * L;
+    for (int64_t o = blockIdx.x * 256ll + threadIdx.x; o < total; o += 256ll * gridDim.x) {
+        // o indexes the gather layout [step, shard_neg, shard, t, l]
+        int64_t r = o;
+        const int64_t l = r % L; r /= L;
+        const int64_t t = r % T; r /= T;
+        const int64_t sh = r % n_shard; r /= n_shard;
+        const int64_t sn = r % n_neg_shard;
+        const int64_t st = r / n_neg_shard;
+        const bool tails = tab_t && (t % per_part) >= half;
+        const int64_t row = lookup[(st * n_shard + sh) * T + t];
+        const int64_t src = (row * n_neg_shard + sn) * L + l;
+        if (ent) ent[o] = (tails ? tab_t : tab_h)[src];
+        if (msk) {
+            const uint8_t m = (tails ? msk_t : msk_h)[src];
+            if (mask_gather_layout) msk[o] = m;
+            else msk[(((st * n_shard + sh) * T + t) * n_neg_shard + sn) * L + l] = m;
+        }
+    }
+}
+
 }  // namespace bess
 
 using namespace bess;
@@ -259,4 +297,29 @@ extern "C" int bess_lookup_triples(const int32_t* triples, int64_t n_triple, con
     k_lookup_triples<<<blocks, 256, 0, as_stream(stream)>>>(triples, n_triple, sample_idx, n_out, n1, n2, per_part,
                                                             swap_tail, head, relation, tail);
     return check_launch("lookup_triples");
+}
+
+extern "C" int bess_gather_candidate_lists(const int32_t* table_h, const int32_t* table_t, const uint8_t* mask_h,
+                                           const uint8_t* mask_t, int64_t n_list, const int64_t* lookup,
+                                           int64_t n_step, int64_t n_shard, int64_t n_triple, int64_t per_part,
+                                           int64_t half, int64_t n_neg_shard, int64_t list_len,
+                                           int32_t mask_gather_layout, int32_t* entities, uint8_t* mask,
+                                           void* stream) {
+    BESS_REQUIRE(n_step >= 0 && n_shard > 0 && n_triple >= 0 && n_neg_shard > 0 && list_len > 0 && n_list > 0,
+                 "gather_candidate_lists: bad sizes");
+    if (n_step == 0 || n_triple == 0) return BESS_OK;
+    BESS_REQUIRE(table_h && lookup && (entities || mask), "gather_candidate_lists: NULL pointer");
+    BESS_REQUIRE(!mask || mask_h, "gather_candidate_lists: mask output without a mask table");
+    BESS_REQUIRE(!table_t || (per_part > 0 && half >= 0 && half <= per_part && n_triple % per_part == 0 &&
+                              (!mask || mask_t)),
+                 "gather_candidate_lists: the two-table form needs per_part | n_triple, 0 <= half <= per_part");
+    if (!table_t) per_part = 1, half = 1;
+    const int64_t total = n_step * n_neg_shard * n_shard * n_triple * list_len;
+    BESS_REQUIRE(total < (1ll << 40), "gather_candidate_lists: output too large");
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 8192) blocks = 8192;
+    k_gather_candidate_lists<<<static_cast<unsigned>(blocks), 256, 0, as_stream(stream)>>>(
+        table_h, table_t, mask_h, mask_t, lookup, n_step, n_shard, n_triple, per_part, half, n_neg_shard, list_len,
+        mask_gather_layout, entities, mask);
+    return check_launch("gather_candidate_lists");
 }

@@ -524,6 +524,21 @@ int bess_sample_negatives(const bess_pcg64_state* gen, const uint64_t* jump_tabl
                           const int32_t* type_counts, const int32_t* type_offsets, int32_t n_type,
                           int32_t local_sampling, int32_t* out, void* stream);
 
+/* `TripleBasedShardedNegativeSampler.__call__` (negative_sampler.py:422-477): per-step look-up of the fixed
+ * candidate lists and their layout for the exchange.  table_h (int32 [n_list, n_neg_shard, list_len]: local
+ * rows per owning shard, padded; mask_h uint8 of the same shape marks the real entries) is made once by the
+ * host sampler and kept in HBM; lookup (int64 [n_step, n_shard, n_triple]) names the list of every sampled
+ * triple (n_triple = the (block, triple) axes folded).  Outputs (either may be NULL):
+ *   entities int32 [n_step, n_neg_shard, n_shard, n_triple, list_len]   (what the gathering shard needs)
+ *   mask     uint8, that layout (mask_gather_layout != 0) or [n_step, n_shard, n_triple, n_neg_shard, list_len]
+ * With table_t != NULL ("ht"): in every block of per_part triples the first `half` take table_h / mask_h
+ * (heads are corrupted), the rest table_t / mask_t. */
+int bess_gather_candidate_lists(const int32_t* table_h, const int32_t* table_t, const uint8_t* mask_h,
+                                const uint8_t* mask_t, int64_t n_list, const int64_t* lookup,
+                                int64_t n_step, int64_t n_shard, int64_t n_triple, int64_t per_part,
+                                int64_t half, int64_t n_neg_shard, int64_t list_len,
+                                int32_t mask_gather_layout, int32_t* entities, uint8_t* mask, void* stream);
+
 /* `RandomShardedBatchSampler.sample_triples` (batch_sampler.py:373-399):
  *   out[f] = offsets[b] + rng.integers(1 << 63, size=n_out)[f] % counts[b],
  *   b = (f / inner) % n_bucket   (out flat over [n_step, buckets..., inner]) */

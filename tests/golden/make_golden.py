@@ -699,7 +699,8 @@ def run_bess_case(
         axis=1,
     )
     tb = neg_kind.startswith("tb")
-    flat = neg_kind.endswith("flat")
+    local = neg_kind.endswith("_local")  # negatives sampled on (and scored against) the processing shard
+    flat = neg_kind.replace("_local", "").endswith("flat")
     nh = nt = None
     if tb:
         n_tb = 11
@@ -715,7 +716,7 @@ def run_bess_case(
     else:
         ns = RandomShardedNegativeSampler(
             n_negative=n_negative, sharding=sharding, seed=seed, corruption_scheme=scheme,
-            local_sampling=False, flat_negative_format=flat,
+            local_sampling=local, flat_negative_format=flat,
         )
     dup = scheme == "ht" and tb
     bcls = RigidShardedBatchSampler if batch_kind == "rigid" else RandomShardedBatchSampler
@@ -829,6 +830,26 @@ def gen_bess() -> None:
         names.append(name)
     put("bess", "cases", np.array(names))
 
+
+
+def gen_bess_local() -> None:
+    """EmbeddingMoving with `local_sampling=True` (bess.py:340-347, 383-393): tails travel, negatives are rows
+    of the processing shard; with and without augmentation, shared and per-triple negatives."""
+    EM = EmbeddingMovingBessKGE
+    cases = [
+        ("tr_EM_loc_aug_t_flat_n2", EM, "TransE", 1, 2, "t", "random_flat_local", "ssce", True, True),
+        ("tr_EM_loc_aug_ht_flat_n4", EM, "ComplEx", 0, 4, "ht", "random_flat_local", "logsigmoid", True, True),
+        ("tr_EM_loc_aug_h_flat_n2", EM, "DistMult", 0, 2, "h", "random_flat_local", "logsigmoid", True, True),
+        ("tr_EM_loc_aug_t_ptshare_n2", EM, "RotatE", 1, 2, "t", "random_pt_local", "margin", True, True),
+        ("tr_EM_loc_aug_ht_ptshare_n2", EM, "TransE", 2, 2, "ht", "random_pt_local", "logsigmoid", True, True),
+        ("tr_EM_loc_t_pt_n2", EM, "ComplEx", 0, 2, "t", "random_pt_local", "logsigmoid", False, False),
+        ("tr_EM_loc_ht_flat_n2", EM, "RotatE", 2, 2, "ht", "random_flat_local", "margin", False, True),
+    ]
+    names = []
+    for name, mcls, scorer, p, n, scheme, nk, loss, aug, sharing in cases:
+        run_bess_case(name, mcls, scorer, p, n, scheme, nk, loss, aug, sharing, fix="bess_local")
+        names.append(name)
+    put("bess_local", "cases", np.array(names))
 
 
 def gen_bess_affine() -> None:
@@ -1017,6 +1038,7 @@ def main() -> None:
         bess_boxe=gen_bess_boxe,
         scoring_conve=gen_scoring_conve,
         bess_conve=gen_bess_conve,
+        bess_local=gen_bess_local,
     )
     for name, g in gens.items():
         if only and name not in only:

@@ -247,15 +247,90 @@ def test_device_sampler_rank_slices(dev, case):
                 _same(got[k], want[k][:, 1:3], f"{case}/{step}/pair/{k}")
 
 
+TRIPLE_BASED = [  # (scheme, flat, mask_on_gather, return_sort_idx, partition mode, n_shard)
+    ("t", False, False, False, "ht_shardpair", 3),
+    ("h", False, True, True, "ht_shardpair", 2),
+    ("t", True, False, True, "h_shard", 4),
+    ("h", True, True, False, "t_shard", 2),
+    ("ht", False, False, True, "ht_shardpair", 3),
+    ("ht", False, True, False, "h_shard", 2),
+    ("ht", True, False, True, "ht_shardpair", 4),
+    ("ht", True, True, False, "ht_shardpair", 2),
+]
+
+
+def _triple_based(scheme, flat, on_gather, sort_idx, mode, n_shard, seed=21):
+    n_entity, n_rel, n_triple, n_cand = 700, 5, 2400, 37
+    rng = np.random.default_rng(seed)
+    triples = np.stack([rng.integers(n_entity, size=n_triple), rng.integers(n_rel, size=n_triple),
+                        rng.integers(n_entity, size=n_triple)], axis=1)
+    ds = _dataset(n_entity, n_rel, triples)
+    sharding = Sharding.create(n_entity, n_shard, seed=seed)
+    pts = PartitionedTripleSet.create_from_dataset(ds, "train", sharding, partition_mode=mode)
+    n_list = 1 if flat else pts.triples.shape[0]
+    crng = np.random.default_rng(seed + 1)
+    # skewed candidates: some shards own few of a list's entities, so the padding (and its mask) matters
+    heads = (crng.integers(n_entity, size=(n_list, n_cand)) // 3).astype(np.int32)
+    tails = crng.integers(n_entity, size=(n_list, n_cand)).astype(np.int32)
+
+    def build():
+        ns = TripleBasedShardedNegativeSampler(
+            negative_heads=heads if scheme in ("h", "ht") else None, negative_tails=tails if scheme in ("t", "ht") else None,
+            sharding=sharding, corruption_scheme=scheme, seed=seed, mask_on_gather=on_gather, return_sort_idx=sort_idx)
+        return RigidShardedBatchSampler(partitioned_triple_set=pts, negative_sampler=ns, shard_bs=24, batches_per_step=2,
+                                        seed=seed + 2)
+
+    return build(), build()
+
+
 @pytest.mark.gpu
-def test_device_sampler_rejects_fixed_candidate_sampler(dev):
+@pytest.mark.parametrize("scheme,flat,on_gather,sort_idx,mode,n_shard", TRIPLE_BASED)
+def test_device_sampler_triple_based_candidate_lists(dev, scheme, flat, on_gather, sort_idx, mode, n_shard):
+    """`TripleBasedShardedNegativeSampler` on the device: candidate lists resident in HBM,
+    per-step look-up + layout by `bess_gather_candidate_lists`; every tensor equals the host sampler's, and
+    a rank asked for its own shard gets the slice it needs."""
     from besskge.device_sampler import DeviceBatchSampler
 
-    host, _ = _make(**dict(CASES["odd_sizes"]))
-    n_tr = host.triples.shape[0]
-    cands = np.random.default_rng(0).integers(1001, size=(n_tr, 8))
-    host.negative_sampler = TripleBasedShardedNegativeSampler(
-        negative_heads=None, negative_tails=cands, sharding=host.negative_sampler.sharding, corruption_scheme="t",
-        seed=0, return_sort_idx=False)
-    with pytest.raises(TypeError, match="no device twin"):
-        DeviceBatchSampler(host, dev)
+    host, twin = _triple_based(scheme, flat, on_gather, sort_idx, mode, n_shard)
+    dbs = DeviceBatchSampler(twin, dev)
+    own = DeviceBatchSampler(twin, dev, shards=[n_shard - 1])
+    order = list(host.get_dataloader_sampler(shuffle=False))
+    for step in range(3):
+        idx = order[step % len(order)]
+        want = host[idx]
+        got = dbs.sample(idx)
+        assert sorted(got.keys()) == sorted(want.keys())
+        assert "negative_mask" in want and ("negative_sort_idx" in want) == sort_idx
+        for k in want:
+            _same(got[k], want[k], f"{scheme}/{flat}/{step}/{k}")
+        mine = own.sample(idx)
+        for k in want:
+            _same(mine[k], want[k][:, n_shard - 1:], f"own/{scheme}/{flat}/{step}/{k}")
+    assert not bool(want["negative_mask"].all()) or flat  # the skewed lists do get padded
+
+
+@pytest.mark.gpu
+def test_device_triple_based_sampler_feeds_the_step(dev):
+    """Validation against fixed candidate tails (the wikikg2 setup, notebooks/3_wikikg2_fp16.ipynb:962-995):
+    ScoreMoving inference fed by the device sampler gives the scores of the run fed by the host sampler."""
+    from besskge import runtime
+    from besskge.bess import ScoreMovingBessKGE
+    from besskge.device_sampler import DeviceBatchSampler
+    from besskge.scoring import TransE
+
+    host, twin = _triple_based("t", False, False, False, "ht_shardpair", 2)
+    sharding = host.negative_sampler.sharding
+    out = []
+    for sampler in (host, DeviceBatchSampler(twin, dev)):
+        torch.manual_seed(0)
+        fn = TransE(False, 1, sharding, 5, 32)
+        model = ScoreMovingBessKGE(negative_sampler=host.negative_sampler, score_fn=fn, return_scores=True)
+        runner = runtime.inference_model(model, runtime.Options(device_iterations=2), device=dev)
+        idx = list(host.get_dataloader_sampler(shuffle=False))[0]
+        b = sampler[idx] if sampler is host else sampler.sample(idx)
+        res = runner(**{k: v.flatten(end_dim=1) for k, v in b.items() if k in ("head", "relation", "tail", "negative",
+                                                                                 "negative_mask", "triple_mask")})
+        out.append({k: v.float().cpu() for k, v in res.items()})
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]), k
+    assert float(out[0]["negative_score"].min()) < -40000  # padded candidates were masked

@@ -308,7 +308,7 @@ def build_model(c, dev, lr_loss=True):
     kind = TripleBasedShardedNegativeSampler if spec.triple_based else RandomShardedNegativeSampler
     ns = object.__new__(kind)
     ns.flat_negative_format = spec.flat
-    ns.local_sampling = False
+    ns.local_sampling = spec.local_sampling
     ns.corruption_scheme = spec.scheme
     cls = EmbeddingMovingBessKGE if c["model_cls"] == "EmbeddingMoving" else ScoreMovingBessKGE
     return cls(negative_sampler=ns, score_fn=fn, loss_fn=loss, return_scores=True, augment_negative=spec.augment)
