@@ -75,6 +75,7 @@ class OptDesc(ctypes.Structure):
         ("eps", _f32),
         ("weight_decay", _f32),
         ("step_ptr", _i64),
+        ("slot_map", _i64),
     ]
 
 
@@ -153,6 +154,7 @@ SIGNATURES = {
     "bess_neg_pertriple_step_segments": [_MD, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
                                          _vp, _i64, _vp, _vp, ctypes.POINTER(OptDesc), _vp, _vp, _vp, _vp, _vp],
     "bess_map_extra_rows": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp],
+    "bess_assign_state_rows": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
     "bess_coalesced_update": [ctypes.POINTER(OptDesc), _i32, _i32, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_i64),
                               _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "bess_neg_pertriple_items": [_MD, _i64, _i64, ctypes.POINTER(ctypes.c_int32)],
@@ -945,11 +947,8 @@ def apply_segments_opt(o: OptDesc, table: torch.Tensor, seg: SegmentIndex, grad_
     _f32(grad_seg, "grad_seg")
     if tuple(grad_seg.shape) != (seg.max_seg, W):
         raise ValueError("apply_segments_opt: grad_seg shape mismatch")
-    for st, nm in ((state1, "state1"), (state2, "state2")):
-        if st is not None:
-            _f32(st, nm)
-            if tuple(st.shape) != tuple(table.shape):
-                raise ValueError(f"apply_segments_opt: {nm} must have the shape of the table")
+    _state_ok(state1, table, o, "state1")
+    _state_ok(state2, table, o, "state2")
     with torch.cuda.device(dev):
         rc = load().bess_apply_segments_opt(ctypes.byref(o), _dtype_code(table), W, table.data_ptr(),
                                             seg.seg_rows.data_ptr(), seg.n_seg.data_ptr(), seg.max_seg,
@@ -982,11 +981,8 @@ def coalesced_update(o: Optional[OptDesc], table: torch.Tensor, seg: SegmentInde
         total += int(g.shape[0])
     if total != seg.n_refs:
         raise ValueError(f"coalesced_update: the lists hold {total} rows, the index {seg.n_refs} references")
-    for st, nm in ((state1, "state1"), (state2, "state2")):
-        if st is not None:
-            _f32(st, nm)
-            if tuple(st.shape) != tuple(table.shape):
-                raise ValueError(f"coalesced_update: {nm} must have the shape of the table")
+    _state_ok(state1, table, o, "state1")
+    _state_ok(state2, table, o, "state2")
     ptrs = (_vp * len(grads))(*[g.data_ptr() for g in grads])
     rows = (_i64 * len(grads))(*[int(g.shape[0]) for g in grads])
     out = torch.empty((seg.max_seg, W), dtype=torch.float32, device=dev) if sum_only else None
@@ -998,6 +994,28 @@ def coalesced_update(o: Optional[OptDesc], table: torch.Tensor, seg: SegmentInde
             keep.data_ptr() if keep is not None else None, out.data_ptr() if out is not None else None, _stream(dev))
     _check(rc, "bess_coalesced_update")
     return out
+
+
+def assign_state_rows(seg: Any, slot_map: torch.Tensor, counter: torch.Tensor, capacity: int,
+                      keep: Optional[torch.Tensor] = None) -> None:
+    """Paged optimiser state: give the unique rows of `seg` (those with keep != 0) a state row."""
+    dev = _same_device([("seg_rows", seg.seg_rows), ("slot_map", slot_map), ("counter", counter), ("keep", keep)])
+    if slot_map.dtype != torch.int32 or counter.dtype != torch.int32 or not slot_map.is_contiguous():
+        raise ValueError("assign_state_rows: slot_map / counter must be int32")
+    with torch.cuda.device(dev):
+        rc = load().bess_assign_state_rows(seg.seg_rows.data_ptr(), seg.n_seg.data_ptr(), seg.max_seg,
+                                           keep.data_ptr() if keep is not None else None, slot_map.data_ptr(),
+                                           counter.data_ptr(), int(capacity), _stream(dev))
+    _check(rc, "bess_assign_state_rows")
+
+
+def _state_ok(st: Optional[torch.Tensor], table: torch.Tensor, o: Optional[OptDesc], name: str) -> None:
+    if st is None:
+        return
+    _f32(st, name)
+    paged = o is not None and o.slot_map != 0
+    if st.dim() != 2 or st.shape[1] != table.shape[1] or (not paged and st.shape[0] != table.shape[0]):
+        raise ValueError(f"{name} must be [{'capacity' if paged else table.shape[0]}, {table.shape[1]}] float32")
 
 
 def map_extra_rows(seg: SegmentIndex, extra: SegmentIndex) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -1029,11 +1047,8 @@ def neg_pertriple_step_segments(d: ModelDesc, query: torch.Tensor, table: torch.
     if _dtype_code(table) != d.dtype or tuple(query.shape) != (nq, query_width(d)) \
             or tuple(d_out.shape) != (nq, n_neg) or seg.n_refs != nq * n_neg:
         raise ValueError("neg_pertriple_step_segments: operand shapes do not match")
-    for st, nm in ((state1, "state1"), (state2, "state2")):
-        if st is not None:
-            _f32(st, nm)
-            if tuple(st.shape) != tuple(table.shape):
-                raise ValueError(f"neg_pertriple_step_segments: {nm} must have the shape of the table")
+    _state_ok(state1, table, o, "state1")
+    _state_ok(state2, table, o, "state2")
     if (extra_map is None) != (extra_sum is None):
         raise ValueError("neg_pertriple_step_segments: extra_map and extra_sum come together")
     if extra_sum is not None:

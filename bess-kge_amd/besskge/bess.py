@@ -387,14 +387,37 @@ class BessKGE(torch.nn.Module, ABC):
         return None
 
     # ------------------------------------------------------- optimiser step
-    def _opt_state(self, table: torch.Tensor, n_state: int) -> Dict[str, Any]:
-        """Lazily allocated per-row optimiser state of one table."""
+    def _opt_state(self, table: torch.Tensor, n_state: int, state_rows: Optional[int] = None) -> Dict[str, Any]:
+        """Lazily allocated per-row optimiser state of one table.  `state_rows` (the optimiser's
+        `state_rows` option; only for tables with more rows than that): paged state - pools of that
+        many rows plus a row -> state-row map, rows get a state row the first time they are stepped
+        (a 128 GB shard cannot carry Adam's two fp32 tables of its own size)."""
         if not hasattr(self, "_optimizer_state"):
             self._optimizer_state: Dict[int, Dict[str, Any]] = {}
         st = self._optimizer_state.setdefault(table.data_ptr(), dict(step=0, s=[]))
+        paged = state_rows is not None and int(state_rows) < table.shape[0]
+        if paged and "slot_map" not in st and n_state > 0:
+            st["capacity"] = int(state_rows)
+            st["slot_map"] = torch.full((table.shape[0],), -1, dtype=torch.int32, device=table.device)
+            st["slot_counter"] = torch.zeros((1,), dtype=torch.int32, device=table.device)
+        shape = (st["capacity"], table.shape[1]) if "slot_map" in st else tuple(table.shape)
         while len(st["s"]) < n_state:
-            st["s"].append(torch.zeros(table.shape, dtype=torch.float32, device=table.device))
+            st["s"].append(torch.zeros(shape, dtype=torch.float32, device=table.device))
         return st
+
+    def optimizer_state_rows_used(self) -> Dict[int, Tuple[int, int]]:
+        """{table pointer: (state rows asked for so far, capacity)} of the tables with paged optimiser
+        state; asked > capacity means rows are being stepped without state (raise `state_rows`)."""
+        out = {}
+        for key, st in getattr(self, "_optimizer_state", {}).items():
+            if "slot_map" in st:
+                out[key] = (int(st["slot_counter"].item()), st["capacity"])
+        return out
+
+    def _assign_state_rows(self, table: torch.Tensor, seg: Any, keep: Optional[torch.Tensor] = None) -> None:
+        st = getattr(self, "_optimizer_state", {}).get(table.data_ptr())
+        if st is not None and "slot_map" in st:
+            nat.assign_state_rows(seg, st["slot_map"], st["slot_counter"], st["capacity"], keep)
 
     def _opt_desc(self, opt: Any, table: torch.Tensor) -> Tuple[Any, Optional[torch.Tensor], Optional[torch.Tensor]]:
         """(descriptor, state1, state2) of one optimiser step on `table` (advances its step count)."""
@@ -402,10 +425,12 @@ class BessKGE(torch.nn.Module, ABC):
             n_state = 1 if opt.momentum != 0.0 else 0
         else:
             n_state = 1 if opt.kind == nat.OPT_ADAGRAD else 2
-        state = self._opt_state(table, n_state)
+        state = self._opt_state(table, n_state, getattr(opt, "state_rows", None))
         state["step"] += 1
         o = nat.OptDesc()
         o.kind, o.step, o.lr = opt.kind, state["step"], float(opt.lr)
+        if "slot_map" in state:
+            o.slot_map = state["slot_map"].data_ptr()
         if getattr(self, "_device_step", False) and opt.kind == nat.OPT_ADAM:
             # hipGraph replay (runtime.Options.use_graphs): the launch is recorded once, so the step count of
             # Adam's bias correction lives on the device and the increment is part of the recorded step
@@ -435,6 +460,7 @@ class BessKGE(torch.nn.Module, ABC):
         if seg is None:
             seg = nat.SegmentIndex(torch.cat(ids).contiguous(), table.shape[0])
         o, s1, s2 = self._opt_desc(opt, table)
+        self._assign_state_rows(table, seg)
         grads = [g.contiguous() for _, g in contributions]
         if len(grads) > nat.MAX_ROW_LISTS:
             grads = [torch.cat(grads, dim=0)]
@@ -512,8 +538,10 @@ class BessKGE(torch.nn.Module, ABC):
             xseg = nat.SegmentIndex(idx, table.shape[0])
             xsum = nat.coalesced_update(None, table, xseg, grads, sum_only=True)
             xmap, keep = nat.map_extra_rows(seg, xseg)
+        self._assign_state_rows(table, seg)
         nat.neg_pertriple_step_segments(desc, g.query, table, g.n_per_query, go, seg, o, s1, s2, xmap, xsum)
         if extras:  # rows of the small lists that no negative points at
+            self._assign_state_rows(table, xseg, keep)
             nat.apply_segments_opt(o, table, xseg, xsum, s1, s2, keep=keep)
 
     def _wants_segments(self, g: _NegGroup, st: _ReplicaStep) -> bool:

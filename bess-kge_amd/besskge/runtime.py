@@ -69,6 +69,9 @@ class SGD:
     lr: float = 0.01
     momentum: float = 0.0
     weight_decay: float = 0.0
+    #: paged state: keep at most this many rows of momentum per shard (rows get one when first stepped);
+    #: None = a state table of the shard's own size
+    state_rows: Optional[int] = None
     #: how replicated-parameter gradients are combined over replicas ("sum" is
     #: d(sum of replica losses); PopTorch's choice is not visible in the
     #: reference repo -> parity unpinned)
@@ -89,6 +92,8 @@ class Adagrad:
     eps: float = 1e-10
     weight_decay: float = 0.0
     replica_reduction: str = "sum"
+    #: paged state (see :class:`SGD`)
+    state_rows: Optional[int] = None
     kind = 1  # BESS_OPT_ADAGRAD
     is_plain_sgd = False
 
@@ -105,6 +110,10 @@ class Adam:
     eps: float = 1e-8
     weight_decay: float = 0.0
     replica_reduction: str = "sum"
+    #: paged state: the two moment tables hold at most this many rows per shard, a row gets its pair the
+    #: first time it is stepped (BASELINE configs[4]: Adam state of a 128 GB shard's own size would be
+    #: 256 GB); `BessKGE.optimizer_state_rows_used()` tells when the pool is exhausted.  None = full tables
+    state_rows: Optional[int] = None
     kind = 2  # BESS_OPT_ADAM
     is_plain_sgd = False
 
@@ -231,7 +240,9 @@ class Runner:
             buffers=[(b, b.clone()) for b in fn.buffers()], opt={})
         for key, st in getattr(self.model, "_optimizer_state", {}).items():
             snap["opt"][key] = dict(step=st["step"], s=[t.clone() for t in st["s"]],
-                                    step_dev=st["step_dev"].clone() if "step_dev" in st else None)
+                                    step_dev=st["step_dev"].clone() if "step_dev" in st else None,
+                                    paging=(st["slot_map"].clone(), st["slot_counter"].clone())
+                                    if "slot_map" in st else None)
         return snap
 
     def _restore_training_snapshot(self, snap: Dict[str, Any]) -> None:
@@ -251,6 +262,13 @@ class Runner:
                     t.copy_(old["s"][i])
                 else:
                     t.zero_()
+            if "slot_map" in st:  # paged state: which row owns which state row
+                if old and old.get("paging") is not None:
+                    st["slot_map"].copy_(old["paging"][0])
+                    st["slot_counter"].copy_(old["paging"][1])
+                else:
+                    st["slot_map"].fill_(-1)
+                    st["slot_counter"].zero_()
             if "step_dev" in st:
                 if old and old["step_dev"] is not None:
                     st["step_dev"].copy_(old["step_dev"])

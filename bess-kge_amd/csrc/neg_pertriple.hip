@@ -237,9 +237,12 @@ __global__ __launch_bounds__(256) void k_combine_dq(const float* __restrict__ st
 
 // Backward: d_neg[(q, k), :] = g * df/de ; d_query[q, :] += sum_k g * df/dq  with
 // g = d_out[q, k].  f = q.e (DOT) | -||q-e||_1 | -||q-e||_2 (sign folded in).
-// Same mapping as forward; the per-item partial of d_query is added atomically
-// (items_per_query partials per query).
-template <typename T, int VEC, int IT, int RED>
+// Same mapping and the same load discipline as the forward: UNROLL row groups issued back to back,
+// unconditional loads at clamped rows, the row ids and score gradients of the next groups fetched
+// while the current rows are in flight (the first version of this kernel loaded one row group per
+// iteration behind its own index load: 675 us for the launch the forward does in 293).  The per-item
+// partial of d_query is added atomically (items_per_query partials per query).
+template <typename T, int VEC, int IT, int RED, int UNROLL>
 __global__ __launch_bounds__(256) void k_neg_pertriple_bwd(NegPtArgs a,
                                                            const float* __restrict__ d_out,
                                                            int64_t ld_dout,
@@ -258,66 +261,78 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_bwd(NegPtArgs a,
     const float* qp = a.query + q * a.W;
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int c = g + 16 * it;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            qv[it][v] = 0.f;
-            dq[it][v] = 0.f;
-        }
-        load_chunk<float, VEC>(qp, c, a.nch, qv[it]);
+        for (int v = 0; v < VEC; ++v) dq[it][v] = 0.f;
+        load_chunk<float, VEC>(qp, g + 16 * it, a.nch, qv[it]);
     }
     const T* base = static_cast<const T*>(a.base);
     const int32_t* idx = a.idx + q * a.n_neg;
+    const float* grow = d_out + q * ld_dout;
 
-    for (int kb = k0; kb < k1; kb += 4) {
-        const int k = kb + sub;
-        const bool valid = k < k1;
-        const int ks = valid ? k : (k1 - 1);
-        const T* rp = base + static_cast<int64_t>(idx[ks]) * a.W;
-        float ev[IT][VEC];
+    int32_t nrow[UNROLL];
+    float ngo[UNROLL];
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int c = g + 16 * it;
+    for (int u = 0; u < UNROLL; ++u) {
+        const int kk = min(k0 + sub + 4 * u, k1 - 1);
+        nrow[u] = idx[kk];
+        ngo[u] = grow[kk];
+    }
+    for (int kb = k0; kb < k1; kb += 4 * UNROLL) {  // kb is wave-uniform
+        float ev[UNROLL][IT][VEC], go[UNROLL];
+        int ks[UNROLL];
+        bool valid[UNROLL];
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) ev[it][v] = 0.f;
-            load_chunk<T, VEC>(rp, c, a.nch, ev[it]);
+        for (int u = 0; u < UNROLL; ++u) {
+            const int k = kb + sub + 4 * u;
+            valid[u] = k < k1;
+            ks[u] = min(k, k1 - 1);
+            const T* rp = base + static_cast<int64_t>(nrow[u]) * a.W;
+            go[u] = valid[u] ? a.sign * ngo[u] : 0.f;
+            const int kn = min(k + 4 * UNROLL, k1 - 1);
+            nrow[u] = idx[kn];
+            ngo[u] = grow[kn];
+#pragma unroll
+            for (int it = 0; it < IT; ++it) load_chunk<T, VEC>(rp, g + 16 * it, a.nch, ev[u][it]);
         }
-        float go = valid ? a.sign * d_out[q * ld_dout + ks] : 0.f;
-        if (RED == RED_L2) {
-            float ss = 0.f;
 #pragma unroll
-            for (int it = 0; it < IT; ++it)
+        for (int u = 0; u < UNROLL; ++u) {
+            float gg = go[u];
+            if (RED == RED_L2) {
+                float ss = 0.f;
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const float dlt = qv[it][v] - ev[u][it][v];
+                        ss = fmaf(dlt, dlt, ss);
+                    }
+                ss = row16_allreduce_sum(ss);
+                gg = ss > 0.f ? gg / sqrtf(ss) : 0.f;
+            }
+            float* dn = d_neg + (q * a.n_neg + ks[u]) * a.W;
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = g + 16 * it;
+                float de[VEC];
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
-                    const float dlt = qv[it][v] - ev[it][v];
-                    ss = fmaf(dlt, dlt, ss);
+                    float dqe;  // d f / d q_w  (d f / d e_w = -dqe for distances)
+                    if (RED == RED_DOT) {
+                        dqe = gg * ev[u][it][v];
+                        de[v] = gg * qv[it][v];
+                    } else if (RED == RED_L1) {
+                        dqe = gg * sgnf(qv[it][v] - ev[u][it][v]);
+                        de[v] = -dqe;
+                    } else {
+                        dqe = gg * (qv[it][v] - ev[u][it][v]);
+                        de[v] = -dqe;
+                    }
+                    dq[it][v] += dqe;
                 }
-            ss = row16_allreduce_sum(ss);
-            go = ss > 0.f ? go / sqrtf(ss) : 0.f;
-        }
-        float* dn = d_neg + (q * a.n_neg + ks) * a.W;
+                if (d_neg && valid[u] && c < a.nch) {  // d_neg == NULL: only d_query is wanted
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int c = g + 16 * it;
-            float de[VEC];
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                float dqe;  // d f / d q_w  (d f / d e_w = -dqe for distances)
-                if (RED == RED_DOT) {
-                    dqe = go * ev[it][v];
-                    de[v] = go * qv[it][v];
-                } else if (RED == RED_L1) {
-                    dqe = go * sgnf(qv[it][v] - ev[it][v]);
-                    de[v] = -dqe;
-                } else {
-                    dqe = go * (qv[it][v] - ev[it][v]);
-                    de[v] = -dqe;
+                    for (int v = 0; v < VEC; ++v) dn[c * VEC + v] = de[v];
                 }
-                dq[it][v] += dqe;
-            }
-            if (d_neg && valid && c < a.nch) {  // d_neg == NULL: only d_query is wanted
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) dn[c * VEC + v] = de[v];
             }
         }
     }
@@ -356,7 +371,9 @@ template <typename T, int VEC, int IT, int RED>
 static void launch_bwd(const NegPtArgs& a, const float* d_out, int64_t ld, float* dq, float* dn,
                        hipStream_t st) {
     const int64_t items = a.n_query * a.items_per_query;
-    k_neg_pertriple_bwd<T, VEC, IT, RED><<<ceil_div(items, 4), 256, 0, st>>>(a, d_out, ld, dq, dn);
+    constexpr int EPL = IT * VEC;          // scalars per lane per row; the running d_query sum takes EPL registers too
+    constexpr int BU = EPL <= 16 ? 2 : 1;  // (as the fused forward)
+    k_neg_pertriple_bwd<T, VEC, IT, RED, BU><<<ceil_div(items, 4), 256, 0, st>>>(a, d_out, ld, dq, dn);
 }
 
 template <typename T, int VEC, int IT>

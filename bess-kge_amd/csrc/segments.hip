@@ -145,7 +145,15 @@ struct OptArgs {
     float lr, momentum, beta1, beta2, eps, weight_decay;
     float bias1, bias2;           // 1 - beta^t for Adam (from the host's step count)
     const int32_t* step_ptr;      // optional: step count on the device, overrides bias1 / bias2
+    const int32_t* slot_map;      // optional: state row of every table row (paged state), -1 = none
 };
+
+// Row of the state tables that belongs to table row `row`: the row itself, or - paged state - the slot
+// bess_assign_state_rows gave it (-1 when the pool is exhausted: the row is then stepped from zero state
+// and its state is not kept).
+__device__ __forceinline__ int64_t state_row(const OptArgs& o, int64_t row) {
+    return o.slot_map ? static_cast<int64_t>(o.slot_map[row]) : row;
+}
 
 // bias corrections from the device-side step count, when there is one
 __device__ __forceinline__ OptArgs opt_resolve(OptArgs o) {
@@ -304,9 +312,12 @@ __device__ __forceinline__ void seg_finish(const SegArgs& a, int g, int64_t seg,
             if (x >= 0) load_chunk<float, VEC>(a.opt.xsum + static_cast<int64_t>(x) * a.W, c, a.nch, xs);
             typedef float fvec __attribute__((ext_vector_type(VEC)));
             const int64_t at = row * a.W + c * VEC;
+            const int64_t srow = state_row(oo, row);
+            const int64_t sat = srow * a.W + c * VEC;
+            const bool has1 = a.opt.state1 && srow >= 0, has2 = a.opt.state2 && srow >= 0;
             fvec s1v = 0.f, s2v = 0.f;
-            if (a.opt.state1) s1v = __builtin_nontemporal_load(reinterpret_cast<const fvec*>(a.opt.state1 + at));
-            if (a.opt.state2) s2v = __builtin_nontemporal_load(reinterpret_cast<const fvec*>(a.opt.state2 + at));
+            if (has1) s1v = __builtin_nontemporal_load(reinterpret_cast<const fvec*>(a.opt.state1 + sat));
+            if (has2) s2v = __builtin_nontemporal_load(reinterpret_cast<const fvec*>(a.opt.state2 + sat));
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 float p = ev[it][v], s1 = s1v[v], s2 = s2v[v];
@@ -315,8 +326,8 @@ __device__ __forceinline__ void seg_finish(const SegArgs& a, int g, int64_t seg,
                 s1v[v] = s1;
                 s2v[v] = s2;
             }
-            if (a.opt.state1) __builtin_nontemporal_store(s1v, reinterpret_cast<fvec*>(a.opt.state1 + at));
-            if (a.opt.state2) __builtin_nontemporal_store(s2v, reinterpret_cast<fvec*>(a.opt.state2 + at));
+            if (has1) __builtin_nontemporal_store(s1v, reinterpret_cast<fvec*>(a.opt.state1 + sat));
+            if (has2) __builtin_nontemporal_store(s2v, reinterpret_cast<fvec*>(a.opt.state2 + sat));
         }
         return;
     }
@@ -538,13 +549,34 @@ __global__ __launch_bounds__(256) void k_coalesced_update(OptArgs o, RowLists L,
                 continue;
             }
             const int64_t at = row * W + c;
+            const int64_t srow = state_row(o, row);
+            const int64_t sat = srow * W + c;
             float p = static_cast<float>(table[at]);
-            float s1 = state1 ? state1[at] : 0.f, s2 = state2 ? state2[at] : 0.f;
+            float s1 = (state1 && srow >= 0) ? state1[sat] : 0.f, s2 = (state2 && srow >= 0) ? state2[sat] : 0.f;
             opt_step(o, p, acc, s1, s2);
-            if (state1) state1[at] = s1;
-            if (state2) state2[at] = s2;
+            if (state1 && srow >= 0) state1[sat] = s1;
+            if (state2 && srow >= 0) state2[sat] = s2;
             table[at] = static_cast<T>(p);
         }
+    }
+}
+
+// Paged optimiser state: the state tables hold `capacity` rows; a table row gets one when it is first
+// stepped (slot_map[row] = its state row, -1 before).  One thread per unique row of the step; rows are
+// unique, so no two threads assign the same row.  counter[0] counts the assignments asked for - beyond
+// `capacity` a row stays at -1 (the host reads counter[0] to notice an exhausted pool).
+__global__ __launch_bounds__(256) void k_assign_state_rows(const int32_t* __restrict__ seg_rows,
+                                                           const int32_t* __restrict__ n_seg,
+                                                           const int32_t* __restrict__ keep,
+                                                           int32_t* __restrict__ slot_map, int32_t* __restrict__ counter,
+                                                           int32_t capacity) {
+    const int ns = *n_seg;
+    for (int64_t s = blockIdx.x * 256ll + threadIdx.x; s < ns; s += 256ll * gridDim.x) {
+        if (keep && keep[s] == 0) continue;
+        const int64_t row = seg_rows[s];
+        if (slot_map[row] >= 0) continue;
+        const int slot = atomicAdd(counter, 1);
+        if (slot < capacity) slot_map[row] = slot;
     }
 }
 
@@ -563,12 +595,15 @@ __global__ __launch_bounds__(256) void k_apply_segments_opt(OptArgs o, T* __rest
         const int64_t s = t / W;
         if (keep && keep[s] == 0) continue;
         const int c = static_cast<int>(t - s * W);
-        const int64_t at = static_cast<int64_t>(seg_rows[s]) * W + c;
+        const int64_t row = seg_rows[s];
+        const int64_t at = row * W + c;
+        const int64_t srow = state_row(o, row);
+        const int64_t sat = srow * W + c;
         float p = static_cast<float>(table[at]);
-        float s1 = state1 ? state1[at] : 0.f, s2 = state2 ? state2[at] : 0.f;
+        float s1 = (state1 && srow >= 0) ? state1[sat] : 0.f, s2 = (state2 && srow >= 0) ? state2[sat] : 0.f;
         opt_step(o, p, grad_seg[t], s1, s2);
-        if (state1) state1[at] = s1;
-        if (state2) state2[at] = s2;
+        if (state1 && srow >= 0) state1[sat] = s1;
+        if (state2 && srow >= 0) state2[sat] = s2;
         table[at] = static_cast<T>(p);
     }
 }
@@ -780,7 +815,8 @@ static int grad_segments_impl(const bess_model_desc* d, const float* query, int6
 
 static OptArgs opt_args(const bess_opt_desc* o) {
     OptArgs a{o->kind, o->lr, o->momentum, o->beta1, o->beta2, o->eps, o->weight_decay, 1.f, 1.f,
-              reinterpret_cast<const int32_t*>(static_cast<uintptr_t>(o->step_ptr))};
+              reinterpret_cast<const int32_t*>(static_cast<uintptr_t>(o->step_ptr)),
+              reinterpret_cast<const int32_t*>(static_cast<uintptr_t>(o->slot_map))};
     if (o->kind == BESS_OPT_ADAM && !o->step_ptr) {
         a.bias1 = 1.f - powf(o->beta1, static_cast<float>(o->step));
         a.bias2 = 1.f - powf(o->beta2, static_cast<float>(o->step));
@@ -934,4 +970,15 @@ extern "C" int bess_coalesced_update(const bess_opt_desc* o, int32_t dtype, int3
                                                                         refs_sorted, seg_rows, seg_offsets, n_seg, s1,
                                                                         s2, keep, sum_out);
     return check_launch("coalesced_update");
+}
+
+extern "C" int bess_assign_state_rows(const int32_t* seg_rows, const int32_t* n_seg, int64_t max_seg,
+                                      const int32_t* keep, int32_t* slot_map, int32_t* counter, int64_t capacity,
+                                      void* stream) {
+    BESS_REQUIRE(seg_rows && n_seg && slot_map && counter, "assign_state_rows: NULL pointer");
+    BESS_REQUIRE(max_seg > 0 && capacity > 0 && capacity < (1ll << 31), "assign_state_rows: bad sizes");
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(max_seg, 256), 1024));
+    k_assign_state_rows<<<grid, 256, 0, as_stream(stream)>>>(seg_rows, n_seg, keep, slot_map, counter,
+                                                            static_cast<int32_t>(capacity));
+    return check_launch("assign_state_rows");
 }

@@ -120,6 +120,10 @@ typedef struct bess_opt_desc {
     float weight_decay;
     int64_t step_ptr; /* 0, or a device `const int32_t*`: the step count is read there by the kernels
                          instead of `step` (a hipGraph replays the same launch with a growing count) */
+    int64_t slot_map; /* 0: state1 / state2 are [M, W] like the table.  Else a device `const int32_t*` [M] (paged
+                         state): the state of table row r is row slot_map[r] of state1 / state2 [capacity, W]
+                         (-1: the row has none - it is stepped from zero state and none is kept);
+                         bess_assign_state_rows hands the rows of a step their state rows first */
 } bess_opt_desc;
 
 typedef struct bess_loss_desc {
@@ -448,6 +452,16 @@ int bess_coalesced_update(const bess_opt_desc* o, int32_t dtype, int32_t width, 
                           const int32_t* seg_offsets, const int32_t* n_seg, int64_t max_seg,
                           float* state1, float* state2, const int32_t* keep, float* sum_out,
                           void* stream);
+
+/* Paged optimiser state (a shard of tens of GB cannot carry one or two fp32 state tables of its own size:
+ * BASELINE configs[4] is 128 GB per shard): state tables of `capacity` rows, a table row gets one the first
+ * time it is stepped.  For every unique row seg_rows[s], s < *n_seg (with keep[s] != 0 where keep is given)
+ * that has slot_map[row] < 0: slot_map[row] = counter[0]++ while that is below capacity.  The state pools
+ * must be zero when a slot is first used (allocate them zeroed).  counter[0] > capacity afterwards tells
+ * the host that the pool is exhausted. */
+int bess_assign_state_rows(const int32_t* seg_rows, const int32_t* n_seg, int64_t max_seg,
+                           const int32_t* keep, int32_t* slot_map, int32_t* counter, int64_t capacity,
+                           void* stream);
 
 /* K9 + K10 in one pass for the stateful optimisers (what bess_neg_pertriple_grad_segments
  * with fused_sgd_lr is for plain SGD): the summed gradient of each unique row is consumed by

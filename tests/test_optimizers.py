@@ -305,3 +305,40 @@ def test_coalesced_update_of_several_lists(dev, kind, dtype):
     assert torch.equal(got[rows[0]], table[rows[0]])
     with pytest.raises(ValueError, match="references"):
         nat.coalesced_update(o, t_dev, seg, grads[:2], s1, s2)
+
+
+@pytest.mark.parametrize("case", ["tr_EM_ComplEx0_h_pt_n1", "tr_EM_TransE1_t_flat_n1"])
+@pytest.mark.parametrize("graphs", [False, True])
+def test_paged_optimizer_state(dev, case, graphs):
+    """`Adam(state_rows=...)`: moment tables of `state_rows` rows instead of the shard's size, a row gets its
+    pair of state rows when it is first stepped (bess_assign_state_rows).  With room for every touched row
+    the trajectory is that of full-size state; an exhausted pool is reported and does not fault."""
+    from besskge import runtime
+    from test_hip_parity import build_model
+
+    c = load_bess_case(case)
+    keys = ("head", "relation", "tail", "negative", "negative_mask")
+    bps = c["meta"]["bps"]
+    batches = [{k: c["batch"][k].flatten(end_dim=1)[i: i + 1] for k in keys if k in c["batch"]} for i in range(bps)]
+    out = []
+    for rows in (None, 100):  # the golden shard has 120 rows, ~50 of them touched per step
+        model = build_model(c, dev)
+        opt = runtime.Adam(lr=0.01, weight_decay=0.01, state_rows=rows)
+        runner = runtime.training_model(model, runtime.Options(device_iterations=1, use_graphs=graphs), opt, device=dev)
+        for i in range(4):
+            runner(**batches[i % bps])
+        out.append(model.score_fn.entity_embedding.detach().float().cpu().clone())
+        if rows is not None:
+            (used, cap), = model.optimizer_state_rows_used().values()
+            assert cap == 100 and 0 < used <= 100
+            st = next(iter(model._optimizer_state.values()))
+            assert all(tuple(t.shape) == (100, model.entity_embedding_size) for t in st["s"]) or "slot_map" not in st
+    torch.testing.assert_close(out[1], out[0], rtol=1e-5, atol=1e-6)
+    if not graphs:
+        model = build_model(c, dev)
+        runner = runtime.training_model(model, optimizer=runtime.Adam(lr=0.01, state_rows=8), device=dev)
+        for i in range(3):
+            runner(**batches[i % bps])
+        (used, cap), = model.optimizer_state_rows_used().values()
+        assert cap == 8 and used > 8  # exhausted: reported, rows beyond the pool were stepped from zero state
+        assert bool(torch.isfinite(model.score_fn.entity_embedding.detach().float()).all())
