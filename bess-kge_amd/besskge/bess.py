@@ -501,6 +501,10 @@ class BessKGE(torch.nn.Module, ABC):
                     add(g.ent)
             if not ok or not plan:
                 continue
+            if sum(int(x.numel()) for x in plan) < 4096:
+                # a short list is indexed in ~10 us: not worth a fork / join of the streams (which costs
+                # about as much inside a replayed hipGraph); `_apply_optimizer` builds it where it is needed
+                continue
             if st.n > 1:
                 if st.ext_src is not None:
                     add(st.ext_src)

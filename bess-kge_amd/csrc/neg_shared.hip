@@ -179,17 +179,31 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
     const int64_t a0 = static_cast<int64_t>(blockIdx.y) * TM;
     const int w0 = blockIdx.x * TN;
     float acc[4][4], xv[4][4];
+    // this thread's 4 x 4 values of X: rows and columns past the end are clamped (their results are dropped
+    // at the store), so the 4 row loads are issued together - a per-element `in range ? load : 0` made the
+    // compiler wait for each of the 16 loads (and the index load in front of it) in turn: 16 round trips
+    // to L2 / HBM at the start of every workgroup, ~8 us of a ~50 us workgroup
+    {
+        const TX* xr[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t a = a0 + ty * 4 + i;
+        for (int i = 0; i < 4; ++i) xr[i] = X.row(min(a0 + ty * 4 + i, X.n - 1), W);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int w = w0 + tx * 4 + j;
-            acc[i][j] = 0.f;
-            xv[i][j] = (a < X.n && w < W) ? to_f32(X.row(a, W)[w]) : 0.f;
-            if (ROUND16) xv[i][j] = static_cast<float>(static_cast<_Float16>(xv[i][j]));
-            if (RED == RED_L1) xv[i][j] *= SGN_PRESCALE;
+        for (int i = 0; i < 4; ++i) {
+            if (VEC4) {
+                VecLoad<TX, 4>::load(xr[i] + min(w0 + tx * 4, W - 4), xv[i]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xv[i][j] = to_f32(xr[i][min(w0 + tx * 4 + j, W - 1)]);
+            }
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = 0.f;
+                if (ROUND16) xv[i][j] = static_cast<float>(static_cast<_Float16>(xv[i][j]));
+                if (RED == RED_L1) xv[i][j] *= SGN_PRESCALE;
+            }
     }
     // blockIdx.z owns the slice [b_lo, b_hi) of the reduction; partial sums of
     // several slices are combined with fp32 atomics (dX zeroed by the host)

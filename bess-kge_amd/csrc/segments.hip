@@ -22,14 +22,22 @@
 
 #include "common.h"
 
+#ifndef BESS_SORT_RADIX_BITS
+#define BESS_SORT_RADIX_BITS 9
+#endif
+
 namespace bess {
 
 static inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 
 // rocPRIM's default sorts up to 2^20 items with ~10 merge passes; the row ids have
 // few significant bits, so the Onesweep LSD radix sort (stable) is 3 passes instead.
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                              rocprim::default_config, 32768>;
+// 9 bits per place instead of rocPRIM's 8: the 17 significant bits of a 93,773-row shard (BASELINE
+// configs[1]), and the 18-19 of a 312,576-row one, then take two passes over the references instead of three.
+using OnesweepConfig = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>,
+                                                           rocprim::kernel_config<1024, 8>, BESS_SORT_RADIX_BITS,
+                                                           rocprim::block_radix_rank_algorithm::match>;
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, OnesweepConfig, 32768>;
 
 struct CubSizes {
     size_t sort, rle, scan, total_cub;
