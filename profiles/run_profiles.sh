@@ -8,7 +8,8 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+# the headline leg only: the extra legs of the bench line (roofline_hbm, c4, train_step) have their own runs below
+BENCH="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs"
 # 1. kernel trace + stats, score mode (the bench default) and train mode
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/score -- $BENCH > $OUT/score.json 2> $OUT/score.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- $BENCH --mode train > $OUT/train.json 2> $OUT/train.err || exit 1
@@ -19,3 +20,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write 
 $BENCH --entities-per-shard 4000000 > $OUT/score_hbm.json 2> $OUT/score_hbm.err || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_hbm -- $BENCH --entities-per-shard 4000000 > $OUT/pmc_fetch_hbm.json 2> $OUT/pmc_fetch_hbm.err || exit 1
 find $OUT -name "*.csv" | head -50
+# 4. one traced training step per workload (kernel by kernel, in start order): C2 (SGD, AdamW), C4 (S=512 eager /
+#    hipGraph, S=4096)
+bash profiles/run_step_traces.sh $TAG "c2 c2adam c4s c4g c4" || exit 1
+cp gpurun_out/step_${TAG}_*.txt $OUT/ 2>/dev/null

@@ -44,13 +44,31 @@ lines.append(f"| 4,000,000-row shard (8.2 GB, HBM resident) | FETCH_SIZE | {pm['
 lines.append("\nFETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for 16 B/lane coalesced reads on gfx950;"
              " WRITE_SIZE is used as read (4-byte scattered score stores: uncalibrated width, small).  Algorithmic bytes"
              " of the launch: 2,164,260,864.\n")
-json.dump({"neg_score_pertriple_fwd_bytes_per_launch": 2 * fetch * 1024 + write * 1024, "fetch_size_kib": fetch,
-           "write_size_kib": write, "fetch_size_kib_hbm_resident_8GB_shard": fetch_hbm,
-           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python3 bench.py --steps 20 --warmup 5"
-                   " --no-cpu-baseline`; traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (profiles/summarize.py)"},
-          open("profiles/pmc_traffic.json", "w"), indent=1)
+pmc = {"neg_score_pertriple_fwd_bytes_per_launch": 2 * fetch * 1024 + write * 1024, "fetch_size_kib": fetch,
+       "write_size_kib": write, "fetch_size_kib_hbm_resident_8GB_shard": fetch_hbm,
+       "hbm_resident_bytes_per_launch": 2 * fetch_hbm * 1024 + write * 1024,
+       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python3 bench.py --steps 20 --warmup 5"
+               " --no-cpu-baseline --no-extra-legs`; traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (profiles/summarize.py)"}
+json.dump(pmc, open(f"{out}/pmc_traffic.json", "w"), indent=1)
+json.dump(pmc, open("profiles/pmc_traffic.json", "w"), indent=1)
 for name in ("score.json", "train.json", "score_hbm.json"):
     os.system(f"cp {src}/{name} {out}/bench_{name}")
+os.system(f"cp {src}/step_{tag}_*.txt {out}/ 2>/dev/null")
+steps = sorted(glob.glob(f"{out}/step_{tag}_*.txt"))
+if steps:
+    lines.append("## One training step, kernel by kernel (`profiles/step_trace.py`, rocprofv3 --kernel-trace)\n\n"
+                 "| file | workload | dispatches | span (us) | sum of kernel durations (us) |\n|---|---|---|---|---|\n")
+    what = {"c2": "C2 ComplEx d=256 fp32, S=4096 x 256 per-triple, SGD", "c2adam": "same, AdamW",
+            "c4s": "C4 TransE d=256 fp16, S=512, K=32, eager", "c4g": "C4 TransE d=256 fp16, S=512, K=32, hipGraph replay",
+            "c4": "C4 TransE d=256 fp16, S=4096, K=256, eager"}
+    for f in steps:
+        txt = open(f).read().splitlines()
+        key = os.path.basename(f)[len(f"step_{tag}_"):-4]
+        n = txt[0].split()[1]
+        tail = txt[-1].replace("# span ", "").replace(" us, sum of kernel durations ", "|").replace(" us", "")
+        span, busy = tail.split("|")
+        lines.append(f"| `{os.path.basename(f)}` | {what.get(key, key)} | {n} | {span} | {busy} |\n")
+    lines.append("\n")
 # index of the other logs kept for this round (each is the stdout of the script named in its first column)
 INDEX = [
     ("bench_default.json", "python bench.py", "the driver's line: value, roofline, train_step (SGD and AdamW), cpu_baseline"),
@@ -69,6 +87,9 @@ INDEX = [
     ("stress_topk.log", "profiles/stress_topk.py", "150 random top-k problems (ties, masks, padded rows) vs a stable sort"),
     ("ubench_hbm_bw.log", "profiles/ubench/hbm_bw.hip", "what the memory system delivers: streaming and random-row reads"),
     ("ubench_valu_rate.log", "profiles/ubench/valu_rate.hip", "VALU ceiling of the p-norm tile kernels (scalar and packed)"),
+    ("ubench_valu_pk.log", "profiles/ubench/valu_pk.hip", "issue rate of every packed 16-bit / dot2 instruction against v_add_f32 (0.6x), and of the packed L1 forms"),
+    ("bench_c5.log", "profiles/bench_c5.py", "BASELINE configs[4]: one shard at its real size (62.5 M x 512 fp32 = 128 GB), dominant kernel TB/s, train step"),
+    ("microbench_l1.log", "profiles/microbench.py \"L1 shared\"", "packed-fp16 L1 forward vs the fp32 kernels; backward"),
     ("ubench_mfma_f32.log", "profiles/ubench/mfma_f32.hip", "fp32 MFMA inner loop ceiling"),
     ("ubench_mfma_f16.log", "profiles/ubench/mfma_f16.hip", "fp16 MFMA consumer loop of the split GEMM: rate and clocks"),
     ("ubench_l1_tile.log", "profiles/ubench/l1_tile.hip", "the steps that took the L1 tile kernel from 35 to 48 T lane-ops/s"),
