@@ -25,7 +25,7 @@ import besskge  # noqa: E402,F401
 from besskge import runtime, scoring  # noqa: E402
 from besskge.batch_sampler import RandomShardedBatchSampler, RigidShardedBatchSampler  # noqa: E402
 from besskge.bess import EmbeddingMovingBessKGE, TopKQueryBessKGE  # noqa: E402
-from besskge.collectives import DistributedGroup  # noqa: E402
+from besskge.collectives import DistributedGroup, NativeGroup  # noqa: E402
 from besskge.dataset import KGDataset  # noqa: E402
 from besskge.device_sampler import DeviceBatchSampler  # noqa: E402
 from besskge.loss import LogSigmoidLoss  # noqa: E402
@@ -46,15 +46,20 @@ def main(argv=None) -> dict:
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist.init_process_group(backend, **(dict(device_id=dev) if backend == "nccl" else {}))
-    group = DistributedGroup()
+    # nccl: the library's own RCCL entry points on the kernels' stream (bess_comm_*); gloo (several ranks sharing one
+    # GPU in a test): c10d with host staging
+    group = NativeGroup(dev) if backend == "nccl" else DistributedGroup()
 
     # every rank builds the same (seeded) graph, sharding and samplers; only its shard goes to its GPU
     train, test = synthetic_graph(args.n_entity, 8, 30000, seed=0)
     ds = KGDataset(n_entity=args.n_entity, n_relation_type=8, triples={"train": train, "test": test},
                    original_triple_ids={"train": np.arange(len(train)), "test": np.arange(len(test))})
     sharding = Sharding.create(args.n_entity, world, seed=0)
+    # only this rank's shard is allocated, directly on its GPU; the relation table is replicated (same seed everywhere)
+    torch.manual_seed(100 + rank)
+    fn = scoring.TransE(True, 1, sharding, 8, args.embedding_size, device=dev, shards=[rank])
     torch.manual_seed(0)
-    fn = scoring.TransE(True, 1, sharding, 8, args.embedding_size)
+    torch.nn.init.uniform_(fn.relation_embedding.data, -1.0 / args.embedding_size, 1.0 / args.embedding_size)
     pts = PartitionedTripleSet.create_from_dataset(ds, "train", sharding, partition_mode="ht_shardpair")
     ns = RandomShardedNegativeSampler(n_negative=64, sharding=sharding, seed=1, corruption_scheme="t",
                                       local_sampling=False, flat_negative_format=True)
