@@ -327,9 +327,12 @@ static int run_bwd_one(const bess_model_desc* d, RowSrc<TX> X, RowSrc<TY> Y, con
                        int64_t sa, int64_t sb, const float* out, int64_t oa, int64_t ob, float* dX,
                        hipStream_t st, bool round16 = false) {
     const int64_t tiles = ceil_div(d->width, TN) * ceil_div(X.n, TM);
-    // split the reduction over Y until ~4 workgroups per CU are in flight
-    int64_t split = 1;
-    while (tiles * split < 1024 && ceil_div(Y.n, split * 2) >= 4 * KT) split *= 2;
+    // split the reduction over Y until 5 workgroups per CU are in flight - what the kernel's 94 VGPRs admit
+    // (rocprofv3 SQ counters at 4 per CU: VALU issue 61 % of the cycles, waves parked at waits / barriers 27 %
+    // of theirs - a wave alone issues at half rate, so resident waves are what fills the pipe), in slices of
+    // at least 4 stages
+    int64_t split = ceil_div(256 * 5, tiles);
+    while (split > 1 && ceil_div(Y.n, split) < 4 * KT) --split;
     int64_t chunk = ceil_div(ceil_div(Y.n, split), KT) * KT;
     split = ceil_div(Y.n, chunk);
     if (split > 1) {
