@@ -458,7 +458,8 @@ class BessKGE(torch.nn.Module, ABC):
                 a.data_ptr() == b.data_ptr() and a.numel() == b.numel() for a, b in zip(ahead[0], ids)):
             seg = ahead[1]
         if seg is None:
-            seg = nat.SegmentIndex(torch.cat(ids).contiguous(), table.shape[0])
+            seg = nat.SegmentIndex(torch.cat(ids).contiguous(), table.shape[0],
+                                   scratch=self.__dict__.setdefault("_seg_scratch", {}))
         o, s1, s2 = self._opt_desc(opt, table)
         self._assign_state_rows(table, seg)
         grads = [g.contiguous() for _, g in contributions]
@@ -513,7 +514,8 @@ class BessKGE(torch.nn.Module, ABC):
             side = self._aux_stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                out[id(st)] = (plan, nat.SegmentIndex(torch.cat(plan).contiguous(), st.table.shape[0]))
+                out[id(st)] = (plan, nat.SegmentIndex(torch.cat(plan).contiguous(), st.table.shape[0],
+                                                      scratch=self.__dict__.setdefault("_seg_scratch", {})))
         return out
 
     def _apply_optimizer_dense(self, opt: Any, table: torch.Tensor, grad: torch.Tensor) -> None:

@@ -187,16 +187,17 @@ class Runner:
             # the optimiser state lives in device tables the recorded kernels update in place; Adam's step
             # count moves to the device (BessKGE._opt_desc).  Hyper-parameters are recorded by value.
             self.model._device_step = True
-        n = self.group.n_shard
-        sig = tuple((k, tuple(v.shape[1:]), v.dtype) for k, v in sorted(batch.items()))
+        # ONE graph per call: all `device_iterations` micro-batches are recorded back to back (as PopTorch runs
+        # its device iterations inside one compiled program), reading their inputs from a static copy of the
+        # whole call's batch - so a call costs one copy per input tensor and one graph launch, not one of each
+        # per micro-batch (at the notebooks' micro-batch the four input copies, the replay and the output
+        # clones were a third of the step).
+        sig = (iters,) + tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()))
         cache = self.__dict__.setdefault("_graphs", {})
         if sig not in cache:
-            static = [{k: torch.empty((1, *v.shape[1:]), dtype=v.dtype, device=self.device) for k, v in batch.items()}
-                      for _ in self.group.local_shards]
-            for slot, rep in zip(static, self._split(batch, 0)):
-                for k, v in rep.items():
-                    slot[k].copy_(v)
-            fn = self.model.score_fn
+            static = {k: torch.empty(v.shape, dtype=v.dtype, device=self.device) for k, v in batch.items()}
+            for k, v in batch.items():
+                static[k].copy_(v)
             training = self.optimizer is not None
             # The warm-up steps (index maps, allocator pools) and the capture must not train: everything a
             # training step writes is saved here and put back afterwards - the tables, the optimiser state
@@ -207,30 +208,23 @@ class Runner:
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    self._step(static)
+                    self._step(self._split(static, 0))
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                outs = self._step(static)
+                outs = [self._step(self._split(static, it)) for it in range(iters)]
+                stacked = self._stack_outputs(outs)  # the stacking of the outputs is part of the recording too
             if snapshot is not None:
                 self._restore_training_snapshot(snapshot)
-            cache[sig] = (graph, static, outs)
-        graph, static, outs = cache[sig]
-        collected: List[List[Dict[str, Any]]] = []
-        for it in range(iters):
-            for slot, rep in zip(static, self._split(batch, it)):
-                for k, v in rep.items():
-                    slot[k].copy_(v, non_blocking=True)
-            graph.replay()
-            step_out = []
-            for o in outs:
-                if isinstance(o, dict):
-                    step_out.append({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in o.items()})
-                else:
-                    step_out.append(o.clone())
-            collected.append(step_out)
-        return self._stack_outputs(collected)
+            cache[sig] = (graph, static, stacked)
+        graph, static, stacked = cache[sig]
+        for k, v in batch.items():
+            static[k].copy_(v, non_blocking=True)
+        graph.replay()
+        if isinstance(stacked, dict):
+            return {k: v.clone() for k, v in stacked.items()}
+        return stacked.clone()
 
     def _training_snapshot(self) -> Dict[str, Any]:
         fn = self.model.score_fn
