@@ -43,6 +43,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -68,6 +69,7 @@ C4_ROWS_PER_SHARD = 312_576  # ceil(2,500,604 / 8)
 C4_N_ENTITY = 2_500_604
 C4_N_REL = 535
 C4_D = 256
+C4_GRAPH_DEADLINE_S = 180  # wall-clock bound on the recorded-collectives variant at N > 1 (see main)
 C4_SWEEP = ((512, 32), (4096, 256), (4096, 2048))  # (S per GPU, K per shard pair); first = the notebook's point
 
 
@@ -280,7 +282,8 @@ def hbm_leg(dev: torch.device, steps: int, warmup: int):
     return out
 
 
-def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, comm_name: str, steps: int):
+def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, comm_name: str, steps: int,
+           state: dict, variants=("eager", "graph")):
     """north_star's scaling workload: one shard of the 8-way wikikg2 setup per GPU (weak scaling:
     312,576 rows per shard whatever N), TransE d=256 fp16, flat negatives, augmentation,
     sampled-softmax CE, EmbeddingMoving, full training step (forward + backward + C8 + sparse SGD)."""
@@ -295,23 +298,23 @@ def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, c
     iters = 8
     n = world
     sharding = Sharding.create(C4_ROWS_PER_SHARD * n, n, seed=0)
-    points = []
-    for S_, K_ in C4_SWEEP:
-        ppp = S_ // n
-        if ppp * n != S_:
+    points = state.setdefault("points", {})
+    for name in variants:
+        graphs = name == "graph"
+        if graphs and isinstance(group, DistributedGroup):
             continue
-        rng = np.random.default_rng(100 + rank)
-        M = int(sharding.shard_counts[rank])
-        batch = dict(head=rng.integers(M, size=(iters, n, ppp)), relation=rng.integers(C4_N_REL, size=(iters, n, ppp)),
-                     tail=rng.integers(M, size=(iters, n, ppp)), negative=rng.integers(M, size=(iters, n, 1, K_)))
-        batch = {k: torch.from_numpy(v.astype(np.int32)).to(dev) for k, v in batch.items()}
-        n_neg = n * K_ + S_  # augmentation adds the S tails of the micro-batch
-        scored = world * S_ * (1 + n_neg)
-        point = dict(shard_bs=S_, negatives_per_shard_pair=K_, negatives_per_triple=n_neg)
-        variants = [("eager", False)]
-        if not isinstance(group, DistributedGroup):
-            variants.append(("graph", True))
-        for name, graphs in variants:
+        for S_, K_ in C4_SWEEP:
+            ppp = S_ // n
+            if ppp * n != S_:
+                continue
+            rng = np.random.default_rng(100 + rank)
+            M = int(sharding.shard_counts[rank])
+            batch = dict(head=rng.integers(M, size=(iters, n, ppp)), relation=rng.integers(C4_N_REL, size=(iters, n, ppp)),
+                         tail=rng.integers(M, size=(iters, n, ppp)), negative=rng.integers(M, size=(iters, n, 1, K_)))
+            batch = {k: torch.from_numpy(v.astype(np.int32)).to(dev) for k, v in batch.items()}
+            n_neg = n * K_ + S_  # augmentation adds the S tails of the micro-batch
+            scored = world * S_ * (1 + n_neg)
+            point = points.setdefault((S_, K_), dict(shard_bs=S_, negatives_per_shard_pair=K_, negatives_per_triple=n_neg))
             try:
                 torch.manual_seed(rank)
                 fn = TransE(True, 1, sharding, C4_N_REL, C4_D, device=dev, shards=[rank], dtype=torch.float16)
@@ -344,17 +347,22 @@ def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, c
             finally:
                 runner = model = fn = None
                 torch.cuda.empty_cache()
-        best = min((point[k] for k in ("eager_ms_per_step", "graph_ms_per_step") if k in point), default=None)
-        if best is not None:
-            point["ms_per_step"] = best
-            point["value"] = scored / (best * 1e-3)
-            # VALU work of the L1 distance matrix per GPU and step: forward |q - e| accumulate and the two
-            # backward products, S x N x W elements each (csrc/neg_shared.hip states the ops per element)
-            elems = S_ * n_neg * C4_D
-            point["valu"] = dict(bound="valu", elements_per_product=elems,
-                                 achieved=3 * elems / (best * 1e-3) / 1e12, unit="T element-updates/s (3 products/step)",
-                                 peak=VALU_PEAK_TLOPS, peak_unit="T lane-ops/s")
-        points.append(point)
+            best = min((point[k] for k in ("eager_ms_per_step", "graph_ms_per_step") if k in point), default=None)
+            if best is not None:
+                point["ms_per_step"] = best
+                point["value"] = scored / (best * 1e-3)
+                # VALU work of the L1 distance matrix per GPU and step: forward |q - e| accumulate and the two
+                # backward products, S x N x W elements each (csrc/neg_shared.hip states the ops per element)
+                elems = S_ * n_neg * C4_D
+                point["valu"] = dict(bound="valu", elements_per_product=elems,
+                                     achieved=3 * elems / (best * 1e-3) / 1e12, unit="T element-updates/s (3 products/step)",
+                                     peak=VALU_PEAK_TLOPS, peak_unit="T lane-ops/s")
+    return c4_summary(state, world, comm_name)
+
+
+def c4_summary(state: dict, world: int, comm_name: str) -> dict:
+    points = list(state.get("points", {}).values())
+    n = world
     return dict(
         what="BASELINE configs[3] / north_star scaling workload: ogbl-wikikg2-shaped TransE d=256 fp16, "
              f"{C4_ROWS_PER_SHARD:,} rows per shard, n_shard={n}, flat negatives K per shard pair, augment_negative, "
@@ -503,6 +511,9 @@ def main() -> None:
 
     def fence() -> None:
         if distributed:
+            # drain this rank's own streams before the process group's barrier kernel is queued: the barrier runs
+            # on torch's communicator, the steps on the library's - two communicators are never in flight together
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -532,7 +543,6 @@ def main() -> None:
     torch.cuda.empty_cache()
     if not distributed and extra_legs and args.entities_per_shard == N_ENTITY_C2:
         hbm = hbm_leg(dev, max(10, min(args.steps, 50)), 5)
-    c4 = c4_leg(world, rank, dev, group, distributed, comm_name, max(16, min(args.steps, 48))) if extra_legs else None
 
     n_neg = K_TOTAL  # negatives per positive, over all shards
     scored_per_step = world * S * (1 + n_neg)
@@ -558,44 +568,68 @@ def main() -> None:
     roof["traffic_source"] = (f"{src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of a separate run of this command "
                               "(counters cannot be read inside the timed run)") if src else None
 
+    line = {
+        "metric": "positive+negative triples scored/sec",
+        "value": value,
+        "unit": "triples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"ogbl-biokg-shaped ComplEx d=256 fp32 (W=512), {args.entities_per_shard:,} entities per shard, "
+                        f"n_shard={world}, S=4096 positives x 256 per-triple negatives per GPU per step, "
+                        f"{'ScoreMoving' if distributed else 'EmbeddingMoving'}, mode={args.mode} "
+                        "(gather+score+loss" + ("+backward+sparse SGD)" if args.mode == "train" else ")"),
+            "n_shard": world,
+            "shard_bs": S,
+            "negatives_per_triple": n_neg,
+            "mode": args.mode,
+            "collectives": comm_name,
+        },
+        "roofline": roof,
+    }
+    line["kernel_avg_ms"] = {k: float(np.mean(v)) for k, v in kernel_ms.items() if v}
+    if hbm is not None:
+        line["roofline_hbm"] = hbm
+    if train_extra is not None:
+        line["train_step"] = train_extra
+    if rank == 0 and not distributed and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
+    if extra_legs:
+        c4_steps = max(16, min(args.steps, 48))
+        state: dict = {}
+        line["c4"] = c4_leg(world, rank, dev, group, distributed, comm_name, c4_steps, state, variants=("eager",))
+        # The hipGraph variant records RCCL send/recv into the graph.  With more than one rank that has only been
+        # rehearsed on a one-rank communicator (1-GPU boxes), so it runs last and under a deadline: if it has not
+        # come back in time every rank prints / drops what it has and leaves, and the eager numbers are kept.
+        deadline = None
+        if world > 1:
+            def give_up() -> None:
+                if rank == 0:
+                    line["c4"] = c4_summary(state, world, comm_name)
+                    line["c4"]["graph_note"] = f"hipGraph variant abandoned after {C4_GRAPH_DEADLINE_S} s"
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+
+            deadline = threading.Timer(C4_GRAPH_DEADLINE_S, give_up)
+            deadline.daemon = True
+            deadline.start()
+        line["c4"] = c4_leg(world, rank, dev, group, distributed, comm_name, c4_steps, state, variants=("graph",))
+        if deadline is not None:
+            deadline.cancel()
     if rank == 0:
-        line = {
-            "metric": "positive+negative triples scored/sec",
-            "value": value,
-            "unit": "triples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"ogbl-biokg-shaped ComplEx d=256 fp32 (W=512), {args.entities_per_shard:,} entities per shard, "
-                            f"n_shard={world}, S=4096 positives x 256 per-triple negatives per GPU per step, "
-                            f"{'ScoreMoving' if distributed else 'EmbeddingMoving'}, mode={args.mode} "
-                            "(gather+score+loss" + ("+backward+sparse SGD)" if args.mode == "train" else ")"),
-                "n_shard": world,
-                "shard_bs": S,
-                "negatives_per_triple": n_neg,
-                "mode": args.mode,
-                "collectives": comm_name,
-            },
-            "roofline": roof,
-        }
-        line["kernel_avg_ms"] = {k: float(np.mean(v)) for k, v in kernel_ms.items() if v}
-        if hbm is not None:
-            line["roofline_hbm"] = hbm
-        if c4 is not None:
-            line["c4"] = c4
-        if train_extra is not None:
-            line["train_step"] = train_extra
-        if not distributed and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if distributed:
+        # the line is out: a rank that cannot finish the teardown (a peer left at the deadline above) just exits
+        bye = threading.Timer(60, lambda: os._exit(0))
+        bye.daemon = True
+        bye.start()
         dist.barrier()
         if hasattr(group, "close"):
             group.close()

@@ -694,8 +694,13 @@ def neg_score_shared_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, out:
     hat = inv = None
     if d.scorer == AFFINE:
         neg, hat, inv = _affine_candidates(d, neg)
-    dq = torch.empty((nq, query_width(d)), dtype=torch.float32, device=dev)
-    dn = torch.empty((n_neg, d.width), dtype=torch.float32, device=dev)
+    qw = query_width(d)
+    if qw == d.width:  # one allocation: the library then zeroes both partial-sum targets with one memset
+        both = torch.empty(((nq + n_neg), qw), dtype=torch.float32, device=dev)
+        dq, dn = both[:nq], both[nq:]
+    else:
+        dq = torch.empty((nq, qw), dtype=torch.float32, device=dev)
+        dn = torch.empty((n_neg, d.width), dtype=torch.float32, device=dev)
     lib = load()
     ws_bytes = int(lib.bess_neg_score_shared_bwd_workspace(ctypes.byref(d), nq, n_neg))  # see neg_score_shared_fwd
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes > 0 else None

@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void k_neg_shared_fwd(RowSrc<float> Q, RowSrc<
 // ROUND16: f32 operands (the query matrix) are rounded to fp16 (nearest even) as they are loaded - the
 // backward of the packed-fp16 forward (l1_f16.hip), whose scores are a function of the rounded query;
 // differences of fp16 values are exact in fp32, so sgn(x - y) (0 at a tie) is exact.
-template <typename TX, typename TY, int RED, bool VEC4, bool ROUND16 = false>
+// MI: rows of X per thread (4: 64-row tile; 2: 32-row tile for problems whose 64-row grid cannot fill the chip).
+template <typename TX, typename TY, int RED, bool VEC4, bool ROUND16 = false, int MI = 4>
 __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY> Y, int W,
                                                         float sign, const float* __restrict__ d_out,
                                                         int64_t sa, int64_t sb,
@@ -176,19 +177,20 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
     __shared__ __attribute__((aligned(16))) float Cs[KT][LDP];  // [b][a]
     __shared__ __attribute__((aligned(16))) float Ys[KT][LDP];  // [b][w]
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int64_t a0 = static_cast<int64_t>(blockIdx.y) * TM;
+    constexpr int TMB = 16 * MI;  // rows of X in this workgroup's tile
+    const int64_t a0 = static_cast<int64_t>(blockIdx.y) * TMB;
     const int w0 = blockIdx.x * TN;
-    float acc[4][4], xv[4][4];
+    float acc[MI][4], xv[MI][4];
     // this thread's 4 x 4 values of X: rows and columns past the end are clamped (their results are dropped
     // at the store), so the 4 row loads are issued together - a per-element `in range ? load : 0` made the
     // compiler wait for each of the 16 loads (and the index load in front of it) in turn: 16 round trips
     // to L2 / HBM at the start of every workgroup, ~8 us of a ~50 us workgroup
     {
-        const TX* xr[4];
+        const TX* xr[MI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xr[i] = X.row(min(a0 + ty * 4 + i, X.n - 1), W);
+        for (int i = 0; i < MI; ++i) xr[i] = X.row(min(a0 + ty * MI + i, X.n - 1), W);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
             if (VEC4) {
                 VecLoad<TX, 4>::load(xr[i] + min(w0 + tx * 4, W - 4), xv[i]);
             } else {
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 acc[i][j] = 0.f;
@@ -211,23 +213,23 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
     const int64_t b_hi = min(b_lo + b_chunk, Y.n);
     if (b_lo >= b_hi) return;
 
-    // what this thread stages: 4 coefficients Cs[cb[i]][ca[i]] and 4 scalars Ys[yb][ywc..+3].
+    // what this thread stages: MI coefficients Cs[bb][al] and 4 scalars Ys[yb][ywc..+3].
     // Lanes run along the unit-stride dimension of d_out.  Out-of-range rows are clamped
     // (their coefficient is forced to 0), so the stage has no divergent branches.
     const int t = threadIdx.x;
     const int yb = t >> 4, ywc = (t & 15) * 4;
     const int ycol = VEC4 ? min(w0 + ywc, W - 4) : w0 + ywc;  // clamped columns are dropped at the store
-    float cv[4], yv[4];
+    float cv[MI], yv[4];
     auto fetch = [&](int64_t b0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
             int bb, al;
             if (sb == 1) {  // d_out[a, b] contiguous in b
                 bb = t & 15;
                 al = (t >> 4) + 16 * i;
             } else {        // read transposed: contiguous in a
-                al = t & 63;
-                bb = (t >> 6) + 4 * i;
+                al = t % TMB;
+                bb = t / TMB + (256 / TMB) * i;
             }
             const int64_t a = a0 + al;
             const bool ok = a < X.n && b0 + bb < b_hi;
@@ -260,9 +262,9 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
             if (sb == 1) Cs[t & 15][(t >> 4) + 16 * i] = cv[i];
-            else Cs[(t >> 6) + 4 * i][t & 63] = cv[i];
+            else Cs[t / TMB + (256 / TMB) * i][t % TMB] = cv[i];
         }
         *reinterpret_cast<float4*>(&Ys[yb][ywc]) = make_float4(yv[0], yv[1], yv[2], yv[3]);
     };
@@ -274,12 +276,18 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
         if (b0 + KT < b_hi) fetch(b0 + KT);  // next stage in flight under the compute
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-            const float4 c4 = *reinterpret_cast<const float4*>(&Cs[k][ty * 4]);
+            float c[MI];
+            if (MI == 4) {
+                const float4 c4 = *reinterpret_cast<const float4*>(&Cs[k][ty * 4]);
+                c[0] = c4.x, c[1] = c4.y, c[MI - 2] = c4.z, c[MI - 1] = c4.w;
+            } else {
+                const float2 c2 = *reinterpret_cast<const float2*>(&Cs[k][ty * 2]);
+                c[0] = c2.x, c[1] = c2.y;
+            }
             const float4 y4 = *reinterpret_cast<const float4*>(&Ys[k][tx * 4]);
-            const float c[4] = {c4.x, c4.y, c4.z, c4.w};
             const float y[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (RED == RED_DOT) acc[i][j] = fmaf(c[i], y[j], acc[i][j]);
@@ -290,8 +298,8 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t a = a0 + ty * 4 + i;
+    for (int i = 0; i < MI; ++i) {
+        const int64_t a = a0 + ty * MI + i;
         if (a >= X.n) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -325,32 +333,52 @@ static int run_fwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<T> E, float
 template <typename TX, typename TY>
 static int run_bwd_one(const bess_model_desc* d, RowSrc<TX> X, RowSrc<TY> Y, const float* d_out,
                        int64_t sa, int64_t sb, const float* out, int64_t oa, int64_t ob, float* dX,
-                       hipStream_t st, bool round16 = false) {
-    const int64_t tiles = ceil_div(d->width, TN) * ceil_div(X.n, TM);
-    // split the reduction over Y until 5 workgroups per CU are in flight - what the kernel's 94 VGPRs admit
-    // (rocprofv3 SQ counters at 4 per CU: VALU issue 61 % of the cycles, waves parked at waits / barriers 27 %
-    // of theirs - a wave alone issues at half rate, so resident waves are what fills the pipe), in slices of
-    // at least 4 stages
-    int64_t split = ceil_div(256 * 5, tiles);
-    while (split > 1 && ceil_div(Y.n, split) < 4 * KT) --split;
+                       hipStream_t st, bool round16 = false, bool zeroed = false) {
+    // Workgroups resident at once: 5 per CU is what the kernel's 94 VGPRs admit (rocprofv3 SQ counters at 4 per
+    // CU: VALU issue 61 % of the cycles, waves parked at waits / barriers 27 % of theirs - a wave alone issues
+    // at half rate, so resident waves are what fills the pipe).  The reduction over Y is cut into `split`
+    // slices of at least 4 stages so that the grid fills those slots in whole rounds: cost(split) = rounds of
+    // the grid over the slots / split, a little extra per slice for its prologue and the atomics.
+    const int64_t slots = 256 * 5;
+    auto plan = [&](int64_t tile_rows, int64_t* best_split) {
+        const int64_t tiles = ceil_div(d->width, TN) * ceil_div(X.n, tile_rows);
+        double best = 1e30;
+        for (int64_t s = 1; s <= 32; ++s) {
+            if (s > 1 && ceil_div(Y.n, s) < 4 * KT) break;
+            const double cost = static_cast<double>(ceil_div(tiles * s, slots)) / s * (1.0 + 0.01 * s);
+            if (cost < best) best = cost, *best_split = s;
+        }
+        return tiles * *best_split;
+    };
+    int64_t split = 1, split32 = 1;
+    const int64_t blocks64 = plan(TM, &split);
+    // 32-row tiles when the 64-row grid leaves most of the chip idle (under two workgroups per CU)
+    const bool small = blocks64 < 2 * 256 && plan(TM / 2, &split32) > blocks64;
+    if (small) split = split32;
+    const int64_t tile_rows = small ? TM / 2 : TM;
     int64_t chunk = ceil_div(ceil_div(Y.n, split), KT) * KT;
     split = ceil_div(Y.n, chunk);
-    if (split > 1) {
+    if (split > 1 && !zeroed) {
         hipError_t e = hipMemsetAsync(dX, 0, sizeof(float) * X.n * d->width, st);
         if (e != hipSuccess) return fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
     }
-    const dim3 grid(static_cast<unsigned>(ceil_div(d->width, TN)), static_cast<unsigned>(ceil_div(X.n, TM)),
+    const dim3 grid(static_cast<unsigned>(ceil_div(d->width, TN)), static_cast<unsigned>(ceil_div(X.n, tile_rows)),
                     static_cast<unsigned>(split));
     const float sign = is_distance(d->scorer) ? -1.f : 1.f;
     const bool vec4 = d->width % 4 == 0;
-#define BESS_BWD(RED)                                                                                          \
-    (vec4 ? k_neg_shared_bwd<TX, TY, RED, true><<<grid, 256, 0, st>>>(X, Y, d->width, sign, d_out, sa, sb, out, \
-                                                                       oa, ob, dX, chunk)                       \
-          : k_neg_shared_bwd<TX, TY, RED, false><<<grid, 256, 0, st>>>(X, Y, d->width, sign, d_out, sa, sb,     \
-                                                                        out, oa, ob, dX, chunk))
+#define BESS_BWD_ARGS <<<grid, 256, 0, st>>>(X, Y, d->width, sign, d_out, sa, sb, out, oa, ob, dX, chunk)
+#define BESS_BWD_MI(RED, V, R16)                                         \
+    do {                                                                 \
+        if (small) k_neg_shared_bwd<TX, TY, RED, V, R16, 2> BESS_BWD_ARGS; \
+        else k_neg_shared_bwd<TX, TY, RED, V, R16, 4> BESS_BWD_ARGS;       \
+    } while (0)
+#define BESS_BWD(RED)                          \
+    do {                                       \
+        if (vec4) BESS_BWD_MI(RED, true, false); \
+        else BESS_BWD_MI(RED, false, false);     \
+    } while (0)
     if (round16 && vec4 && reduce_of(d) == RED_L1) {
-        k_neg_shared_bwd<TX, TY, RED_L1, true, true><<<grid, 256, 0, st>>>(X, Y, d->width, sign, d_out, sa, sb, out, oa,
-                                                                        ob, dX, chunk);
+        BESS_BWD_MI(RED_L1, true, true);
         return BESS_OK;
     }
     switch (reduce_of(d)) {
@@ -359,6 +387,8 @@ static int run_bwd_one(const bess_model_desc* d, RowSrc<TX> X, RowSrc<TY> Y, con
         default: BESS_BWD(RED_L2);
     }
 #undef BESS_BWD
+#undef BESS_BWD_MI
+#undef BESS_BWD_ARGS
     return BESS_OK;
 }
 
@@ -499,14 +529,22 @@ extern "C" int bess_neg_score_shared_bwd_ws(const bess_model_desc* d, const floa
     // the packed-fp16 forward scores the query rounded to fp16: differentiate that function
     const bool r16 = use_l1_pk(d, query, neg_base);
     RowSrc<float> Q{query, nullptr, n_query};
+    // both gradients in one allocation (d_neg right behind d_query) and small: one memset for the two partial-sum
+    // targets instead of one in front of each kernel (launch-bound sizes: a launch saved counts)
+    bool z = false;
+    if (d_neg == d_query + n_query * d->width && (n_query + n_neg) * d->width <= (int64_t{1} << 22)) {
+        hipError_t e = hipMemsetAsync(d_query, 0, sizeof(float) * (n_query + n_neg) * d->width, st);
+        if (e != hipSuccess) return fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
+        z = true;
+    }
     if (d->dtype == BESS_F32) {
         RowSrc<float> E{static_cast<const float*>(neg_base), neg_idx, n_neg};
-        if (int e = run_bwd_one<float, float>(d, Q, E, d_out, ld_dout, 1, out, ld_out, 1, d_query, st)) return e;
-        if (int e = run_bwd_one<float, float>(d, E, Q, d_out, 1, ld_dout, out, 1, ld_out, d_neg, st)) return e;
+        if (int e = run_bwd_one<float, float>(d, Q, E, d_out, ld_dout, 1, out, ld_out, 1, d_query, st, false, z)) return e;
+        if (int e = run_bwd_one<float, float>(d, E, Q, d_out, 1, ld_dout, out, 1, ld_out, d_neg, st, false, z)) return e;
     } else {
         RowSrc<half_t> E{static_cast<const half_t*>(neg_base), neg_idx, n_neg};
-        if (int e = run_bwd_one<float, half_t>(d, Q, E, d_out, ld_dout, 1, out, ld_out, 1, d_query, st, r16)) return e;
-        if (int e = run_bwd_one<half_t, float>(d, E, Q, d_out, 1, ld_dout, out, 1, ld_out, d_neg, st, r16)) return e;
+        if (int e = run_bwd_one<float, half_t>(d, Q, E, d_out, ld_dout, 1, out, ld_out, 1, d_query, st, r16, z)) return e;
+        if (int e = run_bwd_one<half_t, float>(d, E, Q, d_out, 1, ld_dout, out, 1, ld_out, d_neg, st, r16, z)) return e;
     }
     return check_launch("neg_score_shared_bwd");
 }

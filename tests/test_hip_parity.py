@@ -1032,3 +1032,44 @@ def test_split_fp16_gemm_falls_back_to_fp32_outside_the_fp16_range(dev, where):
     assert nat.load().bess_neg_score_shared_workspace(ctypes.byref(d), S, N) == 0
     got32 = nat.neg_score_shared_fwd(d, q, neg)
     assert float((got32.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("p,dtype", [(1, torch.float32), (2, torch.float32), (1, torch.float16), (2, torch.float16)])
+@pytest.mark.parametrize("S,N,W", [(512, 1024, 256),   # 64-row tiles, reduction split 16 / 8 ways
+                                   (512, 544, 256),    # the notebook's micro-batch: 32-row tiles
+                                   (70, 1300, 100),    # 32-row tiles, ragged rows and columns, scalar loads
+                                   (1024, 70, 400),    # one slice only on the dE side
+                                   (33, 17, 64)])
+def test_shared_distance_backward_tile_variants(dev, p, dtype, S, N, W):
+    """k_neg_shared_bwd (distance scorers, shared negatives): both tile heights and every split the launcher's
+    planner picks, against the float64 gradients of -||q - e||_p (sgn(0) = 0, the p = 2 gradient 0 at zero
+    distance; reference scoring.py:94-128 + torch autograd)."""
+    from besskge import _native as nat
+
+    g = torch.Generator().manual_seed(S * 7 + N)
+    M = 2000
+    table = (torch.randn(M, W, generator=g) * 0.5).to(dtype).to(dev)
+    q = (torch.randn(S, W, generator=g) * 0.5).half().float().to(dev)  # fp16-exact queries: any rounding mode agrees
+    idx = torch.randint(M, (N,), generator=g, dtype=torch.int32).to(dev)
+    go = (torch.softmax(torch.randn(S, N, generator=g) * 2, -1) * torch.rand(S, 1, generator=g)).to(dev)
+    d = nat.make_desc(nat.TRANSE, p, table, W)
+    src = nat.RowSource(table, idx)
+    out = nat.neg_score_shared_fwd(d, q, src)
+    dq, dn = nat.neg_score_shared_bwd(d, q, src, out, go)
+    rows = table[idx.long()].double()
+    qd = q.double()
+    want_q = torch.zeros(S, W, dtype=torch.float64, device=dev)
+    want_n = torch.zeros(N, W, dtype=torch.float64, device=dev)
+    for a0 in range(0, S, 64):  # [64, N, W] float64 at a time
+        diff = qd[a0:a0 + 64, None, :] - rows[None, :, :]
+        if p == 1:
+            coef = torch.sign(diff)
+        else:
+            nrm = diff.norm(dim=-1, keepdim=True)
+            coef = torch.where(nrm > 0, diff / nrm.clamp(min=1e-300), torch.zeros_like(diff))
+        t = go[a0:a0 + 64].double()[:, :, None] * coef
+        want_q[a0:a0 + 64] = -t.sum(1)
+        want_n += t.sum(0)
+    tol = 2e-5 if p == 2 else 1e-5  # p = 2 divides by the fp32 forward score
+    assert float((dq.double() - want_q).abs().max()) <= tol * float(want_q.abs().max())
+    assert float((dn.double() - want_n).abs().max()) <= tol * float(want_n.abs().max())
