@@ -154,6 +154,75 @@ static void single(float* out, const char* name) {
     printf("%-22s %8.3f ms  %6.2f T lane-instructions/s\n", name, ms, double(blocks) * 256 * iters * 16.0 / ms / 1e9);
 }
 
+// fp32 forms of the L1 backward step acc += c * sgn(x - y) (operands pre-scaled so that med3(d, -1, 1) is the sign):
+//   OP 0  v_sub_f32 + v_med3_f32 + v_fmac_f32 per element                                  (csrc/neg_shared.hip)
+//   OP 1  v_pk_add_f32 (2 differences) + 2 v_med3_f32 + v_pk_fma_f32 per 2 elements        (packed fp32 candidates)
+//   OP 2..6  single instructions: v_pk_fma_f32, v_pk_add_f32, v_med3_f32, v_fma_f32 (VOP3), v_fmac_f32 (VOP2)
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <int OP>
+__global__ __launch_bounds__(256) void k_f32(float* out, int iters) {
+    f2 acc[8], x[8];
+    f2 y = {0.25f + threadIdx.x, 0.75f}, c = {1.5f, -0.5f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { acc[i] = f2{0.f, 0.f}; x[i] = f2{float(i) + threadIdx.x, float(i) * 0.5f}; }
+    asm volatile("" : "+v"(y), "+v"(c));
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (OP == 0) {
+                float d0, d1;
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d0) : "v"(x[i].x), "v"(y.x));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d1) : "v"(x[i].y), "v"(y.y));
+                asm volatile("v_med3_f32 %0, %0, -1.0, 1.0" : "+v"(d0));
+                asm volatile("v_med3_f32 %0, %0, -1.0, 1.0" : "+v"(d1));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[i].x) : "v"(c.x), "v"(d0));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[i].y) : "v"(c.x), "v"(d1));
+            } else if (OP == 1) {
+                f2 d;
+                asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x[i]), "v"(y));
+                asm volatile("v_med3_f32 %0, %0, -1.0, 1.0" : "+v"(d.x));
+                asm volatile("v_med3_f32 %0, %0, -1.0, 1.0" : "+v"(d.y));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(c), "v"(d));
+            } else if (OP == 2) {
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(c), "v"(y));
+            } else if (OP == 3) {
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc[i]) : "v"(y));
+            } else if (OP == 4) {
+                asm volatile("v_med3_f32 %0, %0, -1.0, 1.0" : "+v"(acc[i].x));
+                asm volatile("v_med3_f32 %0, %0, -1.0, 1.0" : "+v"(acc[i].y));
+            } else if (OP == 5) {
+                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[i].x) : "v"(c.x), "v"(y.x));
+                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[i].y) : "v"(c.y), "v"(y.y));
+            } else {
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[i].x) : "v"(c.x), "v"(y.x));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[i].y) : "v"(c.y), "v"(y.y));
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i].x + acc[i].y;
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int OP>
+static void f32(float* out, const char* name, double instr_per_pair) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int iters = 20000, blocks = 256 * 8;
+    k_f32<OP><<<blocks, 256>>>(out, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k_f32<OP><<<blocks, 256>>>(out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double pairs = double(blocks) * 256 * iters * 8.0;
+    printf("%-34s %8.3f ms  %6.2f T elements/s  %6.2f T lane-instructions/s\n", name, ms, 2.0 * pairs / ms / 1e9,
+           instr_per_pair * pairs / ms / 1e9);
+}
+
 int main() {
     float* out;
     hipMalloc(&out, sizeof(float) * 256 * 256 * 64);
@@ -169,6 +238,13 @@ int main() {
     single<9>(out, "v_max_f16");
     single<10>(out, "v_sad_u16");
     single<11>(out, "v_sad_u8");
+    f32<2>(out, "v_pk_fma_f32", 1);
+    f32<3>(out, "v_pk_add_f32", 1);
+    f32<4>(out, "v_med3_f32 (x2)", 2);
+    f32<5>(out, "v_fma_f32 (x2)", 2);
+    f32<6>(out, "v_fmac_f32 (x2)", 2);
+    f32<0>(out, "bwd f32: sub+med3+fmac", 6);
+    f32<1>(out, "bwd pk f32: pk_add+2 med3+pk_fma", 4);
     bench<0, false>(out, "fwd pk_max+dot2", 2);
     bench<0, true>(out, "fwd pk_max+dot2", 2);
     bench<1, false>(out, "bwd sub+min+max+sdot2", 4);
