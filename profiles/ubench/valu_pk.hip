@@ -2,6 +2,8 @@
 //   mode 0  forward:   m = v_pk_max_f16(q2, e2);  acc = v_dot2_f32_f16(m, {1,1}, acc)        2 ops / 2 elements
 //   mode 1  backward:  d = v_pk_add_f16(x2, -y2); t = v_pk_max_i16(v_pk_min_i16(d, 1), -1);
 //                      acc = v_dot2_i32_i16(t, c2, acc)                                       4 ops / 2 elements
+//   mode 3  forward, hybrid: v_max_f16 (low halves), v_max_f16 op_sel (high halves), v_dot2_f32_f16   3 ops / 2 elements,
+//           two of them on the full-rate pipe
 //   mode 2  backward, sign by bit transfer (ties -> +c): d; c ^ (d & 0x80008000); v_dot2_f32_f16   4 ops / 2 elements
 // with the LDS read mix of a 4 x 4 register tile (2 ds_read_b128 per 16 (i, j) pairs).
 //   hipcc -O3 --offload-arch=gfx950 valu_pk.hip -o valu_pk && ./valu_pk
@@ -64,6 +66,13 @@ __global__ __launch_bounds__(256) void k_probe(float* out, int iters, float seed
                 (void)x; (void)y;
                 if (MODE == 0) {
                     const uint32_t m = pk_max_f16(a[i], b[j]);
+                    facc[4 * i + j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, m), ones, facc[4 * i + j], false);
+                } else if (MODE == 3) {
+                    // hybrid: the two maxima on the full-rate pipe (v_max_f16, low and high halves), the sum on the
+                    // packed pipe
+                    uint32_t m;
+                    asm("v_max_f16 %0, %1, %2" : "=v"(m) : "v"(a[i]), "v"(b[j]));
+                    asm("v_max_f16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(m) : "v"(a[i]), "v"(b[j]));
                     facc[4 * i + j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, m), ones, facc[4 * i + j], false);
                 } else if (MODE == 1) {
                     const uint32_t d = pk_sub_f16(a[i], b[j]);
@@ -245,6 +254,8 @@ int main() {
     f32<6>(out, "v_fmac_f32 (x2)", 2);
     f32<0>(out, "bwd f32: sub+med3+fmac", 6);
     f32<1>(out, "bwd pk f32: pk_add+2 med3+pk_fma", 4);
+    bench<3, false>(out, "fwd 2 v_max_f16 + dot2", 3);
+    bench<3, true>(out, "fwd 2 v_max_f16 + dot2", 3);
     bench<0, false>(out, "fwd pk_max+dot2", 2);
     bench<0, true>(out, "fwd pk_max+dot2", 2);
     bench<1, false>(out, "bwd sub+min+max+sdot2", 4);
