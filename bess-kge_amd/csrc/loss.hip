@@ -49,7 +49,10 @@ __device__ __forceinline__ float log_sigmoid(float x) {
 }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
-template <int KIND, bool ADV, bool GRAD>
+// One wave per triple.  CH > 0: the row of negative scores is read ONCE, as CH 16-byte chunks per lane held in
+// registers (rows of up to 256 * CH scores, n_neg % 4 == 0, 16-byte aligned rows), and the gradient row is written
+// with 16-byte stores; CH = 0: any shape, the row is streamed from memory (cache) in each of the passes.
+template <int KIND, bool ADV, bool GRAD, int CH>
 __global__ __launch_bounds__(256) void k_loss_rows(bess_loss_desc l, const float* __restrict__ pos,
                                                    const float* __restrict__ neg, int64_t n_triple,
                                                    int64_t n_neg, int64_t ld_neg,
@@ -66,20 +69,57 @@ __global__ __launch_bounds__(256) void k_loss_rows(bess_loss_desc l, const float
     const float p = pos[s];
     const int n = static_cast<int>(n_neg);
 
+    float4 v[CH > 0 ? CH : 1];
+    if (CH > 0) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int j = (c * 64 + lane) * 4;
+            v[c] = j < n ? *reinterpret_cast<const float4*>(nr + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // f(score) for every score of the row
+    auto sweep = [&](auto&& f) {
+        if (CH > 0) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if ((c * 64 + lane) * 4 < n) {
+                    f(v[c].x);
+                    f(v[c].y);
+                    f(v[c].z);
+                    f(v[c].w);
+                }
+            }
+        } else {
+            for (int j = lane; j < n; j += 64) f(nr[j]);
+        }
+    };
+    // d_neg[j] = f(score[j])
+    auto sweep_grad = [&](auto&& f) {
+        if (CH > 0) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int j = (c * 64 + lane) * 4;
+                if (j < n) *reinterpret_cast<float4*>(dn + j) = make_float4(f(v[c].x), f(v[c].y), f(v[c].z), f(v[c].w));
+            }
+        } else {
+            for (int j = lane; j < n; j += 64) dn[j] = f(nr[j]);
+        }
+    };
+
     if (KIND == BESS_LOSS_SSCE) {
         // cross entropy of [pos, neg + shift] against class 0
         float m = p;
-        for (int j = lane; j < n; j += 64) m = fmaxf(m, nr[j] + l.ssce_shift);
+        sweep([&](float x) { m = fmaxf(m, x + l.ssce_shift); });
         m = wave_allreduce_max(m);
         float z = 0.f;
-        for (int j = lane; j < n; j += 64) z += expf(nr[j] + l.ssce_shift - m);
+        sweep([&](float x) { z += expf(x + l.ssce_shift - m); });
         z = wave_allreduce_sum(z) + expf(p - m);
         const float lse = m + logf(z);
         if (lane == 0) row_loss[s] = l.loss_scale * w * (lse - p);
         if (GRAD) {
             const float c = l.loss_scale * w;
             if (lane == 0) d_pos[s] = c * (expf(p - lse) - 1.f);
-            for (int j = lane; j < n; j += 64) dn[j] = c * expf(nr[j] + l.ssce_shift - lse);
+            sweep_grad([&](float x) { return c * expf(x + l.ssce_shift - lse); });
         }
         return;
     }
@@ -88,28 +128,25 @@ __global__ __launch_bounds__(256) void k_loss_rows(bess_loss_desc l, const float
     float m = 0.f, inv_z = 1.f / static_cast<float>(n);
     if (ADV) {
         m = -INFINITY;
-        for (int j = lane; j < n; j += 64) m = fmaxf(m, l.adversarial_scale * nr[j]);
+        sweep([&](float x) { m = fmaxf(m, l.adversarial_scale * x); });
         m = wave_allreduce_max(m);
         float z = 0.f;
-        for (int j = lane; j < n; j += 64) z += expf(l.adversarial_scale * nr[j] - m);
+        sweep([&](float x) { z += expf(l.adversarial_scale * x - m); });
         inv_z = 1.f / wave_allreduce_sum(z);
     }
     float acc = 0.f, dsum = 0.f;
-    for (int j = lane; j < n; j += 64) {
-        const float x = nr[j];
-        const float aw = ADV ? expf(l.adversarial_scale * x - m) * inv_z : inv_z;
-        if (KIND == BESS_LOSS_LOGSIGMOID) {
-            acc += aw * log_sigmoid(-x - l.margin);
-            if (GRAD) dn[j] = 0.5f * l.loss_scale * w * aw * sigmoidf(x + l.margin);
-        } else {
-            const float c = x - p + l.margin;
-            acc += aw * fmaxf(c, 0.f);
-            if (GRAD) {
-                const float gj = (c > 0.f) ? l.loss_scale * w * aw : 0.f;
-                dn[j] = gj;
+    auto aw_of = [&](float x) { return ADV ? expf(l.adversarial_scale * x - m) * inv_z : inv_z; };
+    if (KIND == BESS_LOSS_LOGSIGMOID) {
+        sweep([&](float x) { acc += aw_of(x) * log_sigmoid(-x - l.margin); });
+        if (GRAD) sweep_grad([&](float x) { return 0.5f * l.loss_scale * w * aw_of(x) * sigmoidf(x + l.margin); });
+    } else {
+        sweep([&](float x) { acc += aw_of(x) * fmaxf(x - p + l.margin, 0.f); });
+        if (GRAD)
+            sweep_grad([&](float x) {
+                const float gj = (x - p + l.margin > 0.f) ? l.loss_scale * w * aw_of(x) : 0.f;
                 dsum += gj;
-            }
-        }
+                return gj;
+            });
     }
     acc = wave_allreduce_sum(acc);
     if (KIND == BESS_LOSS_LOGSIGMOID) {
@@ -189,13 +226,28 @@ __global__ __launch_bounds__(1024) void k_sum_rows(const float* __restrict__ row
     if (threadIdx.x == 0) loss[0] = part[0];
 }
 
+template <int KIND, bool ADV, int CH>
+static void launch_loss_ch(bool grad, const bess_loss_desc& l, const float* pos, const float* neg,
+                           int64_t S, int64_t N, int64_t ld, const float* w, int64_t wl, float* rl,
+                           float* dp, float* dn, int64_t ldd, hipStream_t st) {
+    const unsigned grid = static_cast<unsigned>(ceil_div(S, 4));
+    if (grad) k_loss_rows<KIND, ADV, true, CH><<<grid, 256, 0, st>>>(l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd);
+    else k_loss_rows<KIND, ADV, false, CH><<<grid, 256, 0, st>>>(l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd);
+}
+
 template <int KIND, bool ADV>
 static void launch_loss(bool grad, const bess_loss_desc& l, const float* pos, const float* neg,
                         int64_t S, int64_t N, int64_t ld, const float* w, int64_t wl, float* rl,
                         float* dp, float* dn, int64_t ldd, hipStream_t st) {
-    const unsigned grid = static_cast<unsigned>(ceil_div(S, 4));
-    if (grad) k_loss_rows<KIND, ADV, true><<<grid, 256, 0, st>>>(l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd);
-    else k_loss_rows<KIND, ADV, false><<<grid, 256, 0, st>>>(l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd);
+    // rows in registers when their shape allows 16-byte accesses (see k_loss_rows)
+    const bool vec = N % 4 == 0 && ld % 4 == 0 && reinterpret_cast<uintptr_t>(neg) % 16 == 0 &&
+                     (!grad || (ldd % 4 == 0 && reinterpret_cast<uintptr_t>(dn) % 16 == 0));
+#define BESS_LOSS_CH(CH) launch_loss_ch<KIND, ADV, CH>(grad, l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd, st)
+    if (!vec || N > 256 * 24) BESS_LOSS_CH(0);
+    else if (N <= 256 * 4) BESS_LOSS_CH(4);
+    else if (N <= 256 * 12) BESS_LOSS_CH(12);
+    else BESS_LOSS_CH(24);
+#undef BESS_LOSS_CH
 }
 
 }  // namespace bess
