@@ -232,6 +232,63 @@ static void f32(float* out, const char* name, double instr_per_pair) {
            instr_per_pair * pairs / ms / 1e9);
 }
 
+// Do the two instruction families overlap when DIFFERENT waves of a SIMD run them?  SPLIT of every 8 waves run the
+// packed forward (v_pk_max_f16 + v_dot2: 2 elements per pair of instructions), the others the fp32 forward
+// (v_sub_f32 + v_add_f32 |d|: 1 element per pair of instructions); same number of instruction pairs per wave.
+template <int SPLIT>
+__global__ __launch_bounds__(256) void k_mix(float* out, int iters) {
+    float facc[16];
+    uint32_t a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { facc[i] = 0.f; a[i] = 0x3c003800u + i * 257u + threadIdx.x; }
+    uint32_t b = 0x35003900u + threadIdx.x;
+    float bf = 0.37f + threadIdx.x;
+    asm volatile("" : "+v"(b), "+v"(bf));
+    const h2 ones = {(_Float16)1.f, (_Float16)1.f};
+    const int wave = (blockIdx.x * 4 + (threadIdx.x >> 6)) & 7;
+    if (wave < SPLIT) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t m = pk_max_f16(a[i], b);
+                facc[i] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, m), ones, facc[i], false);
+            }
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float d;
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(__builtin_bit_cast(float, a[i])), "v"(bf));
+                asm volatile("v_add_f32 %0, %0, |%1|" : "+v"(facc[i]) : "v"(d));
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += facc[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int SPLIT>
+static void mix(float* out) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int iters = 20000, blocks = 256 * 8;
+    k_mix<SPLIT><<<blocks, 256>>>(out, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k_mix<SPLIT><<<blocks, 256>>>(out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double pairs = double(blocks) * 256 * iters * 16.0;  // instruction pairs
+    const double elems = pairs * (SPLIT / 8.0) * 2.0 + pairs * (1.0 - SPLIT / 8.0);
+    printf("mix: %d of 8 waves packed, %d fp32: %8.3f ms  %6.2f T elements/s  %6.2f T lane-instructions/s\n", SPLIT, 8 - SPLIT,
+           ms, elems / ms / 1e9, 2.0 * pairs / ms / 1e9);
+}
+
 int main() {
     float* out;
     hipMalloc(&out, sizeof(float) * 256 * 256 * 64);
@@ -247,6 +304,11 @@ int main() {
     single<9>(out, "v_max_f16");
     single<10>(out, "v_sad_u16");
     single<11>(out, "v_sad_u8");
+    mix<8>(out);
+    mix<6>(out);
+    mix<4>(out);
+    mix<2>(out);
+    mix<0>(out);
     f32<2>(out, "v_pk_fma_f32", 1);
     f32<3>(out, "v_pk_add_f32", 1);
     f32<4>(out, "v_med3_f32 (x2)", 2);
