@@ -167,19 +167,32 @@ __global__ __launch_bounds__(256) void k_neg_shared_fwd(RowSrc<float> Q, RowSrc<
 // backward of the packed-fp16 forward (l1_f16.hip), whose scores are a function of the rounded query;
 // differences of fp16 values are exact in fp32, so sgn(x - y) (0 at a tie) is exact.
 // MI: rows of X per thread (4: 64-row tile; 2: 32-row tile for problems whose 64-row grid cannot fill the chip).
-template <typename TX, typename TY, int RED, bool VEC4, bool ROUND16 = false, int MI = 4>
-__global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY> Y, int W,
-                                                        float sign, const float* __restrict__ d_out,
-                                                        int64_t sa, int64_t sb,
-                                                        const float* __restrict__ out, int64_t oa,
-                                                        int64_t ob, float* __restrict__ dX,
-                                                        int64_t b_chunk) {
-    __shared__ __attribute__((aligned(16))) float Cs[KT][LDP];  // [b][a]
-    __shared__ __attribute__((aligned(16))) float Ys[KT][LDP];  // [b][w]
+// One of the two products of a backward call: its operands, the strides of d_out / out seen from it, its
+// output and its grid (gx column tiles x gy row tiles x gz slices of the reduction, b_chunk rows each).
+template <typename TX, typename TY>
+struct BwdSide {
+    RowSrc<TX> X;
+    RowSrc<TY> Y;
+    int64_t sa, sb, oa, ob;
+    float* dX;
+    int64_t b_chunk;
+    int gx, gy, gz;
+};
+
+template <typename TX, typename TY, int RED, bool VEC4, bool ROUND16, int MI>
+__device__ __forceinline__ void neg_shared_bwd_tile(const BwdSide<TX, TY>& S, int W, float sign,
+                                                    const float* __restrict__ d_out,
+                                                    const float* __restrict__ out, int block,
+                                                    float (*Cs)[LDP], float (*Ys)[LDP]) {
+    const RowSrc<TX> X = S.X;
+    const RowSrc<TY> Y = S.Y;
+    const int64_t sa = S.sa, sb = S.sb, oa = S.oa, ob = S.ob, b_chunk = S.b_chunk;
+    float* __restrict__ dX = S.dX;
+    const int bx = block % S.gx, by = (block / S.gx) % S.gy, bz = block / (S.gx * S.gy);
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     constexpr int TMB = 16 * MI;  // rows of X in this workgroup's tile
-    const int64_t a0 = static_cast<int64_t>(blockIdx.y) * TMB;
-    const int w0 = blockIdx.x * TN;
+    const int64_t a0 = static_cast<int64_t>(by) * TMB;
+    const int w0 = bx * TN;
     float acc[MI][4], xv[MI][4];
     // this thread's 4 x 4 values of X: rows and columns past the end are clamped (their results are dropped
     // at the store), so the 4 row loads are issued together - a per-element `in range ? load : 0` made the
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
     }
     // blockIdx.z owns the slice [b_lo, b_hi) of the reduction; partial sums of
     // several slices are combined with fp32 atomics (dX zeroed by the host)
-    const int64_t b_lo = static_cast<int64_t>(blockIdx.z) * b_chunk;
+    const int64_t b_lo = static_cast<int64_t>(bz) * b_chunk;
     const int64_t b_hi = min(b_lo + b_chunk, Y.n);
     if (b_lo >= b_hi) return;
 
@@ -305,11 +318,25 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(RowSrc<TX> X, RowSrc<TY>
         for (int j = 0; j < 4; ++j) {
             const int w = w0 + tx * 4 + j;
             if (w < W) {
-                if (gridDim.z == 1) dX[a * W + w] = acc[i][j];
+                if (S.gz == 1) dX[a * W + w] = acc[i][j];
                 else unsafeAtomicAdd(dX + a * W + w, acc[i][j]);
             }
         }
     }
+}
+
+// Both products of a backward call in ONE launch: workgroups [0, blocks_a) compute d_query tiles, the rest d_neg
+// tiles.  The products are independent, so at notebook sizes (a few hundred workgroups each) they run side by
+// side instead of one after the other, and at large sizes the second fills the chip as the first drains.
+template <typename TE, int RED, bool VEC4, bool ROUND16, int MIA, int MIB>
+__global__ __launch_bounds__(256) void k_neg_shared_bwd(BwdSide<float, TE> A, BwdSide<TE, float> B, int W,
+                                                        float sign, const float* __restrict__ d_out,
+                                                        const float* __restrict__ out, int blocks_a) {
+    __shared__ __attribute__((aligned(16))) float Cs[KT][LDP];  // [b][a]
+    __shared__ __attribute__((aligned(16))) float Ys[KT][LDP];  // [b][w]
+    const int block = blockIdx.x;
+    if (block < blocks_a) neg_shared_bwd_tile<float, TE, RED, VEC4, ROUND16, MIA>(A, W, sign, d_out, out, block, Cs, Ys);
+    else neg_shared_bwd_tile<TE, float, RED, VEC4, ROUND16, MIB>(B, W, sign, d_out, out, block - blocks_a, Cs, Ys);
 }
 
 template <typename T>
@@ -330,21 +357,19 @@ static int run_fwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<T> E, float
     return check_launch("neg_score_shared_fwd");
 }
 
+// Launch plan of one product.  Workgroups resident at once: 5 per CU is what the kernel's 94 VGPRs admit
+// (rocprofv3 SQ counters at 4 per CU: VALU issue 61 % of the cycles, waves parked at waits / barriers 27 % of
+// theirs - a wave alone issues at half rate, so resident waves are what fills the pipe).  The reduction over Y is
+// cut into `split` slices of at least 4 stages so that the grid fills those slots in whole rounds:
+// cost(split) = rounds of the grid over the slots / split, a little extra per slice for its prologue and the atomics.
 template <typename TX, typename TY>
-static int run_bwd_one(const bess_model_desc* d, RowSrc<TX> X, RowSrc<TY> Y, const float* d_out,
-                       int64_t sa, int64_t sb, const float* out, int64_t oa, int64_t ob, float* dX,
-                       hipStream_t st, bool round16 = false, bool zeroed = false) {
-    // Workgroups resident at once: 5 per CU is what the kernel's 94 VGPRs admit (rocprofv3 SQ counters at 4 per
-    // CU: VALU issue 61 % of the cycles, waves parked at waits / barriers 27 % of theirs - a wave alone issues
-    // at half rate, so resident waves are what fills the pipe).  The reduction over Y is cut into `split`
-    // slices of at least 4 stages so that the grid fills those slots in whole rounds: cost(split) = rounds of
-    // the grid over the slots / split, a little extra per slice for its prologue and the atomics.
+static bool plan_bwd_side(int W, BwdSide<TX, TY>& S) {
     const int64_t slots = 256 * 5;
     auto plan = [&](int64_t tile_rows, int64_t* best_split) {
-        const int64_t tiles = ceil_div(d->width, TN) * ceil_div(X.n, tile_rows);
+        const int64_t tiles = ceil_div(W, TN) * ceil_div(S.X.n, tile_rows);
         double best = 1e30;
         for (int64_t s = 1; s <= 32; ++s) {
-            if (s > 1 && ceil_div(Y.n, s) < 4 * KT) break;
+            if (s > 1 && ceil_div(S.Y.n, s) < 4 * KT) break;
             const double cost = static_cast<double>(ceil_div(tiles * s, slots)) / s * (1.0 + 0.01 * s);
             if (cost < best) best = cost, *best_split = s;
         }
@@ -355,38 +380,54 @@ static int run_bwd_one(const bess_model_desc* d, RowSrc<TX> X, RowSrc<TY> Y, con
     // 32-row tiles when the 64-row grid leaves most of the chip idle (under two workgroups per CU)
     const bool small = blocks64 < 2 * 256 && plan(TM / 2, &split32) > blocks64;
     if (small) split = split32;
-    const int64_t tile_rows = small ? TM / 2 : TM;
-    int64_t chunk = ceil_div(ceil_div(Y.n, split), KT) * KT;
-    split = ceil_div(Y.n, chunk);
-    if (split > 1 && !zeroed) {
-        hipError_t e = hipMemsetAsync(dX, 0, sizeof(float) * X.n * d->width, st);
-        if (e != hipSuccess) return fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
+    S.b_chunk = ceil_div(ceil_div(S.Y.n, split), KT) * KT;
+    S.gx = static_cast<int>(ceil_div(W, TN));
+    S.gy = static_cast<int>(ceil_div(S.X.n, small ? TM / 2 : TM));
+    S.gz = static_cast<int>(ceil_div(S.Y.n, S.b_chunk));
+    return small;
+}
+
+template <typename TE>
+static int run_bwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<TE> E, const float* d_out, int64_t ld_dout,
+                   const float* out, int64_t ld_out, float* d_query, float* d_neg, hipStream_t st, bool round16) {
+    const int W = d->width;
+    BwdSide<float, TE> A{Q, E, ld_dout, 1, ld_out, 1, d_query, 0, 0, 0, 0};
+    BwdSide<TE, float> B{E, Q, 1, ld_dout, 1, ld_out, d_neg, 0, 0, 0, 0};
+    const bool small_a = plan_bwd_side(W, A), small_b = plan_bwd_side(W, B);
+    const int64_t blocks_a = static_cast<int64_t>(A.gx) * A.gy * A.gz, blocks_b = static_cast<int64_t>(B.gx) * B.gy * B.gz;
+    BESS_REQUIRE(blocks_a + blocks_b < (1ll << 31), "neg_score_shared_bwd: problem too large for one launch");
+    // partial sums of several slices are combined with fp32 atomics: zero their targets - with one memset
+    // when both gradients share an allocation (d_neg right behind d_query)
+    auto zero = [&](float* p, int64_t n) -> int {
+        hipError_t e = hipMemsetAsync(p, 0, sizeof(float) * n, st);
+        return e == hipSuccess ? BESS_OK : fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
+    };
+    if (A.gz > 1 && B.gz > 1 && d_neg == d_query + Q.n * W) {
+        if (int e = zero(d_query, (Q.n + E.n) * W)) return e;
+    } else {
+        if (A.gz > 1)
+            if (int e = zero(d_query, Q.n * W)) return e;
+        if (B.gz > 1)
+            if (int e = zero(d_neg, E.n * W)) return e;
     }
-    const dim3 grid(static_cast<unsigned>(ceil_div(d->width, TN)), static_cast<unsigned>(ceil_div(X.n, tile_rows)),
-                    static_cast<unsigned>(split));
+    const unsigned grid = static_cast<unsigned>(blocks_a + blocks_b);
+    const int ba = static_cast<int>(blocks_a);
     const float sign = is_distance(d->scorer) ? -1.f : 1.f;
-    const bool vec4 = d->width % 4 == 0;
-#define BESS_BWD_ARGS <<<grid, 256, 0, st>>>(X, Y, d->width, sign, d_out, sa, sb, out, oa, ob, dX, chunk)
-#define BESS_BWD_MI(RED, V, R16)                                         \
-    do {                                                                 \
-        if (small) k_neg_shared_bwd<TX, TY, RED, V, R16, 2> BESS_BWD_ARGS; \
-        else k_neg_shared_bwd<TX, TY, RED, V, R16, 4> BESS_BWD_ARGS;       \
+    const bool vec4 = W % 4 == 0;
+#define BESS_BWD_ARGS <<<grid, 256, 0, st>>>(A, B, W, sign, d_out, out, ba)
+#define BESS_BWD_MI(RED, V, R16)                                                   \
+    do {                                                                           \
+        if (small_a && small_b) k_neg_shared_bwd<TE, RED, V, R16, 2, 2> BESS_BWD_ARGS; \
+        else if (small_a) k_neg_shared_bwd<TE, RED, V, R16, 2, 4> BESS_BWD_ARGS;       \
+        else if (small_b) k_neg_shared_bwd<TE, RED, V, R16, 4, 2> BESS_BWD_ARGS;       \
+        else k_neg_shared_bwd<TE, RED, V, R16, 4, 4> BESS_BWD_ARGS;                    \
     } while (0)
-#define BESS_BWD(RED)                          \
-    do {                                       \
-        if (vec4) BESS_BWD_MI(RED, true, false); \
-        else BESS_BWD_MI(RED, false, false);     \
-    } while (0)
-    if (round16 && vec4 && reduce_of(d) == RED_L1) {
-        BESS_BWD_MI(RED_L1, true, true);
-        return BESS_OK;
-    }
-    switch (reduce_of(d)) {
-        case RED_DOT: BESS_BWD(RED_DOT); break;
-        case RED_L1: BESS_BWD(RED_L1); break;
-        default: BESS_BWD(RED_L2);
-    }
-#undef BESS_BWD
+    const int red = reduce_of(d);  // RED_L1 or RED_L2: the bilinear scorers' products run on the matrix cores
+    if (red == RED_L1 && vec4 && round16) BESS_BWD_MI(RED_L1, true, true);
+    else if (red == RED_L1 && vec4) BESS_BWD_MI(RED_L1, true, false);
+    else if (red == RED_L1) BESS_BWD_MI(RED_L1, false, false);
+    else if (vec4) BESS_BWD_MI(RED_L2, true, false);
+    else BESS_BWD_MI(RED_L2, false, false);
 #undef BESS_BWD_MI
 #undef BESS_BWD_ARGS
     return BESS_OK;
@@ -529,22 +570,12 @@ extern "C" int bess_neg_score_shared_bwd_ws(const bess_model_desc* d, const floa
     // the packed-fp16 forward scores the query rounded to fp16: differentiate that function
     const bool r16 = use_l1_pk(d, query, neg_base);
     RowSrc<float> Q{query, nullptr, n_query};
-    // both gradients in one allocation (d_neg right behind d_query) and small: one memset for the two partial-sum
-    // targets instead of one in front of each kernel (launch-bound sizes: a launch saved counts)
-    bool z = false;
-    if (d_neg == d_query + n_query * d->width && (n_query + n_neg) * d->width <= (int64_t{1} << 22)) {
-        hipError_t e = hipMemsetAsync(d_query, 0, sizeof(float) * (n_query + n_neg) * d->width, st);
-        if (e != hipSuccess) return fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
-        z = true;
-    }
     if (d->dtype == BESS_F32) {
         RowSrc<float> E{static_cast<const float*>(neg_base), neg_idx, n_neg};
-        if (int e = run_bwd_one<float, float>(d, Q, E, d_out, ld_dout, 1, out, ld_out, 1, d_query, st, false, z)) return e;
-        if (int e = run_bwd_one<float, float>(d, E, Q, d_out, 1, ld_dout, out, 1, ld_out, d_neg, st, false, z)) return e;
+        if (int e = run_bwd<float>(d, Q, E, d_out, ld_dout, out, ld_out, d_query, d_neg, st, false)) return e;
     } else {
         RowSrc<half_t> E{static_cast<const half_t*>(neg_base), neg_idx, n_neg};
-        if (int e = run_bwd_one<float, half_t>(d, Q, E, d_out, ld_dout, 1, out, ld_out, 1, d_query, st, r16, z)) return e;
-        if (int e = run_bwd_one<half_t, float>(d, E, Q, d_out, 1, ld_dout, out, 1, ld_out, d_neg, st, r16, z)) return e;
+        if (int e = run_bwd<half_t>(d, Q, E, d_out, ld_dout, out, ld_out, d_query, d_neg, st, r16)) return e;
     }
     return check_launch("neg_score_shared_bwd");
 }
