@@ -77,6 +77,8 @@ __device__ __forceinline__ void kill_row(const KillArgs& k, int64_t s, int64_t* 
 }
 
 // out[q, j] = -sum_w |fp16(Q[q, w]) - E[idx[j], w]|        W % 32 == 0
+// MI: query rows per thread (4: 64 x 64 tile; 2: 32 x 64 tile for launches whose 64-row grid leaves CUs idle)
+template <int MI>
 __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, int64_t nq,
                                                    const half_t* __restrict__ E, const int32_t* __restrict__ eidx,
                                                    int64_t ne, int W, float* __restrict__ out, int64_t ld,
@@ -86,18 +88,20 @@ __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, 
     __shared__ float rsq[PT], rse[PT];
     const int t = threadIdx.x;
     const int tx = t & 15, ty = t >> 4;
-    const int64_t q0 = static_cast<int64_t>(blockIdx.y) * PT;
+    constexpr int QT = 16 * MI;  // query rows of the tile
+    const int64_t q0 = static_cast<int64_t>(blockIdx.y) * QT;
     const int64_t j0 = static_cast<int64_t>(blockIdx.x) * PT;
-    float acc[4][4];
+    float acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
     // staging: thread t brings 8 scalars of row m of each operand per stage (rows past the end are
     // clamped, their results dropped at the store)
     const int m = t >> 2, kc = t & 3;
-    const float* qp = Q + min(q0 + m, nq - 1) * W + kc * 8;
+    const bool stage_q = m < QT;  // wave-uniform (16 rows per wave)
+    const float* qp = Q + min(q0 + (stage_q ? m : 0), nq - 1) * W + kc * 8;
     const int64_t er = min(j0 + m, ne - 1);
     const half_t* ep = E + (eidx ? static_cast<int64_t>(eidx[er]) : er) * W + kc * 8;
     float4 qa = *reinterpret_cast<const float4*>(qp), qb = *reinterpret_cast<const float4*>(qp + 4);
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, 
         const uint32_t ed[4] = {ev.x, ev.y, ev.z, ev.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            Qs[kc * 4 + i][m] = qd[i];
+            if (stage_q) Qs[kc * 4 + i][m] = qd[i];
             Es[kc * 4 + i][m] = ed[i];
             sq = dot2_ones(qd[i], sq);
             se = dot2_ones(ed[i], se);
@@ -121,12 +125,18 @@ __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, 
         }
 #pragma unroll
         for (int k = 0; k < FKH / 2; ++k) {
-            const uint4 a4 = *reinterpret_cast<const uint4*>(&Qs[k][ty * 4]);
+            uint32_t a[MI];
+            if constexpr (MI == 4) {
+                const uint4 a4 = *reinterpret_cast<const uint4*>(&Qs[k][ty * 4]);
+                a[0] = a4.x, a[1] = a4.y, a[2] = a4.z, a[3] = a4.w;
+            } else {
+                const uint2 a2 = *reinterpret_cast<const uint2*>(&Qs[k][ty * 2]);
+                a[0] = a2.x, a[1] = a2.y;
+            }
             const uint4 b4 = *reinterpret_cast<const uint4*>(&Es[k][tx * 4]);
-            const uint32_t a[4] = {a4.x, a4.y, a4.z, a4.w};
             const uint32_t b[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = dot2_ones(pk_max_f16(a[i], b[j]), acc[i][j]);
         }
@@ -137,15 +147,15 @@ __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, 
     se += __shfl_xor(se, 1, 64);
     se += __shfl_xor(se, 2, 64);
     if (kc == 0) {
-        rsq[m] = sq;
+        if (stage_q) rsq[m] = sq;
         rse[m] = se;
     }
     __syncthreads();
     const bool any_kill = kill.diag_step > 0 || kill.mask;  // wave-uniform
     const int64_t mask_from = kill.n_neg - kill.mask_cols;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t q = q0 + ty * 4 + i;
+    for (int i = 0; i < MI; ++i) {
+        const int64_t q = q0 + ty * MI + i;
         if (q >= nq) continue;
         float* o = out + q * ld;
         int64_t kcol = -1;
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, 
         for (int j = 0; j < 4; ++j) {
             const int64_t jj = j0 + tx * 4 + j;
             if (jj < ne) {
-                float v = -((2.f * acc[i][j] - rsq[ty * 4 + i]) - rse[tx * 4 + j]);
+                float v = -((2.f * acc[i][j] - rsq[ty * MI + i]) - rse[tx * 4 + j]);
                 if (any_kill) {
                     bool kl = jj == kcol;
                     // the mask overrides the diagonal on its columns (bess.py:227-228)
@@ -178,9 +188,15 @@ int l1_pk_fwd(const bess_model_desc* d, const float* query, int64_t n_query, con
               hipStream_t st) {
     KillArgs ka{};
     if (k) ka = KillArgs{k->diag_step, k->ht, k->ppp, k->mask, k->mask_rows, k->mask ? k->mask_cols : 0, n_neg};
-    const dim3 grid(static_cast<unsigned>(ceil_div(n_neg, PT)), static_cast<unsigned>(ceil_div(n_query, PT)));
-    k_l1_fwd_pk<<<grid, 256, 0, st>>>(query, n_query, static_cast<const half_t*>(neg_base), neg_idx, n_neg, d->width,
-                                      out, ld_out, ka);
+    // 32-row tiles when the 64-row grid would leave most CUs without a workgroup
+    const bool small = ceil_div(n_neg, PT) * ceil_div(n_query, PT) < 192;
+    const dim3 grid(static_cast<unsigned>(ceil_div(n_neg, PT)), static_cast<unsigned>(ceil_div(n_query, small ? PT / 2 : PT)));
+    if (small)
+        k_l1_fwd_pk<2><<<grid, 256, 0, st>>>(query, n_query, static_cast<const half_t*>(neg_base), neg_idx, n_neg,
+                                             d->width, out, ld_out, ka);
+    else
+        k_l1_fwd_pk<4><<<grid, 256, 0, st>>>(query, n_query, static_cast<const half_t*>(neg_base), neg_idx, n_neg,
+                                             d->width, out, ld_out, ka);
     return check_launch("neg_score_shared_fwd (packed f16 L1)");
 }
 

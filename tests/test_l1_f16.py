@@ -43,7 +43,8 @@ def problem(S, N, W, M, scale, seed, ties=False):
 
 
 @pytest.mark.parametrize("S,N,W,scale", [(64, 64, 32, 1.0), (70, 130, 96, 1.0), (256, 300, 256, 0.01),
-                                         (33, 17, 64, 3e-5), (128, 64, 512, 30.0)])
+                                         (33, 17, 64, 3e-5), (128, 64, 512, 30.0),
+                                         (1000, 900, 64, 1.0)])  # 240 tiles: the 64-row tile; the others the 32-row one
 def test_forward_matches_the_fp16_query_oracle(dev, S, N, W, scale):
     from besskge import _native as nat
 
@@ -67,12 +68,13 @@ def test_forward_matches_the_fp16_query_oracle(dev, S, N, W, scale):
     torch.testing.assert_close(got32.double(), want32, rtol=1e-5, atol=1e-5 * float(mag.max()))
 
 
+@pytest.mark.parametrize("ppp", [16, 512])  # 32-row / 64-row tile kernels
 @pytest.mark.parametrize("variant", ["augment", "augment_ht", "mask1", "mask2_ht", "mask_rows", "augment_mask"])
-def test_forward_with_the_kill_in_its_epilogue_equals_mask_scores(dev, variant):
+def test_forward_with_the_kill_in_its_epilogue_equals_mask_scores(dev, variant, ppp):
     """bess_neg_score_shared_fwd_masked == scores, then bess_mask_scores (bit for bit)."""
     from besskge import _native as nat
 
-    n, ppp, K, W = 2, 16, 24, 64
+    n, K, W = 2, 24 if ppp == 16 else 420, 64
     S = n * ppp
     ht = variant.endswith("ht")
     N = (S // 2 if ht else S) + n * K if variant.startswith("augment") else n * K
