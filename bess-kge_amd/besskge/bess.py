@@ -492,9 +492,14 @@ class BessKGE(torch.nn.Module, ABC):
                 add(st.tail)
             for g in st.groups:
                 if not g.shared and g.neg.base is st.table and fn.supports_fused_segments:
-                    ok = False  # reduced by the segmented K9: the small lists ride along there
-                    break
-                add(g.neg)
+                    # reduced by the segmented K9.  With ONE such group and a stateful optimiser the small lists
+                    # ride along there (`_apply_optimizer_fused`) through an index of their own - the one built
+                    # here; several groups go through `_apply_optimizer` with lists that do not exist yet
+                    ok = len(st.groups) == 1 and not plain and st.n == 1
+                    if not ok:
+                        break
+                else:
+                    add(g.neg)
                 if st.fused_qt:
                     add(head)
                     add(st.tail)
@@ -529,7 +534,8 @@ class BessKGE(torch.nn.Module, ABC):
         nat.apply_segments_opt(o, table, cache[key], grad.contiguous(), s1, s2)
 
     def _apply_optimizer_fused(self, opt: Any, desc: nat.ModelDesc, table: torch.Tensor, g: _NegGroup,
-                               go: torch.Tensor, seg: Any, extras: List[Tuple[torch.Tensor, torch.Tensor]]) -> None:
+                               go: torch.Tensor, seg: Any, extras: List[Tuple[torch.Tensor, torch.Tensor]],
+                               ahead: Optional[Tuple[List[torch.Tensor], Any]] = None) -> None:
         """K9 + K10 of a shard whose per-triple negatives form one group, for a stateful optimiser:
         the big per-row reduction applies the optimiser itself (no [unique rows, W] gradient, no host
         sync); the small lists (heads, tails, ...) are summed per unique row first and ride along, so
@@ -537,11 +543,15 @@ class BessKGE(torch.nn.Module, ABC):
         o, s1, s2 = self._opt_desc(opt, table)
         xmap = xsum = xseg = keep = None
         if extras:
-            idx = torch.cat([i.reshape(-1) for i, _ in extras]).contiguous()
+            ids = [i.reshape(-1) for i, _ in extras]
             grads = [x.contiguous() for _, x in extras]
             if len(grads) > nat.MAX_ROW_LISTS:
                 grads = [torch.cat(grads, dim=0)]
-            xseg = nat.SegmentIndex(idx, table.shape[0])
+            if ahead is not None and len(ahead[0]) == len(ids) and all(
+                    a.data_ptr() == b.data_ptr() and a.numel() == b.numel() for a, b in zip(ahead[0], ids)):
+                xseg = ahead[1]  # built on the side stream behind the forward (`_small_index_ahead`)
+            else:
+                xseg = nat.SegmentIndex(torch.cat(ids).contiguous(), table.shape[0])
             xsum = nat.coalesced_update(None, table, xseg, grads, sum_only=True)
             xmap, keep = nat.map_extra_rows(seg, xseg)
         self._assign_state_rows(table, seg)
@@ -619,7 +629,8 @@ class BessKGE(torch.nn.Module, ABC):
                 mine = [item for item in deferred if item[0] is st.table]
                 if native and len(mine) == 1:
                     table, g, go = mine[0]
-                    self._apply_optimizer_fused(optimizer, desc, table, g, go, seg_index[id(g)], list(upd))
+                    self._apply_optimizer_fused(optimizer, desc, table, g, go, seg_index[id(g)], list(upd),
+                                                (getattr(self, "_small_ahead", None) or {}).get(id(st)))
                     continue
                 contrib = list(upd)
                 for table, g, go in deferred:
@@ -768,6 +779,11 @@ class EmbeddingMovingBessKGE(BessKGE):
             else:
                 st.positive_score, st.triple_ctx = fn.triple_fwd(
                     RowSource(st.table, st.head_idx), st.tail, st.rel_idx)
+            early = getattr(self, "_small_early", None)
+            if early is not None:
+                # training: the index of the step's small update lists needs only row ids - start it on the side
+                # stream before the scoring kernels are queued, so that it runs under them
+                early.update(self._small_index_ahead([st], self._ahead_optimizer))
             outs = self._run_groups(st, desc, fuse[len(done)] if fuse else None)
             done.append(st)
             if len(outs) == 1:
@@ -914,13 +930,19 @@ class EmbeddingMovingBessKGE(BessKGE):
         W = self.entity_embedding_size
         self._train_fuse = [self._fusable(b) for b in batches]
         self._seg_ahead = {}
+        self._small_early: Optional[Dict[int, Any]] = {}
+        self._ahead_optimizer = optimizer
         try:
             steps = self._score_replicas(batches)
             seg_index = self._prefetch_segment_indices(steps)
+            self._small_ahead = dict(self._small_early)
         finally:
             self._train_fuse = None
             self._seg_ahead = None
-        self._small_ahead = self._small_index_ahead(steps, optimizer)
+            self._small_early = None
+            self._ahead_optimizer = None
+        self._small_ahead.update(self._small_index_ahead([st for st in steps if id(st) not in self._small_ahead],
+                                                         optimizer))
         desc = fn.kernel_desc()
         rel_table = fn.relation_embedding.data
         results = []
