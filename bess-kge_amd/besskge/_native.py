@@ -10,6 +10,7 @@ There is deliberately no CPU fallback: every wrapper raises if a tensor is not
 on a CUDA/HIP device or if the library is missing.
 """
 
+import contextlib
 import ctypes
 import pathlib
 from typing import Any, List, Optional, Sequence, Tuple
@@ -328,7 +329,19 @@ def _row_count(base: torch.Tensor, idx: Optional[torch.Tensor]) -> int:
 
 
 def _stream(dev: torch.device) -> int:
-    return torch.cuda.current_stream(dev).cuda_stream
+    """Raw handle of PyTorch's current HIP stream on `dev` (no Stream object is built: this runs per launch)."""
+    return torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+_NO_SWITCH = contextlib.nullcontext()
+
+
+def _on(dev: torch.device) -> Any:
+    """`torch.cuda.device(dev)` only when `dev` is not the current device already (the usual case: one
+    process per GPU) - the context manager costs more host time than the launch it wraps."""
+    if dev.index is None or torch.cuda.current_device() == dev.index:
+        return _NO_SWITCH
+    return torch.cuda.device(dev)
 
 
 class RowSource:
@@ -369,7 +382,7 @@ def gather_rows(table: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tens
         _rows(out, "out", W)
         if out.shape[0] != n or out.dtype != table.dtype:
             raise ValueError("gather_rows: `out` does not match idx / table dtype")
-    with torch.cuda.device(dev), _Timed("bess_gather_rows", dev):
+    with _on(dev), _Timed("bess_gather_rows", dev):
         rc = load().bess_gather_rows(_dtype_code(table), W, table.data_ptr(), ip, n, out.data_ptr(), _stream(dev))
     _check(rc, "bess_gather_rows")
     return out
@@ -397,7 +410,7 @@ def score_triple_fwd(d: ModelDesc, head: RowSource, tail: RowSource, rel_table: 
                      rel_idx: torch.Tensor) -> torch.Tensor:
     dev, n = _triple_operands(d, head, tail, rel_table, rel_idx)
     out = torch.empty((n,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_score_triple_fwd(
             ctypes.byref(d), head.base.data_ptr(), _idx(head.idx, "head_idx"), tail.base.data_ptr(),
             _idx(tail.idx, "tail_idx"), rel_table.data_ptr(), rel_idx.data_ptr(), n, out.data_ptr(), _stream(dev))
@@ -417,7 +430,7 @@ def score_triple_bwd(d: ModelDesc, head: RowSource, tail: RowSource, rel_table: 
         raise ValueError("score_triple_bwd: gradient shapes do not match")
     dh = torch.empty((n, d.width), dtype=torch.float32, device=dev)
     dt = torch.empty((n, d.width), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_score_triple_bwd(
             ctypes.byref(d), head.base.data_ptr(), _idx(head.idx, "head_idx"), tail.base.data_ptr(),
             _idx(tail.idx, "tail_idx"), rel_table.data_ptr(), rel_idx.data_ptr(), n, d_out.data_ptr(),
@@ -432,7 +445,7 @@ def query_triple_fwd(d: ModelDesc, side: int, head: RowSource, tail: RowSource, 
     dev, n = _triple_operands(d, head, tail, rel_table, rel_idx)
     q = torch.empty((n, d.width), dtype=torch.float32, device=dev)
     out = torch.empty((n,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_query_triple_fwd(
             ctypes.byref(d), side, head.base.data_ptr(), _idx(head.idx, "head_idx"), tail.base.data_ptr(),
             _idx(tail.idx, "tail_idx"), rel_table.data_ptr(), rel_idx.data_ptr(), n, q.data_ptr(), out.data_ptr(),
@@ -453,7 +466,7 @@ def query_triple_bwd(d: ModelDesc, side: int, head: RowSource, tail: RowSource, 
         raise ValueError("query_triple_bwd: gradient shapes do not match")
     dh = torch.empty((n, d.width), dtype=torch.float32, device=dev)
     dt = torch.empty((n, d.width), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_query_triple_bwd(
             ctypes.byref(d), side, head.base.data_ptr(), _idx(head.idx, "head_idx"), tail.base.data_ptr(),
             _idx(tail.idx, "tail_idx"), rel_table.data_ptr(), rel_idx.data_ptr(), n, d_out.data_ptr(),
@@ -477,7 +490,7 @@ def _query_operands(d: ModelDesc, ent: RowSource, rel_table: torch.Tensor, rel_i
 def query_fwd(d: ModelDesc, side: int, ent: RowSource, rel_table: torch.Tensor, rel_idx: torch.Tensor) -> torch.Tensor:
     dev, n = _query_operands(d, ent, rel_table, rel_idx)
     q = torch.empty((n, query_width(d)), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_query_fwd(ctypes.byref(d), side, ent.base.data_ptr(), _idx(ent.idx, "entity idx"),
                                    rel_table.data_ptr(), rel_idx.data_ptr(), n, q.data_ptr(), _stream(dev))
     _check(rc, "bess_query_fwd")
@@ -494,7 +507,7 @@ def query_bwd(d: ModelDesc, side: int, ent: RowSource, rel_table: torch.Tensor, 
     if tuple(d_query.shape) != (n, query_width(d)) or tuple(d_rel_table.shape) != tuple(rel_table.shape):
         raise ValueError("query_bwd: gradient shapes do not match")
     dx = torch.empty((n, d.width), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_query_bwd(ctypes.byref(d), side, ent.base.data_ptr(), _idx(ent.idx, "entity idx"),
                                    rel_table.data_ptr(), rel_idx.data_ptr(), n, d_query.data_ptr(),
                                    dx.data_ptr(), d_rel_table.data_ptr(), _stream(dev))
@@ -543,7 +556,7 @@ def neg_score_pertriple_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n
     if tuple(out.shape) != (nq, n_neg):
         raise ValueError("neg_score_pertriple_fwd: bad `out` shape")
     ip, keep = _neg_idx_ptr(neg, dev)
-    with torch.cuda.device(dev), _Timed("bess_neg_score_pertriple_fwd", dev):
+    with _on(dev), _Timed("bess_neg_score_pertriple_fwd", dev):
         rc = load().bess_neg_score_pertriple_fwd(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(), ip,
                                                  n_neg, out.data_ptr(), n_neg, _stream(dev))
     _check(rc, "bess_neg_score_pertriple_fwd")
@@ -573,7 +586,7 @@ def neg_score_pertriple_fwd_dq(d: ModelDesc, l: LossDesc, query: torch.Tensor, n
     st_ml = torch.empty((nq, items.value, 2), dtype=torch.float32, device=dev)
     st_acc = torch.empty((nq, items.value, d.width), dtype=torch.float32, device=dev)
     ip, keep = _neg_idx_ptr(neg, dev)
-    with torch.cuda.device(dev), _Timed("bess_neg_score_pertriple_fwd_dq", dev):
+    with _on(dev), _Timed("bess_neg_score_pertriple_fwd_dq", dev):
         rc = load().bess_neg_score_pertriple_fwd_dq(
             ctypes.byref(d), ctypes.byref(l), query.data_ptr(), nq, neg.base.data_ptr(), ip, n_neg,
             pos.data_ptr() if pos is not None else 0, weight.data_ptr(), weight.numel(), out.data_ptr(), n_neg,
@@ -596,7 +609,7 @@ def neg_score_pertriple_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n
     dq = torch.empty((nq, query_width(d)), dtype=torch.float32, device=dev)
     dn = torch.empty((nq * n_neg, d.width), dtype=torch.float32, device=dev) if want_d_neg else None
     ip, keep = _neg_idx_ptr(neg, dev)
-    with torch.cuda.device(dev), _Timed("bess_neg_score_pertriple_bwd", dev):
+    with _on(dev), _Timed("bess_neg_score_pertriple_bwd", dev):
         rc = load().bess_neg_score_pertriple_bwd(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(), ip,
                                                  n_neg, d_out.data_ptr(), n_neg, dq.data_ptr(),
                                                  dn.data_ptr() if want_d_neg else 0, _stream(dev))
@@ -613,7 +626,7 @@ def normalize_rows(neg: RowSource, n_part: int, normalize: bool) -> Tuple[torch.
     n = len(neg)
     hat = torch.empty((n, W), dtype=torch.float32, device=dev)
     inv = torch.empty((n, n_part), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_normalize_rows(_dtype_code(neg.base), neg.base.data_ptr(), _idx(neg.idx, "idx"), n, W, n_part,
                                         int(normalize), hat.data_ptr(), inv.data_ptr(), _stream(dev))
     _check(rc, "bess_normalize_rows")
@@ -627,7 +640,7 @@ def normalize_rows_bwd(hat: torch.Tensor, inv: torch.Tensor, d_hat: torch.Tensor
     if hat.shape != d_hat.shape or inv.shape[0] != hat.shape[0]:
         raise ValueError("normalize_rows_bwd: shape mismatch")
     out = torch.empty_like(hat)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_normalize_rows_bwd(hat.data_ptr(), inv.data_ptr(), d_hat.data_ptr(), hat.shape[0],
                                             hat.shape[1], inv.shape[1], out.data_ptr(), _stream(dev))
     _check(rc, "bess_normalize_rows_bwd")
@@ -667,7 +680,7 @@ def neg_score_shared_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, pad_
             if mask.dtype != torch.bool or mask.dim() != 2 or not mask.is_contiguous():
                 raise ValueError("negative_mask must be a contiguous 2-D bool tensor")
             kd.mask, kd.mask_rows, kd.mask_cols = mask.data_ptr(), int(mask.shape[0]), int(mask.shape[1])
-    with torch.cuda.device(dev), _Timed("bess_neg_score_shared_fwd", dev):
+    with _on(dev), _Timed("bess_neg_score_shared_fwd", dev):
         if kd is None:
             rc = lib.bess_neg_score_shared_fwd_ws(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
                                                   _idx(neg.idx, "negative idx"), n_neg, out.data_ptr(), ld,
@@ -704,7 +717,7 @@ def neg_score_shared_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, out:
     lib = load()
     ws_bytes = int(lib.bess_neg_score_shared_bwd_workspace(ctypes.byref(d), nq, n_neg))  # see neg_score_shared_fwd
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
-    with torch.cuda.device(dev), _Timed("bess_neg_score_shared_bwd", dev):
+    with _on(dev), _Timed("bess_neg_score_shared_bwd", dev):
         rc = lib.bess_neg_score_shared_bwd_ws(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
                                               _idx(neg.idx, "negative idx"), n_neg, out.data_ptr(), n_neg,
                                               d_out.data_ptr(), n_neg, dq.data_ptr(), dn.data_ptr(),
@@ -727,7 +740,7 @@ def mask_scores(neg: torch.Tensor, diag_step: int, ht: bool, ppp: int, mask: Opt
         if mask.dtype != torch.bool or mask.dim() != 2 or not mask.is_contiguous():
             raise ValueError("negative_mask must be a contiguous 2-D bool tensor")
         mp, mrows, mcols = mask.data_ptr(), int(mask.shape[0]), int(mask.shape[1])
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_mask_scores(neg.data_ptr(), S, N, N, diag_step, int(ht), ppp, mp, mrows, mcols, _stream(dev))
     _check(rc, "bess_mask_scores")
 
@@ -745,7 +758,7 @@ def loss_fwd_bwd(l: LossDesc, pos: torch.Tensor, neg: torch.Tensor, weight: torc
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
     dp = torch.empty((S,), dtype=torch.float32, device=dev) if want_grad else None
     dn = torch.empty((S, N), dtype=torch.float32, device=dev) if want_grad else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_loss_fwd_bwd(ctypes.byref(l), pos.data_ptr(), neg.data_ptr(), S, N, N, weight.data_ptr(),
                                       weight.numel(), row_loss.data_ptr(), loss.data_ptr(),
                                       dp.data_ptr() if want_grad else 0, dn.data_ptr() if want_grad else 0, N,
@@ -763,7 +776,7 @@ def scatter_add_rows(dst: torch.Tensor, idx: torch.Tensor, src: torch.Tensor, sc
     _rows(src, "src", W)
     n = int(src.shape[0])
     ip = _idx(idx, "idx", n)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_scatter_add_rows(dst.data_ptr(), W, ip, src.data_ptr(), n, scale, _stream(dev))
     _check(rc, "bess_scatter_add_rows")
 
@@ -776,7 +789,7 @@ def sparse_sgd(table: torch.Tensor, idx: torch.Tensor, grad: torch.Tensor, lr: f
     _rows(grad, "grad", W)
     n = int(grad.shape[0])
     ip = _idx(idx, "idx", n)
-    with torch.cuda.device(dev), _Timed("bess_sparse_sgd", dev):
+    with _on(dev), _Timed("bess_sparse_sgd", dev):
         rc = load().bess_sparse_sgd(_dtype_code(table), W, table.data_ptr(), ip, grad.data_ptr(), n, lr, _stream(dev))
     _check(rc, "bess_sparse_sgd")
 
@@ -796,7 +809,7 @@ def sparse_sgd_lists(table: torch.Tensor, lists: Sequence[Tuple[torch.Tensor, to
     ip = (_vp * len(lists))(*[x.data_ptr() for x, _ in lists])
     gp = (_vp * len(lists))(*[g.data_ptr() for _, g in lists])
     rows = (_i64 * len(lists))(*[int(g.shape[0]) for _, g in lists])
-    with torch.cuda.device(dev), _Timed("bess_sparse_sgd_lists", dev):
+    with _on(dev), _Timed("bess_sparse_sgd_lists", dev):
         rc = load().bess_sparse_sgd_lists(_dtype_code(table), W, table.data_ptr(), len(lists), ip, gp, rows, lr, _stream(dev))
     _check(rc, "bess_sparse_sgd_lists")
 
@@ -806,7 +819,7 @@ def dense_sgd(table: torch.Tensor, grad: torch.Tensor, lr: float) -> None:
     _f32(grad, "grad")
     if not table.is_contiguous() or table.numel() != grad.numel():
         raise ValueError("dense_sgd: table / grad mismatch")
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_dense_sgd(_dtype_code(table), table.data_ptr(), grad.data_ptr(), table.numel(), lr, _stream(dev))
     _check(rc, "bess_dense_sgd")
 
@@ -843,7 +856,7 @@ class SegmentIndex:
         self.long_cap = n // SEGMENT_CAP + 1
         self.long_segs = torch.empty((self.long_cap + 1,), dtype=torch.int32, device=dev)
         bits = max(1, int(n_rows - 1).bit_length())
-        with torch.cuda.device(dev), _Timed("bess_build_segment_index", dev):
+        with _on(dev), _Timed("bess_build_segment_index", dev):
             rc = load().bess_build_segment_index(ip, n, bits, self.refs.data_ptr(), self.seg_rows.data_ptr(),
                                                  self.seg_offsets.data_ptr(), self.n_seg.data_ptr(),
                                                  self.long_segs.data_ptr(), self.long_cap, ws.data_ptr(),
@@ -899,7 +912,7 @@ def neg_pertriple_grad_segments(d: ModelDesc, query: torch.Tensor, table: torch.
     if native and (seg.long_grad is None or seg.long_grad.shape[1] != d.width):
         seg.long_grad = torch.zeros((seg.long_cap, d.width), dtype=torch.float32, device=dev)
     long_grad = seg.long_grad
-    with torch.cuda.device(dev), _Timed("bess_neg_pertriple_grad_segments", dev):
+    with _on(dev), _Timed("bess_neg_pertriple_grad_segments", dev):
         rc = load().bess_neg_pertriple_grad_segments(ctypes.byref(d), query.data_ptr(), nq, table.data_ptr(), n_neg,
                                                      d_out.data_ptr(), n_neg, seg.refs.data_ptr(),
                                                      seg.seg_rows.data_ptr(), seg.seg_offsets.data_ptr(),
@@ -921,7 +934,7 @@ def apply_segments_sgd(table: torch.Tensor, seg: SegmentIndex, grad_seg: torch.T
     _f32(grad_seg, "grad_seg")
     if tuple(grad_seg.shape) != (seg.max_seg, W):
         raise ValueError("apply_segments_sgd: grad_seg shape mismatch")
-    with torch.cuda.device(dev), _Timed("bess_apply_segments_sgd", dev):
+    with _on(dev), _Timed("bess_apply_segments_sgd", dev):
         rc = load().bess_apply_segments_sgd(_dtype_code(table), W, table.data_ptr(), seg.seg_rows.data_ptr(),
                                             seg.n_seg.data_ptr(), seg.max_seg, grad_seg.data_ptr(), lr, _stream(dev))
     _check(rc, "bess_apply_segments_sgd")
@@ -935,7 +948,7 @@ def segment_sum_rows(src: torch.Tensor, seg: SegmentIndex) -> torch.Tensor:
         raise ValueError("segment_sum_rows: src must be [n_refs, W]")
     W = int(src.shape[1])
     out = torch.empty((seg.max_seg, W), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_segment_sum_rows(W, src.data_ptr(), seg.refs.data_ptr(), seg.seg_offsets.data_ptr(),
                                           seg.n_seg.data_ptr(), seg.max_seg, out.data_ptr(), _stream(dev))
     _check(rc, "bess_segment_sum_rows")
@@ -954,7 +967,7 @@ def apply_segments_opt(o: OptDesc, table: torch.Tensor, seg: SegmentIndex, grad_
         raise ValueError("apply_segments_opt: grad_seg shape mismatch")
     _state_ok(state1, table, o, "state1")
     _state_ok(state2, table, o, "state2")
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_apply_segments_opt(ctypes.byref(o), _dtype_code(table), W, table.data_ptr(),
                                             seg.seg_rows.data_ptr(), seg.n_seg.data_ptr(), seg.max_seg,
                                             grad_seg.data_ptr(), state1.data_ptr() if state1 is not None else 0,
@@ -991,7 +1004,7 @@ def coalesced_update(o: Optional[OptDesc], table: torch.Tensor, seg: SegmentInde
     ptrs = (_vp * len(grads))(*[g.data_ptr() for g in grads])
     rows = (_i64 * len(grads))(*[int(g.shape[0]) for g in grads])
     out = torch.empty((seg.max_seg, W), dtype=torch.float32, device=dev) if sum_only else None
-    with torch.cuda.device(dev), _Timed("bess_coalesced_update", dev):
+    with _on(dev), _Timed("bess_coalesced_update", dev):
         rc = load().bess_coalesced_update(
             ctypes.byref(o) if o is not None else None, _dtype_code(table), W, table.data_ptr(), len(grads), ptrs, rows,
             seg.refs.data_ptr(), seg.seg_rows.data_ptr(), seg.seg_offsets.data_ptr(), seg.n_seg.data_ptr(), seg.max_seg,
@@ -1007,7 +1020,7 @@ def assign_state_rows(seg: Any, slot_map: torch.Tensor, counter: torch.Tensor, c
     dev = _same_device([("seg_rows", seg.seg_rows), ("slot_map", slot_map), ("counter", counter), ("keep", keep)])
     if slot_map.dtype != torch.int32 or counter.dtype != torch.int32 or not slot_map.is_contiguous():
         raise ValueError("assign_state_rows: slot_map / counter must be int32")
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_assign_state_rows(seg.seg_rows.data_ptr(), seg.n_seg.data_ptr(), seg.max_seg,
                                            keep.data_ptr() if keep is not None else None, slot_map.data_ptr(),
                                            counter.data_ptr(), int(capacity), _stream(dev))
@@ -1028,7 +1041,7 @@ def map_extra_rows(seg: SegmentIndex, extra: SegmentIndex) -> Tuple[torch.Tensor
     dev = _same_device([("seg_rows", seg.seg_rows), ("extra_rows", extra.seg_rows)])
     xmap = torch.empty((seg.max_seg,), dtype=torch.int32, device=dev)
     keep = torch.empty((extra.max_seg,), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_map_extra_rows(seg.seg_rows.data_ptr(), seg.n_seg.data_ptr(), seg.max_seg,
                                         extra.seg_rows.data_ptr(), extra.n_seg.data_ptr(), extra.max_seg,
                                         xmap.data_ptr(), keep.data_ptr(), _stream(dev))
@@ -1062,7 +1075,7 @@ def neg_pertriple_step_segments(d: ModelDesc, query: torch.Tensor, table: torch.
             raise ValueError("neg_pertriple_step_segments: extra_map / extra_sum shapes")
     if seg.long_grad is None or seg.long_grad.shape[1] != d.width:
         seg.long_grad = torch.zeros((seg.long_cap, d.width), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _Timed("bess_neg_pertriple_step_segments", dev):
+    with _on(dev), _Timed("bess_neg_pertriple_step_segments", dev):
         rc = load().bess_neg_pertriple_step_segments(
             ctypes.byref(d), query.data_ptr(), nq, table.data_ptr(), n_neg, d_out.data_ptr(), n_neg,
             seg.refs.data_ptr(), seg.seg_rows.data_ptr(), seg.seg_offsets.data_ptr(), seg.n_seg.data_ptr(),
@@ -1081,7 +1094,7 @@ def ranks_from_scores(pos: torch.Tensor, cand: torch.Tensor, mode: int, worst_ra
     if cand.dim() != 2 or cand.shape[0] != pos.numel():
         raise ValueError("`pos_score` and `candidate_score` need to have same size at dimension 0")
     out = torch.empty((pos.numel(),), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_ranks_from_scores(pos.data_ptr(), cand.data_ptr(), pos.numel(), cand.shape[1], cand.shape[1],
                                            mode, int(worst_rank_infty), out.data_ptr(), _stream(dev))
     _check(rc, "bess_ranks_from_scores")
@@ -1095,7 +1108,7 @@ def ranks_from_indices(truth: torch.Tensor, cand: torch.Tensor, worst_rank_infty
     if cand.dim() != 2 or cand.shape[0] != truth.numel():
         raise ValueError("`ground_truth` and `candidate_indices` need to have the same size for dimension 0")
     out = torch.empty((truth.numel(),), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = load().bess_ranks_from_indices(truth.data_ptr(), cand.data_ptr(), truth.numel(), cand.shape[1],
                                             int(worst_rank_infty), out.data_ptr(), _stream(dev))
     _check(rc, "bess_ranks_from_indices")
@@ -1126,7 +1139,7 @@ def topk_update(scores: torch.Tensor, best_score: torch.Tensor, best_id: torch.T
                 or not mask.is_contiguous():
             raise ValueError("topk_update: mask must be a contiguous bool [1 | rows, L] tensor")
         mp, mr = mask.data_ptr(), int(mask.shape[0])
-    with torch.cuda.device(dev), _Timed("bess_topk_update", dev):
+    with _on(dev), _Timed("bess_topk_update", dev):
         ld = int(scores.stride(0)) if R > 1 else L
         rc = load().bess_topk_update(scores.data_ptr(), R, L, max(ld, L), ip, ir, int(id_base), mp, mr,
                                      best_score.data_ptr(), best_id.data_ptr(), kk, _stream(dev))
@@ -1243,7 +1256,7 @@ def gather_candidate_lists(table_h: torch.Tensor, mask_h: Optional[torch.Tensor]
     if want_mask and mask_h is not None:
         shape = (n_step, n_neg_shard, n_shard, T, L) if mask_gather_layout else (n_step, n_shard, T, n_neg_shard, L)
         msk = torch.empty(shape, dtype=torch.bool, device=dev)
-    with torch.cuda.device(dev), _Timed("bess_gather_candidate_lists", dev):
+    with _on(dev), _Timed("bess_gather_candidate_lists", dev):
         rc = load().bess_gather_candidate_lists(
             table_h.data_ptr(), table_t.data_ptr() if table_t is not None else None,
             mask_h.data_ptr() if mask_h is not None else None, mask_t.data_ptr() if mask_t is not None else None,
@@ -1307,7 +1320,7 @@ class Communicator:
         elif recv.shape != send.shape or recv.dtype != send.dtype:
             raise ValueError("all_to_all: recv does not match send")
         per_peer = send[0].numel() * send.element_size()
-        with torch.cuda.device(self.device), _Timed("bess_alltoall", self.device):
+        with _on(self.device), _Timed("bess_alltoall", self.device):
             rc = load().bess_alltoall(self._h, self._buf(send, "send"), self._buf(recv, "recv"), per_peer,
                                       _stream(self.device))
         _check(rc, "bess_alltoall")
@@ -1316,7 +1329,7 @@ class Communicator:
     def all_gather(self, send: torch.Tensor) -> torch.Tensor:
         """recv [world, *send.shape] in rank order."""
         recv = torch.empty((self.world, *send.shape), dtype=send.dtype, device=send.device)
-        with torch.cuda.device(self.device), _Timed("bess_allgather", self.device):
+        with _on(self.device), _Timed("bess_allgather", self.device):
             rc = load().bess_allgather(self._h, self._buf(send, "send"), self._buf(recv, "recv"),
                                        send.numel() * send.element_size(), _stream(self.device))
         _check(rc, "bess_allgather")
@@ -1325,7 +1338,7 @@ class Communicator:
     def all_reduce_sum_(self, x: torch.Tensor) -> torch.Tensor:
         """In-place sum over ranks of a float32 tensor."""
         _f32(x, "x")
-        with torch.cuda.device(self.device), _Timed("bess_allreduce_sum_f32", self.device):
+        with _on(self.device), _Timed("bess_allreduce_sum_f32", self.device):
             p = self._buf(x, "x")
             rc = load().bess_allreduce_sum_f32(self._h, p, p, x.numel(), _stream(self.device))
         _check(rc, "bess_allreduce_sum_f32")
@@ -1340,7 +1353,7 @@ class Communicator:
         L = int(idx.shape[1])
         send = torch.empty((self.world, L, W), dtype=table.dtype, device=table.device)
         recv = torch.empty_like(send)
-        with torch.cuda.device(self.device), _Timed("bess_pack_exchange", self.device):
+        with _on(self.device), _Timed("bess_pack_exchange", self.device):
             rc = load().bess_pack_exchange(self._h, _dtype_code(table), W, self._buf(table, "table"),
                                            self._buf(idx, "idx"), L, send.data_ptr(), recv.data_ptr(),
                                            _stream(self.device))
