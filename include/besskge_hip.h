@@ -279,7 +279,9 @@ int bess_neg_score_shared_fwd_ws(const bess_model_desc* d, const float* query,
                                  void* stream);
 
 /* backward of K4.  `out` is the forward result (needed for p = 2).
- * d_query [n_query, W] and d_neg [n_neg, W] (f32) are overwritten. */
+ * d_query [n_query, W] and d_neg [n_neg, W] (f32) are overwritten.  The distance scorers compute
+ * both products in one launch; when d_neg == d_query + n_query * W (one allocation holding both)
+ * the partial-sum targets are zeroed with one memset instead of two. */
 int bess_neg_score_shared_bwd(const bess_model_desc* d, const float* query,
                               int64_t n_query, const void* neg_base,
                               const int32_t* neg_idx, int64_t n_neg,
