@@ -80,7 +80,7 @@ def test_training_resumes_from_a_checkpoint(tmp_path, opt_name):
         got = runner2(**b)
     # (the relation gradient is summed with fp32 atomics: the last bits depend on their order, run to run;
     # a lost momentum / Adam state or step count would be off by orders of magnitude more)
-    tol = dict(rtol=1e-5, atol=1e-7)
+    tol = dict(rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(got["loss"], want["loss"], **tol)
     torch.testing.assert_close(fresh.score_fn.entity_embedding.detach(), want_ent, **tol)
     torch.testing.assert_close(fresh.score_fn.relation_embedding.detach(), want_rel, **tol)

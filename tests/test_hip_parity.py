@@ -261,7 +261,8 @@ def test_loss_golden(dev, name, wname):
 
 
 @pytest.mark.parametrize("kind", ["logsigmoid", "margin", "ssce"])
-@pytest.mark.parametrize("S,N", [(1, 1), (65, 64), (130, 1000), (7, 4097)])
+@pytest.mark.parametrize("S,N", [(1, 1), (65, 64), (130, 1000), (7, 4097),
+                                 (9, 2048), (5, 4352), (3, 8192)])  # rows held in 12 / 24 register chunks, streamed
 def test_loss_vs_oracle(dev, kind, S, N):
     from besskge import _native as nat
 
