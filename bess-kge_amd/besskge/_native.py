@@ -160,6 +160,8 @@ SIGNATURES = {
                               _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "bess_neg_pertriple_items": [_MD, _i64, _i64, ctypes.POINTER(ctypes.c_int32)],
     "bess_neg_score_pertriple_fwd_dq": [_MD, _LD, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
+    "bess_neg_score_pertriple_fwd_partials": [_MD, _LD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
+    "bess_combine_dq_partials": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
     "bess_normalize_rows": [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
     "bess_normalize_rows_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
     "bess_sample_negatives": [_PG, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
@@ -594,6 +596,45 @@ def neg_score_pertriple_fwd_dq(d: ModelDesc, l: LossDesc, query: torch.Tensor, n
     _check(rc, "bess_neg_score_pertriple_fwd_dq")
     del keep
     return out, dq
+
+
+def neg_score_pertriple_fwd_partials(d: ModelDesc, l: LossDesc, query: torch.Tensor, neg: RowSource, n_neg: int
+                                     ) -> Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+    """Training forward on a shard that holds only a part of each query's negatives (ScoreMoving): scores
+    [nq, n_neg] and the partials (state_ml [nq, items, 2], state_acc [nq, items, W]) that
+    `combine_dq_partials` turns into this shard's share of d loss / d query."""
+    nq = int(query.shape[0])
+    dev = _neg_operands(d, query, neg, nq * n_neg)
+    items = ctypes.c_int32(0)
+    _check(load().bess_neg_pertriple_items(ctypes.byref(d), nq, n_neg, ctypes.byref(items)), "bess_neg_pertriple_items")
+    out = torch.empty((nq, n_neg), dtype=torch.float32, device=dev)
+    st_ml = torch.empty((nq, items.value, 2), dtype=torch.float32, device=dev)
+    st_acc = torch.empty((nq, items.value, d.width), dtype=torch.float32, device=dev)
+    ip, keep = _neg_idx_ptr(neg, dev)
+    with _on(dev), _Timed("bess_neg_score_pertriple_fwd_partials", dev):
+        rc = load().bess_neg_score_pertriple_fwd_partials(
+            ctypes.byref(d), ctypes.byref(l), query.data_ptr(), nq, neg.base.data_ptr(), ip, n_neg, out.data_ptr(),
+            n_neg, st_ml.data_ptr(), st_acc.data_ptr(), _stream(dev))
+    _check(rc, "bess_neg_score_pertriple_fwd_partials")
+    del keep
+    return out, (st_ml, st_acc)
+
+
+def combine_dq_partials(state: Tuple[torch.Tensor, torch.Tensor], norm: torch.Tensor) -> torch.Tensor:
+    """d_query [nq, W] of this shard's negatives from its partials and the per-query (m, L / C) of the whole
+    softmax, `norm` [nq, 2] f32 (see include/besskge_hip.h)."""
+    st_ml, st_acc = state
+    nq, items, W = (int(x) for x in st_acc.shape)
+    dev = _same_device([("state_ml", st_ml), ("state_acc", st_acc), ("norm", norm)])
+    _f32(norm, "norm")
+    if tuple(norm.shape) != (nq, 2) or not norm.is_contiguous():
+        raise ValueError("combine_dq_partials: `norm` must be a contiguous [n_query, 2] tensor")
+    dq = torch.empty((nq, W), dtype=torch.float32, device=dev)
+    with _on(dev):
+        rc = load().bess_combine_dq_partials(st_ml.data_ptr(), st_acc.data_ptr(), nq, items, W, norm.data_ptr(),
+                                             dq.data_ptr(), _stream(dev))
+    _check(rc, "bess_combine_dq_partials")
+    return dq
 
 
 def neg_score_pertriple_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n_neg: int,

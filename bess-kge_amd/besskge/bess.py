@@ -85,6 +85,7 @@ class _NegGroup:
         self.query_ctx: Any = None  # what the scorer's query_bwd needs
         self.out: Optional[torch.Tensor] = None
         self.dq: Optional[torch.Tensor] = None  # d loss / d query from the fused training forward
+        self.partials: Any = None  # ScoreMoving: online-softmax partials of this shard's negatives (fused forward)
         self.kill: Any = None  # K7 applied together with the scores (shared negatives, one group)
 
 
@@ -669,7 +670,7 @@ class BessKGE(torch.nn.Module, ABC):
 
     # ------------------------------------------------------ group execution
     def _run_groups_one(self, g: _NegGroup, desc: nat.ModelDesc, st: Optional[_ReplicaStep] = None,
-                        fuse: Optional[Dict[str, Any]] = None) -> torch.Tensor:
+                        fuse: Optional[Dict[str, Any]] = None, partials_loss: Any = None) -> torch.Tensor:
         ahead = getattr(self, "_seg_ahead", None)
         if ahead is not None and st is not None and self._wants_segments(g, st):
             # training: the inverted index of the negatives only needs their row ids - start it on the
@@ -688,6 +689,10 @@ class BessKGE(torch.nn.Module, ABC):
                 w = w if w.numel() == 1 else w[g.sel].contiguous()
             g.out, g.dq = nat.neg_score_pertriple_fwd_dq(desc, fuse["loss"](g.n_per_query), g.query, g.neg,
                                                          g.n_per_query, pos, w)
+        elif partials_loss is not None:
+            # ScoreMoving training: this shard holds a part of each query's negatives - scores plus the partials
+            # from which its share of d loss / d query is formed once the owner has normalised over all shards
+            g.out, g.partials = nat.neg_score_pertriple_fwd_partials(desc, partials_loss, g.query, g.neg, g.n_per_query)
         else:
             g.out = nat.neg_score_pertriple_fwd(desc, g.query, g.neg, g.n_per_query)
         return g.out
@@ -1114,6 +1119,7 @@ class ScoreMovingBessKGE(BessKGE):
         scheme = ns.corruption_scheme
         steps, tails_out = ctx["steps"], ctx["tails_out"]
         rel_all, tq_all, hq_all = ctx["rel_all"], ctx["tq_all"], ctx["hq_all"]
+        sm_fuse = getattr(self, "_sm_fuse", None)  # training, fusable loss: loss.kernel_desc (see train_step_replicas)
 
         scores_out = []
         for r, st in enumerate(steps):
@@ -1147,7 +1153,10 @@ class ScoreMovingBessKGE(BessKGE):
                 st.groups.append(g)
                 if queries_sent:  # what was gathered are the finished queries
                     g.query = rows if rows.is_contiguous() else rows.contiguous()
-                return self._run_groups_one(g, desc)
+                pl = None
+                if sm_fuse is not None and not g.shared:
+                    pl = sm_fuse(n * g.n_per_query)  # the loss sees the negatives of all shards
+                return self._run_groups_one(g, desc, partials_loss=pl)
 
             if scheme == "h":
                 sc = problem(nat.CORRUPT_HEAD, tq_all[r], True, relr, neg.reshape(nB * B, K))
@@ -1193,6 +1202,25 @@ class ScoreMovingBessKGE(BessKGE):
             yo.append(o[:, cut:].reshape(y.shape))
         return xo, yo
 
+    def _softmax_norm(self, st: _ReplicaStep, weight: torch.Tensor) -> torch.Tensor:
+        """[S, 2] = (m, L / C) per triple: maximum and normaliser of beta * (negative score + shift) over the
+        negatives of ALL shards (and the positive score, sampled softmax), C = loss_scale * w (x 1/2 for the
+        log-sigmoid loss) - what `bess_combine_dq_partials` needs on the shards that scored them
+        (include/besskge_hip.h; same arithmetic as k_combine_dq for one shard)."""
+        neg, pos = st.negative_score, st.positive_score
+        l = self.loss_fn.kernel_desc(int(neg.shape[1]))
+        ssce = l.kind == nat.LOSS_SSCE
+        beta = 1.0 if ssce else (float(l.adversarial_scale) if l.adversarial else 0.0)
+        z = beta * (neg + (float(l.ssce_shift) if ssce else 0.0))
+        m = z.max(dim=1).values
+        if ssce:
+            m = torch.maximum(m, pos)
+        big_l = torch.exp(z - m[:, None]).sum(dim=1)
+        if ssce:
+            big_l = big_l + torch.exp(pos - m)
+        c = (1.0 if ssce else 0.5) * float(l.loss_scale) * weight
+        return torch.stack([m, big_l / c.expand_as(big_l)], dim=1).contiguous()
+
     # ---------------------------------------------------------------- training
     def train_step_replicas(self, batches: List[_Batch], optimizer: Any) -> List[Dict[str, Any]]:
         """Forward + backward + sparse optimiser update (ScoreMoving).
@@ -1213,12 +1241,21 @@ class ScoreMovingBessKGE(BessKGE):
         scheme = self.negative_sampler.corruption_scheme
         self.__dict__["_training_pass"] = True  # the backward needs the gathered embeddings, not finished queries
         self.__dict__["_seg_ahead"] = {}
+        # Fused training forward (per-triple negatives, nothing masked, a loss whose negative weights do not need
+        # the positive score): every shard keeps the online-softmax partials of the queries it scored; the second
+        # pass over the negative rows (`neg_score_pertriple_bwd`) is replaced by a rescaling of those partials
+        fuse = [self._fusable(b) for b in batches]
+        kind = getattr(self.loss_fn, "_kind", -1)
+        fused = (all(f is not None for f in fuse) and kind in (nat.LOSS_LOGSIGMOID, nat.LOSS_SSCE)
+                 and fn.supports_fused_segments)
+        self.__dict__["_sm_fuse"] = self.loss_fn.kernel_desc if fused else None
         try:
             steps = self._score_replicas(batches)
             seg_index = self._prefetch_segment_indices(steps)
         finally:
             self.__dict__["_training_pass"] = False
             self.__dict__["_seg_ahead"] = None
+            self.__dict__["_sm_fuse"] = None
         desc = fn.kernel_desc()
         rel_table = fn.relation_embedding.data
         d_rel = torch.zeros(rel_table.shape, dtype=torch.float32, device=rel_table.device)
@@ -1228,7 +1265,12 @@ class ScoreMovingBessKGE(BessKGE):
             out, d_pos, d_neg = self._finish(st, b, want_grad=True)
             results.append(out)
             S = d_neg.shape[0]
-            d_scores.append(d_neg.reshape(S, n, -1).transpose(0, 1).contiguous())  # [n(shard), S, Nl]
+            d_sc = d_neg.reshape(S, n, -1).transpose(0, 1)  # [n(shard), S, Nl]
+            if fused and any(g.partials is not None for g in st.groups):
+                # two more columns ride with the score gradients: (m, L / C) of each triple's softmax
+                norm = self._softmax_norm(st, fuse[len(results) - 1]["weight"])  # [S, 2]
+                d_sc = torch.cat([d_sc, norm.unsqueeze(0).expand(n, S, 2)], dim=2)
+            d_scores.append(d_sc.contiguous())
             dh, dt = fn.triple_bwd(RowSource(st.table, st.head_idx), st.tail, st.rel_idx, st.triple_ctx, d_pos,
                                    d_rel)
             local_updates.append([(st.head_idx, dh)])
@@ -1247,10 +1289,17 @@ class ScoreMovingBessKGE(BessKGE):
                 d_outs = [d4[:, :, :cut].reshape(n * n * cut, -1).contiguous(),
                           d4[:, :, cut:].reshape(n * n * (ppp - cut), -1).contiguous()]
             for g, go in zip(st.groups, d_outs):
+                norm = None
+                if g.partials is not None:  # the last two columns are the softmax normalisation
+                    norm = go[:, -2:].contiguous()
+                    go = go[:, :-2]
                 go = go.contiguous()
                 if g.shared:
                     dq, dn = nat.neg_score_shared_bwd(desc, g.query, g.neg, g.out, go)
                     upd.append((g.neg.idx, dn))
+                elif norm is not None:
+                    dq = nat.combine_dq_partials(g.partials, norm)
+                    deferred.append((st.table, g, go))
                 elif fn.supports_fused_segments:
                     dq, _ = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go, want_d_neg=False)
                     deferred.append((st.table, g, go))

@@ -187,28 +187,38 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_fwd(NegPtArgs a, float* _
 // d_query[q, :] = C_q / L_q * sum_items exp(m_i - m) acc_i,  m = max_i m_i (and the positive for
 // ssce), L_q = sum_i exp(m_i - m) l_i (+ exp(pos - m) for ssce);  C_q = loss_scale * w_q (x 1/2
 // for the log-sigmoid loss).  One wave per query.
+// With `norm` ([n_query, 2] = (m, L / C_q) taken over ALL the negatives of the query, of which these items
+// hold a part - the other parts were scored on other shards, ScoreMoving) the items are only rescaled.
 __global__ __launch_bounds__(256) void k_combine_dq(const float* __restrict__ st_ml, const float* __restrict__ st_acc,
                                                     int64_t n_query, int items, int W, int kind, float loss_scale,
                                                     const float* __restrict__ pos, const float* __restrict__ weight,
-                                                    int64_t weight_len, float* __restrict__ d_query) {
+                                                    int64_t weight_len, const float* __restrict__ norm,
+                                                    float* __restrict__ d_query) {
     const int lane = threadIdx.x & 63;
     const int64_t q = blockIdx.x * 4ll + (threadIdx.x >> 6);
     if (q >= n_query) return;
-    // (m_i, l_i) of the items, strided over the lanes
-    float m = -INFINITY;
-    for (int i = lane; i < items; i += 64) m = fmaxf(m, st_ml[(q * items + i) * 2]);
-    m = wave_allreduce_max(m);
-    if (kind == BESS_LOSS_SSCE) m = fmaxf(m, pos[q]);
-    float L = 0.f;
-    for (int i = lane; i < items; i += 64) {
-        const float mi = st_ml[(q * items + i) * 2];
-        if (mi != -INFINITY) L += st_ml[(q * items + i) * 2 + 1] * expf(mi - m);
+    float m, scale;
+    if (norm) {
+        m = norm[2 * q];
+        const float l_over_c = norm[2 * q + 1];
+        scale = (l_over_c > 0.f && l_over_c < INFINITY) ? 1.f / l_over_c : 0.f;
+    } else {
+        // (m_i, l_i) of the items, strided over the lanes
+        m = -INFINITY;
+        for (int i = lane; i < items; i += 64) m = fmaxf(m, st_ml[(q * items + i) * 2]);
+        m = wave_allreduce_max(m);
+        if (kind == BESS_LOSS_SSCE) m = fmaxf(m, pos[q]);
+        float L = 0.f;
+        for (int i = lane; i < items; i += 64) {
+            const float mi = st_ml[(q * items + i) * 2];
+            if (mi != -INFINITY) L += st_ml[(q * items + i) * 2 + 1] * expf(mi - m);
+        }
+        L = wave_allreduce_sum(L);
+        if (kind == BESS_LOSS_SSCE) L += expf(pos[q] - m);
+        const float w = weight[weight_len == 1 ? 0 : q];
+        const float C = (kind == BESS_LOSS_LOGSIGMOID ? 0.5f : 1.f) * loss_scale * w;
+        scale = L > 0.f ? C / L : 0.f;
     }
-    L = wave_allreduce_sum(L);
-    if (kind == BESS_LOSS_SSCE) L += expf(pos[q] - m);
-    const float w = weight[weight_len == 1 ? 0 : q];
-    const float C = (kind == BESS_LOSS_LOGSIGMOID ? 0.5f : 1.f) * loss_scale * w;
-    const float scale = L > 0.f ? C / L : 0.f;
     const float* ap = st_acc + q * items * W;
     float* dq = d_query + q * W;
     if ((W & 3) == 0) {
@@ -531,6 +541,41 @@ extern "C" int bess_neg_score_pertriple_fwd_dq(const bess_model_desc* d, const b
     if (rc) return rc;
     const int items = static_cast<int>(ceil_div(n_neg, negatives_per_item(n_query, n_neg, row_bytes_of(d))));
     k_combine_dq<<<static_cast<unsigned>(ceil_div(n_query, 4)), 256, 0, as_stream(stream)>>>(
-        state_ml, state_acc, n_query, items, d->width, l->kind, l->loss_scale, pos, weight, weight_len, d_query);
+        state_ml, state_acc, n_query, items, d->width, l->kind, l->loss_scale, pos, weight, weight_len, nullptr, d_query);
     return check_launch("neg_score_pertriple_fwd_dq");
+}
+
+extern "C" int bess_neg_score_pertriple_fwd_partials(const bess_model_desc* d, const bess_loss_desc* l,
+                                                     const float* query, int64_t n_query, const void* neg_base,
+                                                     const int32_t* neg_idx, int64_t n_neg, float* out,
+                                                     int64_t ld_out, float* state_ml, float* state_acc, void* stream) {
+    using namespace bess;
+    if (int e = check_desc(d)) return e;
+    BESS_REQUIRE(l, "neg_score_pertriple_fwd_partials: NULL loss descriptor");
+    BESS_REQUIRE(d->scorer <= BESS_COMPLEX, "neg_score_pertriple_fwd_partials: scorer %d has no fused form", d->scorer);
+    if (l->kind != BESS_LOSS_LOGSIGMOID && l->kind != BESS_LOSS_SSCE)
+        return fail(BESS_EUNSUPPORTED, "neg_score_pertriple_fwd_partials: loss %d weighs a negative by the positive score, "
+                                       "which the scoring shard does not have", l->kind);
+    if (n_query <= 0 || n_neg <= 0) return BESS_OK;
+    BESS_REQUIRE(out && state_ml && state_acc, "neg_score_pertriple_fwd_partials: NULL pointer");
+    FuseArgs f;
+    f.pos = nullptr;
+    f.kind = l->kind;
+    f.beta = l->kind == BESS_LOSS_SSCE ? 1.f : (l->adversarial ? l->adversarial_scale : 0.f);
+    f.margin = l->margin;
+    f.shift = l->kind == BESS_LOSS_SSCE ? l->ssce_shift : 0.f;
+    f.st_ml = state_ml;
+    f.st_acc = state_acc;
+    return run(d, true, query, n_query, neg_base, neg_idx, n_neg, out, nullptr, ld_out, nullptr, nullptr, stream, &f);
+}
+
+extern "C" int bess_combine_dq_partials(const float* state_ml, const float* state_acc, int64_t n_query, int32_t items,
+                                        int32_t width, const float* norm, float* d_query, void* stream) {
+    using namespace bess;
+    BESS_REQUIRE(n_query >= 0 && items > 0 && width > 0, "combine_dq_partials: bad sizes");
+    if (n_query == 0) return BESS_OK;
+    BESS_REQUIRE(state_ml && state_acc && norm && d_query, "combine_dq_partials: NULL pointer");
+    k_combine_dq<<<static_cast<unsigned>(ceil_div(n_query, 4)), 256, 0, as_stream(stream)>>>(
+        state_ml, state_acc, n_query, items, width, 0, 1.f, nullptr, nullptr, 1, norm, d_query);
+    return check_launch("combine_dq_partials");
 }

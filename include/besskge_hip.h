@@ -508,6 +508,24 @@ int bess_neg_score_pertriple_fwd_dq(const bess_model_desc* d, const bess_loss_de
                                     int64_t ld_out, float* d_query, float* state_ml,
                                     float* state_acc, void* stream);
 
+/* The same pass for queries whose negatives are spread over several shards (ScoreMoving: each shard
+ * scores the gathered queries against its own rows).  bess_neg_score_pertriple_fwd_partials writes the
+ * scores and leaves the per-item partials (m_i, l_i, acc_i) of the online softmax in state_ml / state_acc
+ * (log-sigmoid and sampled-softmax losses; margin ranking weighs by the positive score, which only the
+ * triple's own shard has: BESS_EUNSUPPORTED).  Once the owner of the triples has seen all scores it sends
+ * back, per query, norm = (m, L / C_q): the maximum and the normaliser of beta * (score + shift) over ALL
+ * negatives of the query (and the positive, sampled softmax), C_q = loss_scale * w_q (x 1/2 log-sigmoid);
+ * bess_combine_dq_partials then gives this shard's share of d loss / d query,
+ *   d_query[q] = C_q / L * sum_i exp(m_i - m) acc_i,
+ * without a second pass over the negative rows. */
+int bess_neg_score_pertriple_fwd_partials(const bess_model_desc* d, const bess_loss_desc* l,
+                                          const float* query, int64_t n_query, const void* neg_base,
+                                          const int32_t* neg_idx, int64_t n_neg, float* out,
+                                          int64_t ld_out, float* state_ml, float* state_acc, void* stream);
+int bess_combine_dq_partials(const float* state_ml, const float* state_acc, int64_t n_query,
+                             int32_t items, int32_t width, const float* norm, float* d_query,
+                             void* stream);
+
 /* `torch.nn.functional.normalize(part, p=2, dim=-1)` of every d-wide part of the rows
  * (scoring.py:549-551 and the like), fused with the gather and the f32 conversion:
  *   out[i, p*d + w] = row_i[p*d + w] * inv[i, p],  inv = 1 / max(||part||_2, 1e-12)

@@ -6,7 +6,7 @@
 
 `run <workload>` does a few warm-up steps and then 4 steps separated by a marker kernel (a fill of an int64
 tensor: `FillFunctor<long>`); `show` lists the dispatches of the last marked step in start order with their
-duration and the idle gap in front of each (all streams), and the totals.  Workloads: c2 (bench headline as a
+duration and the idle gap in front of each (all streams), and the totals.  Workloads: c2score (the bench headline: gather + score + loss), c2 (the same as a
 training step), c2adam, c4s (S=512, K=32: the notebook's micro-batch), c4 (S=4096, K=256), c4g (c4s replayed
 from a hipGraph).
 """
@@ -35,7 +35,11 @@ def run(workload: str) -> None:
         opt = runtime.Adam(lr=1e-3, weight_decay=1e-2) if workload == "c2adam" else 1e-3
 
         def step(i):
-            model.train_step_replicas([batches[i % 4]], opt)
+            if workload == "c2score":
+                with torch.no_grad():
+                    model.forward_replicas([batches[i % 4]])
+            else:
+                model.train_step_replicas([batches[i % 4]], opt)
     else:
         from besskge.bess import EmbeddingMovingBessKGE
         from besskge.loss import SampledSoftmaxCrossEntropyLoss

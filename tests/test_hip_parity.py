@@ -1074,3 +1074,32 @@ def test_shared_distance_backward_tile_variants(dev, p, dtype, S, N, W):
     tol = 2e-5 if p == 2 else 1e-5  # p = 2 divides by the fp32 forward score
     assert float((dq.double() - want_q).abs().max()) <= tol * float(want_q.abs().max())
     assert float((dn.double() - want_n).abs().max()) <= tol * float(want_n.abs().max())
+
+
+@pytest.mark.parametrize("case,fused", [("tr_SM_ComplEx0_t_pt_n2", True),   # log-sigmoid, per-triple negatives
+                                        ("tr_SM_ht_pt_n2", True),           # sampled softmax, two groups per shard
+                                        ("tr_SM_ht_flat_n2", False)])       # margin ranking: needs the positive score
+def test_score_moving_training_forward_keeps_its_partials(dev, case, fused):
+    """ScoreMoving training with per-triple negatives: every shard scores the gathered queries against its own
+    rows ONCE (`bess_neg_score_pertriple_fwd_partials`) and later rescales the partials it kept
+    (`bess_combine_dq_partials`) - no second pass over the negative rows (`bess_neg_score_pertriple_bwd`) -
+    and still moves the tables by the reference's gradients (reference bess.py:490-603 + autograd)."""
+    from besskge import _native as nat
+    from besskge import runtime
+
+    c = load_bess_case(case)
+    lr = 0.125
+    model = build_model(c, dev)
+    runner = runtime.training_model(model, runtime.Options(device_iterations=1), runtime.SGD(lr=lr), device=dev)
+    keys = ("head", "relation", "tail", "negative", "negative_mask")
+    watched = ["bess_neg_score_pertriple_fwd_partials", "bess_neg_score_pertriple_bwd", "bess_neg_score_pertriple_fwd"]
+    nat.start_kernel_timing(watched)
+    runner(**{k: c["batch"][k][0] for k in keys if k in c["batch"]})
+    calls = {k: len(v) for k, v in nat.stop_kernel_timing().items()}
+    if fused:
+        assert calls.get("bess_neg_score_pertriple_fwd_partials", 0) > 0, calls
+        assert calls.get("bess_neg_score_pertriple_bwd", 0) == 0 and calls.get("bess_neg_score_pertriple_fwd", 0) == 0, calls
+    else:
+        assert calls.get("bess_neg_score_pertriple_fwd_partials", 0) == 0, calls
+    close(model.score_fn.entity_embedding, c["table"] - lr * c["grads"]["entity"], rtol=1e-4, atol=2e-5)
+    close(model.score_fn.relation_embedding, c["rel"] - lr * c["grads"]["relation"].sum(0), rtol=1e-4, atol=2e-5)
