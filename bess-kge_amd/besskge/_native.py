@@ -139,6 +139,7 @@ SIGNATURES = {
     "bess_neg_score_shared_bwd_ws": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
     "bess_mask_scores": [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _vp],
     "bess_loss_fwd_bwd": [_LD, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
+    "bess_loss_fwd_bwd_norm": [_LD, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "bess_scatter_add_rows": [_vp, _i32, _vp, _vp, _i64, _f32, _vp],
     "bess_sparse_sgd": [_i32, _i32, _vp, _vp, _vp, _i64, _f32, _vp],
     "bess_dense_sgd": [_i32, _vp, _vp, _i64, _f32, _vp],
@@ -786,9 +787,10 @@ def mask_scores(neg: torch.Tensor, diag_step: int, ht: bool, ppp: int, mask: Opt
     _check(rc, "bess_mask_scores")
 
 
-def loss_fwd_bwd(l: LossDesc, pos: torch.Tensor, neg: torch.Tensor, weight: torch.Tensor, want_grad: bool
-                 ) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
-    """Returns (loss [] f32, d_pos [S] | None, d_neg [S, N] | None)."""
+def loss_fwd_bwd(l: LossDesc, pos: torch.Tensor, neg: torch.Tensor, weight: torch.Tensor, want_grad: bool,
+                 want_norm: bool = False) -> Tuple[Any, ...]:
+    """Returns (loss [] f32, d_pos [S] | None, d_neg [S, N] | None) - and, with `want_norm`, a fourth item:
+    (m, L / C) of every row's softmax, [S, 2] (what `combine_dq_partials` takes; include/besskge_hip.h)."""
     dev = _same_device([("positive_score", pos), ("negative_score", neg), ("triple_weight", weight)])
     for t, nm in ((pos, "positive_score"), (neg, "negative_score"), (weight, "triple_weight")):
         _f32(t, nm)
@@ -799,12 +801,15 @@ def loss_fwd_bwd(l: LossDesc, pos: torch.Tensor, neg: torch.Tensor, weight: torc
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
     dp = torch.empty((S,), dtype=torch.float32, device=dev) if want_grad else None
     dn = torch.empty((S, N), dtype=torch.float32, device=dev) if want_grad else None
+    norm = torch.empty((S, 2), dtype=torch.float32, device=dev) if want_norm else None
     with _on(dev):
-        rc = load().bess_loss_fwd_bwd(ctypes.byref(l), pos.data_ptr(), neg.data_ptr(), S, N, N, weight.data_ptr(),
-                                      weight.numel(), row_loss.data_ptr(), loss.data_ptr(),
-                                      dp.data_ptr() if want_grad else 0, dn.data_ptr() if want_grad else 0, N,
-                                      _stream(dev))
-    _check(rc, "bess_loss_fwd_bwd")
+        rc = load().bess_loss_fwd_bwd_norm(ctypes.byref(l), pos.data_ptr(), neg.data_ptr(), S, N, N, weight.data_ptr(),
+                                           weight.numel(), row_loss.data_ptr(), loss.data_ptr(),
+                                           dp.data_ptr() if want_grad else 0, dn.data_ptr() if want_grad else 0, N,
+                                           norm.data_ptr() if want_norm else 0, _stream(dev))
+    _check(rc, "bess_loss_fwd_bwd_norm")
+    if want_norm:
+        return loss.reshape(()), dp, dn, norm
     return loss.reshape(()), dp, dn
 
 

@@ -110,6 +110,7 @@ class _ReplicaStep:
         self.local_tail: torch.Tensor = None  # type: ignore
         self.positive_score: torch.Tensor = None  # type: ignore
         self.negative_score: torch.Tensor = None  # type: ignore
+        self.loss_norm: Optional[torch.Tensor] = None  # [S, 2] (m, L / C) of each triple's softmax (ScoreMoving, fused)
         self.kill_applied = False  # the scoring call already applied K7 (mask / augment kill)
         self.fused_qt = False  # query + positive score came out of one launch (so will their backwards)
 
@@ -320,7 +321,7 @@ class BessKGE(torch.nn.Module, ABC):
         raise NotImplementedError
 
     # -------------------------------------------------- mask / loss / metrics
-    def _finish(self, st: _ReplicaStep, batch: _Batch, want_grad: bool
+    def _finish(self, st: _ReplicaStep, batch: _Batch, want_grad: bool, want_norm: bool = False
                 ) -> Tuple[Dict[str, Any], Optional[torch.Tensor], Optional[torch.Tensor]]:
         pos, neg = st.positive_score, st.negative_score
         dev = pos.device
@@ -343,7 +344,10 @@ class BessKGE(torch.nn.Module, ABC):
             else:
                 w = w.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
             ld = self.loss_fn.kernel_desc(int(neg.shape[1]))
-            loss, d_pos, d_neg = nat.loss_fwd_bwd(ld, pos, neg, w, want_grad)
+            if want_norm:  # ScoreMoving's fused training forward: the softmax normalisation goes back to the shards
+                loss, d_pos, d_neg, st.loss_norm = nat.loss_fwd_bwd(ld, pos, neg, w, want_grad, want_norm=True)
+            else:
+                loss, d_pos, d_neg = nat.loss_fwd_bwd(ld, pos, neg, w, want_grad)
             out["loss"] = loss
             if isinstance(self.loss_fn, SampledSoftmaxCrossEntropyLoss) and self.return_scores \
                     and self.score_fn.relation_embedding.dtype == torch.float32:
@@ -1202,25 +1206,6 @@ class ScoreMovingBessKGE(BessKGE):
             yo.append(o[:, cut:].reshape(y.shape))
         return xo, yo
 
-    def _softmax_norm(self, st: _ReplicaStep, weight: torch.Tensor) -> torch.Tensor:
-        """[S, 2] = (m, L / C) per triple: maximum and normaliser of beta * (negative score + shift) over the
-        negatives of ALL shards (and the positive score, sampled softmax), C = loss_scale * w (x 1/2 for the
-        log-sigmoid loss) - what `bess_combine_dq_partials` needs on the shards that scored them
-        (include/besskge_hip.h; same arithmetic as k_combine_dq for one shard)."""
-        neg, pos = st.negative_score, st.positive_score
-        l = self.loss_fn.kernel_desc(int(neg.shape[1]))
-        ssce = l.kind == nat.LOSS_SSCE
-        beta = 1.0 if ssce else (float(l.adversarial_scale) if l.adversarial else 0.0)
-        z = beta * (neg + (float(l.ssce_shift) if ssce else 0.0))
-        m = z.max(dim=1).values
-        if ssce:
-            m = torch.maximum(m, pos)
-        big_l = torch.exp(z - m[:, None]).sum(dim=1)
-        if ssce:
-            big_l = big_l + torch.exp(pos - m)
-        c = (1.0 if ssce else 0.5) * float(l.loss_scale) * weight
-        return torch.stack([m, big_l / c.expand_as(big_l)], dim=1).contiguous()
-
     # ---------------------------------------------------------------- training
     def train_step_replicas(self, batches: List[_Batch], optimizer: Any) -> List[Dict[str, Any]]:
         """Forward + backward + sparse optimiser update (ScoreMoving).
@@ -1262,14 +1247,15 @@ class ScoreMovingBessKGE(BessKGE):
         results, d_scores, d_tails = [], [], []
         local_updates: List[List[Tuple[torch.Tensor, torch.Tensor]]] = []
         for st, b in zip(steps, batches):
-            out, d_pos, d_neg = self._finish(st, b, want_grad=True)
+            with_norm = fused and any(g.partials is not None for g in st.groups)
+            out, d_pos, d_neg = self._finish(st, b, want_grad=True, want_norm=with_norm)
             results.append(out)
             S = d_neg.shape[0]
             d_sc = d_neg.reshape(S, n, -1).transpose(0, 1)  # [n(shard), S, Nl]
-            if fused and any(g.partials is not None for g in st.groups):
-                # two more columns ride with the score gradients: (m, L / C) of each triple's softmax
-                norm = self._softmax_norm(st, fuse[len(results) - 1]["weight"])  # [S, 2]
-                d_sc = torch.cat([d_sc, norm.unsqueeze(0).expand(n, S, 2)], dim=2)
+            if with_norm:
+                # two more columns ride with the score gradients: (m, L / C) of each triple's softmax, written by
+                # the loss kernel (bess_loss_fwd_bwd_norm) - what bess_combine_dq_partials needs on the shards
+                d_sc = torch.cat([d_sc, st.loss_norm.unsqueeze(0).expand(n, S, 2)], dim=2)
             d_scores.append(d_sc.contiguous())
             dh, dt = fn.triple_bwd(RowSource(st.table, st.head_idx), st.tail, st.rel_idx, st.triple_ctx, d_pos,
                                    d_rel)

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void k_loss_rows(bess_loss_desc l, const float
                                                    const float* __restrict__ weight,
                                                    int64_t weight_len, float* __restrict__ row_loss,
                                                    float* __restrict__ d_pos,
-                                                   float* __restrict__ d_neg, int64_t ld_dneg) {
+                                                   float* __restrict__ d_neg, int64_t ld_dneg,
+                                                   float* __restrict__ row_norm) {
     const int lane = threadIdx.x & 63;
     const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
     if (s >= n_triple) return;
@@ -116,6 +117,10 @@ __global__ __launch_bounds__(256) void k_loss_rows(bess_loss_desc l, const float
         z = wave_allreduce_sum(z) + expf(p - m);
         const float lse = m + logf(z);
         if (lane == 0) row_loss[s] = l.loss_scale * w * (lse - p);
+        if (row_norm && lane == 0) {  // (m, L / C) of the row's softmax: see bess_combine_dq_partials
+            row_norm[2 * s] = m;
+            row_norm[2 * s + 1] = z / (l.loss_scale * w);
+        }
         if (GRAD) {
             const float c = l.loss_scale * w;
             if (lane == 0) d_pos[s] = c * (expf(p - lse) - 1.f);
@@ -133,6 +138,10 @@ __global__ __launch_bounds__(256) void k_loss_rows(bess_loss_desc l, const float
         float z = 0.f;
         sweep([&](float x) { z += expf(l.adversarial_scale * x - m); });
         inv_z = 1.f / wave_allreduce_sum(z);
+    }
+    if (row_norm && lane == 0) {
+        row_norm[2 * s] = m;
+        row_norm[2 * s + 1] = (1.f / inv_z) / ((KIND == BESS_LOSS_LOGSIGMOID ? 0.5f : 1.f) * l.loss_scale * w);
     }
     float acc = 0.f, dsum = 0.f;
     auto aw_of = [&](float x) { return ADV ? expf(l.adversarial_scale * x - m) * inv_z : inv_z; };
@@ -229,20 +238,20 @@ __global__ __launch_bounds__(1024) void k_sum_rows(const float* __restrict__ row
 template <int KIND, bool ADV, int CH>
 static void launch_loss_ch(bool grad, const bess_loss_desc& l, const float* pos, const float* neg,
                            int64_t S, int64_t N, int64_t ld, const float* w, int64_t wl, float* rl,
-                           float* dp, float* dn, int64_t ldd, hipStream_t st) {
+                           float* dp, float* dn, int64_t ldd, float* rn, hipStream_t st) {
     const unsigned grid = static_cast<unsigned>(ceil_div(S, 4));
-    if (grad) k_loss_rows<KIND, ADV, true, CH><<<grid, 256, 0, st>>>(l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd);
-    else k_loss_rows<KIND, ADV, false, CH><<<grid, 256, 0, st>>>(l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd);
+    if (grad) k_loss_rows<KIND, ADV, true, CH><<<grid, 256, 0, st>>>(l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd, rn);
+    else k_loss_rows<KIND, ADV, false, CH><<<grid, 256, 0, st>>>(l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd, rn);
 }
 
 template <int KIND, bool ADV>
 static void launch_loss(bool grad, const bess_loss_desc& l, const float* pos, const float* neg,
                         int64_t S, int64_t N, int64_t ld, const float* w, int64_t wl, float* rl,
-                        float* dp, float* dn, int64_t ldd, hipStream_t st) {
+                        float* dp, float* dn, int64_t ldd, float* rn, hipStream_t st) {
     // rows in registers when their shape allows 16-byte accesses (see k_loss_rows)
     const bool vec = N % 4 == 0 && ld % 4 == 0 && reinterpret_cast<uintptr_t>(neg) % 16 == 0 &&
                      (!grad || (ldd % 4 == 0 && reinterpret_cast<uintptr_t>(dn) % 16 == 0));
-#define BESS_LOSS_CH(CH) launch_loss_ch<KIND, ADV, CH>(grad, l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd, st)
+#define BESS_LOSS_CH(CH) launch_loss_ch<KIND, ADV, CH>(grad, l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd, rn, st)
     if (!vec || N > 256 * 24) BESS_LOSS_CH(0);
     else if (N <= 256 * 4) BESS_LOSS_CH(4);
     else if (N <= 256 * 12) BESS_LOSS_CH(12);
@@ -283,6 +292,15 @@ extern "C" int bess_loss_fwd_bwd(const bess_loss_desc* l, const float* pos, cons
                                  const float* weight, int64_t weight_len, float* row_loss,
                                  float* loss, float* d_pos, float* d_neg, int64_t ld_dneg,
                                  void* stream) {
+    return bess_loss_fwd_bwd_norm(l, pos, neg, n_triple, n_neg, ld_neg, weight, weight_len, row_loss, loss, d_pos, d_neg,
+                                  ld_dneg, nullptr, stream);
+}
+
+extern "C" int bess_loss_fwd_bwd_norm(const bess_loss_desc* l, const float* pos, const float* neg,
+                                      int64_t n_triple, int64_t n_neg, int64_t ld_neg,
+                                      const float* weight, int64_t weight_len, float* row_loss,
+                                      float* loss, float* d_pos, float* d_neg, int64_t ld_dneg,
+                                      float* row_norm, void* stream) {
     BESS_REQUIRE(l, "loss: NULL descriptor");
     BESS_REQUIRE(l->kind >= BESS_LOSS_LOGSIGMOID && l->kind <= BESS_LOSS_SSCE, "loss: unknown kind %d", l->kind);
     BESS_REQUIRE(n_triple > 0 && n_neg > 0 && n_neg < (1ll << 31), "loss: bad sizes");
@@ -294,7 +312,8 @@ extern "C" int bess_loss_fwd_bwd(const bess_loss_desc* l, const float* pos, cons
     hipStream_t st = as_stream(stream);
     const bool adv = l->adversarial != 0;
 #define BESS_LOSS(KIND, ADV) \
-    launch_loss<KIND, ADV>(grad, *l, pos, neg, n_triple, n_neg, ld_neg, weight, weight_len, row_loss, d_pos, d_neg, ld_dneg, st)
+    launch_loss<KIND, ADV>(grad, *l, pos, neg, n_triple, n_neg, ld_neg, weight, weight_len, row_loss, d_pos, d_neg, ld_dneg, \
+                           row_norm, st)
     switch (l->kind) {
         case BESS_LOSS_LOGSIGMOID: adv ? BESS_LOSS(BESS_LOSS_LOGSIGMOID, true) : BESS_LOSS(BESS_LOSS_LOGSIGMOID, false); break;
         case BESS_LOSS_MARGIN: adv ? BESS_LOSS(BESS_LOSS_MARGIN, true) : BESS_LOSS(BESS_LOSS_MARGIN, false); break;

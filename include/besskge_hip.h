@@ -327,6 +327,19 @@ int bess_loss_fwd_bwd(const bess_loss_desc* l, const float* pos, const float* ne
                       float* loss, float* d_pos, float* d_neg, int64_t ld_dneg,
                       void* stream);
 
+/* The same, also writing row_norm [n_triple, 2] (optional, may be NULL) = (m, L / C) of every row's
+ * softmax over its negative scores - what bess_combine_dq_partials takes on the shards that scored
+ * the negatives (ScoreMoving training): m = max of beta * (score + shift) (and the positive score,
+ * sampled softmax), L = sum of exp(beta * (score + shift) - m) (+ exp(pos - m)), C = loss_scale * w
+ * (x 1/2 for the log-sigmoid loss); beta = adversarial_scale, 1 (sampled softmax) or 0 (uniform
+ * weights: m = 0, L = n_neg).  Margin ranking: the negatives' weights do not depend on the positive
+ * score, the gradients' gate does - row_norm is written but of no use to the fused form. */
+int bess_loss_fwd_bwd_norm(const bess_loss_desc* l, const float* pos, const float* neg,
+                           int64_t n_triple, int64_t n_neg, int64_t ld_neg,
+                           const float* weight, int64_t weight_len, float* row_loss,
+                           float* loss, float* d_pos, float* d_neg, int64_t ld_dneg,
+                           float* row_norm, void* stream);
+
 /* next-1 / K11 - streaming top-k (reference bess.py:771-822 loop body, 889-894):
  * merge the n_col candidates of every row into its running list of the kk best
  * (best_score / best_id [n_row, kk], sorted by descending score, in place).

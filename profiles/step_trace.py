@@ -7,7 +7,7 @@
 `run <workload>` does a few warm-up steps and then 4 steps separated by a marker kernel (a fill of an int64
 tensor: `FillFunctor<long>`); `show` lists the dispatches of the last marked step in start order with their
 duration and the idle gap in front of each (all streams), and the totals.  Workloads: c2score (the bench headline: gather + score + loss), c2 (the same as a
-training step), c2adam, c4s (S=512, K=32: the notebook's micro-batch), c4 (S=4096, K=256), c4g (c4s replayed
+training step), c2sm (that step in its multi-GPU form, ScoreMovingBessKGE, on one shard), c2adam, c4s (S=512, K=32: the notebook's micro-batch), c4 (S=4096, K=256), c4g (c4s replayed
 from a hipGraph).
 """
 import csv
@@ -30,7 +30,8 @@ def run(workload: str) -> None:
     dev = torch.device("cuda", 0)
     marker = torch.zeros(1, dtype=torch.int64, device=dev)
     if workload.startswith("c2"):
-        model, sharding, k_pair = bench.build_c2(bench.N_ENTITY_C2, 1, 0, dev, SingleProcessGroup(1), False)
+        # c2sm: the multi-GPU form of the step (ScoreMoving) on one shard
+        model, sharding, k_pair = bench.build_c2(bench.N_ENTITY_C2, 1, 0, dev, SingleProcessGroup(1), workload == "c2sm")
         batches = bench.make_batches_c2(1, 0, sharding, k_pair, pool=4, dev=dev)
         opt = runtime.Adam(lr=1e-3, weight_decay=1e-2) if workload == "c2adam" else 1e-3
 

@@ -59,6 +59,8 @@ if steps:
     lines.append("## One training step, kernel by kernel (`profiles/step_trace.py`, rocprofv3 --kernel-trace)\n\n"
                  "| file | workload | dispatches | span (us) | sum of kernel durations (us) |\n|---|---|---|---|---|\n")
     what = {"c2": "C2 ComplEx d=256 fp32, S=4096 x 256 per-triple, SGD", "c2adam": "same, AdamW",
+            "c2score": "C2, the bench headline step (gather + score + loss)",
+            "c2sm": "C2 training step in its multi-GPU form (ScoreMovingBessKGE, fused forward with partials), one shard",
             "c4s": "C4 TransE d=256 fp16, S=512, K=32, eager", "c4g": "C4 TransE d=256 fp16, S=512, K=32, hipGraph replay",
             "c4": "C4 TransE d=256 fp16, S=4096, K=256, eager"}
     for f in steps:

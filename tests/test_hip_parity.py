@@ -1103,3 +1103,48 @@ def test_score_moving_training_forward_keeps_its_partials(dev, case, fused):
         assert calls.get("bess_neg_score_pertriple_fwd_partials", 0) == 0, calls
     close(model.score_fn.entity_embedding, c["table"] - lr * c["grads"]["entity"], rtol=1e-4, atol=2e-5)
     close(model.score_fn.relation_embedding, c["rel"] - lr * c["grads"]["relation"].sum(0), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("kind,adv", [("logsigmoid", True), ("logsigmoid", False), ("ssce", False)])
+@pytest.mark.parametrize("name,p", [("ComplEx", 0), ("TransE", 1), ("RotatE", 2)])
+def test_partials_of_two_shards_combine_to_the_one_pass_gradient(dev, name, p, kind, adv):
+    """The negatives of every query split over two 'shards': scores + partials per part
+    (`bess_neg_score_pertriple_fwd_partials`), the loss kernel's row normalisation over the concatenated scores
+    (`bess_loss_fwd_bwd_norm`), each part rescaled (`bess_combine_dq_partials`) - the parts add up to the
+    d loss / d query of the one-pass fused forward over all negatives, and the norm is what its header says."""
+    from besskge import _native as nat
+    from besskge.loss import LogSigmoidLoss, SampledSoftmaxCrossEntropyLoss
+
+    torch.manual_seed(5)
+    S, K1, K2, d_emb, M = 70, 40, 24, 32, 500
+    W, Wr = widths(name, d_emb)
+    table = (0.3 * torch.randn(M, W)).to(dev)
+    desc = nat.make_desc(dict(TransE=0, RotatE=1, DistMult=2, ComplEx=3)[name], max(p, 1), table, Wr)
+    q = torch.randn(S, W, device=dev) * 0.3
+    idx = torch.randint(M, (S, K1 + K2), device=dev, dtype=torch.int32)
+    pos = torch.randn(S, device=dev)
+    w = torch.rand(S, device=dev) + 0.1
+    loss_fn = (SampledSoftmaxCrossEntropyLoss(n_entity=10 * M) if kind == "ssce"
+               else LogSigmoidLoss(margin=1.5, negative_adversarial_sampling=adv, negative_adversarial_scale=0.7))
+    ld = loss_fn.kernel_desc(K1 + K2)
+    full = nat.RowSource(table, idx.reshape(-1).contiguous())
+    sc_full, dq_full = nat.neg_score_pertriple_fwd_dq(desc, ld, q, full, K1 + K2, pos, w)
+    parts = []
+    for lo, hi in ((0, K1), (K1, K1 + K2)):
+        src = nat.RowSource(table, idx[:, lo:hi].reshape(-1).contiguous())
+        parts.append(nat.neg_score_pertriple_fwd_partials(desc, ld, q, src, hi - lo))
+    sc = torch.cat([parts[0][0], parts[1][0]], dim=1).contiguous()
+    assert torch.equal(sc, sc_full)
+    _, _, _, norm = nat.loss_fwd_bwd(ld, pos, sc, w, True, want_norm=True)
+    dq = nat.combine_dq_partials(parts[0][1], norm) + nat.combine_dq_partials(parts[1][1], norm)
+    torch.testing.assert_close(dq, dq_full, rtol=2e-5, atol=1e-6 * float(dq_full.abs().max()))
+    # the normalisation itself, in float64
+    beta = 1.0 if kind == "ssce" else (0.7 if adv else 0.0)
+    z = beta * (sc.double() + (float(ld.ssce_shift) if kind == "ssce" else 0.0))
+    m = z.max(1).values
+    if kind == "ssce":
+        m = torch.maximum(m, pos.double())
+    big_l = torch.exp(z - m[:, None]).sum(1) + (torch.exp(pos.double() - m) if kind == "ssce" else 0.0)
+    c = (1.0 if kind == "ssce" else 0.5) * float(ld.loss_scale) * w.double()
+    torch.testing.assert_close(norm[:, 0].double(), m, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(norm[:, 1].double(), big_l / c, rtol=1e-5, atol=0)
