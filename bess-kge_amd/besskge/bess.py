@@ -1160,7 +1160,7 @@ class ScoreMovingBessKGE(BessKGE):
                 pl = None
                 if sm_fuse is not None and not g.shared:
                     pl = sm_fuse(n * g.n_per_query)  # the loss sees the negatives of all shards
-                return self._run_groups_one(g, desc, partials_loss=pl)
+                return self._run_groups_one(g, desc, st=st, partials_loss=pl)  # st: the index of the negatives starts now
 
             if scheme == "h":
                 sc = problem(nat.CORRUPT_HEAD, tq_all[r], True, relr, neg.reshape(nB * B, K))
