@@ -52,6 +52,7 @@ def test_bench_two_ranks_rehearsal():
              "127.0.0.1", "--master-port", "29577", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], env)
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0
     assert "ScoreMoving" in d["config"]["workload"]
+    assert d["train_step"]["ms_per_step"] > 0  # the headline workload as a ScoreMoving training step
     c4 = d["c4"]  # north_star's scaling workload is part of the line at every N
     assert c4["n_gpus"] == 2 and all(pt["value"] > 0 for pt in c4["sweep"]), c4
 
