@@ -70,7 +70,8 @@ C4_N_ENTITY = 2_500_604
 C4_N_REL = 535
 C4_D = 256
 C4_GRAPH_DEADLINE_S = 180  # wall-clock bound on the recorded-collectives variant at N > 1 (see main)
-C4_SWEEP = ((512, 32), (4096, 256), (4096, 2048))  # (S per GPU, K per shard pair); first = the notebook's point
+# (S per GPU, K per shard pair): SURVEY 8d's sweep - K in {32, 256, 2048}, S from the notebook's 512 to 65,536
+C4_SWEEP = ((512, 32), (4096, 256), (4096, 2048), (16384, 256), (65536, 256))
 
 
 # --------------------------------------------------------------------------- #
@@ -305,7 +306,7 @@ def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, c
             continue
         for S_, K_ in C4_SWEEP:
             ppp = S_ // n
-            if ppp * n != S_:
+            if ppp * n != S_ or S_ > state.get("max_s", 1 << 30):
                 continue
             rng = np.random.default_rng(100 + rank)
             M = int(sharding.shard_counts[rank])
@@ -432,6 +433,7 @@ def main() -> None:
                          "(native), torch.distributed (c10d), or native when its self-check passes (auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="headline leg only (no roofline_hbm / c4 / train_step)")
+    ap.add_argument("--c4-max-s", type=int, default=65536, help="largest micro-batch of the c4 sweep (positives per GPU)")
     ap.add_argument("--entities-per-shard", type=int, default=N_ENTITY_C2,
                     help="rows per shard of the headline leg (default: the ogbl-biokg count)")
     args = ap.parse_args()
@@ -626,7 +628,7 @@ def main() -> None:
         line["cpu_baseline"] = cpu_baseline()
     if extra_legs:
         c4_steps = max(16, min(args.steps, 48))
-        state: dict = {}
+        state: dict = {"max_s": args.c4_max_s}
         line["c4"] = c4_leg(world, rank, dev, group, distributed, comm_name, c4_steps, state, variants=("eager",))
         # The hipGraph variant records RCCL send/recv into the graph.  With more than one rank that has only been
         # rehearsed on a one-rank communicator (1-GPU boxes), so it runs last and under a deadline: if it has not

@@ -25,7 +25,7 @@ def run(cmd, env=None):
 
 @pytest.mark.parametrize("mode", ["score", "train"])
 def test_bench_single_gpu(mode):
-    d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--mode", mode])
+    d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--c4-max-s", "4096", "--mode", mode])
     assert KEYS <= set(d)
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
     assert d["unit"] == "triples/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -49,7 +49,8 @@ def test_bench_single_gpu(mode):
 def test_bench_two_ranks_rehearsal():
     env = dict(os.environ, BESS_BENCH_BACKEND="gloo")
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-             "127.0.0.1", "--master-port", "29577", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], env)
+             "127.0.0.1", "--master-port", "29577", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
+             "--c4-max-s", "4096"], env)
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0
     assert "ScoreMoving" in d["config"]["workload"]
     assert d["train_step"]["ms_per_step"] > 0  # the headline workload as a ScoreMoving training step

@@ -174,7 +174,7 @@ def test_bench_distributed_path_over_rccl_single_rank():
     repo = os.path.dirname(HERE)
     env = dict(os.environ, BESS_BENCH_REHEARSE_DIST="1", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(29400 + os.getpid() % 500))
-    res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "10", "--warmup", "3",
+    res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "10", "--warmup", "3", "--c4-max-s", "4096",
                           "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     line = json.loads(res.stdout.strip().splitlines()[-1])
