@@ -308,6 +308,8 @@ def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, c
             ppp = S_ // n
             if ppp * n != S_ or S_ > state.get("max_s", 1 << 30):
                 continue
+            if graphs and S_ > 4096:
+                continue  # steps of 10+ ms: nothing for a replay to save
             rng = np.random.default_rng(100 + rank)
             M = int(sharding.shard_counts[rank])
             batch = dict(head=rng.integers(M, size=(iters, n, ppp)), relation=rng.integers(C4_N_REL, size=(iters, n, ppp)),
