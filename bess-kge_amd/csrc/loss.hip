@@ -51,7 +51,8 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x
 
 // One wave per triple.  CH > 0: the row of negative scores is read ONCE, as CH 16-byte chunks per lane held in
 // registers (rows of up to 256 * CH scores, n_neg % 4 == 0, 16-byte aligned rows), and the gradient row is written
-// with 16-byte stores; CH = 0: any shape, the row is streamed from memory (cache) in each of the passes.
+// with 16-byte stores; CH = 0: any shape, the row is streamed from memory (cache) in each of the passes, 4 bytes per
+// lane; CH = -1: the same with 16-byte accesses (longer rows of the 16-byte-aligned shapes).
 template <int KIND, bool ADV, bool GRAD, int CH>
 __global__ __launch_bounds__(256) void k_loss_rows(bess_loss_desc l, const float* __restrict__ pos,
                                                    const float* __restrict__ neg, int64_t n_triple,
@@ -90,6 +91,14 @@ __global__ __launch_bounds__(256) void k_loss_rows(bess_loss_desc l, const float
                     f(v[c].w);
                 }
             }
+        } else if (CH < 0) {  // streamed, 16 bytes per lane
+            for (int j = lane * 4; j < n; j += 256) {
+                const float4 x = *reinterpret_cast<const float4*>(nr + j);
+                f(x.x);
+                f(x.y);
+                f(x.z);
+                f(x.w);
+            }
         } else {
             for (int j = lane; j < n; j += 64) f(nr[j]);
         }
@@ -101,6 +110,11 @@ __global__ __launch_bounds__(256) void k_loss_rows(bess_loss_desc l, const float
             for (int c = 0; c < CH; ++c) {
                 const int j = (c * 64 + lane) * 4;
                 if (j < n) *reinterpret_cast<float4*>(dn + j) = make_float4(f(v[c].x), f(v[c].y), f(v[c].z), f(v[c].w));
+            }
+        } else if (CH < 0) {
+            for (int j = lane * 4; j < n; j += 256) {
+                const float4 x = *reinterpret_cast<const float4*>(nr + j);
+                *reinterpret_cast<float4*>(dn + j) = make_float4(f(x.x), f(x.y), f(x.z), f(x.w));
             }
         } else {
             for (int j = lane; j < n; j += 64) dn[j] = f(nr[j]);
@@ -252,7 +266,8 @@ static void launch_loss(bool grad, const bess_loss_desc& l, const float* pos, co
     const bool vec = N % 4 == 0 && ld % 4 == 0 && reinterpret_cast<uintptr_t>(neg) % 16 == 0 &&
                      (!grad || (ldd % 4 == 0 && reinterpret_cast<uintptr_t>(dn) % 16 == 0));
 #define BESS_LOSS_CH(CH) launch_loss_ch<KIND, ADV, CH>(grad, l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd, rn, st)
-    if (!vec || N > 256 * 24) BESS_LOSS_CH(0);
+    if (!vec) BESS_LOSS_CH(0);
+    else if (N > 256 * 24) BESS_LOSS_CH(-1);
     else if (N <= 256 * 4) BESS_LOSS_CH(4);
     else if (N <= 256 * 12) BESS_LOSS_CH(12);
     else BESS_LOSS_CH(24);
