@@ -48,16 +48,18 @@ def run(workload: str) -> None:
         from besskge.scoring import TransE
         from besskge.sharding import Sharding
 
-        S_, K_ = (512, 32) if workload in ("c4s", "c4g") else (4096, 256)
-        sharding = Sharding.create(bench.C4_ROWS_PER_SHARD, 1, seed=0)
-        fn = TransE(True, 1, sharding, bench.C4_N_REL, bench.C4_D, device=dev, shards=[0], dtype=torch.float16)
+        S_, K_ = (512, 32) if workload in ("c4s", "c4g", "c4n2") else (4096, 256)
+        nsh = 2 if workload == "c4n2" else 1  # c4n2: two shards stepped in lock-step on this GPU (the n > 1 code path)
+        sharding = Sharding.create(bench.C4_ROWS_PER_SHARD * nsh, nsh, seed=0)
+        fn = TransE(True, 1, sharding, bench.C4_N_REL, bench.C4_D, device=dev, shards=list(range(nsh)), dtype=torch.float16)
         ns = RandomShardedNegativeSampler(K_, sharding, 0, "t", local_sampling=False, flat_negative_format=True)
         model = EmbeddingMovingBessKGE(negative_sampler=ns, score_fn=fn, augment_negative=True,
                                        loss_fn=SampledSoftmaxCrossEntropyLoss(n_entity=bench.C4_N_ENTITY))
         rng = np.random.default_rng(0)
         M = bench.C4_ROWS_PER_SHARD
-        batch = dict(head=rng.integers(M, size=(1, 1, S_)), relation=rng.integers(bench.C4_N_REL, size=(1, 1, S_)),
-                     tail=rng.integers(M, size=(1, 1, S_)), negative=rng.integers(M, size=(1, 1, 1, K_)))
+        pp = S_ // nsh
+        batch = dict(head=rng.integers(M, size=(nsh, nsh, pp)), relation=rng.integers(bench.C4_N_REL, size=(nsh, nsh, pp)),
+                     tail=rng.integers(M, size=(nsh, nsh, pp)), negative=rng.integers(M, size=(nsh, nsh, 1, K_)))
         batch = {k: torch.from_numpy(v.astype(np.int32)).to(dev) for k, v in batch.items()}
         runner = runtime.training_model(model, runtime.Options(device_iterations=1, use_graphs=workload == "c4g"),
                                         runtime.SGD(lr=1e-3), device=dev)

@@ -61,7 +61,8 @@ if steps:
     what = {"c2": "C2 ComplEx d=256 fp32, S=4096 x 256 per-triple, SGD", "c2adam": "same, AdamW",
             "c2score": "C2, the bench headline step (gather + score + loss)",
             "c2sm": "C2 training step in its multi-GPU form (ScoreMovingBessKGE, fused forward with partials), one shard",
-            "c4s": "C4 TransE d=256 fp16, S=512, K=32, eager", "c4g": "C4 TransE d=256 fp16, S=512, K=32, hipGraph replay",
+            "c4s": "C4 TransE d=256 fp16, S=512, K=32, eager",
+            "c4n2": "C4, two shards of S=512 stepped in lock-step on one GPU (the n > 1 code path: pack, exchange, C8), eager", "c4g": "C4 TransE d=256 fp16, S=512, K=32, hipGraph replay",
             "c4": "C4 TransE d=256 fp16, S=4096, K=256, eager"}
     for f in steps:
         txt = open(f).read().splitlines()
