@@ -179,6 +179,42 @@ def sampler(out_dir: str) -> None:
     np.savez(os.path.join(out_dir, f"sampler_{r}.npz"), **out)
 
 
+def checkpoint(out_dir: str) -> None:
+    """CPU, gloo: every rank hosts one shard, saves it, loads it into a differently initialised model; the files
+    of the ranks do not overlap and the replicated tables are written once (by the host of shard 0)."""
+    from besskge import checkpoint as ckpt
+    from besskge.bess import EmbeddingMovingBessKGE
+    from besskge.loss import LogSigmoidLoss
+    from besskge.negative_sampler import RandomShardedNegativeSampler
+    from besskge.scoring import ComplEx
+    from besskge.sharding import Sharding
+
+    g = make_group()
+    n, r = g.n_shard, g.rank
+    sharding = Sharding.create(700, n, seed=4)
+
+    def build(seed: int):
+        torch.manual_seed(seed)
+        fn = ComplEx(False, sharding, 9, 8, shards=[r])  # this rank's slice only
+        ns = RandomShardedNegativeSampler(4, sharding, 1, "t", local_sampling=False, flat_negative_format=False)
+        m = EmbeddingMovingBessKGE(ns, fn, LogSigmoidLoss(margin=1.0, negative_adversarial_sampling=False))
+        m.attach(g, {r: 0})
+        return m
+
+    a = build(100 + r)
+    d = os.path.join(out_dir, "ckpt")
+    ckpt.save_checkpoint(a, d, chunk_bytes=1 << 10)
+    dist.barrier()
+    b = build(999)
+    assert not torch.equal(b.score_fn.entity_embedding, a.score_fn.entity_embedding)
+    ckpt.load_checkpoint(b, d, chunk_bytes=1 << 10)
+    assert torch.equal(b.score_fn.entity_embedding, a.score_fn.entity_embedding)
+    # the replicated relation table is rank 0's (every rank built its own with a different seed)
+    (rel0,) = g.all_gather([a.score_fn.relation_embedding.detach().clone()])
+    assert torch.equal(b.score_fn.relation_embedding.detach(), rel0[0])
+    np.savez(os.path.join(out_dir, f"checkpoint_{r}.npz"), files=np.array(sorted(os.listdir(d))))
+
+
 def main() -> None:
     mode, out_dir = sys.argv[1], sys.argv[2]
     # gloo: several ranks share the box's one GPU (host-staged collectives); nccl (= RCCL): one rank
@@ -193,7 +229,7 @@ def main() -> None:
     else:
         dist.init_process_group("gloo")
     try:
-        {"routing": routing, "bess": bess, "topk": topk, "sampler": sampler}[mode](out_dir)
+        {"routing": routing, "bess": bess, "topk": topk, "sampler": sampler, "checkpoint": checkpoint}[mode](out_dir)
         dist.barrier()
     finally:
         dist.destroy_process_group()

@@ -38,6 +38,15 @@ def launch(mode, world, extra_env=None, timeout=600):
     return out_dir
 
 
+def test_checkpoint_every_rank_its_own_shard():
+    """Per-shard streaming checkpoints with one process per shard (gloo, CPU): besskge/checkpoint.py."""
+    out = launch("checkpoint", 2)
+    files = set(np.load(os.path.join(out, "checkpoint_0.npz"))["files"].tolist())
+    assert {"entity_shard0.npy", "entity_shard1.npy", "relation.npy", "dense.pt",
+            "entity_shard0.meta.json", "entity_shard1.meta.json", "relation.meta.json"} <= files
+    assert not [f for f in files if ".tmp" in f]
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_collectives_gloo(world):
     out = launch("routing", world)
