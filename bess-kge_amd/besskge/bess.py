@@ -969,11 +969,13 @@ class EmbeddingMovingBessKGE(BessKGE):
             if n > 1:
                 d_recv = torch.zeros((st.recv.shape[0], W), dtype=torch.float32, device=dev)
 
+            into_recv: List[Tuple[torch.Tensor, torch.Tensor]] = []  # gradients of rows that came from other shards
+
             def sink(src: RowSource, g: torch.Tensor) -> None:
                 if src.base is st.table:
                     upd.append((src.idx, g))
                 elif src.base is st.recv:
-                    nat.scatter_add_rows(d_recv, src.idx, g)
+                    into_recv.append((src.idx, g))
                 else:  # pragma: no cover
                     raise RuntimeError("gradient for an unknown row space")
 
@@ -1017,6 +1019,14 @@ class EmbeddingMovingBessKGE(BessKGE):
                     dx = fn.query_bwd(g.side, g.ent, g.rel_idx, g.query_ctx, dq, d_rel)
                     sink(g.ent, dx)
             if n > 1:
+                # all of them summed into the receive layout by ONE launch (d_recv -= -1 * g, fp32 atomics)
+                lists = [(x.contiguous(), g.contiguous()) for x, g in into_recv if x is not None]
+                for i in range(0, len(lists), nat.MAX_ROW_LISTS):
+                    nat.sparse_sgd_lists(d_recv, lists[i:i + nat.MAX_ROW_LISTS], -1.0)
+                for x, g in into_recv:
+                    if x is None:  # rows in place
+                        nat.scatter_add_rows(d_recv, None, g)
+                into_recv.clear()
                 if st.ext_src is not None:  # rows appended for augmentation -> their origin
                     sink(st.ext_src, d_recv[st.recv_rows:].contiguous())
                 back.append(d_recv[: st.recv_rows].reshape(n, -1, W))
