@@ -87,6 +87,7 @@ INDEX = [
     ("stress_gemm_split.log", "profiles/stress_gemm_split.py", "80 random shapes through the split-fp16 products vs float64"),
     ("stress_pertriple.log", "profiles/stress_pertriple.py", "150 random problems: dominant kernel and its backward vs torch float64"),
     ("stress_fused_forward.log", "profiles/stress_fused_forward.py", "160 random problems: fused training forward vs the two-pass path"),
+    ("stress_shared_distance.log", "profiles/stress_shared_distance.py", "120 random shapes through the shared-negative L1 / L2 kernels (all tile variants, reduction splits, one-launch backward, packed fp16 forward) vs float64"),
     ("stress_topk.log", "profiles/stress_topk.py", "150 random top-k problems (ties, masks, padded rows) vs a stable sort"),
     ("ubench_hbm_bw.log", "profiles/ubench/hbm_bw.hip", "what the memory system delivers: streaming and random-row reads"),
     ("ubench_valu_rate.log", "profiles/ubench/valu_rate.hip", "VALU ceiling of the p-norm tile kernels (scalar and packed)"),
