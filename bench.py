@@ -357,9 +357,13 @@ def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, c
                 # VALU work of the L1 distance matrix per GPU and step: forward |q - e| accumulate and the two
                 # backward products, S x N x W elements each (csrc/neg_shared.hip states the ops per element)
                 elems = S_ * n_neg * C4_D
+                # lane-instructions per element: forward 1 (a packed max + a packed dot per 2 elements), each
+                # backward product 3 (sub, sign, multiply-add); whole step / step time -> fraction of the issue peak
+                lane_ops = 7 * elems / (best * 1e-3) / 1e12
                 point["valu"] = dict(bound="valu", elements_per_product=elems,
                                      achieved=3 * elems / (best * 1e-3) / 1e12, unit="T element-updates/s (3 products/step)",
-                                     peak=VALU_PEAK_TLOPS, peak_unit="T lane-ops/s")
+                                     lane_ops_per_element=7, achieved_lane_ops=lane_ops,
+                                     peak=VALU_PEAK_TLOPS, peak_unit="T lane-ops/s", frac=lane_ops / VALU_PEAK_TLOPS)
     return c4_summary(state, world, comm_name)
 
 
