@@ -161,6 +161,8 @@ SIGNATURES = {
                               _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "bess_neg_pertriple_items": [_MD, _i64, _i64, ctypes.POINTER(ctypes.c_int32)],
     "bess_neg_score_pertriple_fwd_dq": [_MD, _LD, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
+    "bess_neg_score_pertriple_fwd_dq_masked": [_MD, _LD, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp,
+                                               _vp, _vp, _vp],
     "bess_neg_score_pertriple_fwd_partials": [_MD, _LD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
     "bess_combine_dq_partials": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
     "bess_normalize_rows": [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
@@ -568,10 +570,11 @@ def neg_score_pertriple_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n
 
 
 def neg_score_pertriple_fwd_dq(d: ModelDesc, l: LossDesc, query: torch.Tensor, neg: RowSource, n_neg: int,
-                               pos: Optional[torch.Tensor], weight: torch.Tensor
+                               pos: Optional[torch.Tensor], weight: torch.Tensor, mask: Optional[torch.Tensor] = None
                                ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Fused training forward: (scores [nq, n_neg], d loss / d query [nq, W]) in one pass over
-    the negative rows.  Only valid when the loss is taken over exactly these scores, unmasked."""
+    the negative rows.  Only valid when the loss is taken over exactly these scores; `mask` (bool
+    [1 | nq, cols <= n_neg], False = masked out, over the last `cols` columns) is applied inside the pass."""
     nq = int(query.shape[0])
     dev = _neg_operands(d, query, neg, nq * n_neg)
     _same_device([("pos", pos), ("weight", weight), ("query", query)])
@@ -589,12 +592,19 @@ def neg_score_pertriple_fwd_dq(d: ModelDesc, l: LossDesc, query: torch.Tensor, n
     st_ml = torch.empty((nq, items.value, 2), dtype=torch.float32, device=dev)
     st_acc = torch.empty((nq, items.value, d.width), dtype=torch.float32, device=dev)
     ip, keep = _neg_idx_ptr(neg, dev)
+    mrows = mcols = 0
+    if mask is not None:
+        _same_device([("mask", mask), ("query", query)])
+        if mask.dtype not in (torch.bool, torch.uint8) or mask.dim() != 2 or not mask.is_contiguous():
+            raise ValueError("neg_score_pertriple_fwd_dq: `mask` must be a contiguous 2-D bool / uint8 tensor")
+        mrows, mcols = int(mask.shape[0]), int(mask.shape[1])
     with _on(dev), _Timed("bess_neg_score_pertriple_fwd_dq", dev):
-        rc = load().bess_neg_score_pertriple_fwd_dq(
+        rc = load().bess_neg_score_pertriple_fwd_dq_masked(
             ctypes.byref(d), ctypes.byref(l), query.data_ptr(), nq, neg.base.data_ptr(), ip, n_neg,
-            pos.data_ptr() if pos is not None else 0, weight.data_ptr(), weight.numel(), out.data_ptr(), n_neg,
+            pos.data_ptr() if pos is not None else 0, weight.data_ptr(), weight.numel(),
+            mask.data_ptr() if mask is not None else 0, mrows, mcols, out.data_ptr(), n_neg,
             dq.data_ptr(), st_ml.data_ptr(), st_acc.data_ptr(), _stream(dev))
-    _check(rc, "bess_neg_score_pertriple_fwd_dq")
+    _check(rc, "bess_neg_score_pertriple_fwd_dq_masked")
     del keep
     return out, dq
 

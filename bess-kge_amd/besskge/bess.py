@@ -692,7 +692,7 @@ class BessKGE(torch.nn.Module, ABC):
                 pos = pos[g.sel].contiguous()
                 w = w if w.numel() == 1 else w[g.sel].contiguous()
             g.out, g.dq = nat.neg_score_pertriple_fwd_dq(desc, fuse["loss"](g.n_per_query), g.query, g.neg,
-                                                         g.n_per_query, pos, w)
+                                                         g.n_per_query, pos, w, mask=fuse.get("mask"))
         elif partials_loss is not None:
             # ScoreMoving training: this shard holds a part of each query's negatives - scores plus the partials
             # from which its share of d loss / d query is formed once the owner has normalised over all shards
@@ -710,12 +710,14 @@ class BessKGE(torch.nn.Module, ABC):
         loss taken over exactly the scores of one per-triple group, with nothing masked."""
         if self.loss_fn is None or not self.score_fn.supports_fused_forward or self.augment_negative:
             return None
-        if batch.get("negative_mask") is not None or not hasattr(self.loss_fn, "kernel_desc"):
+        if not hasattr(self.loss_fn, "kernel_desc"):
             return None
         dev = self.score_fn.relation_embedding.device
         w = batch.get("triple_weight")
         w = self._unit_weight(dev) if w is None else w.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
-        return dict(weight=w, loss=self.loss_fn.kernel_desc)
+        # a negative_mask (the padding of triple-specific negatives) is applied inside the fused pass when it
+        # has one row or one per triple (`_run_groups_one`); other layouts take the two-pass path
+        return dict(weight=w, loss=self.loss_fn.kernel_desc, masked=batch.get("negative_mask") is not None)
 
 
 class EmbeddingMovingBessKGE(BessKGE):
@@ -793,7 +795,21 @@ class EmbeddingMovingBessKGE(BessKGE):
                 # training: the index of the step's small update lists needs only row ids - start it on the side
                 # stream before the scoring kernels are queued, so that it runs under them
                 early.update(self._small_index_ahead([st], self._ahead_optimizer))
-            outs = self._run_groups(st, desc, fuse[len(done)] if fuse else None)
+            fz = fuse[len(done)] if fuse else None
+            if fz is not None and fz.get("masked"):
+                # K7 inside the fused pass: one per-triple group over all triples, a mask of 1 or S rows, no 'ht' halves
+                kill = self._kill_spec(b["_kill_from"], st.n, st.ppp, st.n * st.ppp, st.table.device) \
+                    if b.get("_kill_from") is not None else None
+                g0 = st.groups[0]
+                ok = (kill is not None and kill[0] == 0 and not kill[1] and kill[3] is not None
+                      and kill[3].shape[0] in (1, st.n * st.ppp) and len(st.groups) == 1 and g0.sel is None
+                      and not g0.shared and g0.neg.base is st.table and kill[3].shape[1] <= g0.n_per_query)
+                if ok:
+                    fz = dict(fz, mask=kill[3])
+                    st.kill_applied = True
+                else:
+                    fz = None  # two-pass path: scores, K7, loss, backward
+            outs = self._run_groups(st, desc, fz)
             done.append(st)
             if len(outs) == 1:
                 st.negative_score = outs[0]
@@ -1241,8 +1257,8 @@ class ScoreMovingBessKGE(BessKGE):
         # pass over the negative rows (`neg_score_pertriple_bwd`) is replaced by a rescaling of those partials
         fuse = [self._fusable(b) for b in batches]
         kind = getattr(self.loss_fn, "_kind", -1)
-        fused = (all(f is not None for f in fuse) and kind in (nat.LOSS_LOGSIGMOID, nat.LOSS_SSCE)
-                 and fn.supports_fused_segments)
+        fused = (all(f is not None and not f.get("masked") for f in fuse)
+                 and kind in (nat.LOSS_LOGSIGMOID, nat.LOSS_SSCE) and fn.supports_fused_segments)
         self.__dict__["_sm_fuse"] = self.loss_fn.kernel_desc if fused else None
         try:
             steps = self._score_replicas(batches)

@@ -53,6 +53,9 @@ struct FuseArgs {
     float shift;        // ssce: log(n_entity - 1) - log(N), added to the negative scores
     float* st_ml;       // [n_query, items, 2]
     float* st_acc;      // [n_query, items, W]
+    const uint8_t* mask = nullptr;  // [mask_rows (1 | n_query), mask_cols] over the last mask_cols columns, or NULL
+    int64_t mask_rows = 0;
+    int mask_cols = 0, mask_from = 0;
 };
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
@@ -129,9 +132,16 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_fwd(NegPtArgs a, float* _
             }
             acc = row16_allreduce_sum(acc);
             if (RED == RED_L2) acc = sqrtf(acc);
-            if (g == 0 && valid[u]) orow[kb + sub + 4 * u] = a.sign * acc;
+            float sc = a.sign * acc;
+            if (FUSE && f.mask && valid[u]) {
+                // K7 inside the pass (the padding mask of triple-specific negatives): a masked-out candidate gets
+                // BESS_BAD_NEGATIVE_SCORE added before it is stored and before it enters the softmax
+                const int kcol = kb + sub + 4 * u - f.mask_from;
+                const int64_t mrow = f.mask_rows == 1 ? 0 : q;
+                if (kcol >= 0 && f.mask[mrow * f.mask_cols + kcol] == 0) sc += BESS_BAD_NEGATIVE_SCORE;
+            }
+            if (g == 0 && valid[u]) orow[kb + sub + 4 * u] = sc;
             if (FUSE && valid[u]) {  // uniform within the 16-lane group
-                const float sc = a.sign * acc;
                 const float z = f.beta * (sc + f.shift);
                 const float m_new = fmaxf(fm, z);
                 const float corr = expf(fm - m_new);
@@ -518,6 +528,17 @@ extern "C" int bess_neg_score_pertriple_fwd_dq(const bess_model_desc* d, const b
                                                int64_t n_neg, const float* pos, const float* weight,
                                                int64_t weight_len, float* out, int64_t ld_out, float* d_query,
                                                float* state_ml, float* state_acc, void* stream) {
+    return bess_neg_score_pertriple_fwd_dq_masked(d, l, query, n_query, neg_base, neg_idx, n_neg, pos, weight, weight_len,
+                                                  nullptr, 0, 0, out, ld_out, d_query, state_ml, state_acc, stream);
+}
+
+extern "C" int bess_neg_score_pertriple_fwd_dq_masked(const bess_model_desc* d, const bess_loss_desc* l,
+                                                      const float* query, int64_t n_query, const void* neg_base,
+                                                      const int32_t* neg_idx, int64_t n_neg, const float* pos,
+                                                      const float* weight, int64_t weight_len, const uint8_t* mask,
+                                                      int64_t mask_rows, int64_t mask_cols, float* out,
+                                                      int64_t ld_out, float* d_query, float* state_ml,
+                                                      float* state_acc, void* stream) {
     using namespace bess;
     if (int e = check_desc(d)) return e;
     BESS_REQUIRE(l, "neg_score_pertriple_fwd_dq: NULL loss descriptor");
@@ -536,6 +557,15 @@ extern "C" int bess_neg_score_pertriple_fwd_dq(const bess_model_desc* d, const b
     f.shift = l->kind == BESS_LOSS_SSCE ? l->ssce_shift : 0.f;
     f.st_ml = state_ml;
     f.st_acc = state_acc;
+    if (mask) {
+        BESS_REQUIRE(mask_cols > 0 && mask_cols <= n_neg && (mask_rows == 1 || mask_rows == n_query),
+                     "neg_score_pertriple_fwd_dq_masked: mask [%lld, %lld] for %lld queries x %lld negatives",
+                     (long long)mask_rows, (long long)mask_cols, (long long)n_query, (long long)n_neg);
+        f.mask = mask;
+        f.mask_rows = mask_rows;
+        f.mask_cols = static_cast<int>(mask_cols);
+        f.mask_from = static_cast<int>(n_neg - mask_cols);
+    }
     const int rc = run(d, true, query, n_query, neg_base, neg_idx, n_neg, out, nullptr, ld_out, nullptr, nullptr, stream,
                        &f);
     if (rc) return rc;

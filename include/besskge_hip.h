@@ -520,6 +520,17 @@ int bess_neg_score_pertriple_fwd_dq(const bess_model_desc* d, const bess_loss_de
                                     const float* weight, int64_t weight_len, float* out,
                                     int64_t ld_out, float* d_query, float* state_ml,
                                     float* state_acc, void* stream);
+/* The same with K7's mask inside the pass: mask [mask_rows (1 | n_query), mask_cols] (bytes, 0 = masked
+ * out) over the LAST mask_cols columns, as bess_mask_scores applies it - a masked-out candidate gets
+ * BESS_BAD_NEGATIVE_SCORE added before the score is stored and before it enters the loss weights
+ * (the padding mask of triple-specific negatives, negative_sampler.py:479-540); mask == NULL: none. */
+int bess_neg_score_pertriple_fwd_dq_masked(const bess_model_desc* d, const bess_loss_desc* l,
+                                           const float* query, int64_t n_query, const void* neg_base,
+                                           const int32_t* neg_idx, int64_t n_neg, const float* pos,
+                                           const float* weight, int64_t weight_len, const uint8_t* mask,
+                                           int64_t mask_rows, int64_t mask_cols, float* out,
+                                           int64_t ld_out, float* d_query, float* state_ml,
+                                           float* state_acc, void* stream);
 
 /* The same pass for queries whose negatives are spread over several shards (ScoreMoving: each shard
  * scores the gathered queries against its own rows).  bess_neg_score_pertriple_fwd_partials writes the

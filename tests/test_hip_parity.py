@@ -1148,3 +1148,80 @@ def test_partials_of_two_shards_combine_to_the_one_pass_gradient(dev, name, p, k
     c = (1.0 if kind == "ssce" else 0.5) * float(ld.loss_scale) * w.double()
     torch.testing.assert_close(norm[:, 0].double(), m, rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(norm[:, 1].double(), big_l / c, rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("mask_rows", ["one", "per_triple"])
+@pytest.mark.parametrize("kind", ["logsigmoid", "ssce", "margin"])
+@pytest.mark.parametrize("name,p,dtype", [("ComplEx", 0, torch.float32), ("TransE", 1, torch.float16), ("RotatE", 2, torch.float32)])
+def test_fused_forward_with_the_mask_inside_matches_mask_then_two_pass(dev, name, p, dtype, kind, mask_rows):
+    """bess_neg_score_pertriple_fwd_dq_masked: the padding mask of triple-specific negatives applied inside the fused
+    pass == scores, bess_mask_scores, loss kernel, backward kernel (bess.py:182-245 then loss.py:28-251)."""
+    from besskge import _native as nat
+    from besskge.loss import LogSigmoidLoss, MarginRankingLoss, SampledSoftmaxCrossEntropyLoss
+
+    gen = torch.Generator().manual_seed(21)
+    S, N, cols, d_emb, M = 70, 96, 80, 24, 400
+    W, Wr = widths(name, d_emb)
+    table = (0.4 * torch.randn(M, W, generator=gen)).to(dtype).to(dev)
+    desc = nat.make_desc(dict(TransE=0, RotatE=1, DistMult=2, ComplEx=3)[name], max(p, 1), table, Wr)
+    q = (0.4 * torch.randn(S, W, generator=gen)).to(dev)
+    idx = torch.randint(M, (S * N,), generator=gen, dtype=torch.int32).to(dev)
+    pos = torch.randn(S, generator=gen).to(dev)
+    w = (torch.rand(S, generator=gen) + 0.5).to(dev)
+    rows = 1 if mask_rows == "one" else S
+    mask = (torch.rand(rows, cols, generator=gen) < 0.7).to(dev)  # over the LAST `cols` columns
+    fn = {"logsigmoid": LogSigmoidLoss(1.0, True, 0.8), "margin": MarginRankingLoss(2.0, True, 0.8),
+          "ssce": SampledSoftmaxCrossEntropyLoss(10 * M)}[kind]
+    ld = fn.kernel_desc(N)
+    neg = nat.RowSource(table, idx)
+    out, dq = nat.neg_score_pertriple_fwd_dq(desc, ld, q, neg, N, pos, w, mask=mask)
+    ref = nat.neg_score_pertriple_fwd(desc, q, neg, N)
+    nat.mask_scores(ref, 0, False, 0, mask)
+    assert torch.equal(out, ref)
+    assert int((out < -40000).sum()) > 0
+    _, _, dn = nat.loss_fwd_bwd(ld, pos, ref, w, True)
+    dq_ref, _ = nat.neg_score_pertriple_bwd(desc, q, neg, N, dn, want_d_neg=False)
+    close(dq, dq_ref, rtol=2e-4, atol=1e-6, scale=4e-6)
+
+
+@pytest.mark.parametrize("rows", ["one", "per_triple"])
+def test_training_step_with_a_negative_mask_takes_the_fused_forward(dev, rows):
+    """EmbeddingMoving, one shard, per-triple negatives + negative_mask: the fused training forward applies the mask
+    inside its pass (no second pass over the negative rows) and moves the tables like the two-pass path does."""
+    from besskge import _native as nat
+    from besskge import runtime
+    from besskge.bess import EmbeddingMovingBessKGE
+    from besskge.loss import LogSigmoidLoss
+    from besskge.negative_sampler import RandomShardedNegativeSampler
+    from besskge.scoring import ComplEx
+    from besskge.sharding import Sharding
+
+    S, K, n_ent, n_rel, d_emb = 48, 20, 600, 7, 16
+    rng = np.random.default_rng(3)
+    batch = dict(head=rng.integers(n_ent, size=(1, 1, S)), relation=rng.integers(n_rel, size=(1, 1, S)),
+                 tail=rng.integers(n_ent, size=(1, 1, S)), negative=rng.integers(n_ent, size=(1, 1, S, K)))
+    batch = {k: torch.from_numpy(v.astype(np.int32)) for k, v in batch.items()}
+    batch["negative_mask"] = torch.from_numpy(rng.random((1, 1 if rows == "one" else S, 1, K)) < 0.7)
+
+    def run(fused: bool):
+        torch.manual_seed(1)
+        sharding = Sharding.create(n_ent, 1, seed=2)
+        fn = ComplEx(False, sharding, n_rel, d_emb)
+        ns = RandomShardedNegativeSampler(K, sharding, 0, "h", local_sampling=False, flat_negative_format=False)
+        model = EmbeddingMovingBessKGE(ns, fn, LogSigmoidLoss(margin=1.0, negative_adversarial_sampling=True))
+        if not fused:
+            model._fusable = lambda b: None  # type: ignore[method-assign]
+        runner = runtime.training_model(model, optimizer=runtime.SGD(lr=0.1), device=dev)
+        nat.start_kernel_timing(["bess_neg_score_pertriple_fwd_dq", "bess_neg_score_pertriple_bwd"])
+        res = runner(**batch)
+        calls = {k: len(v) for k, v in nat.stop_kernel_timing().items()}
+        return res, model.score_fn.entity_embedding.detach().clone(), model.score_fn.relation_embedding.detach().clone(), calls
+
+    res_f, ent_f, rel_f, calls_f = run(True)
+    res_t, ent_t, rel_t, calls_t = run(False)
+    assert calls_f.get("bess_neg_score_pertriple_fwd_dq", 0) == 1 and calls_f.get("bess_neg_score_pertriple_bwd", 0) == 0, calls_f
+    assert calls_t.get("bess_neg_score_pertriple_fwd_dq", 0) == 0 and calls_t.get("bess_neg_score_pertriple_bwd", 0) == 1, calls_t
+    torch.testing.assert_close(res_f["loss"], res_t["loss"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ent_f, ent_t, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(rel_f, rel_t, rtol=1e-5, atol=1e-7)
+    assert float((ent_f - ent_t).abs().max()) < 1e-5 and float(ent_f.abs().max()) > 0
