@@ -113,7 +113,7 @@ class TopKQueryBessKGE(_QueryModule):
         window_size: int = 100,
     ) -> None:
         """
-        :param k: number of completions returned per query (k + 1 <= 64).
+        :param k: number of completions returned per query (k + 1 <= 128).
         :param candidate_sampler: `PlaceholderNegativeSampler` (score against
             every entity) or a `TripleBasedShardedNegativeSampler` built with
             `mask_on_gather=True`.
@@ -127,8 +127,8 @@ class TopKQueryBessKGE(_QueryModule):
         self.return_scores = return_scores
         self.k = k
         self.window_size = window_size
-        if k + 1 > 64:
-            raise ValueError("the streaming top-k kernel keeps k + 1 <= 64 entries per query")
+        if k + 1 > 128:
+            raise ValueError("the streaming top-k kernel keeps k + 1 <= 128 entries per query")
         if self.negative_sampler.flat_negative_format:
             assert score_fn.negative_sample_sharing, "Using flat negative format requires negative sample sharing"
         elif score_fn.negative_sample_sharing:

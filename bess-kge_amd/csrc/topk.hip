@@ -5,7 +5,7 @@
 // the final `torch.topk` over the shards' lists (bess.py:889-894).
 //
 // One workgroup (four wavefronts) per query row.  A wave's list (kk <= 64 entries, sorted by
-// descending score) lives in registers, entry j in lane j.  The window is
+// descending score) lives in registers, entry j in lane j (65 .. 128 entries: two registers per lane).  The window is
 // streamed 64 candidates at a time; a candidate enters only if it beats the
 // current kk-th score tau (`__ballot(x > tau)`), so after the first few chunks
 // almost every chunk costs one load, one compare and one ballot: the expected
@@ -23,42 +23,74 @@ namespace bess {
 // empty lists; at the end wave 0 examines the other three lists as three more chunks, in wave
 // order - quarters are in column order, so ties resolve exactly as in a single left-to-right pass.
 // VEC: rows are 16-B aligned (ld % 4 == 0), a lane loads 4 consecutive columns with one instruction.
-template <int WPR, bool VEC>
+// TWO: lists of 65 .. 128 entries - entry j < 64 in lane j of the first register pair, entry 64 + j in lane j of
+// the second; an insertion shifts the first into the second through lane 63 -> lane 0.
+template <int WPR, bool VEC, bool TWO>
 __global__ __launch_bounds__(256) void k_topk_update(const float* __restrict__ scores, int64_t n_row,
                                                      int64_t n_col, int64_t ld, const int32_t* __restrict__ ids,
                                                      int64_t ids_rows, int32_t id_base,
                                                      const uint8_t* __restrict__ mask, int64_t mask_rows,
                                                      float* __restrict__ best_score,
                                                      int32_t* __restrict__ best_id, int kk) {
-    __shared__ float l_s[3][64];
-    __shared__ int32_t l_i[3][64];
+    __shared__ float l_s[3][TWO ? 128 : 64];
+    __shared__ int32_t l_i[3][TWO ? 128 : 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int part = WPR == 4 ? wave : 0;  // which quarter of the columns
     const int64_t row = WPR == 4 ? static_cast<int64_t>(blockIdx.x) : blockIdx.x * 4ll + wave;
     if (row >= n_row) return;  // WPR == 1 only (whole waves; no barrier on that path)
-    float bs = -INFINITY;
-    int32_t bi = 0;
-    if (part == 0 && lane < kk) {
+    float bs = -INFINITY, bs1 = -INFINITY;  // (bs1, bi1): entries 64 .. 127 (TWO)
+    int32_t bi = 0, bi1 = 0;
+    const int k0 = TWO ? 64 : kk;  // entries held by the first pair
+    if (part == 0 && lane < k0) {
         bs = best_score[row * kk + lane];
         bi = best_id[row * kk + lane];
     }
-    float tau = __shfl(bs, kk - 1, 64);
+    if (TWO && part == 0 && 64 + lane < kk) {
+        bs1 = best_score[row * kk + 64 + lane];
+        bi1 = best_id[row * kk + 64 + lane];
+    }
+    float tau = TWO ? __shfl(bs1, kk - 65, 64) : __shfl(bs, kk - 1, 64);
     // candidate (xv, iv) enters the list if it beats the kk-th entry
     auto insert = [&](float xv, int32_t iv) {
         // entries that stay ahead of the newcomer (>=: earlier entries win ties)
-        const int pos = __popcll(__ballot(lane < kk && bs >= xv));
+        const int pos0 = __popcll(__ballot(lane < k0 && bs >= xv));
         const float up_s = __shfl_up(bs, 1, 64);
         const int32_t up_i = __shfl_up(bi, 1, 64);
-        if (lane < kk) {
-            if (lane > pos) {
+        if (TWO) {
+            // the second half: shifted as a whole when the newcomer lands in the first (whose last entry
+            // moves over), from the newcomer's place on when it lands here
+            const int pos1 = __popcll(__ballot(64 + lane < kk && bs1 >= xv));
+            const float last_s = __shfl(bs, 63, 64);
+            const int32_t last_i = __shfl(bi, 63, 64);
+            float up1_s = __shfl_up(bs1, 1, 64);
+            int32_t up1_i = __shfl_up(bi1, 1, 64);
+            if (lane == 0) {
+                up1_s = last_s;
+                up1_i = last_i;
+            }
+            if (64 + lane < kk) {
+                if (pos0 < 64) {  // newcomer in the first half: everything here moves up by one
+                    bs1 = up1_s;
+                    bi1 = up1_i;
+                } else if (lane > pos1) {
+                    bs1 = up1_s;
+                    bi1 = up1_i;
+                } else if (lane == pos1) {
+                    bs1 = xv;
+                    bi1 = iv;
+                }
+            }
+        }
+        if (lane < k0) {
+            if (lane > pos0) {
                 bs = up_s;
                 bi = up_i;
-            } else if (lane == pos) {
+            } else if (lane == pos0) {
                 bs = xv;
                 bi = iv;
             }
         }
-        tau = __shfl(bs, kk - 1, 64);
+        tau = TWO ? __shfl(bs1, kk - 65, 64) : __shfl(bs, kk - 1, 64);
     };
     // a chunk of 64 candidates (one per lane), examined in lane order
     auto examine = [&](float x, int32_t xi) {
@@ -133,18 +165,29 @@ __global__ __launch_bounds__(256) void k_topk_update(const float* __restrict__ s
     }
     if (WPR == 4) {
         if (wave > 0) {
-            l_s[wave - 1][lane] = lane < kk ? bs : -INFINITY;
+            l_s[wave - 1][lane] = lane < k0 ? bs : -INFINITY;
             l_i[wave - 1][lane] = bi;
+            if (TWO) {
+                l_s[wave - 1][64 + lane] = 64 + lane < kk ? bs1 : -INFINITY;
+                l_i[wave - 1][64 + lane] = bi1;
+            }
         }
         __syncthreads();
         if (wave == 0) {
 #pragma unroll
-            for (int w = 0; w < 3; ++w) examine(l_s[w][lane], l_i[w][lane]);
+            for (int w = 0; w < 3; ++w) {
+                examine(l_s[w][lane], l_i[w][lane]);
+                if (TWO) examine(l_s[w][64 + lane], l_i[w][64 + lane]);
+            }
         }
     }
-    if (part == 0 && lane < kk) {
+    if (part == 0 && lane < k0) {
         best_score[row * kk + lane] = bs;
         best_id[row * kk + lane] = bi;
+    }
+    if (TWO && part == 0 && 64 + lane < kk) {
+        best_score[row * kk + 64 + lane] = bs1;
+        best_id[row * kk + 64 + lane] = bi1;
     }
 }
 
@@ -157,7 +200,7 @@ extern "C" int bess_topk_update(const float* scores, int64_t n_row, int64_t n_co
                                 int64_t mask_rows, float* best_score, int32_t* best_id, int32_t kk,
                                 void* stream) {
     BESS_REQUIRE(n_row >= 0 && n_row < (1ll << 31) && n_col >= 0 && ld >= n_col, "topk_update: bad sizes");
-    BESS_REQUIRE(kk >= 1 && kk <= 64, "topk_update: list length %d not in [1, 64]", kk);
+    BESS_REQUIRE(kk >= 1 && kk <= 128, "topk_update: list length %d not in [1, 128]", kk);
     if (n_row == 0 || n_col == 0) return BESS_OK;
     BESS_REQUIRE(scores && best_score && best_id, "topk_update: NULL pointer");
     BESS_REQUIRE(!ids || ids_rows == 1 || ids_rows == n_row, "topk_update: ids_rows must be 1 or n_row");
@@ -168,9 +211,15 @@ extern "C" int bess_topk_update(const float* scores, int64_t n_row, int64_t n_co
     const bool vec = ld % 4 == 0 && reinterpret_cast<uintptr_t>(scores) % 16 == 0;
     const unsigned grid = static_cast<unsigned>(wide ? n_row : ceil_div(n_row, 4));
     hipStream_t st = as_stream(stream);
-#define BESS_TOPK(WPR, VEC)                                                                                  \
-    k_topk_update<WPR, VEC><<<grid, 256, 0, st>>>(scores, n_row, n_col, ld, ids, ids_rows, id_base, mask,   \
-                                                  mask_rows, best_score, best_id, kk)
+#define BESS_TOPK(WPR, VEC)                                                                                       \
+    do {                                                                                                          \
+        if (kk > 64)                                                                                              \
+            k_topk_update<WPR, VEC, true><<<grid, 256, 0, st>>>(scores, n_row, n_col, ld, ids, ids_rows, id_base, \
+                                                                mask, mask_rows, best_score, best_id, kk);        \
+        else                                                                                                      \
+            k_topk_update<WPR, VEC, false><<<grid, 256, 0, st>>>(scores, n_row, n_col, ld, ids, ids_rows, id_base, \
+                                                                 mask, mask_rows, best_score, best_id, kk);       \
+    } while (0)
     if (wide) {
         if (vec) BESS_TOPK(4, true);
         else BESS_TOPK(4, false);

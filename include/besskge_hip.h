@@ -345,7 +345,7 @@ int bess_loss_fwd_bwd_norm(const bess_loss_desc* l, const float* pos, const floa
  * (best_score / best_id [n_row, kk], sorted by descending score, in place).
  * Candidate j of row r has score scores[r*ld + j] (+ BAD_NEGATIVE_SCORE where
  * mask says padding) and id ids[(ids_rows == 1 ? 0 : r)*n_col + j], or
- * id_base + j when ids == NULL.  kk <= 64.  Earlier entries win ties. */
+ * id_base + j when ids == NULL.  kk <= 128.  Earlier entries win ties. */
 int bess_topk_update(const float* scores, int64_t n_row, int64_t n_col, int64_t ld,
                      const int32_t* ids, int64_t ids_rows, int32_t id_base,
                      const uint8_t* mask, int64_t mask_rows, float* best_score,

@@ -13,7 +13,7 @@ n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 for it in range(n_iter):
     rows = int(torch.randint(1, 40, (1,), generator=gen)) if it % 3 else int(torch.randint(6000, 8000, (1,), generator=gen))
     L = int(torch.randint(1, 3000 if rows < 100 else 300, (1,), generator=gen))
-    kk = int(torch.randint(1, 65, (1,), generator=gen))
+    kk = int(torch.randint(1, 129, (1,), generator=gen))  # up to 64: one register per lane, beyond: two
     pad = bool(it % 2)
     bs = torch.full((rows, kk), -50000.0, device=dev)
     bi = torch.full((rows, kk), -1, dtype=torch.int32, device=dev)
