@@ -14,7 +14,7 @@ for d in ("a", "b"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "k_neg_shared_bwd" in k or "k_l1_fwd_pk" in k:
-            short = "fwd_pk" if "k_l1_fwd" in k else ("bwd_dQ" if "IfDF16_" in k or "<float, _Float16" in k else "bwd_dE")
+            short = "fwd_pk" if "k_l1_fwd" in k else "bwd"  # both backward products are one launch
             agg[(short, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in sorted(agg.items()):
         print(f"{k:8s} {c:24s} n={len(v):3d} mean={sum(v)/len(v):.4g}")
