@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, 
     }
     __syncthreads();
     const bool any_kill = kill.diag_step > 0 || kill.mask;  // wave-uniform
+    const bool row16 = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
     const int64_t mask_from = kill.n_neg - kill.mask_cols;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -161,19 +162,26 @@ __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, 
         int64_t kcol = -1;
         const uint8_t* mrow = nullptr;
         if (any_kill) kill_row(kill, q, &kcol, &mrow);
+        float v4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t jj = j0 + tx * 4 + j;
-            if (jj < ne) {
-                float v = -((2.f * acc[i][j] - rsq[ty * MI + i]) - rse[tx * 4 + j]);
-                if (any_kill) {
-                    bool kl = jj == kcol;
-                    // the mask overrides the diagonal on its columns (bess.py:227-228)
-                    if (mrow && jj >= mask_from) kl = mrow[jj - mask_from] == 0;
-                    if (kl) v += BESS_BAD_NEGATIVE_SCORE;
-                }
-                o[jj] = v;
+            float v = -((2.f * acc[i][j] - rsq[ty * MI + i]) - rse[tx * 4 + j]);
+            if (any_kill && jj < ne) {
+                bool kl = jj == kcol;
+                // the mask overrides the diagonal on its columns (bess.py:227-228)
+                if (mrow && jj >= mask_from) kl = mrow[jj - mask_from] == 0;
+                if (kl) v += BESS_BAD_NEGATIVE_SCORE;
             }
+            v4[j] = v;
+        }
+        const int64_t jj0 = j0 + tx * 4;
+        if (row16 && jj0 + 3 < ne) {  // 16-byte aligned rows: one store for the thread's four scores
+            *reinterpret_cast<float4*>(o + jj0) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (jj0 + j < ne) o[jj0 + j] = v4[j];
         }
     }
 }
