@@ -141,19 +141,26 @@ __global__ __launch_bounds__(256) void k_neg_shared_fwd(RowSrc<float> Q, RowSrc<
             __syncthreads();
         }
     }
+    const bool row16 = (ld_out & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t q = q0 + ty * 4 + i;
         if (q >= Q.n) continue;
         float* o = out + q * ld_out;
+        float v4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int64_t jj = j0 + tx * 4 + j;
-            if (jj < E.n) {
-                float v = acc[i][j];
-                if (RED == RED_L2) v = sqrtf(v);
-                o[jj] = sign * v;
-            }
+            float v = acc[i][j];
+            if (RED == RED_L2) v = sqrtf(v);
+            v4[j] = sign * v;
+        }
+        const int64_t jj0 = j0 + tx * 4;
+        if (row16 && jj0 + 3 < E.n) {  // 16-byte aligned rows: one store for the thread's four scores
+            *reinterpret_cast<float4*>(o + jj0) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (jj0 + j < E.n) o[jj0 + j] = v4[j];
         }
     }
 }
