@@ -76,30 +76,38 @@ __device__ __forceinline__ void stage_store(float (*tile)[LDP], int kc, int m, c
 // last valid row (their results are dropped at the store) so the loop has no
 // bounds branches; the next stage is fetched into registers before the current
 // one is computed.  (profiles/ubench/l1_tile.hip: 35 -> 48 T lane-ops/s.)
-template <typename T, int RED, bool ALIGNED>
+// MI: query rows per thread (4: 64 x 64 tile; 2: 32 x 64 tile for launches whose 64-row grid leaves CUs idle - the
+// stage still brings 64 query rows, the upper half unused).
+template <typename T, int RED, bool ALIGNED, int MI>
 __global__ __launch_bounds__(256) void k_neg_shared_fwd(RowSrc<float> Q, RowSrc<T> E, int W,
                                                         float sign, float* __restrict__ out,
                                                         int64_t ld_out) {
     __shared__ __attribute__((aligned(16))) float Qs[KT][LDP];
     __shared__ __attribute__((aligned(16))) float Es[KT][LDP];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int64_t q0 = static_cast<int64_t>(blockIdx.y) * TM;
+    const int64_t q0 = static_cast<int64_t>(blockIdx.y) * (16 * MI);
     const int64_t j0 = static_cast<int64_t>(blockIdx.x) * TN;
-    float acc[4][4];
+    float acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
     auto compute = [&]() {
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-            const float4 a4 = *reinterpret_cast<const float4*>(&Qs[k][ty * 4]);
+            float a[MI];
+            if constexpr (MI == 4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&Qs[k][ty * 4]);
+                a[0] = a4.x, a[1] = a4.y, a[2] = a4.z, a[3] = a4.w;
+            } else {
+                const float2 a2 = *reinterpret_cast<const float2*>(&Qs[k][ty * 2]);
+                a[0] = a2.x, a[1] = a2.y;
+            }
             const float4 b4 = *reinterpret_cast<const float4*>(&Es[k][tx * 4]);
-            const float a[4] = {a4.x, a4.y, a4.z, a4.w};
             const float b[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (RED == RED_DOT) {
@@ -143,8 +151,8 @@ __global__ __launch_bounds__(256) void k_neg_shared_fwd(RowSrc<float> Q, RowSrc<
     }
     const bool row16 = (ld_out & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t q = q0 + ty * 4 + i;
+    for (int i = 0; i < MI; ++i) {
+        const int64_t q = q0 + ty * MI + i;
         if (q >= Q.n) continue;
         float* o = out + q * ld_out;
         float v4[4];
@@ -349,18 +357,26 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(BwdSide<float, TE> A, Bw
 template <typename T>
 static int run_fwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<T> E, float* out, int64_t ld,
                    hipStream_t st) {
-    const dim3 grid(static_cast<unsigned>(ceil_div(E.n, TN)), static_cast<unsigned>(ceil_div(Q.n, TM)));
+    // 32-row tiles when the 64-row grid would leave most CUs without a workgroup
+    const bool small = ceil_div(E.n, TN) * ceil_div(Q.n, TM) < 192;
+    const dim3 grid(static_cast<unsigned>(ceil_div(E.n, TN)), static_cast<unsigned>(ceil_div(Q.n, small ? TM / 2 : TM)));
     const float sign = is_distance(d->scorer) ? -1.f : 1.f;
     const bool aligned = d->width % KT == 0;
-#define BESS_FWD(RED)                                                                              \
-    (aligned ? k_neg_shared_fwd<T, RED, true><<<grid, 256, 0, st>>>(Q, E, d->width, sign, out, ld) \
-             : k_neg_shared_fwd<T, RED, false><<<grid, 256, 0, st>>>(Q, E, d->width, sign, out, ld))
+#define BESS_FWD_ARGS <<<grid, 256, 0, st>>>(Q, E, d->width, sign, out, ld)
+#define BESS_FWD(RED)                                                         \
+    do {                                                                      \
+        if (aligned && small) k_neg_shared_fwd<T, RED, true, 2> BESS_FWD_ARGS;  \
+        else if (aligned) k_neg_shared_fwd<T, RED, true, 4> BESS_FWD_ARGS;      \
+        else if (small) k_neg_shared_fwd<T, RED, false, 2> BESS_FWD_ARGS;       \
+        else k_neg_shared_fwd<T, RED, false, 4> BESS_FWD_ARGS;                  \
+    } while (0)
     switch (reduce_of(d)) {
         case RED_DOT: BESS_FWD(RED_DOT); break;
         case RED_L1: BESS_FWD(RED_L1); break;
         default: BESS_FWD(RED_L2);
     }
 #undef BESS_FWD
+#undef BESS_FWD_ARGS
     return check_launch("neg_score_shared_fwd");
 }
 

@@ -1040,6 +1040,7 @@ def test_split_fp16_gemm_falls_back_to_fp32_outside_the_fp16_range(dev, where):
                                    (512, 544, 256),    # the notebook's micro-batch: 32-row tiles
                                    (70, 1300, 100),    # 32-row tiles, ragged rows and columns, scalar loads
                                    (1024, 70, 400),    # one slice only on the dE side
+                                   (1024, 1030, 64),   # 272 forward tiles: the 64-row forward tile (the others: 32-row)
                                    (33, 17, 64)])
 def test_shared_distance_backward_tile_variants(dev, p, dtype, S, N, W):
     """k_neg_shared_bwd (distance scorers, shared negatives): both tile heights and every split the launcher's
@@ -1061,17 +1062,21 @@ def test_shared_distance_backward_tile_variants(dev, p, dtype, S, N, W):
     qd = q.double()
     want_q = torch.zeros(S, W, dtype=torch.float64, device=dev)
     want_n = torch.zeros(N, W, dtype=torch.float64, device=dev)
+    want_out = torch.zeros(S, N, dtype=torch.float64, device=dev)
     for a0 in range(0, S, 64):  # [64, N, W] float64 at a time
         diff = qd[a0:a0 + 64, None, :] - rows[None, :, :]
         if p == 1:
             coef = torch.sign(diff)
+            want_out[a0:a0 + 64] = -diff.abs().sum(-1)
         else:
             nrm = diff.norm(dim=-1, keepdim=True)
             coef = torch.where(nrm > 0, diff / nrm.clamp(min=1e-300), torch.zeros_like(diff))
+            want_out[a0:a0 + 64] = -nrm[..., 0]
         t = go[a0:a0 + 64].double()[:, :, None] * coef
         want_q[a0:a0 + 64] = -t.sum(1)
         want_n += t.sum(0)
     tol = 2e-5 if p == 2 else 1e-5  # p = 2 divides by the fp32 forward score
+    assert float((out.double() - want_out).abs().max()) <= 2e-6 * float(want_out.abs().max())
     assert float((dq.double() - want_q).abs().max()) <= tol * float(want_q.abs().max())
     assert float((dn.double() - want_n).abs().max()) <= tol * float(want_n.abs().max())
 
