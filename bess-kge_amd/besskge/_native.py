@@ -609,6 +609,16 @@ def neg_score_pertriple_fwd_dq(d: ModelDesc, l: LossDesc, query: torch.Tensor, n
     return out, dq
 
 
+def row_fits_registers(d: ModelDesc) -> bool:
+    """Do the per-triple kernels keep a whole row in a 16-lane group's registers (1024 f32 / 2048 f16 scalars at full
+    vector width)?  Wider rows are scored in column windows, which the fused training forward cannot use."""
+    W = int(d.width)
+    vec = 4 if d.dtype == F32 else 8
+    if W % vec:
+        vec = 2 if (d.dtype == F16 and W % 2 == 0) else 1
+    return W <= 256 * vec
+
+
 def neg_score_pertriple_fwd_partials(d: ModelDesc, l: LossDesc, query: torch.Tensor, neg: RowSource, n_neg: int
                                      ) -> Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
     """Training forward on a shard that holds only a part of each query's negatives (ScoreMoving): scores

@@ -710,8 +710,8 @@ class BessKGE(torch.nn.Module, ABC):
         loss taken over exactly the scores of one per-triple group, with nothing masked."""
         if self.loss_fn is None or not self.score_fn.supports_fused_forward or self.augment_negative:
             return None
-        if not hasattr(self.loss_fn, "kernel_desc"):
-            return None
+        if not hasattr(self.loss_fn, "kernel_desc") or not nat.row_fits_registers(self.score_fn.kernel_desc()):
+            return None  # (rows wider than a group's registers are scored in column windows: two-pass path)
         dev = self.score_fn.relation_embedding.device
         w = batch.get("triple_weight")
         w = self._unit_weight(dev) if w is None else w.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()

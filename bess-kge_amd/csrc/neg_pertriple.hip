@@ -35,6 +35,7 @@ struct NegPtArgs {
     int nb;   // negatives per work item
     int items_per_query;
     float sign;
+    int accum = 0;  // forward: add to the scores already there (a later column window of a wide row)
 };
 
 // Fused training forward (FUSE): besides the scores, accumulate the loss gradient wrt the query,
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_fwd(NegPtArgs a, float* _
                 const int64_t mrow = f.mask_rows == 1 ? 0 : q;
                 if (kcol >= 0 && f.mask[mrow * f.mask_cols + kcol] == 0) sc += BESS_BAD_NEGATIVE_SCORE;
             }
-            if (g == 0 && valid[u]) orow[kb + sub + 4 * u] = sc;
+            if (g == 0 && valid[u]) orow[kb + sub + 4 * u] = a.accum ? orow[kb + sub + 4 * u] + sc : sc;
             if (FUSE && valid[u]) {  // uniform within the 16-lane group
                 const float z = f.beta * (sc + f.shift);
                 const float m_new = fmaxf(fm, z);
@@ -470,23 +471,47 @@ static int run(const bess_model_desc* d, bool fwd, const float* query, int64_t n
     a.nb = negatives_per_item(n_query, n_neg, static_cast<int64_t>(W) * (d->dtype == BESS_F32 ? 4 : 2));  // == row_bytes_of(d)
     a.items_per_query = static_cast<int>(ceil_div(n_neg, a.nb));
     a.sign = is_distance(d->scorer) ? -1.f : 1.f;
-    const int it = static_cast<int>(ceil_div(a.nch, 16));
     const int red = reduce_of(d);
     hipStream_t st = as_stream(stream);
     if (!fwd && a.items_per_query > 1) {
         hipError_t e = hipMemsetAsync(dq, 0, sizeof(float) * n_query * W, st);
         if (e != hipSuccess) return fail(static_cast<int>(e), "memset d_query: %s", hipGetErrorString(e));
     }
-    int rc = BESS_OK;
-    if (d->dtype == BESS_F32) {
-        if (vec == 4) rc = by_it<float, 4>(it, red, fwd, a, out, d_out, ld, dq, dn, fuse, st);
-        else rc = by_it<float, 1>(it, red, fwd, a, out, d_out, ld, dq, dn, fuse, st);
-    } else {
-        if (vec == 8) rc = by_it<half_t, 8>(it, red, fwd, a, out, d_out, ld, dq, dn, fuse, st);
-        else if (vec == 2) rc = by_it<half_t, 2>(it, red, fwd, a, out, d_out, ld, dq, dn, fuse, st);
-        else rc = by_it<half_t, 1>(it, red, fwd, a, out, d_out, ld, dq, dn, fuse, st);
+    // A 16-lane group keeps 16 x 16 chunks of a row in registers (1024 f32 / 2048 f16 scalars at full vector
+    // width).  Wider rows are processed in column windows of that size: the dot product and the p = 1 distance are
+    // sums over columns (forward: later windows add to the scores; backward: every window writes its own columns).
+    // Not for the p = 2 distance (its square root and its gradient need the whole row) nor for the fused training
+    // forward (the softmax needs the finished score): BESS_EUNSUPPORTED, the callers use the shared / two-pass forms.
+    const int max_cols = 16 * 16 * vec;
+    if (W > max_cols) {
+        if (red == RED_L2)
+            return fail(BESS_EUNSUPPORTED, "neg_score_pertriple: p = 2 on rows of %d scalars (more than %d)", W, max_cols);
+        if (fuse)
+            return fail(BESS_EUNSUPPORTED, "neg_score_pertriple: fused training forward on rows of %d scalars (more than %d)",
+                        W, max_cols);
     }
-    if (rc) return rc;
+    const int64_t sz = d->dtype == BESS_F32 ? 4 : 2;
+    for (int col0 = 0; col0 < W; col0 += max_cols) {
+        const int cols = W - col0 < max_cols ? W - col0 : max_cols;
+        NegPtArgs w = a;
+        w.query = query + col0;
+        w.base = static_cast<const char*>(neg_base) + col0 * sz;
+        w.nch = cols / vec;
+        w.accum = col0 > 0;
+        const int it = static_cast<int>(ceil_div(w.nch, 16));
+        float* dqw = dq ? dq + col0 : nullptr;
+        float* dnw = dn ? dn + col0 : nullptr;
+        int rc = BESS_OK;
+        if (d->dtype == BESS_F32) {
+            if (vec == 4) rc = by_it<float, 4>(it, red, fwd, w, out, d_out, ld, dqw, dnw, fuse, st);
+            else rc = by_it<float, 1>(it, red, fwd, w, out, d_out, ld, dqw, dnw, fuse, st);
+        } else {
+            if (vec == 8) rc = by_it<half_t, 8>(it, red, fwd, w, out, d_out, ld, dqw, dnw, fuse, st);
+            else if (vec == 2) rc = by_it<half_t, 2>(it, red, fwd, w, out, d_out, ld, dqw, dnw, fuse, st);
+            else rc = by_it<half_t, 1>(it, red, fwd, w, out, d_out, ld, dqw, dnw, fuse, st);
+        }
+        if (rc) return rc;
+    }
     return check_launch(fwd ? "neg_score_pertriple_fwd" : "neg_score_pertriple_bwd");
 }
 

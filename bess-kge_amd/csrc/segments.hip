@@ -778,6 +778,9 @@ static int grad_segments_impl(const bess_model_desc* d, const float* query, int6
         const int64_t fit = (4ll << 20) / (n_query * 4);
         if (fit >= unit) win = static_cast<int>(fit / unit) * unit;
     }
+    // ... and a window is at most what a 16-lane group keeps in registers (16 iterations): rows wider than that
+    // (1024 f32 / 2048 f16 scalars) are windowed for this reason alone; the p = 2 norm needs the whole row
+    if (red != RED_L2 && win > 16 * unit) win = 16 * unit;
     const int64_t sz = d->dtype == BESS_F32 ? 4 : 2;
     for (int col0 = 0; col0 < W; col0 += win) {
         const int cols = W - col0 < win ? W - col0 : win;
@@ -803,20 +806,33 @@ static int grad_segments_impl(const bess_model_desc* d, const float* query, int6
     }
     if (long_segs) {  // the rows left out above (usually none: one launch that finds nothing to do)
         const int32_t cap = static_cast<int32_t>(long_cap);
-        SegArgs a{query, table, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg,
-                  static_cast<int>(n_neg), W, W / vec, is_distance(d->scorer) ? -1.f : 1.f, long_segs, opt};
-        const int it = static_cast<int>(ceil_div(a.nch, 16));
-        const unsigned lgrid = 1024;  // 16 K groups share the slices
-        int rc;
-        if (d->dtype == BESS_F32) {
-            rc = (vec == 4) ? seg_by_it<float, 4>(it, red, a, grad_seg, table, fused_sgd_lr, lgrid, st, long_grad, long_count, cap)
-                            : seg_by_it<float, 1>(it, red, a, grad_seg, table, fused_sgd_lr, lgrid, st, long_grad, long_count, cap);
-        } else {
-            rc = (vec == 8) ? seg_by_it<half_t, 8>(it, red, a, grad_seg, table, fused_sgd_lr, lgrid, st, long_grad, long_count, cap)
-                 : (vec == 2) ? seg_by_it<half_t, 2>(it, red, a, grad_seg, table, fused_sgd_lr, lgrid, st, long_grad, long_count, cap)
-                              : seg_by_it<half_t, 1>(it, red, a, grad_seg, table, fused_sgd_lr, lgrid, st, long_grad, long_count, cap);
+        // whole rows, unless they are wider than a group's registers (windows as above; the scratch rows and the
+        // counters are left zero by every launch, so the windows can share them)
+        const int lwin = (red != RED_L2 && W > 16 * unit) ? 16 * unit : W;
+        for (int col0 = 0; col0 < W; col0 += lwin) {
+            const int cols = W - col0 < lwin ? W - col0 : lwin;
+            SegOpt wopt = opt;
+            if (wopt.state1) wopt.state1 += col0;
+            if (wopt.state2) wopt.state2 += col0;
+            if (wopt.xsum) wopt.xsum += col0;
+            char* tab = static_cast<char*>(table) + col0 * sz;
+            SegArgs a{query + col0, tab, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg,
+                      static_cast<int>(n_neg), W, cols / vec, is_distance(d->scorer) ? -1.f : 1.f, long_segs, wopt};
+            const int it = static_cast<int>(ceil_div(a.nch, 16));
+            const unsigned lgrid = 1024;  // 16 K groups share the slices
+            float* gs = grad_seg ? grad_seg + col0 : nullptr;
+            float* lg = long_grad + col0;
+            int rc;
+            if (d->dtype == BESS_F32) {
+                rc = (vec == 4) ? seg_by_it<float, 4>(it, red, a, gs, tab, fused_sgd_lr, lgrid, st, lg, long_count, cap)
+                                : seg_by_it<float, 1>(it, red, a, gs, tab, fused_sgd_lr, lgrid, st, lg, long_count, cap);
+            } else {
+                rc = (vec == 8) ? seg_by_it<half_t, 8>(it, red, a, gs, tab, fused_sgd_lr, lgrid, st, lg, long_count, cap)
+                     : (vec == 2) ? seg_by_it<half_t, 2>(it, red, a, gs, tab, fused_sgd_lr, lgrid, st, lg, long_count, cap)
+                                  : seg_by_it<half_t, 1>(it, red, a, gs, tab, fused_sgd_lr, lgrid, st, lg, long_count, cap);
+            }
+            if (rc) return rc;
         }
-        if (rc) return rc;
     }
     return check_launch("neg_pertriple_grad_segments");
 }

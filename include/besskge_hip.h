@@ -207,9 +207,12 @@ int bess_query_triple_bwd(const bess_model_desc* d, int32_t side, const void* he
 /* K5 - per-triple negatives, `reduce_embedding(q[:,None] o N)` (scoring.py:199,254):
  *   out[q*ld_out + k] = score(query[q], neg_base[neg_idx[q*n_neg + k]]),  k < n_neg
  * HBM-bound: one gathered row per scored triple, read straight from the shard.
- * Row width W (the row lives in registers, 16 lanes x 16 chunks): f32 rows up to 1024
- * scalars when W % 4 == 0, else 256; f16 rows up to 2048 when W % 8 == 0, 512 when
- * W % 2 == 0, else 256; wider rows are refused (BESS_EUNSUPPORTED). */
+ * Row width W: a row lives in registers, 16 lanes x 16 chunks - f32 up to 1024 scalars when
+ * W % 4 == 0, else 256; f16 up to 2048 when W % 8 == 0, 512 when W % 2 == 0, else 256.  Wider rows
+ * (embedding_size 1000 of RotatE / ComplEx ...) are scored, back-propagated and reduced (K9) in column
+ * windows of that size - the dot product and the p = 1 distance are sums over columns.  Refused on such
+ * rows (BESS_EUNSUPPORTED): the p = 2 distance (its root and gradient need the whole row) and the fused
+ * training forward (the softmax needs the finished score; callers take the two-pass path). */
 int bess_neg_score_pertriple_fwd(const bess_model_desc* d, const float* query,
                                  int64_t n_query, const void* neg_base,
                                  const int32_t* neg_idx, int64_t n_neg, float* out,

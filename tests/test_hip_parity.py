@@ -1230,3 +1230,86 @@ def test_training_step_with_a_negative_mask_takes_the_fused_forward(dev, rows):
     torch.testing.assert_close(ent_f, ent_t, rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(rel_f, rel_t, rtol=1e-5, atol=1e-7)
     assert float((ent_f - ent_t).abs().max()) < 1e-5 and float(ent_f.abs().max()) > 0
+
+
+@pytest.mark.parametrize("name,p,dtype,d_emb", [("ComplEx", 0, torch.float32, 1000),   # W = 2000: two windows
+                                                ("RotatE", 1, torch.float32, 1000),    # W = 2000, relation 1000
+                                                ("DistMult", 0, torch.float32, 1027),  # odd width: 256-scalar windows
+                                                ("TransE", 1, torch.float16, 2560)])   # f16: windows of 2048
+def test_rows_wider_than_a_groups_registers_are_scored_in_column_windows(dev, name, p, dtype, d_emb):
+    """Per-triple kernels on rows of more than 1024 f32 / 2048 f16 scalars (RotatE / ComplEx with embedding_size
+    1000, the literature's setting): forward, backward and the segmented K9 against float64 torch; the fused
+    training forward and the p = 2 distance say so loudly instead (BESS_EUNSUPPORTED)."""
+    from besskge import _native as nat
+    from besskge._native import RowSource
+    from besskge.loss import LogSigmoidLoss
+
+    gen = torch.Generator().manual_seed(d_emb)
+    M, S, N = 200, 40, 24
+    W, Wr = widths(name, d_emb)
+    table = (0.2 * torch.randn(M, W, generator=gen)).to(dtype).to(dev)
+    q = (0.2 * torch.randn(S, W, generator=gen)).to(dev)
+    idx = torch.randint(M, (S * N,), generator=gen, dtype=torch.int32).to(dev)
+    go = torch.randn(S, N, generator=gen).to(dev)
+    desc = nat.make_desc(dict(TransE=0, RotatE=1, DistMult=2, ComplEx=3)[name], max(p, 1), table, Wr)
+    assert not nat.row_fits_registers(desc)
+    src = RowSource(table, idx)
+    out = nat.neg_score_pertriple_fwd(desc, q, src, N)
+    rows = table[idx.long()].double().view(S, N, W).requires_grad_(True)
+    qq = q.double()[:, None, :].requires_grad_(True)
+    ref = (qq * rows).sum(-1) if p == 0 else -(qq - rows).abs().sum(-1)
+    ref.backward(go.double())
+    close(out, ref.detach().float(), rtol=1e-5, atol=1e-5, scale=2e-6)
+    dq, dn = nat.neg_score_pertriple_bwd(desc, q, src, N, go)
+    close(dq, qq.grad[:, 0].float(), rtol=1e-5, atol=1e-5, scale=2e-6)
+    close(dn, rows.grad.reshape(S * N, W).float(), rtol=1e-5, atol=1e-5, scale=2e-6)
+    seg = nat.SegmentIndex(idx, M)
+    n_seg = int(seg.n_seg.item())
+    g1 = nat.neg_pertriple_grad_segments(desc, q, table, N, go, seg)
+    want = torch.zeros(M, W, dtype=torch.float64, device=dev).index_add_(0, idx.long(), rows.grad.reshape(S * N, W))
+    close(g1[:n_seg], want[seg.seg_rows[:n_seg].long()].float(), rtol=1e-4, atol=1e-5, scale=2e-6)
+    # loud refusals
+    ld = LogSigmoidLoss(1.0, True).kernel_desc(N)
+    with pytest.raises(RuntimeError, match="fused training forward"):
+        nat.neg_score_pertriple_fwd_dq(desc, ld, q, src, N, torch.zeros(S, device=dev), torch.ones(1, device=dev))
+    if name in ("TransE", "RotatE"):
+        d2 = nat.make_desc(dict(TransE=0, RotatE=1)[name], 2, table, Wr)
+        with pytest.raises(RuntimeError, match="p = 2"):
+            nat.neg_score_pertriple_fwd(d2, q, src, N)
+
+
+def test_training_step_on_embedding_size_1000_matches_the_oracle(dev):
+    """ComplEx with embedding_size 1000 (rows of 2000 scalars: column windows in the per-triple kernels, two-pass
+    training forward), per-triple negatives, log-sigmoid loss, one SGD step against the CPU restatement."""
+    from besskge import runtime
+    from besskge.bess import EmbeddingMovingBessKGE
+    from besskge.loss import LogSigmoidLoss
+    from besskge.negative_sampler import RandomShardedNegativeSampler
+    from besskge.scoring import ComplEx
+    from besskge.sharding import Sharding
+    from oracle import kge
+
+    torch.manual_seed(0)
+    n_entity, n_rel, d_emb, S, K = 500, 9, 1000, 32, 12
+    sharding = Sharding.create(n_entity, 1, seed=3)
+    ent = torch.randn(1, sharding.max_entity_per_shard, 2 * d_emb) * 0.05
+    rel = torch.randn(n_rel, 2 * d_emb) * 0.05
+    fn = ComplEx(False, sharding, n_rel, d_emb, ent, rel)
+    ns = RandomShardedNegativeSampler(K, sharding, 5, "h", local_sampling=False, flat_negative_format=False)
+    model = EmbeddingMovingBessKGE(ns, fn, LogSigmoidLoss(margin=1.0, negative_adversarial_sampling=True))
+    rng = np.random.default_rng(2)
+    batch = dict(head=rng.integers(n_entity, size=(1, 1, S)), relation=rng.integers(n_rel, size=(1, 1, S)),
+                 tail=rng.integers(n_entity, size=(1, 1, S)), negative=rng.integers(n_entity, size=(1, 1, S, K)))
+    batch = {k: torch.from_numpy(v.astype(np.int32)) for k, v in batch.items()}
+    spec = kge.StepSpec("ComplEx", 0, False, "h", False)
+    t0, r0 = ent.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+    want = kge.bess_step(spec, "EmbeddingMoving", t0, r0, batch,
+                         dict(kind="logsigmoid", margin=1.0, adversarial=True, adversarial_scale=1.0))
+    want["loss"][0].backward()
+    lr = 0.5
+    runner = runtime.training_model(model, optimizer=runtime.SGD(lr=lr), device=dev)
+    res = runner(**batch)
+    torch.testing.assert_close(res["loss"].float().cpu().reshape(()), want["loss"][0].detach(), rtol=2e-5, atol=1e-5)
+    close(model.score_fn.entity_embedding, ent - lr * t0.grad, rtol=1e-4, atol=2e-6)
+    close(model.score_fn.relation_embedding, rel - lr * r0.grad, rtol=1e-4, atol=2e-6)
+    assert float(t0.grad.abs().max()) > 0
