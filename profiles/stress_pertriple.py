@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Stress of the dominant kernel (per-triple negatives, csrc/neg_pertriple.hip) and its backward:
-random widths (incl. odd), table dtypes, query / negative counts against torch on the same device."""
+random widths (incl. odd, and rows wider than the 1024 / 2048 scalars a lane group holds), table dtypes, query /
+negative counts against torch on the same device."""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(REPO, "bess-kge_amd"), REPO]
@@ -19,8 +20,11 @@ for it in range(n_iter):
         W = (W + 3) // 4 * 4
     else:
         W = W % 256 + 1  # rows that are not a multiple of 4 scalars are read scalar-wise: up to 256 scalars
+    if it % 7 == 3 and red != 2:
+        # rows wider than a lane group's registers: scored and back-propagated in column windows
+        W = 1024 + 4 * int(torch.randint(1, 500, (1,), generator=gen))
     S = int(torch.randint(1, 300, (1,), generator=gen))
-    N = int(torch.randint(1, 500, (1,), generator=gen))
+    N = int(torch.randint(1, 500 if W <= 1024 else 60, (1,), generator=gen))
     M = int(torch.randint(10, 3000, (1,), generator=gen))
     dtype = torch.float16 if it % 5 == 0 else torch.float32
     if dtype == torch.float16 and W % 8 and W > 256:
