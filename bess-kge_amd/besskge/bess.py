@@ -115,6 +115,29 @@ class _ReplicaStep:
         self.fused_qt = False  # query + positive score came out of one launch (so will their backwards)
 
 
+class _PendingUpdate:
+    """Gradients of one micro-batch that have not been applied yet (gradient accumulation)."""
+
+    __slots__ = ("steps", "local_updates", "deferred", "d_rel")
+
+    def __init__(self, steps: List[_ReplicaStep], local_updates: List[List[Tuple[torch.Tensor, torch.Tensor]]],
+                 deferred: List[Tuple[torch.Tensor, _NegGroup, torch.Tensor]], d_rel: torch.Tensor) -> None:
+        self.steps = steps                  # one per hosted replica
+        self.local_updates = local_updates  # per replica: (rows of the shard, gradient rows) lists
+        self.deferred = deferred            # (shard, per-triple group, d loss / d scores): reduced by the segmented K9
+        self.d_rel = d_rel                  # relation-table gradient (shared by the micro-batches of one update)
+
+
+class _MergedGroup:
+    """The per-triple groups of several micro-batches seen as one scoring problem: queries, score
+    gradients and row references stacked along the query axis (what the segmented K9 needs of a group)."""
+
+    __slots__ = ("query", "n_per_query")
+
+    def __init__(self, query: torch.Tensor, n_per_query: int) -> None:
+        self.query, self.n_per_query = query, n_per_query
+
+
 class BessKGE(torch.nn.Module, ABC):
     """Base class of the distributed KGE step (see module docstring)."""
 
@@ -224,6 +247,22 @@ class BessKGE(torch.nn.Module, ABC):
             cache[device] = torch.ones(1, dtype=torch.float32, device=device)
             torch.cuda.current_stream(device).synchronize()
         return cache[device]
+
+    def _triple_weight(self, batch: _Batch, device: torch.device) -> torch.Tensor:
+        """Weights of the micro-batch's triples in the loss ([1] or [S], fp32), times the step's
+        gradient scale (1 unless gradients are averaged over accumulated micro-batches / replicas)."""
+        scale = self.__dict__.get("_grad_scale", 1.0)
+        w = batch.get("triple_weight")
+        if w is None:
+            if scale == 1.0:
+                return self._unit_weight(device)
+            cache = self.__dict__.setdefault("_unit_weights", {})
+            if (device, scale) not in cache:
+                cache[(device, scale)] = torch.full((1,), scale, dtype=torch.float32, device=device)
+                torch.cuda.current_stream(device).synchronize()
+            return cache[(device, scale)]
+        w = w.reshape(-1).to(device=device, dtype=torch.float32).contiguous()
+        return w if scale == 1.0 else w * scale
 
     def _static_map(self, key: Any, build: Any, device: torch.device) -> torch.Tensor:
         k = (key, device)
@@ -338,17 +377,16 @@ class BessKGE(torch.nn.Module, ABC):
         ret_neg = neg
         d_pos = d_neg = None
         if self.loss_fn:
-            w = batch.get("triple_weight")
-            if w is None:
-                w = self._unit_weight(dev)
-            else:
-                w = w.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+            w = self._triple_weight(batch, dev)
             ld = self.loss_fn.kernel_desc(int(neg.shape[1]))
             if want_norm:  # ScoreMoving's fused training forward: the softmax normalisation goes back to the shards
                 loss, d_pos, d_neg, st.loss_norm = nat.loss_fwd_bwd(ld, pos, neg, w, want_grad, want_norm=True)
             else:
                 loss, d_pos, d_neg = nat.loss_fwd_bwd(ld, pos, neg, w, want_grad)
-            out["loss"] = loss
+            scale = self.__dict__.get("_grad_scale", 1.0)
+            # (gradients averaged over accumulated micro-batches / replicas travel as a scaled triple weight;
+            # the value handed back stays the micro-batch's own loss)
+            out["loss"] = loss if scale == 1.0 else loss / scale
             if isinstance(self.loss_fn, SampledSoftmaxCrossEntropyLoss) and self.return_scores \
                     and self.score_fn.relation_embedding.dtype == torch.float32:
                 # the reference shifts fp32 negative scores in place before the
@@ -587,6 +625,50 @@ class BessKGE(torch.nn.Module, ABC):
                     seg_index[id(g)] = self._segment_index_on_side(g, st)
         return seg_index
 
+    def apply_accumulated(self, pending: List[_PendingUpdate], optimizer: Any) -> None:
+        """ONE optimiser step with the summed gradients of the micro-batches in `pending`
+        (`train_step_replicas(..., pending=...)`; PopTorch's `Training.gradientAccumulation`, reference
+        `notebooks/1_biokg_training_inference.ipynb:408-417,470-477`).  All of them were computed from the
+        tables as they are now.  Row lists are concatenated per shard; the per-triple groups of the
+        micro-batches become one group (queries, score gradients and references stacked), so the
+        segmented reduction still sums every row's references on chip and every touched row gets one
+        update - the same kernels as a single micro-batch, one index over all references."""
+        if not pending:
+            return
+        first = pending[0]
+        steps = first.steps
+        local_updates: List[List[Tuple[torch.Tensor, torch.Tensor]]] = [[] for _ in steps]
+        deferred: List[Tuple[torch.Tensor, Any, torch.Tensor]] = []
+        seg_index: Dict[int, Any] = {}
+        for p in pending:
+            for mine, upd in zip(local_updates, p.local_updates):
+                mine.extend(upd)
+        # per-triple groups: merge the k-th group of every micro-batch (same shard, side and list length)
+        by_slot: Dict[Tuple[int, int, int], List[Tuple[torch.Tensor, _NegGroup, torch.Tensor]]] = {}
+        for p in pending:
+            seen: Dict[Tuple[int, int], int] = {}
+            for table, g, go in p.deferred:
+                k = seen.get((table.data_ptr(), g.side), 0)
+                seen[(table.data_ptr(), g.side)] = k + 1
+                by_slot.setdefault((table.data_ptr(), g.side, k), []).append((table, g, go))
+        scratch = self.__dict__.setdefault("_seg_scratch", {})
+        for items in by_slot.values():
+            table, g0, go0 = items[0]
+            if len(items) == 1:
+                merged, go, idx = g0, go0, g0.neg.idx
+            else:
+                if any(g.n_per_query != g0.n_per_query for _, g, _ in items):
+                    raise RuntimeError("accumulated micro-batches differ in negatives per triple")
+                merged = _MergedGroup(torch.cat([g.query for _, g, _ in items], dim=0), g0.n_per_query)
+                go = torch.cat([x for _, _, x in items], dim=0)
+                idx = torch.cat([g.neg.idx.reshape(-1) for _, g, _ in items])
+            seg_index[id(merged)] = nat.SegmentIndex(idx, table.shape[0], width=table.shape[1], scratch=scratch)
+            deferred.append((table, merged, go))
+        self.__dict__["_small_ahead"] = None
+        self._apply_updates(steps, local_updates, deferred, seg_index, optimizer, self.score_fn.kernel_desc(),
+                            first.d_rel)
+        pending.clear()
+
     def _apply_updates(self, steps: List[_ReplicaStep], local_updates: List[List[Tuple[torch.Tensor, torch.Tensor]]],
                        deferred: List[Tuple[torch.Tensor, _NegGroup, torch.Tensor]], seg_index: Dict[int, Any],
                        optimizer: Any, desc: nat.ModelDesc, d_rel: torch.Tensor) -> None:
@@ -653,6 +735,9 @@ class BessKGE(torch.nn.Module, ABC):
         # C9: replicated relation table
         # (single process: d_rel already holds the sum over the local replicas)
         (d_rel,) = group.all_reduce_sum([d_rel]) if len(group.local_shards) == 1 else (d_rel,)
+        mean_over_replicas = getattr(optimizer, "replica_reduction", "sum") == "mean" and group.n_shard > 1
+        if mean_over_replicas:
+            d_rel = d_rel / group.n_shard
         if plain:
             nat.dense_sgd(rel_table, d_rel, lr)
         else:
@@ -666,6 +751,8 @@ class BessKGE(torch.nn.Module, ABC):
             (g,) = group.all_reduce_sum([g.contiguous()]) if len(group.local_shards) == 1 else (g,)
             as_table = p.data.view(p.shape[0], -1) if p.dim() > 1 else p.data.view(1, -1)
             g = g.reshape(as_table.shape).contiguous()
+            if mean_over_replicas:
+                g = g / group.n_shard
             if plain:
                 nat.dense_sgd(as_table, g, lr)
             else:
@@ -713,8 +800,7 @@ class BessKGE(torch.nn.Module, ABC):
         if not hasattr(self.loss_fn, "kernel_desc") or not nat.row_fits_registers(self.score_fn.kernel_desc()):
             return None  # (rows wider than a group's registers are scored in column windows: two-pass path)
         dev = self.score_fn.relation_embedding.device
-        w = batch.get("triple_weight")
-        w = self._unit_weight(dev) if w is None else w.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+        w = self._triple_weight(batch, dev)
         # a negative_mask (the padding of triple-specific negatives) is applied inside the fused pass when it
         # has one row or one per triple (`_run_groups_one`); other layouts take the two-pass path
         return dict(weight=w, loss=self.loss_fn.kernel_desc, masked=batch.get("negative_mask") is not None)
@@ -934,11 +1020,14 @@ class EmbeddingMovingBessKGE(BessKGE):
             raise ValueError(f"corruption scheme {scheme!r} not supported")
 
     # ---------------------------------------------------------------- training
-    def train_step_replicas(self, batches: List[_Batch], optimizer: Any) -> List[Dict[str, Any]]:
+    def train_step_replicas(self, batches: List[_Batch], optimizer: Any,
+                            pending: Optional[List[_PendingUpdate]] = None) -> List[Dict[str, Any]]:
         """Forward + backward + sparse optimiser update of every local replica.
 
         `optimizer`: a learning rate (plain SGD) or one of
-        `besskge.runtime.{SGD, Adagrad, Adam}`.
+        `besskge.runtime.{SGD, Adagrad, Adam}`.  `pending` (gradient accumulation): a list the
+        micro-batch's gradients are appended to instead of being applied; `apply_accumulated`
+        applies the sum of what it holds in one optimiser step.
 
         Backward of the reference's autograd graph (`bess.py:322-468`) written
         out: K8' -> K4'/K5' -> K6' -> K3' give the gradient of every gathered
@@ -954,25 +1043,30 @@ class EmbeddingMovingBessKGE(BessKGE):
         n = group.n_shard
         W = self.entity_embedding_size
         # (per-step scratch goes straight into the instance dict: nn.Module.__setattr__ costs ~2.5 us a piece)
+        accumulating = pending is not None
         self.__dict__["_train_fuse"] = [self._fusable(b) for b in batches]
-        self.__dict__["_seg_ahead"] = {}
-        self.__dict__["_small_early"] = {}
+        # (accumulating: the references of all micro-batches are indexed together when they are applied)
+        self.__dict__["_seg_ahead"] = None if accumulating else {}
+        self.__dict__["_small_early"] = None if accumulating else {}
         self.__dict__["_ahead_optimizer"] = optimizer
         try:
             steps = self._score_replicas(batches)
-            seg_index = self._prefetch_segment_indices(steps)
-            self.__dict__["_small_ahead"] = dict(self._small_early)
+            seg_index = {} if accumulating else self._prefetch_segment_indices(steps)
+            self.__dict__["_small_ahead"] = dict(self._small_early or {})
         finally:
             self.__dict__["_train_fuse"] = None
             self.__dict__["_seg_ahead"] = None
             self.__dict__["_small_early"] = None
             self.__dict__["_ahead_optimizer"] = None
-        self._small_ahead.update(self._small_index_ahead([st for st in steps if id(st) not in self._small_ahead],
-                                                         optimizer))
+        if not accumulating:
+            self._small_ahead.update(self._small_index_ahead([st for st in steps if id(st) not in self._small_ahead],
+                                                             optimizer))
         desc = fn.kernel_desc()
         rel_table = fn.relation_embedding.data
         results = []
-        d_rel = torch.zeros(rel_table.shape, dtype=torch.float32, device=rel_table.device)
+        # (the relation gradient of accumulated micro-batches is summed in the first one's buffer)
+        d_rel = pending[0].d_rel if pending else torch.zeros(rel_table.shape, dtype=torch.float32,
+                                                             device=rel_table.device)
         back: List[torch.Tensor] = []
         deferred: List[Tuple[torch.Tensor, _NegGroup, torch.Tensor]] = []
         local_updates: List[List[Tuple[torch.Tensor, torch.Tensor]]] = []
@@ -1051,6 +1145,10 @@ class EmbeddingMovingBessKGE(BessKGE):
             returned = group.all_to_all(back)  # C8
             for st, upd, g in zip(steps, local_updates, returned):
                 upd.append((st.send_idx.reshape(-1), g.reshape(-1, W)))
+        if accumulating:
+            self.__dict__["_small_ahead"] = None
+            pending.append(_PendingUpdate(steps, local_updates, deferred, d_rel))
+            return results
         try:
             self._apply_updates(steps, local_updates, deferred, seg_index, optimizer, desc, d_rel)
         finally:
@@ -1233,8 +1331,9 @@ class ScoreMovingBessKGE(BessKGE):
         return xo, yo
 
     # ---------------------------------------------------------------- training
-    def train_step_replicas(self, batches: List[_Batch], optimizer: Any) -> List[Dict[str, Any]]:
-        """Forward + backward + sparse optimiser update (ScoreMoving).
+    def train_step_replicas(self, batches: List[_Batch], optimizer: Any,
+                            pending: Optional[List[_PendingUpdate]] = None) -> List[Dict[str, Any]]:
+        """Forward + backward + sparse optimiser update (ScoreMoving; `pending`: see EmbeddingMoving).
 
         Backward of the reference graph `bess.py:490-603`: score gradients travel
         back to the shards that produced them (all-to-all, transpose of C4); each
@@ -1250,8 +1349,9 @@ class ScoreMovingBessKGE(BessKGE):
         fn = self.score_fn
         W = self.entity_embedding_size
         scheme = self.negative_sampler.corruption_scheme
+        accumulating = pending is not None
         self.__dict__["_training_pass"] = True  # the backward needs the gathered embeddings, not finished queries
-        self.__dict__["_seg_ahead"] = {}
+        self.__dict__["_seg_ahead"] = None if accumulating else {}
         # Fused training forward (per-triple negatives, nothing masked, a loss whose negative weights do not need
         # the positive score): every shard keeps the online-softmax partials of the queries it scored; the second
         # pass over the negative rows (`neg_score_pertriple_bwd`) is replaced by a rescaling of those partials
@@ -1262,14 +1362,15 @@ class ScoreMovingBessKGE(BessKGE):
         self.__dict__["_sm_fuse"] = self.loss_fn.kernel_desc if fused else None
         try:
             steps = self._score_replicas(batches)
-            seg_index = self._prefetch_segment_indices(steps)
+            seg_index = {} if accumulating else self._prefetch_segment_indices(steps)
         finally:
             self.__dict__["_training_pass"] = False
             self.__dict__["_seg_ahead"] = None
             self.__dict__["_sm_fuse"] = None
         desc = fn.kernel_desc()
         rel_table = fn.relation_embedding.data
-        d_rel = torch.zeros(rel_table.shape, dtype=torch.float32, device=rel_table.device)
+        d_rel = pending[0].d_rel if pending else torch.zeros(rel_table.shape, dtype=torch.float32,
+                                                             device=rel_table.device)
         results, d_scores, d_tails = [], [], []
         local_updates: List[List[Tuple[torch.Tensor, torch.Tensor]]] = []
         for st, b in zip(steps, batches):
@@ -1339,6 +1440,9 @@ class ScoreMovingBessKGE(BessKGE):
             else:
                 upd.append((tail2d[:, :cut].reshape(-1).contiguous(), back_tq[i].reshape(-1, W)))
                 upd.append((head2d[:, cut:].reshape(-1).contiguous(), back_hq[i].reshape(-1, W)))
+        if accumulating:
+            pending.append(_PendingUpdate(steps, local_updates, deferred, d_rel))
+            return results
         self._apply_updates(steps, local_updates, deferred, seg_index, optimizer, desc, d_rel)
         return results
 

@@ -52,10 +52,61 @@ class Options:
     #: recorded by value).  One process per GPU: with `NativeGroup` (collectives on
     #: the kernels' stream, captured with them), not with c10d's `DistributedGroup`.
     use_graphs: bool = False
+    #: training: micro-batches whose gradients are summed before ONE optimiser step (poptorch
+    #: `Training.gradientAccumulation`; reference `notebooks/1_biokg_training_inference.ipynb:408-417,
+    #: 470-477`, `2_yago_topk_prediction.ipynb:240-280`).  A call consumes `device_iterations *
+    #: gradient_accumulation` micro-batches (`batches_per_step` of the batch sampler) and makes
+    #: `device_iterations` weight updates; every micro-batch of an update sees the same tables.
+    gradient_accumulation: int = 1
+    #: how the gradients of accumulated micro-batches (and, with `replicas=True` semantics of PopTorch's
+    #: `accumulationAndReplicationReductionType`, of the replicas) are combined: "sum" = gradient of the summed
+    #: loss, "mean" = divided by `gradient_accumulation` (and by n_shard for the replicated tables when the
+    #: optimiser says `replica_reduction="mean"`).  The reference never sets it and PopTorch's default is not
+    #: visible in the repository: parity unpinned, "sum" chosen.
+    accumulation_reduction: str = "sum"
 
     def deviceIterations(self, n: int) -> "Options":  # noqa: N802 - poptorch spelling
-        self.device_iterations = n
+        self.device_iterations = int(n)
         return self
+
+    @property
+    def Training(self) -> "_TrainingOptions":  # noqa: N802 - poptorch spelling
+        """`options.Training.gradientAccumulation(k)` as the notebooks write it."""
+        return _TrainingOptions(self)
+
+    @property
+    def _popart(self) -> "_Ignored":
+        """`options._popart.setPatterns(dict(RemoveAllReducePattern=True))` of the notebooks: the shard
+        gradient is never all-reduced here by construction - accepted, nothing to do."""
+        return _Ignored()
+
+    @property
+    def batches_per_call(self) -> int:
+        """Micro-batches one call of a training runner consumes (per replica)."""
+        return self.device_iterations * max(1, self.gradient_accumulation)
+
+
+class _Ignored:
+    def __getattr__(self, name: str) -> Any:
+        return lambda *a, **k: None
+
+
+class _TrainingOptions:
+    def __init__(self, options: Options) -> None:
+        self._options = options
+
+    def gradientAccumulation(self, k: int) -> Options:  # noqa: N802 - poptorch spelling
+        if int(k) < 1:
+            raise ValueError("gradientAccumulation needs a factor >= 1")
+        self._options.gradient_accumulation = int(k)
+        return self._options
+
+    def accumulationAndReplicationReductionType(self, kind: Any) -> Options:  # noqa: N802
+        name = str(getattr(kind, "name", kind)).lower()
+        if name not in ("sum", "mean"):
+            raise ValueError("reduction type must be 'sum' or 'mean'")
+        self._options.accumulation_reduction = name
+        return self._options
 
 
 @dataclasses.dataclass
@@ -177,6 +228,33 @@ class Runner:
         with torch.no_grad():
             return self.model.forward_replicas(reps)
 
+    @property
+    def _accum(self) -> int:
+        return max(1, int(self.options.gradient_accumulation)) if self.optimizer is not None else 1
+
+    def _iteration(self, batch: Dict[str, torch.Tensor], it: int) -> List[List[Any]]:
+        """One device iteration = one weight update: the results of its micro-batches, in order.
+        With gradient accumulation every micro-batch is differentiated against the same tables, their
+        gradients are summed per row and the optimiser runs once (`BessKGE.apply_accumulated`)."""
+        k = self._accum
+        if k == 1:
+            return [self._step(self._split(batch, it))]
+        mean = self.options.accumulation_reduction == "mean"
+        if self.options.accumulation_reduction not in ("sum", "mean"):
+            raise ValueError("Options.accumulation_reduction must be 'sum' or 'mean'")
+        pending: List[Any] = []
+        outs = []
+        if mean:
+            self.model.__dict__["_grad_scale"] = 1.0 / k
+        try:
+            for j in range(k):
+                outs.append(self.model.train_step_replicas(self._split(batch, it * k + j), self.optimizer,
+                                                           pending=pending))  # type: ignore
+        finally:
+            self.model.__dict__["_grad_scale"] = 1.0
+        self.model.apply_accumulated(pending, self.optimizer)  # type: ignore
+        return outs
+
     def _call_with_graphs(self, batch: Dict[str, torch.Tensor], iters: int) -> Dict[str, torch.Tensor]:
         if isinstance(self.group, DistributedGroup):
             raise NotImplementedError(
@@ -208,12 +286,12 @@ class Runner:
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    self._step(self._split(static, 0))
+                    self._iteration(static, 0)
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                outs = [self._step(self._split(static, it)) for it in range(iters)]
+                outs = [o for it in range(iters) for o in self._iteration(static, it)]
                 stacked = self._stack_outputs(outs)  # the stacking of the outputs is part of the recording too
             if snapshot is not None:
                 self._restore_training_snapshot(snapshot)
@@ -273,7 +351,7 @@ class Runner:
         n = self.group.n_shard
         out = []
         local = list(self.group.local_shards)
-        own_rows_only = batch["relation"].shape[0] != self.options.device_iterations * n
+        own_rows_only = batch["relation"].shape[0] != self.options.device_iterations * self._accum * n
         for j, shard in enumerate(local):
             row = it * len(local) + j if own_rows_only else it * n + shard
             out.append({k: v[row: row + 1].to(self.device, non_blocking=True) for k, v in batch.items()})
@@ -287,11 +365,13 @@ class Runner:
         rows = batch["relation"].shape[0]
         iters = self.options.device_iterations
         n_local = len(list(self.group.local_shards))
-        if rows != iters * n and rows != iters * n_local:
+        micro = iters * self._accum
+        if rows != micro * n and rows != micro * n_local:
             raise ValueError(
-                f"inputs have {rows} rows; expected device_iterations * n_shard = {iters} * {n}"
+                f"inputs have {rows} rows; expected device_iterations * gradient_accumulation * n_shard = "
+                f"{iters} * {self._accum} * {n}"
                 " (flatten [batches_per_step, n_shard, ...] with .flatten(end_dim=1)), or"
-                f" {iters} * {n_local} rows holding only this process's shards"
+                f" {micro} * {n_local} rows holding only this process's shards"
                 " (DeviceBatchSampler(..., shards=...))"
             )
         if self.options.use_graphs:
@@ -321,13 +401,7 @@ class Runner:
                     ctx = nxt
         for it in range(0 if not pipelined else iters, iters):
             with torch.cuda.stream(streams[it % len(streams)]):
-                reps = self._split(batch, it)
-                if self.optimizer is not None:
-                    res = self.model.train_step_replicas(reps, self.optimizer)  # type: ignore
-                else:
-                    with torch.no_grad():
-                        res = self.model.forward_replicas(reps)
-            collected.append(res)
+                collected.extend(self._iteration(batch, it))
         for st in streams:
             if st is not main:
                 main.wait_stream(st)
