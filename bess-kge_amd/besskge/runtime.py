@@ -34,8 +34,10 @@ class Options:
 
     #: micro-batches consumed per call (poptorch `deviceIterations`)
     device_iterations: int = 1
-    #: "all": outputs of every micro-batch; "final": only the last one
-    output_mode: str = "all"
+    #: "all": outputs of every micro-batch; "final": only the last one; None = PopTorch's defaults
+    #: (`OutputMode.Final` for a training model - the notebooks read "the loss of the last batch",
+    #: `1_biokg_training_inference.ipynb` training loop - and `OutputMode.All` for an inference model)
+    output_mode: Optional[str] = None
     #: distributed runs: all-gather outputs so every rank sees all replicas
     gather_outputs: bool = False
     #: inference only: micro-batches of one call are issued round-robin on this
@@ -67,6 +69,13 @@ class Options:
 
     def deviceIterations(self, n: int) -> "Options":  # noqa: N802 - poptorch spelling
         self.device_iterations = int(n)
+        return self
+
+    def outputMode(self, mode: Any) -> "Options":  # noqa: N802 - poptorch spelling
+        name = str(getattr(mode, "name", mode)).lower()
+        if name not in ("all", "final"):
+            raise ValueError("output mode must be 'all' or 'final'")
+        self.output_mode = name
         return self
 
     @property
@@ -408,7 +417,8 @@ class Runner:
         return self._stack_outputs(collected)
 
     def _stack_outputs(self, collected: List[List[Any]]) -> Dict[str, torch.Tensor]:
-        if self.options.output_mode == "final":
+        mode = self.options.output_mode or ("final" if self.optimizer is not None else "all")
+        if mode == "final":
             collected = collected[-1:]
         bare = not isinstance(collected[0][0], dict)  # modules returning one tensor (AllScoresBESS)
         if bare:
@@ -440,3 +450,10 @@ def training_model(model: BessKGE, options: Optional[Options] = None, optimizer:
     """`poptorch.trainingModel` analogue (forward + backward + sparse update per call)."""
     model.train()
     return Runner(model, options, group, device, optimizer or SGD(), dtype)
+
+
+# PopTorch's spellings, so that `from besskge import runtime as poptorch` keeps a notebook's lines
+# (`poptorch.trainingModel(model, options=options, optimizer=opt)`; the `replicaGrouping` call that follows
+# in the notebooks has no counterpart: shard r always lives with replica r)
+trainingModel = training_model  # noqa: N816
+inferenceModel = inference_model  # noqa: N816

@@ -30,6 +30,7 @@ def test_options_spelling_and_row_check():
     o._popart.setPatterns(dict(RemoveAllReducePattern=True))  # accepted, nothing to do
     o.Training.accumulationAndReplicationReductionType("Mean")
     assert o.accumulation_reduction == "mean"
+    assert o.output_mode is None and o.outputMode("All").output_mode == "all"
     with pytest.raises(ValueError):
         o.Training.gradientAccumulation(0)
     with pytest.raises(ValueError):
@@ -126,7 +127,7 @@ def test_accumulated_step_equals_one_step_on_the_summed_loss(dev, case, opt_name
     model = build_model(c, dev)
     if c["net"] is not None:
         model.train()
-    options = runtime.Options(device_iterations=1)
+    options = runtime.Options(device_iterations=1).outputMode("all")
     options.Training.gradientAccumulation(len(order))
     runner = runtime.training_model(model, options, opt, device=dev)
     batch = {k: torch.stack([c["batch"][k][it] for it in order]).flatten(end_dim=1) for k in KEYS if k in c["batch"]}
@@ -176,7 +177,8 @@ def test_accumulation_under_graph_replay(dev, case, opt_name):
     for use_graphs in (False, True):
         opt, _ = _optimizers(opt_name)
         model = build_model(c, dev)
-        options = runtime.Options(device_iterations=2, gradient_accumulation=2, use_graphs=use_graphs)
+        options = runtime.Options(device_iterations=2, gradient_accumulation=2, use_graphs=use_graphs,
+                                  output_mode="all")
         runner = runtime.training_model(model, options, opt, device=dev)
         losses = [runner(**batch)["loss"].float().cpu() for _ in range(2)]
         assert losses[0].numel() == 4 * c["meta"]["n_shard"]
@@ -212,6 +214,24 @@ def test_mean_reduction_is_sum_with_a_scaled_rate(dev):
                     res["loss"].cpu()))
     for a, b in zip(out[0], out[1]):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_training_runner_returns_the_last_micro_batch_by_default(dev):
+    """PopTorch's OutputMode.Final for training models (the notebooks' loops read the last batch's loss)."""
+    from besskge import runtime
+    from test_hip_parity import build_model
+
+    c = load_bess_case("tr_EM_TransE1_t_flat_n1")
+    batch = {k: c["batch"][k].flatten(end_dim=1) for k in KEYS if k in c["batch"]}
+    got = {}
+    for mode in (None, "all"):
+        model = build_model(c, dev)
+        runner = runtime.training_model(model, runtime.Options(device_iterations=1, gradient_accumulation=2,
+                                                               output_mode=mode), runtime.SGD(lr=0.01), device=dev)
+        got[mode] = runner(**batch)["loss"].cpu()
+    assert got[None].numel() == 1 and got["all"].numel() == 2
+    torch.testing.assert_close(got[None], got["all"][-1:])
 
 
 @pytest.mark.gpu
