@@ -83,21 +83,42 @@ def load_rows(path: Union[str, Path], into: torch.Tensor, chunk_bytes: int = CHU
     return into
 
 
+def _write_json(path: str, obj: Dict[str, Any]) -> None:
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "w") as f:
+        json.dump(obj, f)
+    os.replace(tmp, path)
+
+
+def _step_of(st: Dict[str, Any]) -> int:
+    """Optimiser steps taken so far.  Under hipGraph replay only the device-side count advances (the host
+    count is restored after the capture): the larger of the two is the truth."""
+    step = int(st["step"])
+    if "step_dev" in st:
+        step = max(step, int(st["step_dev"].item()))
+    return step
+
+
 def _save_table(model: Any, table: torch.Tensor, stem: Path, chunk_bytes: int) -> None:
     save_rows(table, f"{stem}.npy", chunk_bytes)
     st = getattr(model, "_optimizer_state", {}).get(table.data_ptr())
     meta: Dict[str, Any] = dict(step=0, n_state=0, paged=False)
     if st is not None:
-        meta.update(step=int(st["step"]), n_state=len(st["s"]), paged="slot_map" in st)
+        meta.update(step=_step_of(st), n_state=len(st["s"]), paged="slot_map" in st)
         for i, s in enumerate(st["s"]):
             save_rows(s, f"{stem}.state{i}.npy", chunk_bytes)
         if "slot_map" in st:
             save_rows(st["slot_map"], f"{stem}.slots.npy", chunk_bytes)
             meta.update(capacity=int(st["capacity"]), counter=int(st["slot_counter"].item()))
         if "step_dev" in st:
-            meta["step_dev"] = int(st["step_dev"].item())
-    with open(f"{stem}.meta.json", "w") as f:
-        json.dump(meta, f)
+            meta["step_dev"] = _step_of(st)
+    _write_json(f"{stem}.meta.json", meta)
+
+
+def _stale_graphs(model: Any) -> None:
+    """State tensors were replaced: hipGraphs recorded by a Runner hold the old addresses.  Runners compare
+    this counter with the one they recorded under and re-capture (`Runner._call_with_graphs`)."""
+    model.__dict__["_state_generation"] = model.__dict__.get("_state_generation", 0) + 1
 
 
 def _load_table(model: Any, table: torch.Tensor, stem: Path, chunk_bytes: int) -> None:
@@ -105,25 +126,49 @@ def _load_table(model: Any, table: torch.Tensor, stem: Path, chunk_bytes: int) -
     with open(f"{stem}.meta.json") as f:
         meta = json.load(f)
     states = getattr(model, "_optimizer_state", None)
-    if states is not None:
+    have = states.get(table.data_ptr()) if states is not None else None
+    dev = table.device
+    paged = bool(meta["paged"])
+    n_state, step = int(meta["n_state"]), int(meta["step"])
+    shape = (int(meta["capacity"]), table.shape[1]) if paged else tuple(table.shape)
+    if have is not None and ("slot_map" in have) == paged and len(have["s"]) >= n_state \
+            and all(tuple(x.shape) == shape for x in have["s"]) and (not paged or have["capacity"] == int(meta["capacity"])):
+        # same layout as the live state: read into the existing tensors - a hipGraph recorded on them (tables,
+        # moments, slot map, device-side step count) stays valid
+        for i, x in enumerate(have["s"]):
+            if i < n_state:
+                load_rows(f"{stem}.state{i}.npy", x, chunk_bytes)
+            else:
+                x.zero_()
+        if paged:
+            load_rows(f"{stem}.slots.npy", have["slot_map"], chunk_bytes)
+            have["slot_counter"].fill_(int(meta["counter"]))
+        have["step"] = step
+        if "step_dev" in have:
+            have["step_dev"].fill_(step)
+        elif "step_dev" in meta:
+            have["step_dev"] = torch.full((1,), step, dtype=torch.int32, device=dev)
+            _stale_graphs(model)
+        return
+    if have is not None:
         states.pop(table.data_ptr(), None)
-    if meta["n_state"] == 0 and meta["step"] == 0:
+        _stale_graphs(model)
+    if n_state == 0 and step == 0:
         return
     if states is None:
         model._optimizer_state = states = {}
-    st: Dict[str, Any] = dict(step=int(meta["step"]), s=[])
-    dev = table.device
-    if meta["paged"]:
+    st: Dict[str, Any] = dict(step=step, s=[])
+    if paged:
         st["capacity"] = int(meta["capacity"])
         st["slot_map"] = load_rows(f"{stem}.slots.npy", torch.empty((table.shape[0],), dtype=torch.int32, device=dev),
                                    chunk_bytes)
         st["slot_counter"] = torch.full((1,), int(meta["counter"]), dtype=torch.int32, device=dev)
-    shape = (st["capacity"], table.shape[1]) if meta["paged"] else tuple(table.shape)
-    for i in range(int(meta["n_state"])):
+    for i in range(n_state):
         st["s"].append(load_rows(f"{stem}.state{i}.npy", torch.empty(shape, dtype=torch.float32, device=dev), chunk_bytes))
     if "step_dev" in meta:
-        st["step_dev"] = torch.full((1,), int(meta["step_dev"]), dtype=torch.int32, device=dev)
+        st["step_dev"] = torch.full((1,), step, dtype=torch.int32, device=dev)
     states[table.data_ptr()] = st
+    _stale_graphs(model)
 
 
 def _dense_state(model: Any) -> Dict[str, torch.Tensor]:
@@ -152,15 +197,23 @@ def save_checkpoint(model: Any, directory: Union[str, Path], chunk_bytes: int = 
         for name, p in model.score_fn.named_parameters():
             st = states.get(p.data_ptr())
             if st is not None and name not in ("entity_embedding", "relation_embedding"):
-                opt[name] = dict(step=int(st["step"]), s=[x.detach().cpu() for x in st["s"]],
-                                 step_dev=int(st["step_dev"].item()) if "step_dev" in st else -1)
-        torch.save(dict(tensors={k: v.detach().cpu() for k, v in _dense_state(model).items()}, optimizer=opt),
-                   directory / "dense.pt")
+                opt[name] = dict(step=_step_of(st), s=[x.detach().cpu() for x in st["s"]],
+                                 step_dev=_step_of(st) if "step_dev" in st else -1)
+        tmp = directory / f"dense.pt.tmp{os.getpid()}"
+        torch.save(dict(tensors={k: v.detach().cpu() for k, v in _dense_state(model).items()}, optimizer=opt), tmp)
+        os.replace(tmp, directory / "dense.pt")
+    # every rank's files are in place before anyone returns (and before a rank could start loading the
+    # replicated files the host of shard 0 writes)
+    if len(group.local_shards) != group.n_shard and hasattr(group, "barrier"):
+        group.barrier()
 
 
 def load_checkpoint(model: Any, directory: Union[str, Path], chunk_bytes: int = CHUNK_BYTES) -> None:
-    """Read the shards hosted by this process back in place (the tables keep their addresses, so a
-    hipGraph recorded on them stays valid) and restore optimiser state, step counts and paging."""
+    """Read the shards hosted by this process back in place and restore optimiser state, step counts and paging.
+    The tables keep their addresses.  Optimiser state of the same layout as the live one (same number of state
+    tensors, same paging) is read into the existing tensors too, so a hipGraph a Runner recorded earlier stays
+    valid; where the layout differs the state objects are replaced and the model's `_state_generation` is bumped
+    - Runners drop the graphs they recorded under an older generation and capture again on their next call."""
     directory = Path(directory)
     group = model._group()
     for shard in group.local_shards:
@@ -178,7 +231,17 @@ def load_checkpoint(model: Any, directory: Union[str, Path], chunk_bytes: int = 
         p = params[name]
         if not hasattr(model, "_optimizer_state"):
             model._optimizer_state = {}
+        have = model._optimizer_state.get(p.data_ptr())
+        if have is not None and len(have["s"]) == len(st["s"]) and all(
+                a.shape == b.shape for a, b in zip(have["s"], st["s"])) and (("step_dev" in have) == (st["step_dev"] >= 0)):
+            for a, b in zip(have["s"], st["s"]):
+                a.copy_(b)
+            have["step"] = int(st["step"])
+            if "step_dev" in have:
+                have["step_dev"].fill_(int(st["step_dev"]))
+            continue
         new: Dict[str, Any] = dict(step=int(st["step"]), s=[x.to(p.device) for x in st["s"]])
         if st["step_dev"] >= 0:
             new["step_dev"] = torch.full((1,), int(st["step_dev"]), dtype=torch.int32, device=p.device)
         model._optimizer_state[p.data_ptr()] = new
+        _stale_graphs(model)

@@ -281,6 +281,10 @@ class Runner:
         # clones were a third of the step).
         sig = (iters,) + tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()))
         cache = self.__dict__.setdefault("_graphs", {})
+        generation = self.model.__dict__.get("_state_generation", 0)
+        if self.__dict__.get("_graphs_generation", generation) != generation:
+            cache.clear()  # optimiser state tensors were replaced (checkpoint load): recorded addresses are stale
+        self.__dict__["_graphs_generation"] = generation
         if sig not in cache:
             static = {k: torch.empty(v.shape, dtype=v.dtype, device=self.device) for k, v in batch.items()}
             for k, v in batch.items():

@@ -30,6 +30,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.bess_version() == _native.ABI_VERSION == 2
 
 
+def test_integration_doc_matches_the_library():
+    """INTEGRATION.md quotes the number of entry points, the ABI version its stub asserts and the link line."""
+    from besskge import _native
+
+    doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    m = re.search(r"C ABI \((\d+) entry points", doc)
+    assert m and int(m.group(1)) == len(header_functions()), (m and m.group(1), len(header_functions()))
+    m = re.search(r"bess_version\(\) == (\d+)", doc)
+    assert m and int(m.group(1)) == _native.ABI_VERSION
+    makefile = open(os.path.join(REPO, "bess-kge_amd", "csrc", "Makefile")).read()
+    assert ("-lrccl" in makefile) == ("-lrccl" in doc)
+
+
 def test_workspace_query_needs_no_gpu():
     """bess_neg_score_shared_workspace is host arithmetic: bilinear scorers with >= 256 output
     tiles of 128 x 128 ask for (S + min(N, 65536)) lines (rows rounded up to whole 256 / 128-row

@@ -89,3 +89,52 @@ def test_training_resumes_from_a_checkpoint(tmp_path, opt_name):
     if opt_name == "adam_paged":
         assert "entity_shard0.slots.npy" in files
         assert np.load(tmp_path / "ckpt" / "entity_shard0.state0.npy").shape[0] == 300
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("warm", [True, False])
+def test_rollback_in_a_live_process_under_graph_replay(tmp_path, warm):
+    """A Runner that replays hipGraphs keeps training correctly after `load_checkpoint` into its live model:
+    state of the same layout is read into the tensors the graph was recorded on (warm), and a load that has to
+    create or replace state tensors (the graph was recorded before the model had Adam state of that layout)
+    makes the Runner record again instead of replaying stale addresses."""
+    from besskge import checkpoint, runtime
+
+    dev = torch.device("cuda", 0)
+    batches = None
+    results = {}
+    for use_graphs in (False, True):
+        model, sharding = _model(dev)
+        batches = batches or [_batch(sharding, 2, 16, 6, s) for s in range(5)]
+        runner = runtime.training_model(model, runtime.Options(use_graphs=use_graphs),
+                                        runtime.Adam(lr=0.01), device=dev)
+        for b in batches[:2]:
+            runner(**b)
+        ckpt = tmp_path / f"ckpt{int(use_graphs)}"
+        checkpoint.save_checkpoint(model, ckpt, chunk_bytes=4096)
+        for b in batches[2:4]:
+            runner(**b)
+        if not warm:
+            # a different live layout: paged state with its own (smaller) moment tables
+            model2, _ = _model(dev)
+            runner = runtime.training_model(model2, runtime.Options(use_graphs=use_graphs),
+                                            runtime.Adam(lr=0.01), device=dev)
+            runner.optimizer = runtime.Adam(lr=0.01, state_rows=300)
+            runner(**batches[4])  # records a graph on paged state tensors
+            runner.optimizer = runtime.Adam(lr=0.01)
+            model = model2
+        checkpoint.load_checkpoint(model, ckpt, chunk_bytes=4096)  # back to the state after two steps
+        for b in batches[2:4]:
+            out = runner(**b)
+        results[use_graphs] = (model.score_fn.entity_embedding.detach().clone(),
+                               model.score_fn.relation_embedding.detach().clone(), out["loss"].clone())
+        # the step count went back with the tables (Adam's bias correction restarts from step 2, not 4)
+        st = model._optimizer_state[model._local_table(0).data_ptr()]
+        assert checkpoint._step_of(st) == 4
+    # Adam normalises by |g|: entries whose gradient cancels to ~0 take a full +-lr step whose sign depends on
+    # the order of fp32 atomics (tests/test_accumulation.py) - a stale-address replay would leave the tables
+    # where the rollback put them (off by whole steps everywhere), which this still catches
+    for a, b in zip(results[False][:2], results[True][:2]):
+        off = (a - b).abs()
+        assert float((off > 1e-5).float().mean()) < 0.01 and float(off.max()) <= 2 * 0.01 * 1.01
+    torch.testing.assert_close(results[False][2], results[True][2], rtol=1e-4, atol=1e-5)
