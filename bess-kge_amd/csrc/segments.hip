@@ -572,7 +572,8 @@ __global__ __launch_bounds__(256) void k_coalesced_update(OptArgs o, RowLists L,
 // Paged optimiser state: the state tables hold `capacity` rows; a table row gets one when it is first
 // stepped (slot_map[row] = its state row, -1 before).  One thread per unique row of the step; rows are
 // unique, so no two threads assign the same row.  counter[0] counts the assignments asked for - beyond
-// `capacity` a row stays at -1 (the host reads counter[0] to notice an exhausted pool).
+// `capacity` a row stays at -1 (the host reads counter[0] > capacity to notice an exhausted pool; the count
+// saturates a little above capacity: at most one launch's worth of threads beyond it).
 __global__ __launch_bounds__(256) void k_assign_state_rows(const int32_t* __restrict__ seg_rows,
                                                            const int32_t* __restrict__ n_seg,
                                                            const int32_t* __restrict__ keep,
@@ -583,8 +584,12 @@ __global__ __launch_bounds__(256) void k_assign_state_rows(const int32_t* __rest
         if (keep && keep[s] == 0) continue;
         const int64_t row = seg_rows[s];
         if (slot_map[row] >= 0) continue;
+        // saturating: once the pool is exhausted (counter > capacity tells the host so) rows without state
+        // stop counting - they ask again every step, and a counter that kept growing would wrap after 2^31
+        // requests and hand the slots out a second time
+        if (__atomic_load_n(counter, __ATOMIC_RELAXED) > capacity) continue;
         const int slot = atomicAdd(counter, 1);
-        if (slot < capacity) slot_map[row] = slot;
+        if (slot >= 0 && slot < capacity) slot_map[row] = slot;
     }
 }
 

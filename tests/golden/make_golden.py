@@ -20,6 +20,8 @@ The fixtures pin, against the reference itself:
   metric.npz            Evaluation ranks / metrics                       (metric.py:74-273)
   topk.npz              TopKQueryBessKGE.forward (+ Evaluation)          (bess.py:606-921)
   allscores.npz         AllScoresBESS.forward, every window step         (bess.py:924-1062)
+  bess_half.npz         BessKGE.forward + autograd in the fp16 mode (`model.half()`,
+                        notebooks/3_wikikg2_fp16.ipynb:300-392) on torch's CPU half kernels
 """
 
 import copy
@@ -677,10 +679,11 @@ def run_bess_case(
     batch_kind: str = "rigid",
     with_grads: bool = True,
     fix: str = "bess",
+    half: bool = False,
+    d: int = 8,
 ) -> None:
     seed = 1234
     n_entity, n_rel, n_triple = 120, 6, 400
-    d = 8
     bps = 2
     shard_bs = 8 * n_shard if n_shard > 1 else 16
     n_negative = 5
@@ -690,6 +693,13 @@ def run_bess_case(
     sharding = Sharding.create(n_entity, n_shard, seed=seed)
     ent = torch.randn(n_shard, sharding.max_entity_per_shard, W)
     rel = torch.randn(n_rel, Wr)
+    if half:
+        # the reference's fp16 mode is `model.half()` (notebooks/3_wikikg2_fp16.ipynb:300-392): the tables and
+        # every tensor of the score computation are fp16, the loss is computed in fp32 (bess.py:254-260).
+        # The fixture stores the fp16 tables; the replicas below run the reference's forward / autograd on
+        # them with torch's CPU half kernels (element-wise results rounded to fp16, reductions accumulated in
+        # fp32 and rounded once)
+        ent, rel = ent.half(), rel.half()
     triples = np.stack(
         [
             rng.integers(n_entity, size=n_triple),
@@ -724,7 +734,7 @@ def run_bess_case(
         partitioned_triple_set=pts, negative_sampler=ns, shard_bs=shard_bs, batches_per_step=bps,
         seed=seed, hrt_freq_weighting=False, duplicate_batch=dup, return_triple_idx=True,
     )
-    score_fn = scorer_factory(scorer, p, sharing, sharding, n_rel, d, ent, rel)
+    score_fn = scorer_factory(scorer, p, sharing, sharding, n_rel, d, ent.float(), rel.float())
     loss_fn = None
     if loss_name == "logsigmoid":
         loss_fn = LogSigmoidLoss(margin=3.0, negative_adversarial_sampling=True, negative_adversarial_scale=0.5)
@@ -743,6 +753,8 @@ def run_bess_case(
         n_negative=n_negative, n_shard=n_shard, norm=p, augment=int(augment), sharing=int(sharing),
         dup=int(dup), flat=int(flat), tb=int(tb),
     )
+    if half:
+        meta["half"] = 1
     put(fix, p_ + "meta_keys", np.array(list(meta.keys())))
     put(fix, p_ + "meta_vals", np.array(list(meta.values())))
     put(fix, p_ + "strs", np.array([model_cls.__name__, scorer, scheme, neg_kind, loss_name, batch_kind]))
@@ -852,6 +864,36 @@ def gen_bess_local() -> None:
     put("bess_local", "cases", np.array(names))
 
 
+def gen_bess_half() -> None:
+    """The reference's fp16 mode (`model.half()`, notebooks/3_wikikg2_fp16.ipynb:300-392; `scoring.py:194-197, 342`)
+    run by the reference's own code on CPU: fp16 tables, fp16 score arithmetic, fp32 loss, autograd in fp16.
+    TransE / RotatE with p = 1, shared flat negatives, `augment_negative`, sampled-softmax CE - the wikikg2
+    recipe (BASELINE configs[3]) - n_shard 1 and 2, widths the packed-fp16 kernels take (W % 32 == 0) and one
+    they do not; plus log-sigmoid, per-triple and bilinear cases so that every fp16 code path has a
+    reference-made fixture."""
+    EM, SM = EmbeddingMovingBessKGE, ScoreMovingBessKGE
+    cases = [
+        # name, class, scorer, p, n, scheme, negatives, loss, augment, sharing, d
+        ("h16_EM_TransE1_aug_t_flat_n1", EM, "TransE", 1, 1, "t", "random_flat", "ssce", True, True, 32),
+        ("h16_EM_TransE1_aug_t_flat_n2", EM, "TransE", 1, 2, "t", "random_flat", "ssce", True, True, 32),
+        ("h16_EM_TransE1_aug_t_flat_n2_d64", EM, "TransE", 1, 2, "t", "random_flat", "ssce", True, True, 64),
+        ("h16_EM_RotatE1_aug_t_flat_n1", EM, "RotatE", 1, 1, "t", "random_flat", "ssce", True, True, 16),
+        ("h16_EM_RotatE1_aug_t_flat_n2", EM, "RotatE", 1, 2, "t", "random_flat", "ssce", True, True, 32),
+        ("h16_EM_TransE1_aug_ht_flat_n2", EM, "TransE", 1, 2, "ht", "random_flat", "ssce", True, True, 32),
+        ("h16_EM_TransE1_t_flat_n1_d8", EM, "TransE", 1, 1, "t", "random_flat", "logsigmoid", False, True, 8),
+        ("h16_EM_TransE1_h_pt_n2", EM, "TransE", 1, 2, "h", "random_pt", "logsigmoid", False, False, 32),
+        ("h16_SM_RotatE1_t_pt_n2", SM, "RotatE", 1, 2, "t", "random_pt", "logsigmoid", False, False, 16),
+        ("h16_EM_TransE2_aug_t_flat_n2", EM, "TransE", 2, 2, "t", "random_flat", "ssce", True, True, 32),
+        ("h16_EM_ComplEx0_aug_t_flat_n2", EM, "ComplEx", 0, 2, "t", "random_flat", "ssce", True, True, 16),
+        ("h16_EM_DistMult0_h_pt_n1", EM, "DistMult", 0, 1, "h", "random_pt", "logsigmoid", False, False, 32),
+    ]
+    names = []
+    for name, mcls, scorer, p, n, scheme, nk, loss, aug, sharing, d in cases:
+        run_bess_case(name, mcls, scorer, p, n, scheme, nk, loss, aug, sharing, fix="bess_half", half=True, d=d)
+        names.append(name)
+    put("bess_half", "cases", np.array(names))
+
+
 def gen_bess_affine() -> None:
     """PairRE / TripleRE / InterHT / TranS through the reference's BessKGE.forward + autograd."""
     EM, SM = EmbeddingMovingBessKGE, ScoreMovingBessKGE
@@ -928,6 +970,13 @@ def run_query_case(case: str, kind: str, scorer: str, p: int, n_shard: int, sche
     sharding = Sharding.create(n_entity, n_shard, seed=seed)
     ent = torch.randn(n_shard, sharding.max_entity_per_shard, W)
     rel = torch.randn(n_rel, Wr)
+    if half:
+        # the reference's fp16 mode is `model.half()` (notebooks/3_wikikg2_fp16.ipynb:300-392): the tables and
+        # every tensor of the score computation are fp16, the loss is computed in fp32 (bess.py:254-260).
+        # The fixture stores the fp16 tables; the replicas below run the reference's forward / autograd on
+        # them with torch's CPU half kernels (element-wise results rounded to fp16, reductions accumulated in
+        # fp32 and rounded once)
+        ent, rel = ent.half(), rel.half()
     triples = np.stack([rng.integers(n_entity, size=n_triple), rng.integers(n_rel, size=n_triple),
                         rng.integers(n_entity, size=n_triple)], axis=1)
     flat = cand_kind in ("all", "flat")
@@ -1039,6 +1088,7 @@ def main() -> None:
         scoring_conve=gen_scoring_conve,
         bess_conve=gen_bess_conve,
         bess_local=gen_bess_local,
+        bess_half=gen_bess_half,
     )
     for name, g in gens.items():
         if only and name not in only:
