@@ -525,7 +525,7 @@ int affine_pertriple(const bess_model_desc* d, bool fwd, const float* query, int
     a.normalize = d->reserved[1] & 1;
     const int it = static_cast<int>(ceil_div(a.nch, 16));
     if (!fwd && a.items_per_query > 1) {
-        hipError_t e = hipMemsetAsync(dq, 0, sizeof(float) * n_query * (n_part + 1) * dd, st);
+        hipError_t e = fill_words_async(dq, 0u, n_query * (n_part + 1) * dd, st);
         if (e != hipSuccess) return fail(static_cast<int>(e), "memset d_query: %s", hipGetErrorString(e));
     }
     int rc;
@@ -1014,7 +1014,7 @@ static int aff_bwd_launch(const float* X, int64_t nx, const float* Y, int64_t ny
     int64_t chunk = ceil_div(ceil_div(ny, split), AKT) * AKT;
     split = ceil_div(ny, chunk);
     if (split > 1) {
-        hipError_t e = hipMemsetAsync(dX, 0, sizeof(float) * nx * NVX * d, st);
+        hipError_t e = fill_words_async(dX, 0u, nx * NVX * d, st);
         if (e != hipSuccess) return fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
     }
     const dim3 grid(static_cast<unsigned>(ceil_div(d, 64)), static_cast<unsigned>(ceil_div(nx, 64)),

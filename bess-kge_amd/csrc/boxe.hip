@@ -312,8 +312,8 @@ int boxe_negatives(const bess_model_desc* d, bool fwd, bool shared, const float*
     const int it = static_cast<int>(ceil_div(a.nch, 16));
     if (!fwd) {
         hipError_t e = hipSuccess;
-        if (a.items_per_query > 1) e = hipMemsetAsync(dq, 0, sizeof(float) * n_query * 6 * dd, st);
-        if (e == hipSuccess && shared && dn) e = hipMemsetAsync(dn, 0, sizeof(float) * n_neg * 2 * dd, st);
+        if (a.items_per_query > 1) e = fill_words_async(dq, 0u, n_query * 6 * dd, st);
+        if (e == hipSuccess && shared && dn) e = fill_words_async(dn, 0u, n_neg * 2 * dd, st);
         if (e != hipSuccess) return fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
     }
     int rc;

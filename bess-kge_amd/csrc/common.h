@@ -166,6 +166,20 @@ __device__ __forceinline__ float sgn_prescaled(float d_scaled) {
     return __builtin_amdgcn_fmed3f(d_scaled, -1.f, 1.f);
 }
 
+// Fill `n` 32-bit words with `v` on `st` - a kernel, not hipMemsetAsync: memset nodes recorded into a hipGraph
+// (torch.cuda.graph capture of a training step) did not reliably re-run in order on replay - a buffer zeroed
+// this way kept what an earlier replay had left in its (pool-recycled) memory.  A kernel node does.
+static __global__ __launch_bounds__(256) void k_fill_words(uint32_t* __restrict__ p, uint32_t v, int64_t n) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) p[i] = v;
+}
+inline hipError_t fill_words_async(void* p, uint32_t v, int64_t n_words, hipStream_t st) {
+    if (n_words <= 0) return hipSuccess;
+    int64_t blocks = (n_words + 255) / 256;
+    blocks = blocks > 2048 ? 2048 : blocks;
+    k_fill_words<<<static_cast<unsigned>(blocks), 256, 0, st>>>(static_cast<uint32_t*>(p), v, n_words);
+    return hipGetLastError();
+}
+
 template <typename T>
 __device__ __forceinline__ const T* row_ptr(const T* base, const int32_t* idx, int64_t i, int width) {
     const int64_t r = idx ? static_cast<int64_t>(idx[i]) : i;

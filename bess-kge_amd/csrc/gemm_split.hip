@@ -711,7 +711,7 @@ int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const in
     ws_bytes -= FLAG_BYTES;
     int32_t* flag = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + ws_bytes / 16 * 16);
     {
-        hipError_t e = hipMemsetAsync(flag, 0, sizeof(int32_t), st);
+        hipError_t e = fill_words_async(flag, 0u, 1, st);
         if (e != hipSuccess) return fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
     }
     int64_t chunk = (ws_bytes / pitch - pad_a(S)) / 128 * 128;  // candidate rows per pass
@@ -803,7 +803,7 @@ int gemm_split_bwd(int dtype, const float* G, int64_t ldg, int64_t S, const floa
     float* parts = reinterpret_cast<float*>(qt + L.q_trans);
     int32_t* flag = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + L.total - FLAG_BYTES);
     {
-        hipError_t e = hipMemsetAsync(flag, 0, sizeof(int32_t), st);
+        hipError_t e = fill_words_async(flag, 0u, 1, st);
         if (e != hipSuccess) return fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
     }
     const auto al = [](const void* p, int64_t ld, int64_t sz) {

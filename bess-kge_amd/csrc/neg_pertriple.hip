@@ -474,7 +474,7 @@ static int run(const bess_model_desc* d, bool fwd, const float* query, int64_t n
     const int red = reduce_of(d);
     hipStream_t st = as_stream(stream);
     if (!fwd && a.items_per_query > 1) {
-        hipError_t e = hipMemsetAsync(dq, 0, sizeof(float) * n_query * W, st);
+        hipError_t e = fill_words_async(dq, 0u, n_query * W, st);
         if (e != hipSuccess) return fail(static_cast<int>(e), "memset d_query: %s", hipGetErrorString(e));
     }
     // A 16-lane group keeps 16 x 16 chunks of a row in registers (1024 f32 / 2048 f16 scalars at full vector

@@ -422,7 +422,7 @@ static int run_bwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<TE> E, cons
     // partial sums of several slices are combined with fp32 atomics: zero their targets - with one memset
     // when both gradients share an allocation (d_neg right behind d_query)
     auto zero = [&](float* p, int64_t n) -> int {
-        hipError_t e = hipMemsetAsync(p, 0, sizeof(float) * n, st);
+        hipError_t e = fill_words_async(p, 0u, n, st);
         return e == hipSuccess ? BESS_OK : fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
     };
     if (A.gz > 1 && B.gz > 1 && d_neg == d_query + Q.n * W) {

@@ -903,7 +903,7 @@ extern "C" int bess_map_extra_rows(const int32_t* seg_rows, const int32_t* n_seg
     BESS_REQUIRE(seg_rows && n_seg && extra_rows && n_extra && extra_map && keep, "map_extra_rows: NULL pointer");
     BESS_REQUIRE(max_seg > 0 && max_extra > 0, "map_extra_rows: bad sizes");
     hipStream_t st = as_stream(stream);
-    hipError_t e = hipMemsetAsync(extra_map, 0xff, sizeof(int32_t) * max_seg, st);  // -1 everywhere
+    hipError_t e = fill_words_async(extra_map, 0xffffffffu, max_seg, st);  // -1 everywhere
     if (e != hipSuccess) return fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
     k_map_extra_rows<<<static_cast<unsigned>(std::min<int64_t>(ceil_div(max_extra, 256), 1024)), 256, 0, st>>>(
         seg_rows, n_seg, extra_rows, n_extra, extra_map, keep);
