@@ -2,6 +2,7 @@
 """Benchmark of the BESS hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode score|train] [--comm auto|native|c10d]
+                    [--workload c2|c4] [--c4-point S,K] [--c4-graph]
 
 Metric (BASELINE.json): positive+negative triples scored per second, and the
 achieved GB/s of the dominant (gather + score) kernel against the roofline.
@@ -32,6 +33,12 @@ Extra objects on the same JSON line:
                 eager and hipGraph replay).
   cpu_baseline  (N = 1) the oracle (CPU restatement of the reference's torch path) on
                 the same S = 4096 x 256 micro-batch, on this box's host cores.
+  xgmi          (N > 1) the library's all-to-all (`bess_alltoall`: one grouped send/recv per peer)
+                timed at the per-peer message sizes of the c4 sweep, GB/s per GPU against 7 x 153 GB/s.
+
+`--workload c4` makes north_star's scaling workload the line itself: `value`, `ms_per_step`, `dtype: "f16"` and
+`config.workload` are the C4 training step at `--c4-point` (default 4096,256), `roofline` its VALU figure - the line
+to take a 1 -> 8 curve on.  The default (`c2`) keeps BASELINE configs[1] as the headline at every N.
 
 Synthetic indices (uniform), default-initialised tables (the scorers' own
 constructors, allocating only this rank's shard, on the device); the index
@@ -70,6 +77,8 @@ C4_N_ENTITY = 2_500_604
 C4_N_REL = 535
 C4_D = 256
 C4_GRAPH_DEADLINE_S = 180  # wall-clock bound on the recorded-collectives variant at N > 1 (see main)
+XGMI_LINKS, XGMI_LINK_GBS = 7, 153.0  # per GPU: 7 point-to-point links of ~153 GB/s (MI355X_MICROARCH.md)
+EXIT_ABANDONED = 3  # a leg hung and was abandoned: the line says so and the process does NOT report success
 # (S per GPU, K per shard pair): SURVEY 8d's sweep - K in {32, 256, 2048}, S from the notebook's 512 to 65,536
 C4_SWEEP = ((512, 32), (4096, 256), (4096, 2048), (16384, 256), (65536, 256))
 
@@ -284,7 +293,7 @@ def hbm_leg(dev: torch.device, steps: int, warmup: int):
 
 
 def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, comm_name: str, steps: int,
-           state: dict, variants=("eager", "graph")):
+           state: dict, variants=("eager", "graph"), sweep=None, warmup_calls: int = 2):
     """north_star's scaling workload: one shard of the 8-way wikikg2 setup per GPU (weak scaling:
     312,576 rows per shard whatever N), TransE d=256 fp16, flat negatives, augmentation,
     sampled-softmax CE, EmbeddingMoving, full training step (forward + backward + C8 + sparse SGD)."""
@@ -304,7 +313,7 @@ def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, c
         graphs = name == "graph"
         if graphs and isinstance(group, DistributedGroup):
             continue
-        for S_, K_ in C4_SWEEP:
+        for S_, K_ in (sweep or C4_SWEEP):
             ppp = S_ // n
             if ppp * n != S_ or S_ > state.get("max_s", 1 << 30):
                 continue
@@ -328,11 +337,11 @@ def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, c
                                                loss_fn=SampledSoftmaxCrossEntropyLoss(n_entity=C4_N_ENTITY))
                 opts = runtime.Options(device_iterations=iters, use_graphs=graphs, pipeline_streams=1)
                 runner = runtime.training_model(model, opts, runtime.SGD(lr=1e-3), group=group, device=dev)
-                for _ in range(2):
+                for _ in range(max(2, warmup_calls)):
                     runner(**batch)
                 group.barrier()
                 torch.cuda.synchronize()
-                reps = max(1, steps // iters)
+                reps = max(1, -(-steps // iters))
                 t0 = time.perf_counter()
                 for _ in range(reps):
                     runner(**batch)
@@ -345,6 +354,7 @@ def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, c
                     dt = float(t.item())
                 point[f"{name}_ms_per_step"] = 1e3 * dt
                 point[f"{name}_value"] = scored / dt
+                point[f"{name}_steps_timed"] = reps * iters
             except Exception as e:  # noqa: BLE001 - a failing variant must not lose the line
                 point[f"{name}_error"] = f"{type(e).__name__}: {e}"[:300]
             finally:
@@ -376,6 +386,91 @@ def c4_summary(state: dict, world: int, comm_name: str) -> dict:
              "sampled-softmax CE, EmbeddingMovingBessKGE, training step (fwd + bwd + C8 + sparse SGD); "
              "value = whole-job positive+negative triples scored/s",
         unit="triples/s", dtype="f16", scaling="weak", n_gpus=world, collectives=comm_name, sweep=points)
+
+
+def xgmi_leg(group, world: int, rank: int, dev: torch.device) -> dict:
+    """the all-to-all of the exchange step by itself.  Per-peer bytes of the c4 sweep: 49 kB (the notebook's
+    S = 512, K = 32), 344 kB, 2.75 MB (S = 4096, K = 256), 32 MB.  Each GPU sends and receives (n - 1) such blocks
+    over its point-to-point links; rate = bytes sent per GPU / time, max over ranks."""
+    sizes = (49_152, 344_064, 2_752_512, 33_554_432)
+    rows = []
+    for b in sizes:
+        x = torch.empty((world, b // 4), dtype=torch.float32, device=dev).normal_()
+        for _ in range(3):
+            group.all_to_all([x])
+        group.barrier()
+        torch.cuda.synchronize()
+        reps = 20 if b < (1 << 22) else 8
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            group.all_to_all([x])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        sent = (world - 1) * b
+        rows.append(dict(bytes_per_peer=b, us=1e6 * dt, gbs_per_gpu=sent / dt / 1e9,
+                         frac_of_links=sent / dt / 1e9 / (min(world - 1, XGMI_LINKS) * XGMI_LINK_GBS)))
+        del x
+    return dict(what="all-to-all of [n, bytes_per_peer] through the group in use, back-to-back calls (launch + transfer); "
+                     "gbs_per_gpu = (n - 1) * bytes_per_peer / time, one direction",
+                peak_per_gpu_gbs=XGMI_LINKS * XGMI_LINK_GBS, links_used=min(world - 1, XGMI_LINKS), sizes=rows)
+
+
+def newest_pmc_traffic():
+    """(bytes per launch of the dominant kernel, source file) from the newest profiles/r*/pmc_traffic.json:
+    rocprofv3 --pmc counters of a separate run of this command (they cannot be read inside the timed run)."""
+    import glob
+
+    cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9]*", "pmc_traffic.json")), reverse=True)
+    cands.append(os.path.join(REPO, "profiles", "pmc_traffic.json"))
+    for pmc in cands:
+        if os.path.exists(pmc):
+            try:
+                return json.load(open(pmc)).get("neg_score_pertriple_fwd_bytes_per_launch"), os.path.relpath(pmc, REPO)
+            except Exception:  # noqa: BLE001
+                pass
+    return None, None
+
+
+def cpu_baseline_c4(S_: int, K_: int, budget_s: float = 8.0):
+    """The oracle on one C4 micro-batch (TransE d=256 p=1, shared negatives + augmentation, sampled-softmax CE) on
+    this box's host cores; tables hold fp16 values, arithmetic in fp32 (the oracle's restatement of `model.half()`)."""
+    from oracle import kge
+
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    gen = torch.Generator().manual_seed(0)
+    M = 50_000  # rows actually touched are << this; the CPU cost is the S x N x W distance matrix, not the table
+    table = (torch.rand(1, M, C4_D, generator=gen) * 2 - 1).div(C4_D).half().float()
+    rel = (torch.rand(C4_N_REL, C4_D, generator=gen) * 2 - 1).div(C4_D).half().float()
+    spec = kge.StepSpec("TransE", 1, True, "t", True, augment=True)
+    rng = np.random.default_rng(0)
+    batch = dict(head=torch.from_numpy(rng.integers(M, size=(1, 1, S_))),
+                 relation=torch.from_numpy(rng.integers(C4_N_REL, size=(1, 1, S_))),
+                 tail=torch.from_numpy(rng.integers(M, size=(1, 1, S_))),
+                 negative=torch.from_numpy(rng.integers(M, size=(1, 1, 1, K_))))
+    loss = dict(kind="ssce", n_entity=C4_N_ENTITY)
+    tg, rg = table.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+
+    def fwd_bwd():
+        tg.grad = rg.grad = None
+        with kge.half_queries():
+            res = kge.bess_step(spec, "EmbeddingMoving", tg, rg, batch, loss)
+        torch.stack(res["loss"]).sum().backward()
+
+    fwd_bwd()
+    ts, t_all = [], time.perf_counter()
+    while len(ts) < 2 or (time.perf_counter() - t_all < budget_s and len(ts) < 20):
+        t0 = time.perf_counter()
+        fwd_bwd()
+        ts.append(time.perf_counter() - t0)
+    scored = S_ * (1 + K_ + S_)
+    return dict(value=scored / float(np.median(ts)), unit="triples/s", cores=cores, kind="port",
+                sample=f"median of {len(ts)} passes forward + autograd backward over one micro-batch (S = {S_}, "
+                       f"K = {K_}, {K_ + S_} shared negatives), torch CPU fp32 on fp16 table values, {cores} threads, "
+                       f"{sum(ts):.1f} s")
 
 
 def train_leg(model, batches, steps: int):
@@ -437,6 +532,15 @@ def main() -> None:
     ap.add_argument("--comm", choices=["auto", "native", "c10d"], default="auto",
                     help="collectives at N > 1: the library's own RCCL entry points on the kernels' stream "
                          "(native), torch.distributed (c10d), or native when its self-check passes (auto)")
+    ap.add_argument("--workload", choices=["c2", "c4"], default="c2",
+                    help="c2 (default): BASELINE configs[1] is the line; c4: north_star's scaling workload "
+                         "(BASELINE configs[3], wikikg2-shaped TransE fp16 training step) is the line")
+    ap.add_argument("--c4-point", default="4096,256", help="S,K of the --workload c4 headline (positives per GPU, "
+                                                           "negatives per shard pair)")
+    ap.add_argument("--c4-graph", action="store_true",
+                    help="N > 1: also run the c4 sweep with the collectives recorded into a hipGraph.  Opt-in there: "
+                         "recorded RCCL send/recv has only been rehearsed on one-rank communicators; it runs last, under "
+                         "a deadline, and a hang ends the process with a non-zero code (never a silent success)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="headline leg only (no roofline_hbm / c4 / train_step)")
     ap.add_argument("--c4-max-s", type=int, default=65536, help="largest micro-batch of the c4 sweep (positives per GPU)")
@@ -474,6 +578,8 @@ def main() -> None:
     from besskge import _native as nat
 
     group, comm_name = make_group(args.comm, world, rank, dev, distributed, backend)
+    if args.workload == "c4":
+        return main_c4(args, world, rank, dev, group, distributed, comm_name)
     model, sharding, k_pair = build_c2(args.entities_per_shard, world, rank, dev, group, distributed)
     batches = make_batches_c2(world, rank, sharding, k_pair, pool=8, dev=dev)
     lr = 1e-3
@@ -586,15 +692,7 @@ def main() -> None:
     roof["note"] = (f"the {table_mb:.0f} MB shard sits in the 256 MiB Infinity Cache: this rate is a cache figure priced "
                     "against the 8 TB/s HBM spec; the HBM-resident figure of the same launch is `roofline_hbm`"
                     if in_cache else "HBM-resident shard")
-    traffic, src = None, None
-    for cand in ("profiles/r02/pmc_traffic.json", "profiles/pmc_traffic.json"):
-        pmc = os.path.join(REPO, cand)
-        if os.path.exists(pmc):
-            try:
-                traffic, src = json.load(open(pmc)).get("neg_score_pertriple_fwd_bytes_per_launch"), cand
-                break
-            except Exception:  # noqa: BLE001
-                pass
+    traffic, src = newest_pmc_traffic()
     roof["traffic"] = traffic
     roof["traffic_source"] = (f"{src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of a separate run of this command "
                               "(counters cannot be read inside the timed run)") if src else None
@@ -636,35 +734,108 @@ def main() -> None:
         c4_steps = max(16, min(args.steps, 48))
         state: dict = {"max_s": args.c4_max_s}
         line["c4"] = c4_leg(world, rank, dev, group, distributed, comm_name, c4_steps, state, variants=("eager",))
-        # The hipGraph variant records RCCL send/recv into the graph.  With more than one rank that has only been
-        # rehearsed on a one-rank communicator (1-GPU boxes), so it runs last and under a deadline: if it has not
-        # come back in time every rank prints / drops what it has and leaves, and the eager numbers are kept.
-        deadline = None
         if world > 1:
-            def give_up() -> None:
-                if rank == 0:
-                    line["c4"] = c4_summary(state, world, comm_name)
-                    line["c4"]["graph_note"] = f"hipGraph variant abandoned after {C4_GRAPH_DEADLINE_S} s"
-                    print(json.dumps(line), flush=True)
-                os._exit(0)
+            try:
+                line["xgmi"] = xgmi_leg(group, world, rank, dev)
+            except Exception as e:  # noqa: BLE001 - an extra leg must not lose the line
+                line["xgmi"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if world == 1 or args.c4_graph:
+            run_graph_variant(line, "c4", world, rank, dev, group, distributed, comm_name, c4_steps, state)
+        else:
+            line["c4"]["graph_note"] = "hipGraph variant not run at N > 1 (opt-in: --c4-graph)"
+    finish(line, rank, distributed, group)
 
-            deadline = threading.Timer(C4_GRAPH_DEADLINE_S, give_up)
-            deadline.daemon = True
-            deadline.start()
-        line["c4"] = c4_leg(world, rank, dev, group, distributed, comm_name, c4_steps, state, variants=("graph",))
-        if deadline is not None:
-            deadline.cancel()
+
+def run_graph_variant(line: dict, key: str, world: int, rank: int, dev, group, distributed: bool, comm_name: str,
+                      steps: int, state: dict, sweep=None) -> None:
+    """The hipGraph variant of the c4 sweep.  At N > 1 it records RCCL send/recv into the graph; that has only been
+    rehearsed on one-rank communicators (1-GPU boxes), so it runs last and under a deadline.  If it does not come
+    back, rank 0 prints the line it has with `"graph_abandoned": true` and every rank leaves with a NON-ZERO code:
+    a stuck leg is never reported as a success."""
+    deadline = None
+    if world > 1:
+        def give_up() -> None:
+            if rank == 0:
+                line[key] = c4_summary(state, world, comm_name)
+                line[key]["graph_note"] = f"hipGraph variant abandoned after {C4_GRAPH_DEADLINE_S} s"
+                line["graph_abandoned"] = True
+                print(json.dumps(line), flush=True)
+            os._exit(EXIT_ABANDONED)
+
+        deadline = threading.Timer(C4_GRAPH_DEADLINE_S, give_up)
+        deadline.daemon = True
+        deadline.start()
+    line[key] = c4_leg(world, rank, dev, group, distributed, comm_name, steps, state, variants=("graph",), sweep=sweep)
+    if deadline is not None:
+        deadline.cancel()
+
+
+def finish(line: dict, rank: int, distributed: bool, group) -> None:
     if rank == 0:
         print(json.dumps(line), flush=True)
     if distributed:
-        # the line is out: a rank that cannot finish the teardown (a peer left at the deadline above) just exits
-        bye = threading.Timer(60, lambda: os._exit(0))
+        # the line is out.  A rank that cannot finish the teardown (a peer died) must not hang the launcher - and
+        # must not look like a clean run either: non-zero exit code.
+        bye = threading.Timer(60, lambda: os._exit(EXIT_ABANDONED))
         bye.daemon = True
         bye.start()
         dist.barrier()
         if hasattr(group, "close"):
             group.close()
         dist.destroy_process_group()
+        bye.cancel()
+
+
+def main_c4(args, world: int, rank: int, dev, group, distributed: bool, comm_name: str) -> None:
+    """`--workload c4`: the C4 EmbeddingMoving training step IS the line (north_star: 1 -> 8 scaling on
+    ogbl-wikikg2 TransE d=256).  One step = one micro-batch of S positives per GPU against n * K + S shared
+    negatives: K1 gather + C1 exchange, packed-fp16 L1 scoring, sampled-softmax CE, both backward products,
+    C8 return, round-once sparse SGD on the fp16 shard, C9 + relation update."""
+    S_, K_ = (int(x) for x in args.c4_point.split(","))
+    if S_ % world:
+        raise SystemExit(f"--c4-point: S = {S_} is not a multiple of n_shard = {world}")
+    state: dict = {"max_s": 1 << 30}
+    sweep = ((S_, K_),)
+    c4_leg(world, rank, dev, group, distributed, comm_name, args.steps, state, variants=("eager",), sweep=sweep,
+           warmup_calls=-(-args.warmup // 8))
+    line: dict = {}
+    if world == 1 or args.c4_graph:
+        run_graph_variant(line, "c4", world, rank, dev, group, distributed, comm_name, args.steps, state, sweep=sweep)
+    point = state["points"][(S_, K_)]
+    if "ms_per_step" not in point:
+        raise SystemExit(f"c4 leg failed: {point}")
+    which = "graph" if point.get("graph_ms_per_step", 1e30) <= point.get("eager_ms_per_step", 1e30) else "eager"
+    n_neg = point["negatives_per_triple"]
+    valu = dict(point["valu"])
+    valu.update(kernel="k_l1_fwd_pk + k_neg_shared_bwd (both products), whole step", peak=VALU_PEAK_TLOPS,
+                achieved=valu["achieved_lane_ops"], unit="T lane-ops/s", traffic=None,
+                note="the L1 distance matrix has no matrix-core form: 7 VALU lane-instructions per (query, candidate, "
+                     "column) over forward + two backward products; achieved = that count / whole step time")
+    out = {
+        "metric": "positive+negative triples scored/sec",
+        "value": point["value"], "unit": "triples/s", "n_gpus": world,
+        "steps": point[f"{which}_steps_timed"], "warmup": max(2, -(-args.warmup // 8)) * 8,
+        "ms_per_step": point["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {
+            "workload": f"ogbl-wikikg2-shaped TransE d=256 fp16 (BASELINE configs[3]), {C4_ROWS_PER_SHARD:,} rows per "
+                        f"shard, n_shard={world}, S={S_} positives per GPU x {n_neg} shared negatives (K={K_} per shard "
+                        "pair + augmentation), EmbeddingMoving, training step (fwd + bwd + C8 + sparse SGD), "
+                        f"{which} launch",
+            "n_shard": world, "shard_bs": S_, "negatives_per_triple": n_neg, "mode": "train", "collectives": comm_name,
+            "launch": which,
+        },
+        "roofline": valu,
+        "c4": c4_summary(state, world, comm_name),
+    }
+    if world > 1:
+        try:
+            out["xgmi"] = xgmi_leg(group, world, rank, dev)
+        except Exception as e:  # noqa: BLE001
+            out["xgmi"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if rank == 0 and world == 1 and not distributed and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_c4(min(S_, 1024), K_)
+    finish(out, rank, distributed, group)
 
 
 if __name__ == "__main__":

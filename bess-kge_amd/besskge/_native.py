@@ -82,6 +82,7 @@ class OptDesc(ctypes.Structure):
 
 OPT_SGD, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
 FLAG_FP32_MATH = 1  # BESS_FLAG_FP32_MATH (ModelDesc.reserved[0] of the four native scorers)
+FLAG_PREZEROED = 2  # BESS_FLAG_PREZEROED: the targets of bess_neg_score_shared_bwd are zero on entry
 
 
 class KillDesc(ctypes.Structure):
@@ -140,11 +141,15 @@ SIGNATURES = {
     "bess_mask_scores": [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _vp],
     "bess_loss_fwd_bwd": [_LD, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
     "bess_loss_fwd_bwd_norm": [_LD, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    "bess_loss_fwd_bwd_one_launch": [_LD, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "bess_scatter_add_rows": [_vp, _i32, _vp, _vp, _i64, _f32, _vp],
     "bess_sparse_sgd": [_i32, _i32, _vp, _vp, _vp, _i64, _f32, _vp],
     "bess_dense_sgd": [_i32, _vp, _vp, _i64, _f32, _vp],
     "bess_segment_index_workspace": [_i64, ctypes.POINTER(ctypes.c_size_t)],
     "bess_build_segment_index": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, ctypes.c_size_t, _vp],
+    "bess_step_prologue": [_i32, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint32),
+                           ctypes.POINTER(_i64), _i32, ctypes.POINTER(_vp), ctypes.POINTER(_i64), _i32, _vp, _vp, _vp, _vp,
+                           _vp, _i64, _vp],
     "bess_neg_pertriple_grad_segments": [_MD, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _f32,
                                          _vp, _i64, _vp, _vp, _vp],
     "bess_apply_segments_sgd": [_i32, _i32, _vp, _vp, _vp, _i64, _vp, _f32, _vp],
@@ -361,6 +366,12 @@ class RowSource:
 
     def __len__(self) -> int:
         return _row_count(self.base, self.idx)
+
+
+def copy_desc(d: ModelDesc) -> ModelDesc:
+    c = ModelDesc()
+    ctypes.memmove(ctypes.byref(c), ctypes.byref(d), ctypes.sizeof(ModelDesc))
+    return c
 
 
 def make_desc(scorer: int, norm_p: int, table: torch.Tensor, rel_width: int) -> ModelDesc:
@@ -756,9 +767,20 @@ def neg_score_shared_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, pad_
     return out if ld == n_neg else out[:, :n_neg]
 
 
+def shared_bwd_buffer(d: ModelDesc, nq: int, n_neg: int, device: torch.device) -> Optional[torch.Tensor]:
+    """The [nq + n_neg, W] f32 allocation that `neg_score_shared_bwd(..., prezeroed=buf)` takes for d_query and
+    d_neg when a caller clears it itself (with the other fills of its step: `step_prologue`); None for scorers
+    whose query and candidate rows differ in width."""
+    if query_width(d) != d.width or d.scorer == AFFINE:
+        return None
+    return torch.empty((nq + n_neg, d.width), dtype=torch.float32, device=device)
+
+
 def neg_score_shared_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, out: torch.Tensor,
-                         d_out: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Returns (d_query [nq, W], d_neg [n_neg, W])."""
+                         d_out: torch.Tensor, prezeroed: Optional[torch.Tensor] = None
+                         ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Returns (d_query [nq, W], d_neg [n_neg, W]).  `prezeroed`: a `shared_bwd_buffer` the caller has
+    already cleared on this stream - the call then writes into it and does not clear anything."""
     nq, n_neg = int(query.shape[0]), len(neg)
     dev = _neg_operands(d, query, neg, n_neg)
     _same_device([("d_out", d_out), ("out", out), ("query", query)])
@@ -770,7 +792,13 @@ def neg_score_shared_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, out:
     if d.scorer == AFFINE:
         neg, hat, inv = _affine_candidates(d, neg)
     qw = query_width(d)
-    if qw == d.width:  # one allocation: the library then zeroes both partial-sum targets with one memset
+    if prezeroed is not None:
+        if tuple(prezeroed.shape) != (nq + n_neg, d.width) or prezeroed.dtype != torch.float32 or qw != d.width:
+            raise ValueError("neg_score_shared_bwd: `prezeroed` must come from shared_bwd_buffer()")
+        dq, dn = prezeroed[:nq], prezeroed[nq:]
+        d = copy_desc(d)
+        d.reserved[0] |= FLAG_PREZEROED
+    elif qw == d.width:  # one allocation: the library then zeroes both partial-sum targets with one memset
         both = torch.empty(((nq + n_neg), qw), dtype=torch.float32, device=dev)
         dq, dn = both[:nq], both[nq:]
     else:
@@ -807,6 +835,9 @@ def mask_scores(neg: torch.Tensor, diag_step: int, ht: bool, ppp: int, mask: Opt
     _check(rc, "bess_mask_scores")
 
 
+_loss_counters: dict = {}  # (device, raw stream) -> int32 [1], zero between calls
+
+
 def loss_fwd_bwd(l: LossDesc, pos: torch.Tensor, neg: torch.Tensor, weight: torch.Tensor, want_grad: bool,
                  want_norm: bool = False) -> Tuple[Any, ...]:
     """Returns (loss [] f32, d_pos [S] | None, d_neg [S, N] | None) - and, with `want_norm`, a fourth item:
@@ -823,11 +854,16 @@ def loss_fwd_bwd(l: LossDesc, pos: torch.Tensor, neg: torch.Tensor, weight: torc
     dn = torch.empty((S, N), dtype=torch.float32, device=dev) if want_grad else None
     norm = torch.empty((S, 2), dtype=torch.float32, device=dev) if want_norm else None
     with _on(dev):
-        rc = load().bess_loss_fwd_bwd_norm(ctypes.byref(l), pos.data_ptr(), neg.data_ptr(), S, N, N, weight.data_ptr(),
-                                           weight.numel(), row_loss.data_ptr(), loss.data_ptr(),
-                                           dp.data_ptr() if want_grad else 0, dn.data_ptr() if want_grad else 0, N,
-                                           norm.data_ptr() if want_norm else 0, _stream(dev))
-    _check(rc, "bess_loss_fwd_bwd_norm")
+        stream = _stream(dev)
+        # (one launch: its last workgroup sums the row terms; the counter it needs is zero between calls)
+        counter = _loss_counters.get((dev, stream))
+        if counter is None:
+            counter = _loss_counters[(dev, stream)] = torch.zeros((1,), dtype=torch.int32, device=dev)
+        rc = load().bess_loss_fwd_bwd_one_launch(ctypes.byref(l), pos.data_ptr(), neg.data_ptr(), S, N, N,
+                                                 weight.data_ptr(), weight.numel(), row_loss.data_ptr(), loss.data_ptr(),
+                                                 dp.data_ptr() if want_grad else 0, dn.data_ptr() if want_grad else 0, N,
+                                                 norm.data_ptr() if want_norm else 0, counter.data_ptr(), stream)
+    _check(rc, "bess_loss_fwd_bwd_one_launch")
     if want_norm:
         return loss.reshape(()), dp, dn, norm
     return loss.reshape(()), dp, dn
@@ -911,16 +947,7 @@ class SegmentIndex:
         need = ctypes.c_size_t(0)
         _check(load().bess_segment_index_workspace(n, ctypes.byref(need)), "bess_segment_index_workspace")
         ws = torch.empty((need.value,), dtype=torch.uint8, device=dev)
-        self.refs = torch.empty((n,), dtype=torch.int32, device=dev)
-        self.seg_rows = torch.empty((n,), dtype=torch.int32, device=dev)
-        self.seg_offsets = torch.empty((n + 1,), dtype=torch.int32, device=dev)
-        self.n_seg = torch.empty((1,), dtype=torch.int32, device=dev)  # always written by the build
-        self.n_refs = n
-        self.max_seg = min(n, int(n_rows))
-        # rows with more than SEGMENT_CAP references (padded candidate lists, hot entities): listed
-        # here, reduced by the whole device instead of one 16-lane group (include/besskge_hip.h)
-        self.long_cap = n // SEGMENT_CAP + 1
-        self.long_segs = torch.empty((self.long_cap + 1,), dtype=torch.int32, device=dev)
+        self._allocate(n, n_rows, dev)
         bits = max(1, int(n_rows - 1).bit_length())
         with _on(dev), _Timed("bess_build_segment_index", dev):
             rc = load().bess_build_segment_index(ip, n, bits, self.refs.data_ptr(), self.seg_rows.data_ptr(),
@@ -928,6 +955,26 @@ class SegmentIndex:
                                                  self.long_segs.data_ptr(), self.long_cap, ws.data_ptr(),
                                                  need.value, _stream(dev))
         _check(rc, "bess_build_segment_index")
+        self._long_scratch(dev, width, scratch)
+
+    def _allocate(self, n: int, n_rows: int, dev: torch.device) -> None:
+        # ONE allocation for the index arrays (a notebook-size step builds an index per update: five
+        # torch.empty calls were a measurable part of its host time)
+        long_cap = n // SEGMENT_CAP + 1
+        na, nb = (n + 3) & ~3, (n + 4) & ~3  # every array starts on a 16-byte boundary
+        buf = torch.empty((2 * na + nb + 4 + long_cap + 1,), dtype=torch.int32, device=dev)
+        self.refs = buf[:n]
+        self.seg_rows = buf[na: na + n]
+        self.seg_offsets = buf[2 * na: 2 * na + n + 1]
+        self.n_seg = buf[2 * na + nb: 2 * na + nb + 1]  # always written by the build
+        self.n_refs = n
+        self.max_seg = min(n, int(n_rows))
+        # rows with more than SEGMENT_CAP references (padded candidate lists, hot entities): listed
+        # here, reduced by the whole device instead of one 16-lane group (include/besskge_hip.h)
+        self.long_cap = long_cap
+        self.long_segs = buf[2 * na + nb + 4:]
+
+    def _long_scratch(self, dev: torch.device, width: int, scratch: Optional[dict]) -> None:
         # scratch of the long-row tier: zero before the first use, left zero / consistent by every use;
         # zeroed here, i.e. on the stream that builds the index (off the critical path of a training step)
         if scratch is not None:
@@ -941,6 +988,59 @@ class SegmentIndex:
         else:
             self.long_count = torch.zeros((self.long_cap,), dtype=torch.int32, device=dev)
             self.long_grad = torch.zeros((self.long_cap, int(width)), dtype=torch.float32, device=dev) if width else None
+
+
+def step_prologue(jobs: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], int]],
+                  id_lists: Sequence[torch.Tensor] = (), n_rows: int = 0, width: int = 0,
+                  scratch: Optional[dict] = None) -> Optional[SegmentIndex]:
+    """ONE launch in front of a notebook-size training step (`bess_step_prologue`): the copy / fill `jobs`
+    (dst, src | None, fill word) over 4-byte elements - dst (and src) contiguous, same number of elements - and
+    the segment index of the concatenation of the int32 row-id `id_lists` (read where they are; `n_rows` rows
+    in the table they index), returned as a SegmentIndex, or None without lists."""
+    if not jobs and not id_lists:
+        return None
+    if len(jobs) > MAX_WORD_JOBS or len(id_lists) > MAX_ROW_LISTS:
+        raise ValueError("step_prologue: too many jobs / id lists")
+    tensors = [("job dst", j[0]) for j in jobs] + [("job src", j[1]) for j in jobs] + [("ids", x) for x in id_lists]
+    dev = _same_device(tensors)
+    nj = len(jobs)
+    dst, src = (_vp * max(1, nj))(), (_vp * max(1, nj))()
+    val, words = (ctypes.c_uint32 * max(1, nj))(), (_i64 * max(1, nj))()
+    for i, (d_, s_, v_) in enumerate(jobs):
+        if d_.element_size() != 4 or not d_.is_contiguous():
+            raise ValueError("step_prologue: job targets must be contiguous tensors of 4-byte elements")
+        if s_ is not None and (s_.element_size() != 4 or not s_.is_contiguous() or s_.numel() != d_.numel()):
+            raise ValueError("step_prologue: a job's source must match its target")
+        dst[i], src[i], val[i], words[i] = d_.data_ptr(), (s_.data_ptr() if s_ is not None else None), int(v_), d_.numel()
+    nl = len(id_lists)
+    lp, ll = (_vp * max(1, nl))(), (_i64 * max(1, nl))()
+    n_ids = 0
+    for i, x in enumerate(id_lists):
+        if x.dtype != torch.int32 or not x.is_contiguous():
+            raise ValueError("step_prologue: id lists must be contiguous int32 tensors")
+        lp[i], ll[i] = x.data_ptr(), x.numel()
+        n_ids += int(x.numel())
+    seg = None
+    if nl:
+        if not 0 < n_ids <= SMALL_INDEX_MAX:
+            raise ValueError(f"step_prologue: {n_ids} row ids (1 .. {SMALL_INDEX_MAX})")
+        seg = SegmentIndex.__new__(SegmentIndex)
+        seg._allocate(n_ids, n_rows, dev)
+    bits = max(1, int(max(1, n_rows) - 1).bit_length())
+    with _on(dev), _Timed("bess_step_prologue", dev):
+        rc = load().bess_step_prologue(
+            nj, dst, src, val, words, nl, lp, ll, bits,
+            seg.refs.data_ptr() if seg else None, seg.seg_rows.data_ptr() if seg else None,
+            seg.seg_offsets.data_ptr() if seg else None, seg.n_seg.data_ptr() if seg else None,
+            seg.long_segs.data_ptr() if seg else None, seg.long_cap if seg else 0, _stream(dev))
+    _check(rc, "bess_step_prologue")
+    if seg is not None:
+        seg._long_scratch(dev, width, scratch)
+    return seg
+
+
+MAX_WORD_JOBS = 8  # BESS_MAX_WORD_JOBS
+SMALL_INDEX_MAX = 15360  # BESS_SMALL_INDEX_MAX
 
 
 class _IdentitySegments:
@@ -1357,6 +1457,31 @@ class Communicator:
         with torch.cuda.device(device):
             _check(load().bess_comm_init_rank(self.world, self.rank, buf, ctypes.byref(self._h)),
                    "bess_comm_init_rank")
+
+    @classmethod
+    def init_all(cls, devices: Sequence[torch.device]) -> List["Communicator"]:
+        """One process driving several GPUs (`bess_comm_init_all` = ncclCommInitAll): communicator r of the
+        clique lives on `devices[r]`.  Collectives of the clique's ranks must be issued from different host
+        threads or inside one RCCL group; with one device it is a self-contained one-rank communicator."""
+        n = len(devices)
+        if n < 1 or any(d.type != "cuda" for d in devices):
+            raise RuntimeError("besskge: communicators live on HIP devices (there is no CPU fallback)")
+        ids = (ctypes.c_int32 * n)(*[d.index if d.index is not None else torch.cuda.current_device() for d in devices])
+        handles = (_vp * n)()
+        _check(load().bess_comm_init_all(n, ids, handles), "bess_comm_init_all")
+        out = []
+        for r, d in enumerate(devices):
+            c = cls.__new__(cls)
+            c.world, c.rank, c.device = n, r, torch.device("cuda", int(ids[r]))
+            c._h = _vp(handles[r])
+            out.append(c)
+        return out
+
+    def info(self) -> Tuple[int, int, int]:
+        """(world, rank, device index) as the library holds them (`bess_comm_info`)."""
+        w, r, d = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        _check(load().bess_comm_info(self._h, ctypes.byref(w), ctypes.byref(r), ctypes.byref(d)), "bess_comm_info")
+        return w.value, r.value, d.value
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:

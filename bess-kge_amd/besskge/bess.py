@@ -87,6 +87,8 @@ class _NegGroup:
         self.dq: Optional[torch.Tensor] = None  # d loss / d query from the fused training forward
         self.partials: Any = None  # ScoreMoving: online-softmax partials of this shard's negatives (fused forward)
         self.kill: Any = None  # K7 applied together with the scores (shared negatives, one group)
+        self.neg_parts: Optional[List[torch.Tensor]] = None  # neg.idx = their concatenation, written by the prologue
+        self.bwd_buf: Optional[torch.Tensor] = None  # targets of the shared backward, cleared by the prologue
 
 
 class _ReplicaStep:
@@ -113,6 +115,9 @@ class _ReplicaStep:
         self.loss_norm: Optional[torch.Tensor] = None  # [S, 2] (m, L / C) of each triple's softmax (ScoreMoving, fused)
         self.kill_applied = False  # the scoring call already applied K7 (mask / augment kill)
         self.fused_qt = False  # query + positive score came out of one launch (so will their backwards)
+        # training: copy / fill jobs (dst, src | None, fill word) run by ONE launch in front of the step's kernels
+        # (`nat.step_prologue`), together with the index of the step's small update lists
+        self.jobs: Optional[List[Tuple[torch.Tensor, Optional[torch.Tensor], int]]] = None
 
 
 class _PendingUpdate:
@@ -496,68 +501,103 @@ class BessKGE(torch.nn.Module, ABC):
         `ahead`: (row-id lists, their SegmentIndex) built earlier on the side stream (`_small_index_ahead`);
         used when the lists turned out to be exactly those."""
         ids = [i.reshape(-1) for i, _ in contributions]
+        grads = [g.contiguous() for _, g in contributions]
         seg = None
-        if ahead is not None and len(ahead[0]) == len(ids) and all(
-                a.data_ptr() == b.data_ptr() and a.numel() == b.numel() for a, b in zip(ahead[0], ids)):
-            seg = ahead[1]
+        if ahead is not None:
+            seg, grads = self._match_ahead(ahead, ids, grads)
         if seg is None:
             seg = nat.SegmentIndex(torch.cat(ids).contiguous(), table.shape[0],
                                    scratch=self.__dict__.setdefault("_seg_scratch", {}))
         o, s1, s2 = self._opt_desc(opt, table)
         self._assign_state_rows(table, seg)
-        grads = [g.contiguous() for _, g in contributions]
         if len(grads) > nat.MAX_ROW_LISTS:
             grads = [torch.cat(grads, dim=0)]
         nat.coalesced_update(o, table, seg, grads, s1, s2)
 
-    def _small_index_ahead(self, steps: List[_ReplicaStep], optimizer: Any) -> Dict[int, Any]:
-        """The index of a shard's small lists (heads, tails, shared negatives, rows returned by C8) only needs
-        their row ids, which are inputs of the step: when the update will coalesce them (f16 shard or a
-        stateful optimiser, no per-triple group reduced by the segmented K9), it is built here - on the side
-        stream, right behind the forward kernels - instead of on the critical path after the backward.  The
-        lists are named in the order the backward will hand them over (`_apply_optimizer` checks that)."""
+    @staticmethod
+    def _match_ahead(ahead: Tuple[List[torch.Tensor], Any], ids: List[torch.Tensor], grads: List[torch.Tensor]
+                     ) -> Tuple[Any, List[torch.Tensor]]:
+        """Is the index built ahead the index of exactly these lists?  A list of the step may be the concatenation
+        of several planned lists (the candidate list of an augmented step, named by its parts): its gradient
+        rows are then handed over in the same pieces.  (index | None, gradient arrays per planned list)."""
+        plan, seg = ahead
+        out: List[torch.Tensor] = []
+        k = 0
+        for i, g in zip(ids, grads):
+            if k < len(plan) and plan[k].data_ptr() == i.data_ptr() and plan[k].numel() == i.numel():
+                out.append(g)
+                k += 1
+                continue
+            # a concatenation of the next planned lists?
+            n, start = int(i.numel()), k
+            got = 0
+            while k < len(plan) and got < n:
+                got += int(plan[k].numel())
+                k += 1
+            if got != n or k - start < 2:
+                return None, grads
+            at = 0
+            for part in plan[start:k]:
+                out.append(g[at: at + part.numel()])
+                at += part.numel()
+        return (seg, out) if k == len(plan) else (None, grads)
+
+    def _small_plan(self, st: _ReplicaStep, optimizer: Any) -> Optional[List[torch.Tensor]]:
+        """Row-id lists of a shard's small update lists (heads, tails, shared negatives, rows returned by C8), in
+        the order the backward will hand them over (`_apply_optimizer` checks that) - or None when the update
+        will not coalesce them through one index (plain SGD on an fp32 shard: atomics; per-triple groups
+        reduced by the segmented K9 in a way that leaves the lists unknown until the backward has run).  A
+        candidate list that the step's prologue concatenates is named by its parts: the index is built in the
+        same launch, from the lists as the sampler handed them over."""
         plain = not hasattr(optimizer, "kind") or optimizer.is_plain_sgd
         if plain and self.score_fn.entity_embedding.dtype == torch.float32:
-            return {}
+            return None
         fn = self.score_fn
-        out: Dict[int, Any] = {}
-        for st in steps:
-            plan: List[torch.Tensor] = []
-            ok = True
+        plan: List[torch.Tensor] = []
 
-            def add(src: RowSource) -> None:
-                if src.base is st.table and src.idx is not None:
-                    plan.append(src.idx.reshape(-1))
+        def add(src: RowSource, parts: Optional[List[torch.Tensor]] = None) -> None:
+            if src.base is st.table and src.idx is not None:
+                plan.extend(parts if parts is not None else [src.idx.reshape(-1)])
 
-            head = RowSource(st.table, st.head_idx)
-            if not st.fused_qt:
+        head = RowSource(st.table, st.head_idx)
+        if not st.fused_qt:
+            add(head)
+            add(st.tail)
+        for g in st.groups:
+            if not g.shared and g.neg.base is st.table and fn.supports_fused_segments:
+                # reduced by the segmented K9.  With ONE such group and a stateful optimiser the small lists
+                # ride along there (`_apply_optimizer_fused`) through an index of their own - the one planned
+                # here; several groups go through `_apply_optimizer` with lists that do not exist yet
+                if not (len(st.groups) == 1 and not plain and st.n == 1):
+                    return None
+            else:
+                add(g.neg, g.neg_parts)
+            if st.fused_qt:
                 add(head)
                 add(st.tail)
-            for g in st.groups:
-                if not g.shared and g.neg.base is st.table and fn.supports_fused_segments:
-                    # reduced by the segmented K9.  With ONE such group and a stateful optimiser the small lists
-                    # ride along there (`_apply_optimizer_fused`) through an index of their own - the one built
-                    # here; several groups go through `_apply_optimizer` with lists that do not exist yet
-                    ok = len(st.groups) == 1 and not plain and st.n == 1
-                    if not ok:
-                        break
-                else:
-                    add(g.neg)
-                if st.fused_qt:
-                    add(head)
-                    add(st.tail)
-                else:
-                    add(g.ent)
-            if not ok or not plan:
+            else:
+                add(g.ent)
+        if not plan:
+            return None
+        if st.n > 1:
+            if st.ext_src is not None:
+                add(st.ext_src)
+            plan.append(st.send_idx.reshape(-1))
+        return plan
+
+    def _small_index_ahead(self, steps: List[_ReplicaStep], optimizer: Any) -> Dict[int, Any]:
+        """The index of a shard's small lists only needs their row ids, which are inputs of the step: long lists
+        (more than the prologue's one workgroup indexes) are indexed here - on the side stream, right behind the
+        forward kernels - instead of on the critical path after the backward."""
+        out: Dict[int, Any] = {}
+        for st in steps:
+            plan = self._small_plan(st, optimizer)
+            if plan is None:
                 continue
             if sum(int(x.numel()) for x in plan) < 4096:
                 # a short list is indexed in ~10 us: not worth a fork / join of the streams (which costs
                 # about as much inside a replayed hipGraph); `_apply_optimizer` builds it where it is needed
                 continue
-            if st.n > 1:
-                if st.ext_src is not None:
-                    add(st.ext_src)
-                plan.append(st.send_idx.reshape(-1))
             dev = st.table.device
             side = self._aux_stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -565,6 +605,30 @@ class BessKGE(torch.nn.Module, ABC):
                 out[id(st)] = (plan, nat.SegmentIndex(torch.cat(plan).contiguous(), st.table.shape[0],
                                                       scratch=self.__dict__.setdefault("_seg_scratch", {})))
         return out
+
+    def _launch_prologue(self, st: _ReplicaStep, optimizer: Any, d_rel: Optional[torch.Tensor]) -> Optional[Any]:
+        """ONE launch in front of a training step's kernels (`bess_step_prologue`): the concatenated candidate
+        list of an augmented step, the cleared relation gradient and backward targets, and - when the update
+        coalesces them and they are few enough for one workgroup - the index of the step's small update lists.
+        Returns what `_small_index_ahead` would have: (lists, their SegmentIndex), or None."""
+        jobs = st.jobs or []
+        desc = self.score_fn.kernel_desc()
+        for g in st.groups:
+            if g.shared and len(jobs) < nat.MAX_WORD_JOBS - 1 and self.score_fn.supports_fused_query_triple:
+                g.bwd_buf = nat.shared_bwd_buffer(desc, len(g.ent), len(g.neg), st.table.device)
+                if g.bwd_buf is not None:
+                    jobs.append((g.bwd_buf, None, 0))
+        if d_rel is not None:
+            jobs.append((d_rel, None, 0))
+        plan = self._small_plan(st, optimizer)
+        if plan is not None and sum(int(x.numel()) for x in plan) > nat.SMALL_INDEX_MAX:
+            plan = None
+        if plan is not None and len(plan) > nat.MAX_ROW_LISTS:
+            plan = None
+        seg = nat.step_prologue(jobs, plan or (), st.table.shape[0], st.table.shape[1],
+                                self.__dict__.setdefault("_seg_scratch", {}))
+        st.jobs = None
+        return (plan, seg) if plan is not None else None
 
     def _apply_optimizer_dense(self, opt: Any, table: torch.Tensor, grad: torch.Tensor) -> None:
         """Optimiser step on every row of a small replicated table (relation table, dense parameters):
@@ -588,13 +652,13 @@ class BessKGE(torch.nn.Module, ABC):
         if extras:
             ids = [i.reshape(-1) for i, _ in extras]
             grads = [x.contiguous() for _, x in extras]
+            xseg = None
+            if ahead is not None:  # built ahead: by the step's prologue, or on the side stream behind the forward
+                xseg, grads = self._match_ahead(ahead, ids, grads)
+            if xseg is None:
+                xseg = nat.SegmentIndex(torch.cat(ids).contiguous(), table.shape[0])
             if len(grads) > nat.MAX_ROW_LISTS:
                 grads = [torch.cat(grads, dim=0)]
-            if ahead is not None and len(ahead[0]) == len(ids) and all(
-                    a.data_ptr() == b.data_ptr() and a.numel() == b.numel() for a, b in zip(ahead[0], ids)):
-                xseg = ahead[1]  # built on the side stream behind the forward (`_small_index_ahead`)
-            else:
-                xseg = nat.SegmentIndex(torch.cat(ids).contiguous(), table.shape[0])
             xsum = nat.coalesced_update(None, table, xseg, grads, sum_only=True)
             xmap, keep = nat.map_extra_rows(seg, xseg)
         self._assign_state_rows(table, seg)
@@ -828,8 +892,11 @@ class EmbeddingMovingBessKGE(BessKGE):
         # NativeGroup: gather into the send buffer + all-to-all behind one entry point (bess_pack_exchange)
         packed_exchange = (hasattr(group, "pack_exchange")
                            and (W * self.score_fn.entity_embedding.element_size()) % 16 == 0)
+        prologue = self.__dict__.get("_small_early") is not None  # a training step that applies its own update
         for shard, b in zip(group.local_shards, batches):
             st = _ReplicaStep()
+            if prologue:
+                st.jobs = []
             st.table = self._local_table(shard)
             dev = st.table.device
             head, rel, tail, neg = (b[k].to(dev) for k in ("head", "relation", "tail", "negative"))
@@ -869,6 +936,17 @@ class EmbeddingMovingBessKGE(BessKGE):
             g0 = st.groups[0]
             st.fused_qt = (len(st.groups) == 1 and g0.sel is None and fn.supports_fused_query_triple
                            and st.tail.base.dtype == st.table.dtype)
+            early = getattr(self, "_small_early", None)
+            if early is not None:
+                # training: what the step's kernels need prepared - the concatenated candidate list, cleared
+                # gradient targets, the index of the small update lists (it needs only row ids) - in ONE launch
+                d_rel = None
+                if not done:  # the relation gradient is shared by the replicas hosted here
+                    d_rel = self.__dict__["_step_d_rel"] = torch.empty(rel_table.shape, dtype=torch.float32,
+                                                                       device=rel_table.device)
+                ahead = self._launch_prologue(st, self._ahead_optimizer, d_rel)
+                if ahead is not None:
+                    early[id(st)] = ahead
             if st.fused_qt:
                 # K2 + K3 + K6: the query of the one negative-scoring problem and the positive scores, one launch
                 g0.query, st.positive_score = fn.query_triple_fwd(g0.side, RowSource(st.table, st.head_idx), st.tail,
@@ -876,10 +954,8 @@ class EmbeddingMovingBessKGE(BessKGE):
             else:
                 st.positive_score, st.triple_ctx = fn.triple_fwd(
                     RowSource(st.table, st.head_idx), st.tail, st.rel_idx)
-            early = getattr(self, "_small_early", None)
-            if early is not None:
-                # training: the index of the step's small update lists needs only row ids - start it on the side
-                # stream before the scoring kernels are queued, so that it runs under them
+            if early is not None and id(st) not in early:
+                # longer lists: indexed on the side stream, started before the scoring kernels are queued
                 early.update(self._small_index_ahead([st], self._ahead_optimizer))
             fz = fuse[len(done)] if fuse else None
             if fz is not None and fz.get("masked"):
@@ -991,6 +1067,15 @@ class EmbeddingMovingBessKGE(BessKGE):
             if self.augment_negative:
                 # positives of the group become extra candidates (bess.py:369-393, 430-448)
                 assert pos_src.base is base
+                if st.jobs is not None and Bg == 1 and len(st.jobs) + 4 <= nat.MAX_WORD_JOBS:
+                    # training step: the concatenation is one of the jobs of the step's prologue launch
+                    parts = [pos_src.idx.reshape(-1).contiguous(), rows2d.reshape(-1).contiguous()]
+                    lst = torch.empty((parts[0].numel() + parts[1].numel(),), dtype=torch.int32, device=dev)
+                    st.jobs.append((lst[: parts[0].numel()], parts[0], 0))
+                    st.jobs.append((lst[parts[0].numel():], parts[1], 0))
+                    g = _NegGroup(side, sel, ent_src, rel, RowSource(base, lst), True, int(lst.numel()))
+                    g.neg_parts = parts
+                    return g
                 rows2d = torch.cat([pos_src.idx.reshape(Bg, -1), rows2d], dim=1)
             if sharing or Bg == 1:
                 lst = rows2d.reshape(-1).contiguous()
@@ -1065,8 +1150,11 @@ class EmbeddingMovingBessKGE(BessKGE):
         rel_table = fn.relation_embedding.data
         results = []
         # (the relation gradient of accumulated micro-batches is summed in the first one's buffer)
-        d_rel = pending[0].d_rel if pending else torch.zeros(rel_table.shape, dtype=torch.float32,
-                                                             device=rel_table.device)
+        d_rel = self.__dict__.pop("_step_d_rel", None)  # allocated and cleared by the step's prologue launch
+        if pending:
+            d_rel = pending[0].d_rel
+        elif d_rel is None:
+            d_rel = torch.zeros(rel_table.shape, dtype=torch.float32, device=rel_table.device)
         back: List[torch.Tensor] = []
         deferred: List[Tuple[torch.Tensor, _NegGroup, torch.Tensor]] = []
         local_updates: List[List[Tuple[torch.Tensor, torch.Tensor]]] = []
@@ -1105,7 +1193,7 @@ class EmbeddingMovingBessKGE(BessKGE):
                           dn3[:, cut:].reshape(-1, dn3.shape[-1]).contiguous()]
             for g, go in zip(st.groups, d_outs):
                 if g.shared:
-                    dq, dn = nat.neg_score_shared_bwd(desc, g.query, g.neg, g.out, go)
+                    dq, dn = nat.neg_score_shared_bwd(desc, g.query, g.neg, g.out, go, prezeroed=g.bwd_buf)
                     sink(g.neg, dn)
                 elif g.neg.base is st.table and fn.supports_fused_segments:
                     # per-triple negatives read straight from the shard: no [S*N, W]

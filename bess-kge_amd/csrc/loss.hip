@@ -54,17 +54,12 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x
 // with 16-byte stores; CH = 0: any shape, the row is streamed from memory (cache) in each of the passes, 4 bytes per
 // lane; CH = -1: the same with 16-byte accesses (longer rows of the 16-byte-aligned shapes).
 template <int KIND, bool ADV, bool GRAD, int CH>
-__global__ __launch_bounds__(256) void k_loss_rows(bess_loss_desc l, const float* __restrict__ pos,
-                                                   const float* __restrict__ neg, int64_t n_triple,
-                                                   int64_t n_neg, int64_t ld_neg,
-                                                   const float* __restrict__ weight,
-                                                   int64_t weight_len, float* __restrict__ row_loss,
-                                                   float* __restrict__ d_pos,
-                                                   float* __restrict__ d_neg, int64_t ld_dneg,
-                                                   float* __restrict__ row_norm) {
+__device__ __forceinline__ void loss_row_impl(const bess_loss_desc& l, const float* __restrict__ pos,
+                                              const float* __restrict__ neg, int64_t s, int64_t n_neg, int64_t ld_neg,
+                                              const float* __restrict__ weight, int64_t weight_len,
+                                              float* __restrict__ row_loss, float* __restrict__ d_pos,
+                                              float* __restrict__ d_neg, int64_t ld_dneg, float* __restrict__ row_norm) {
     const int lane = threadIdx.x & 63;
-    const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
-    if (s >= n_triple) return;
     const float* nr = neg + s * ld_neg;
     float* dn = GRAD ? d_neg + s * ld_dneg : nullptr;
     const float w = weight[weight_len == 1 ? 0 : s];
@@ -186,6 +181,57 @@ __global__ __launch_bounds__(256) void k_loss_rows(bess_loss_desc l, const float
     }
 }
 
+template <int KIND, bool ADV, bool GRAD, int CH>
+__device__ __forceinline__ void loss_row(const bess_loss_desc& l, const float* __restrict__ pos,
+                                         const float* __restrict__ neg, int64_t s, int64_t n_neg, int64_t ld_neg,
+                                         const float* __restrict__ weight, int64_t weight_len, float* __restrict__ row_loss,
+                                         float* __restrict__ d_pos, float* __restrict__ d_neg, int64_t ld_dneg,
+                                         float* __restrict__ row_norm) {
+    loss_row_impl<KIND, ADV, GRAD, CH>(l, pos, neg, s, n_neg, ld_neg, weight, weight_len, row_loss, d_pos, d_neg, ld_dneg,
+                                       row_norm);
+}
+
+template <int KIND, bool ADV, bool GRAD, int CH>
+__global__ __launch_bounds__(256) void k_loss_rows(bess_loss_desc l, const float* __restrict__ pos,
+                                                   const float* __restrict__ neg, int64_t n_triple,
+                                                   int64_t n_neg, int64_t ld_neg,
+                                                   const float* __restrict__ weight,
+                                                   int64_t weight_len, float* __restrict__ row_loss,
+                                                   float* __restrict__ d_pos,
+                                                   float* __restrict__ d_neg, int64_t ld_dneg,
+                                                   float* __restrict__ row_norm, int32_t* __restrict__ counter,
+                                                   float* __restrict__ loss) {
+    const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (s < n_triple)
+        loss_row<KIND, ADV, GRAD, CH>(l, pos, neg, s, n_neg, ld_neg, weight, weight_len, row_loss, d_pos, d_neg, ld_dneg,
+                                      row_norm);
+    if (!counter) return;  // (uniform: the sum is a second launch, k_sum_rows)
+    // One launch: the workgroup that finishes last sums the row terms, in a fixed order (bitwise reproducible
+    // whatever the order the workgroups ran in), and leaves the counter at zero for the next call.
+    __shared__ float part[256];
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(counter, 1) == static_cast<int>(gridDim.x) - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n_triple; i += 256) acc += __builtin_nontemporal_load(row_loss + i);
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (threadIdx.x < h) part[threadIdx.x] += part[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        loss[0] = part[0];
+        *counter = 0;
+    }
+}
+
 // Prediction rank of the positive among its candidates (reference metric.py:129-182):
 // 1 + #{candidates better}; "better" = '>' (optimistic), '>=' (pessimistic) or the
 // mean of the two (average).  NaN positives count as -inf.  With worst_inf a
@@ -252,20 +298,20 @@ __global__ __launch_bounds__(1024) void k_sum_rows(const float* __restrict__ row
 template <int KIND, bool ADV, int CH>
 static void launch_loss_ch(bool grad, const bess_loss_desc& l, const float* pos, const float* neg,
                            int64_t S, int64_t N, int64_t ld, const float* w, int64_t wl, float* rl,
-                           float* dp, float* dn, int64_t ldd, float* rn, hipStream_t st) {
+                           float* dp, float* dn, int64_t ldd, float* rn, int32_t* cnt, float* loss, hipStream_t st) {
     const unsigned grid = static_cast<unsigned>(ceil_div(S, 4));
-    if (grad) k_loss_rows<KIND, ADV, true, CH><<<grid, 256, 0, st>>>(l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd, rn);
-    else k_loss_rows<KIND, ADV, false, CH><<<grid, 256, 0, st>>>(l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd, rn);
+    if (grad) k_loss_rows<KIND, ADV, true, CH><<<grid, 256, 0, st>>>(l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd, rn, cnt, loss);
+    else k_loss_rows<KIND, ADV, false, CH><<<grid, 256, 0, st>>>(l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd, rn, cnt, loss);
 }
 
 template <int KIND, bool ADV>
 static void launch_loss(bool grad, const bess_loss_desc& l, const float* pos, const float* neg,
                         int64_t S, int64_t N, int64_t ld, const float* w, int64_t wl, float* rl,
-                        float* dp, float* dn, int64_t ldd, float* rn, hipStream_t st) {
+                        float* dp, float* dn, int64_t ldd, float* rn, int32_t* cnt, float* loss, hipStream_t st) {
     // rows in registers when their shape allows 16-byte accesses (see k_loss_rows)
     const bool vec = N % 4 == 0 && ld % 4 == 0 && reinterpret_cast<uintptr_t>(neg) % 16 == 0 &&
                      (!grad || (ldd % 4 == 0 && reinterpret_cast<uintptr_t>(dn) % 16 == 0));
-#define BESS_LOSS_CH(CH) launch_loss_ch<KIND, ADV, CH>(grad, l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd, rn, st)
+#define BESS_LOSS_CH(CH) launch_loss_ch<KIND, ADV, CH>(grad, l, pos, neg, S, N, ld, w, wl, rl, dp, dn, ldd, rn, cnt, loss, st)
     if (!vec) BESS_LOSS_CH(0);
     else if (N > 256 * 24) BESS_LOSS_CH(-1);
     else if (N <= 256 * 4) BESS_LOSS_CH(4);
@@ -311,11 +357,9 @@ extern "C" int bess_loss_fwd_bwd(const bess_loss_desc* l, const float* pos, cons
                                   ld_dneg, nullptr, stream);
 }
 
-extern "C" int bess_loss_fwd_bwd_norm(const bess_loss_desc* l, const float* pos, const float* neg,
-                                      int64_t n_triple, int64_t n_neg, int64_t ld_neg,
-                                      const float* weight, int64_t weight_len, float* row_loss,
-                                      float* loss, float* d_pos, float* d_neg, int64_t ld_dneg,
-                                      float* row_norm, void* stream) {
+static int loss_impl(const bess_loss_desc* l, const float* pos, const float* neg, int64_t n_triple, int64_t n_neg,
+                     int64_t ld_neg, const float* weight, int64_t weight_len, float* row_loss, float* loss,
+                     float* d_pos, float* d_neg, int64_t ld_dneg, float* row_norm, int32_t* counter, void* stream) {
     BESS_REQUIRE(l, "loss: NULL descriptor");
     BESS_REQUIRE(l->kind >= BESS_LOSS_LOGSIGMOID && l->kind <= BESS_LOSS_SSCE, "loss: unknown kind %d", l->kind);
     BESS_REQUIRE(n_triple > 0 && n_neg > 0 && n_neg < (1ll << 31), "loss: bad sizes");
@@ -328,7 +372,7 @@ extern "C" int bess_loss_fwd_bwd_norm(const bess_loss_desc* l, const float* pos,
     const bool adv = l->adversarial != 0;
 #define BESS_LOSS(KIND, ADV) \
     launch_loss<KIND, ADV>(grad, *l, pos, neg, n_triple, n_neg, ld_neg, weight, weight_len, row_loss, d_pos, d_neg, ld_dneg, \
-                           row_norm, st)
+                           row_norm, counter, loss, st)
     switch (l->kind) {
         case BESS_LOSS_LOGSIGMOID: adv ? BESS_LOSS(BESS_LOSS_LOGSIGMOID, true) : BESS_LOSS(BESS_LOSS_LOGSIGMOID, false); break;
         case BESS_LOSS_MARGIN: adv ? BESS_LOSS(BESS_LOSS_MARGIN, true) : BESS_LOSS(BESS_LOSS_MARGIN, false); break;
@@ -336,8 +380,28 @@ extern "C" int bess_loss_fwd_bwd_norm(const bess_loss_desc* l, const float* pos,
     }
 #undef BESS_LOSS
     if (int e = check_launch("loss rows")) return e;
+    if (counter) return BESS_OK;  // summed by the launch's last workgroup
     k_sum_rows<<<1, 1024, 0, st>>>(row_loss, n_triple, loss);
     return check_launch("loss sum");
+}
+
+extern "C" int bess_loss_fwd_bwd_norm(const bess_loss_desc* l, const float* pos, const float* neg,
+                                      int64_t n_triple, int64_t n_neg, int64_t ld_neg,
+                                      const float* weight, int64_t weight_len, float* row_loss,
+                                      float* loss, float* d_pos, float* d_neg, int64_t ld_dneg,
+                                      float* row_norm, void* stream) {
+    return loss_impl(l, pos, neg, n_triple, n_neg, ld_neg, weight, weight_len, row_loss, loss, d_pos, d_neg, ld_dneg,
+                     row_norm, nullptr, stream);
+}
+
+extern "C" int bess_loss_fwd_bwd_one_launch(const bess_loss_desc* l, const float* pos, const float* neg,
+                                            int64_t n_triple, int64_t n_neg, int64_t ld_neg,
+                                            const float* weight, int64_t weight_len, float* row_loss,
+                                            float* loss, float* d_pos, float* d_neg, int64_t ld_dneg,
+                                            float* row_norm, int32_t* counter, void* stream) {
+    BESS_REQUIRE(counter, "loss_one_launch: NULL counter");
+    return loss_impl(l, pos, neg, n_triple, n_neg, ld_neg, weight, weight_len, row_loss, loss, d_pos, d_neg, ld_dneg,
+                     row_norm, counter, stream);
 }
 
 extern "C" int bess_ranks_from_scores(const float* pos, const float* cand, int64_t n_row, int64_t n_cand,

@@ -425,7 +425,9 @@ static int run_bwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<TE> E, cons
         hipError_t e = fill_words_async(p, 0u, n, st);
         return e == hipSuccess ? BESS_OK : fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
     };
-    if (A.gz > 1 && B.gz > 1 && d_neg == d_query + Q.n * W) {
+    if (d->reserved[0] & BESS_FLAG_PREZEROED) {
+        // the caller cleared both targets (one launch for all fills of a step: bess_step_prologue)
+    } else if (A.gz > 1 && B.gz > 1 && d_neg == d_query + Q.n * W) {
         if (int e = zero(d_query, (Q.n + E.n) * W)) return e;
     } else {
         if (A.gz > 1)

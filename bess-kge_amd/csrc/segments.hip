@@ -67,42 +67,61 @@ static hipError_t cub_sizes(int64_t n, CubSizes* cs) {
 constexpr int SEG_CAP_FOR_SMALL = BESS_SEGMENT_CAP;
 constexpr int SMALL_T = 1024, SMALL_N = SMALL_T * 15;  // up to 15,360 references (2, 4 or 15 per thread)
 
+// The row ids to index may sit in several lists (heads, tails, negatives as the sampler handed them over):
+// reference `at` of their concatenation is entry at - first[l] of list l - no concatenated copy is made.
+struct IdLists {
+    const int32_t* p[BESS_MAX_ROW_LISTS];
+    int32_t first[BESS_MAX_ROW_LISTS + 1];  // first[l] = ids in lists 0 .. l-1; first[n ..] = total
+    int n;
+};
+__device__ __forceinline__ int32_t id_at(const IdLists& L, int at) {
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < BESS_MAX_ROW_LISTS; ++k) l += (k < L.n && at >= L.first[k]) ? 1 : 0;
+    return L.p[l][at - L.first[l]];
+}
+
 template <int SMALL_I>
-__global__ __launch_bounds__(SMALL_T) void k_small_segment_index(const int32_t* __restrict__ idx, int n,
-                                                                 int row_bits, int32_t* __restrict__ refs_sorted,
-                                                                 int32_t* __restrict__ seg_rows,
-                                                                 int32_t* __restrict__ seg_offsets,
-                                                                 int32_t* __restrict__ n_seg,
-                                                                 int32_t* __restrict__ long_segs, int32_t long_cap) {
+struct SmallIndexTemp {
     typedef hipcub::BlockRadixSort<int32_t, SMALL_T, SMALL_I, int32_t> Sort;
     typedef hipcub::BlockDiscontinuity<int32_t, SMALL_T> Disc;
     typedef hipcub::BlockScan<int32_t, SMALL_T> Scan;
-    __shared__ union {
+    union {
         typename Sort::TempStorage sort;
         typename Disc::TempStorage disc;
         typename Scan::TempStorage scan;
     } tmp;
-    __shared__ int32_t n_long;
+    int32_t n_long;
+};
+
+// body of the one-workgroup index (SMALL_T threads, all of them call it)
+template <int SMALL_I>
+__device__ __forceinline__ void small_segment_index(SmallIndexTemp<SMALL_I>& sh, const IdLists& ids, int n,
+                                                    int row_bits, int32_t* __restrict__ refs_sorted,
+                                                    int32_t* __restrict__ seg_rows,
+                                                    int32_t* __restrict__ seg_offsets, int32_t* __restrict__ n_seg,
+                                                    int32_t* __restrict__ long_segs, int32_t long_cap) {
+    typedef typename SmallIndexTemp<SMALL_I>::Sort Sort;
+    typedef typename SmallIndexTemp<SMALL_I>::Disc Disc;
+    typedef typename SmallIndexTemp<SMALL_I>::Scan Scan;
     const int t = threadIdx.x;
     int32_t key[SMALL_I], val[SMALL_I];
 #pragma unroll
     for (int i = 0; i < SMALL_I; ++i) {
         const int at = t * SMALL_I + i;  // blocked arrangement; the tail sorts behind every real row
-        key[i] = at < n ? idx[at] : static_cast<int32_t>(1u << row_bits);  // row ids are < 2^row_bits
+        key[i] = at < n ? id_at(ids, at) : static_cast<int32_t>(1u << row_bits);  // row ids are < 2^row_bits
         val[i] = at;
     }
-    Sort(tmp.sort).Sort(key, val, 0, row_bits + 1);  // LSD radix sort: stable
-    constexpr int SMALL_CAP = SMALL_T * SMALL_I;
-    (void)SMALL_CAP;
+    Sort(sh.tmp.sort).Sort(key, val, 0, row_bits + 1);  // LSD radix sort: stable
     __syncthreads();
     int32_t head[SMALL_I];
-    Disc(tmp.disc).FlagHeads(head, key, hipcub::Inequality());  // first item of the block is a head
+    Disc(sh.tmp.disc).FlagHeads(head, key, hipcub::Inequality());  // first item of the block is a head
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < SMALL_I; ++i)
         if (t * SMALL_I + i >= n) head[i] = 0;
     int32_t sid[SMALL_I], total = 0;
-    Scan(tmp.scan).ExclusiveSum(head, sid, total);
+    Scan(sh.tmp.scan).ExclusiveSum(head, sid, total);
 #pragma unroll
     for (int i = 0; i < SMALL_I; ++i) {
         const int at = t * SMALL_I + i;
@@ -117,18 +136,67 @@ __global__ __launch_bounds__(SMALL_T) void k_small_segment_index(const int32_t* 
     if (t == 0) {
         *n_seg = total;
         seg_offsets[total] = n;
-        n_long = 0;
+        sh.n_long = 0;
     }
     if (!long_segs) return;
     __syncthreads();  // offsets written by this workgroup are visible to it
     for (int s2 = t; s2 < total; s2 += SMALL_T) {
         if (seg_offsets[s2 + 1] - seg_offsets[s2] > SEG_CAP_FOR_SMALL) {
-            const int li = atomicAdd(&n_long, 1);
+            const int li = atomicAdd(&sh.n_long, 1);
             if (li < long_cap) long_segs[1 + li] = s2;
         }
     }
     __syncthreads();
-    if (t == 0) long_segs[0] = n_long;
+    if (t == 0) long_segs[0] = sh.n_long;
+}
+
+template <int SMALL_I>
+__global__ __launch_bounds__(SMALL_T) void k_small_segment_index(IdLists ids, int n, int row_bits,
+                                                                 int32_t* __restrict__ refs_sorted,
+                                                                 int32_t* __restrict__ seg_rows,
+                                                                 int32_t* __restrict__ seg_offsets,
+                                                                 int32_t* __restrict__ n_seg,
+                                                                 int32_t* __restrict__ long_segs, int32_t long_cap) {
+    __shared__ SmallIndexTemp<SMALL_I> sh;
+    small_segment_index<SMALL_I>(sh, ids, n, row_bits, refs_sorted, seg_rows, seg_offsets, n_seg, long_segs, long_cap);
+}
+
+// Prologue of a notebook-size training step, ONE launch for what used to be a handful of 2-5 us dispatches
+// in front of and between its kernels: workgroup 0 builds the index of the step's small update lists
+// (their row ids are inputs of the step), the other workgroups run copy / fill jobs on 32-bit words - the
+// concatenated candidate list of an augmented step, the zeroed relation gradient, the zeroed targets of the
+// backward's atomics, ...
+struct WordJobs {
+    uint32_t* dst[BESS_MAX_WORD_JOBS];
+    const uint32_t* src[BESS_MAX_WORD_JOBS];  // NULL: fill with value
+    uint32_t value[BESS_MAX_WORD_JOBS];
+    int64_t first[BESS_MAX_WORD_JOBS + 1];    // prefix sums of the jobs' word counts
+    int n;
+};
+
+template <int SMALL_I>
+__global__ __launch_bounds__(SMALL_T) void k_step_prologue(WordJobs J, IdLists ids, int n_ids, int row_bits,
+                                                           int32_t* __restrict__ refs_sorted,
+                                                           int32_t* __restrict__ seg_rows,
+                                                           int32_t* __restrict__ seg_offsets,
+                                                           int32_t* __restrict__ n_seg,
+                                                           int32_t* __restrict__ long_segs, int32_t long_cap) {
+    __shared__ SmallIndexTemp<SMALL_I> sh;
+    const int index_blocks = n_ids > 0 ? 1 : 0;
+    if (static_cast<int>(blockIdx.x) < index_blocks) {
+        small_segment_index<SMALL_I>(sh, ids, n_ids, row_bits, refs_sorted, seg_rows, seg_offsets, n_seg, long_segs,
+                                     long_cap);
+        return;
+    }
+    const int64_t total = J.first[J.n];
+    const int64_t stride = static_cast<int64_t>(gridDim.x - index_blocks) * SMALL_T;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x - index_blocks) * SMALL_T + threadIdx.x; i < total; i += stride) {
+        int j = 0;
+#pragma unroll
+        for (int k = 1; k < BESS_MAX_WORD_JOBS; ++k) j += (k < J.n && i >= J.first[k]) ? 1 : 0;
+        const int64_t off = i - J.first[j];
+        J.dst[j][off] = J.src[j] ? J.src[j][off] : J.value[j];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_iota(int32_t* __restrict__ out, int64_t n) {
@@ -704,12 +772,16 @@ extern "C" int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int3
     const int n = static_cast<int>(n_refs);
     if (n_refs <= SMALL_N && row_bits <= 30) {
         const int32_t lc = static_cast<int32_t>(long_cap);
+        IdLists ids{};
+        ids.n = 1;
+        ids.p[0] = idx;
+        for (int l = 1; l <= BESS_MAX_ROW_LISTS; ++l) ids.first[l] = n;
         if (n <= SMALL_T * 2)
-            k_small_segment_index<2><<<1, SMALL_T, 0, st>>>(idx, n, row_bits, refs_sorted, seg_rows, seg_offsets, n_seg, long_segs, lc);
+            k_small_segment_index<2><<<1, SMALL_T, 0, st>>>(ids, n, row_bits, refs_sorted, seg_rows, seg_offsets, n_seg, long_segs, lc);
         else if (n <= SMALL_T * 4)
-            k_small_segment_index<4><<<1, SMALL_T, 0, st>>>(idx, n, row_bits, refs_sorted, seg_rows, seg_offsets, n_seg, long_segs, lc);
+            k_small_segment_index<4><<<1, SMALL_T, 0, st>>>(ids, n, row_bits, refs_sorted, seg_rows, seg_offsets, n_seg, long_segs, lc);
         else
-            k_small_segment_index<15><<<1, SMALL_T, 0, st>>>(idx, n, row_bits, refs_sorted, seg_rows, seg_offsets, n_seg, long_segs, lc);
+            k_small_segment_index<15><<<1, SMALL_T, 0, st>>>(ids, n, row_bits, refs_sorted, seg_rows, seg_offsets, n_seg, long_segs, lc);
         return check_launch("build_segment_index (small)");
     }
     char* ws = static_cast<char*>(workspace);
@@ -736,6 +808,61 @@ extern "C" int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int3
             seg_offsets, n_seg, long_segs, static_cast<int32_t>(long_cap));
     }
     return check_launch("build_segment_index");
+}
+
+extern "C" int bess_step_prologue(int32_t n_jobs, void* const* job_dst, const void* const* job_src,
+                                  const uint32_t* job_value, const int64_t* job_words, int32_t n_lists,
+                                  const int32_t* const* id_lists, const int64_t* id_lens, int32_t row_bits,
+                                  int32_t* refs_sorted, int32_t* seg_rows, int32_t* seg_offsets, int32_t* n_seg,
+                                  int32_t* long_segs, int64_t long_cap, void* stream) {
+    BESS_REQUIRE(n_jobs >= 0 && n_jobs <= BESS_MAX_WORD_JOBS, "step_prologue: %d jobs (0 .. %d)", n_jobs, BESS_MAX_WORD_JOBS);
+    BESS_REQUIRE(n_lists >= 0 && n_lists <= BESS_MAX_ROW_LISTS, "step_prologue: %d id lists (0 .. %d)", n_lists,
+                 BESS_MAX_ROW_LISTS);
+    BESS_REQUIRE(n_jobs == 0 || (job_dst && job_src && job_value && job_words), "step_prologue: NULL job arrays");
+    WordJobs J{};
+    J.n = n_jobs;
+    int64_t words = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        BESS_REQUIRE(job_words[j] >= 0 && (job_words[j] == 0 || job_dst[j]), "step_prologue: job %d", j);
+        BESS_REQUIRE(reinterpret_cast<uintptr_t>(job_dst[j]) % 4 == 0 && reinterpret_cast<uintptr_t>(job_src[j]) % 4 == 0,
+                     "step_prologue: job %d is not 4-byte aligned", j);
+        J.dst[j] = static_cast<uint32_t*>(job_dst[j]);
+        J.src[j] = static_cast<const uint32_t*>(job_src[j]);
+        J.value[j] = job_value[j];
+        J.first[j] = words;
+        words += job_words[j];
+    }
+    for (int j = n_jobs; j <= BESS_MAX_WORD_JOBS; ++j) J.first[j] = words;
+    IdLists ids{};
+    ids.n = n_lists;
+    int64_t n_ids = 0;
+    if (n_lists > 0) {
+        BESS_REQUIRE(id_lists && id_lens && refs_sorted && seg_rows && seg_offsets && n_seg, "step_prologue: NULL index pointer");
+        for (int l = 0; l < n_lists; ++l) {
+            BESS_REQUIRE(id_lens[l] >= 0 && (id_lens[l] == 0 || id_lists[l]), "step_prologue: id list %d", l);
+            ids.p[l] = id_lists[l];
+            ids.first[l] = static_cast<int32_t>(n_ids);
+            n_ids += id_lens[l];
+        }
+        BESS_REQUIRE(n_ids > 0 && n_ids <= SMALL_N, "step_prologue: %lld row ids (1 .. %d: larger lists go through "
+                     "bess_build_segment_index)", static_cast<long long>(n_ids), SMALL_N);
+        for (int l = n_lists; l <= BESS_MAX_ROW_LISTS; ++l) ids.first[l] = static_cast<int32_t>(n_ids);
+        BESS_REQUIRE(row_bits >= 1 && row_bits <= 30, "step_prologue: row_bits out of range");
+        BESS_REQUIRE(!long_segs || long_cap >= n_ids / SEG_CAP + 1, "step_prologue: long_cap < n_ids / %d + 1", SEG_CAP);
+    }
+    if (words == 0 && n_ids == 0) return BESS_OK;
+    const int n = static_cast<int>(n_ids);
+    const int32_t lc = static_cast<int32_t>(long_cap);
+    // ~4 words per thread of the job workgroups, at most one workgroup per CU
+    const unsigned grid = static_cast<unsigned>((n > 0 ? 1 : 0) + std::min<int64_t>(ceil_div(words, 4 * SMALL_T), 256));
+    hipStream_t st = as_stream(stream);
+    if (n <= SMALL_T * 2)
+        k_step_prologue<2><<<grid, SMALL_T, 0, st>>>(J, ids, n, row_bits, refs_sorted, seg_rows, seg_offsets, n_seg, long_segs, lc);
+    else if (n <= SMALL_T * 4)
+        k_step_prologue<4><<<grid, SMALL_T, 0, st>>>(J, ids, n, row_bits, refs_sorted, seg_rows, seg_offsets, n_seg, long_segs, lc);
+    else
+        k_step_prologue<15><<<grid, SMALL_T, 0, st>>>(J, ids, n, row_bits, refs_sorted, seg_rows, seg_offsets, n_seg, long_segs, lc);
+    return check_launch("step_prologue");
 }
 
 static int grad_segments_impl(const bess_model_desc* d, const float* query, int64_t n_query, void* table,

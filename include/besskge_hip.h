@@ -91,6 +91,8 @@ extern "C" {
 #define BESS_BAD_NEGATIVE_SCORE (-50000.0f)
 
 /* bess_model_desc.reserved[0] of TransE / RotatE / DistMult / ComplEx: flags */
+#define BESS_FLAG_PREZEROED 2 /* bess_neg_score_shared_bwd(_ws): d_query and d_neg are zero on entry (e.g. cleared by
+                               * bess_step_prologue): the call does not clear them itself */
 #define BESS_FLAG_FP32_MATH 1 /* shared negatives with the plain fp32 kernels only: no packed-fp16 L1 forward
                                  (TransE / RotatE on f16 tables), no split-fp16 matrix-core products (DistMult /
                                  ComplEx) */
@@ -343,6 +345,14 @@ int bess_loss_fwd_bwd_norm(const bess_loss_desc* l, const float* pos, const floa
                            float* loss, float* d_pos, float* d_neg, int64_t ld_dneg,
                            float* row_norm, void* stream);
 
+/* The same in ONE launch: the workgroup that finishes last forms loss[0] from row_loss (fixed order: bitwise
+ * reproducible).  counter: int32 [1] on the device, zero on entry, left zero (keep one per stream). */
+int bess_loss_fwd_bwd_one_launch(const bess_loss_desc* l, const float* pos, const float* neg,
+                                 int64_t n_triple, int64_t n_neg, int64_t ld_neg,
+                                 const float* weight, int64_t weight_len, float* row_loss,
+                                 float* loss, float* d_pos, float* d_neg, int64_t ld_dneg,
+                                 float* row_norm, int32_t* counter, void* stream);
+
 /* next-1 / K11 - streaming top-k (reference bess.py:771-822 loop body, 889-894):
  * merge the n_col candidates of every row into its running list of the kk best
  * (best_score / best_id [n_row, kk], sorted by descending score, in place).
@@ -398,12 +408,31 @@ int bess_sparse_sgd_lists(int32_t dtype, int32_t width, void* table, int32_t n_l
  *   (any order) - rows that very many references point at (padded candidate lists, hot
  *   entities), which bess_neg_pertriple_grad_segments spreads over the whole device. */
 #define BESS_SEGMENT_CAP 256
+#define BESS_MAX_WORD_JOBS 8
+#define BESS_SMALL_INDEX_MAX 15360 /* row ids bess_step_prologue indexes (one workgroup) */
 int bess_segment_index_workspace(int64_t n_refs, size_t* bytes);
 int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int32_t row_bits,
                              int32_t* refs_sorted, int32_t* seg_rows,
                              int32_t* seg_offsets, int32_t* n_seg, int32_t* long_segs,
                              int64_t long_cap, void* workspace,
                              size_t workspace_bytes, void* stream);
+
+/* Prologue of a notebook-size step in ONE launch (the step is launch-bound there: reference micro-batch
+ * S = 512, K = 32 of notebooks/3_wikikg2_fp16.ipynb:251-256):
+ *   - up to BESS_MAX_WORD_JOBS copy / fill jobs over 32-bit words: job j writes job_words[j] words at
+ *     job_dst[j], copied from job_src[j] or, when that is NULL, set to job_value[j] (the concatenated
+ *     candidate list of an augmented step = the `torch.concat` of bess.py:369-393; zeroed gradient buffers);
+ *   - the segment index (as bess_build_segment_index builds it) of the concatenation of up to
+ *     BESS_MAX_ROW_LISTS row-id lists, read where they are (1 .. BESS_SMALL_INDEX_MAX ids in all; n_lists = 0:
+ *     no index).  refs_sorted / seg_rows: int32 [n_ids], seg_offsets: [n_ids + 1], n_seg: [1],
+ *     long_segs: optional, [long_cap + 1].
+ * Jobs and index are independent of each other (different workgroups of the same launch): no job may
+ * produce an id list of the same call. */
+int bess_step_prologue(int32_t n_jobs, void* const* job_dst, const void* const* job_src,
+                       const uint32_t* job_value, const int64_t* job_words, int32_t n_lists,
+                       const int32_t* const* id_lists, const int64_t* id_lens, int32_t row_bits,
+                       int32_t* refs_sorted, int32_t* seg_rows, int32_t* seg_offsets, int32_t* n_seg,
+                       int32_t* long_segs, int64_t long_cap, void* stream);
 
 /* grad_seg[s, :] (f32 [max_seg, W], rows >= *n_seg untouched) = sum over the
  * references (q, k) of segment s of d score(query[q], e) / d e * d_out[q, k],

@@ -65,3 +65,46 @@ def test_bench_two_ranks_rehearsal_train_mode():
              "127.0.0.1", "--master-port", "29579", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
              "--mode", "train", "--no-extra-legs"], env)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["mode"] == "train"
+
+
+def test_bench_c4_workload_single_gpu():
+    """--workload c4: north_star's scaling workload is the line itself (f16, VALU roofline, oracle baseline)."""
+    d = run([sys.executable, "bench.py", "--workload", "c4", "--c4-point", "512,32", "--steps", "16", "--warmup", "8"])
+    assert KEYS <= set(d)
+    assert d["dtype"] == "f16" and d["n_gpus"] == 1 and d["value"] > 0 and d["ms_per_step"] > 0
+    assert "wikikg2" in d["config"]["workload"] and d["config"]["shard_bs"] == 512
+    assert d["config"]["negatives_per_triple"] == 512 + 32
+    r = d["roofline"]
+    assert r["bound"] == "valu" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    pt = d["c4"]["sweep"][0]
+    assert "eager_ms_per_step" in pt and "graph_ms_per_step" in pt and d["ms_per_step"] == pt["ms_per_step"]
+    assert abs(d["value"] - 512 * (1 + 544) / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+
+
+def test_bench_c4_workload_two_ranks_rehearsal():
+    """The same line at N = 2 (gloo, ranks sharing the GPU) with the exchange microbenchmark; the hipGraph variant
+    is opt-in at N > 1 and absent by default."""
+    env = dict(os.environ, BESS_BENCH_BACKEND="gloo")
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+             "127.0.0.1", "--master-port", "29581", "bench.py", "--gpus", "2", "--workload", "c4", "--c4-point", "512,32",
+             "--steps", "8", "--warmup", "8"], env)
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["dtype"] == "f16" and d["value"] > 0
+    assert d["config"]["negatives_per_triple"] == 512 + 2 * 32 and d["config"]["launch"] == "eager"
+    x = d["xgmi"]
+    assert [r["bytes_per_peer"] for r in x["sizes"]] == [49_152, 344_064, 2_752_512, 33_554_432]
+    assert all(r["gbs_per_gpu"] > 0 for r in x["sizes"]) and x["peak_per_gpu_gbs"] == 7 * 153.0
+    assert "cpu_baseline" not in d
+
+
+def test_bench_c4_workload_one_rank_rccl_with_recorded_collectives():
+    """One-rank RCCL rehearsal of the multi-GPU path with --c4-graph: the collectives of the C4 step are recorded
+    into the hipGraph together with the kernels (NativeGroup), and the line says which launch form it reports."""
+    env = dict(os.environ, BESS_BENCH_REHEARSE_DIST="1", MASTER_PORT="29583")
+    d = run([sys.executable, "bench.py", "--workload", "c4", "--c4-point", "512,32", "--steps", "16", "--warmup", "8",
+             "--c4-graph", "--comm", "native"], env)
+    assert d["config"]["collectives"].startswith("native")
+    pt = d["c4"]["sweep"][0]
+    assert "graph_ms_per_step" in pt and "graph_error" not in pt, pt
+    assert d["config"]["launch"] in ("eager", "graph")

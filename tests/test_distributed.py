@@ -194,3 +194,48 @@ def test_bench_distributed_path_over_rccl_single_rank():
     assert line["config"]["collectives"].startswith("native"), line["config"]["collectives"]
     for pt in line["c4"]["sweep"]:
         assert pt["value"] > 0 and "graph_ms_per_step" in pt, pt
+
+
+@pytest.mark.gpu
+def test_comm_init_all_single_device_clique():
+    """`bess_comm_init_all` (one process driving the GPUs it is given; here the one GPU of the box): every
+    collective of the library on the communicator it returns, then `bess_comm_destroy`.  In a subprocess: a
+    communicator is process-wide RCCL state."""
+    code = r'''
+import sys, torch
+sys.path[:0] = [sys.argv[1]]
+from besskge import _native as nat
+dev = torch.device("cuda", 0)
+(comm,) = nat.Communicator.init_all([dev])
+assert comm.info() == (1, 0, 0), comm.info()
+x = torch.arange(24, dtype=torch.float32, device=dev).reshape(1, 6, 4)
+assert torch.equal(comm.all_to_all(x), x)
+assert torch.equal(comm.all_gather(x[0]), x)
+y = x.clone()
+assert torch.equal(comm.all_reduce_sum_(y), x)
+table = torch.randn(50, 8, device=dev).half()
+idx = torch.randint(50, (1, 7), dtype=torch.int32, device=dev)
+send, recv = comm.pack_exchange(table, idx)
+torch.cuda.synchronize()
+assert torch.equal(recv[0], table[idx[0].long()]) and torch.equal(send, recv)
+# the same collectives recorded into a hipGraph with a kernel between them, replayed with new data
+static = torch.zeros(1, 6, 4, device=dev)
+side = torch.cuda.Stream(device=dev)
+with torch.cuda.stream(side):
+    comm.all_to_all(static)
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    out = comm.all_reduce_sum_(comm.all_to_all(static) * 2.0)
+for k in range(3):
+    static.fill_(float(k + 1))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, torch.full_like(out, 2.0 * (k + 1))), (k, out)
+comm.close()
+comm.close()  # idempotent
+print("ok")
+'''
+    res = subprocess.run([sys.executable, "-c", code, os.path.join(os.path.dirname(HERE), "bess-kge_amd")], capture_output=True,
+                         text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
