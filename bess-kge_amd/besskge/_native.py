@@ -1484,6 +1484,8 @@ class Communicator:
         return w.value, r.value, d.value
 
     def close(self) -> None:
+        """`bess_comm_destroy`.  hipGraphs that recorded collectives of this communicator must be destroyed first
+        (drop the `Runner` / `torch.cuda.CUDAGraph` objects): `ncclCommDestroy` waits for them."""
         if getattr(self, "_h", None) is not None and self._h.value:
             torch.cuda.synchronize(self.device)
             h, self._h = self._h, _vp()

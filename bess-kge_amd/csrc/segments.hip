@@ -289,6 +289,11 @@ struct SegArgs {
     float sign;
     const int32_t* long_segs;    // optional: [0] = number of segments longer than SEG_CAP, [1..] = their ids
     SegOpt opt;
+    // column windows that run side by side in ONE launch: workgroup b works on window b % n_win (workgroups go
+    // to the XCDs round-robin, so with n_win dividing 8 an XCD only ever sees the windows b % n_win == xcd %
+    // n_win and its L2 keeps just their slices of the query matrix), on segment groups b / n_win
+    int n_win;
+    int win_cols;  // scalars per window (nch * VEC)
 };
 
 // A row that collects very many references (padded candidate lists, a hot entity) would keep one
@@ -443,8 +448,21 @@ __global__ __launch_bounds__(256) void k_pertriple_grad_segments(SegArgs a, floa
     const int lane = threadIdx.x & 63;
     const int g = lane & 15;
     const int n_seg = *a.n_seg;
-    const int64_t group0 = (blockIdx.x * 256ll + threadIdx.x) >> 4;
-    const int64_t n_group = (gridDim.x * 256ll) >> 4;
+    int64_t block = blockIdx.x, n_block = gridDim.x;
+    if (a.n_win > 1) {
+        const int64_t col0 = static_cast<int64_t>(block % a.n_win) * a.win_cols;
+        block /= a.n_win;
+        n_block /= a.n_win;
+        a.query += col0;
+        a.table = static_cast<const T*>(a.table) + col0;
+        table_rw += col0;
+        if (grad_seg) grad_seg += col0;
+        if (a.opt.state1) a.opt.state1 += col0;
+        if (a.opt.state2) a.opt.state2 += col0;
+        if (a.opt.xsum) a.opt.xsum += col0;
+    }
+    const int64_t group0 = (block * 256ll + threadIdx.x) >> 4;
+    const int64_t n_group = (n_block * 256ll) >> 4;
     const T* table = static_cast<const T*>(a.table);
     for (int64_t seg = group0; seg < n_seg; seg += n_group) {
         const int64_t row = a.seg_rows[seg];
@@ -906,9 +924,19 @@ static int grad_segments_impl(const bess_model_desc* d, const float* query, int6
     // 0.701, 4 windows 0.707, 8 windows 0.806 - the per-window fixed cost sets the optimum.
     const int unit = vec * 16;  // columns one 16-lane group covers per iteration
     int win = W;
+    int n_conc = 1;  // windows of one launch (side by side, mapped to XCDs: SegArgs.n_win)
     if (red != RED_L2 && n_query * static_cast<int64_t>(W) * 4 > (4ll << 20)) {
         const int64_t fit = (4ll << 20) / (n_query * 4);
         if (fit >= unit) win = static_cast<int>(fit / unit) * unit;
+        // side by side instead of one after the other, when W splits evenly into 2, 4 or 8 windows of whole units
+        // whose query slices (n_query x cols x 4 B) leave an XCD's 4 MiB L2 half free for rows, ids and state
+        const char* force = getenv("BESS_K9_WIN");
+        for (int nw = force ? atoi(force) : 0; nw >= 2; nw = 0) {
+            if (W % (nw * unit) == 0 && W / nw <= 16 * unit) {
+                n_conc = nw;
+                win = W;
+            }
+        }
     }
     // ... and a window is at most what a 16-lane group keeps in registers (16 iterations): rows wider than that
     // (1024 f32 / 2048 f16 scalars) are windowed for this reason alone; the p = 2 norm needs the whole row
@@ -922,9 +950,11 @@ static int grad_segments_impl(const bess_model_desc* d, const float* query, int6
         if (wopt.state2) wopt.state2 += col0;
         if (wopt.xsum) wopt.xsum += col0;
         SegArgs a{query + col0, tab, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg,
-                  static_cast<int>(n_neg), W, cols / vec, is_distance(d->scorer) ? -1.f : 1.f, long_segs, wopt};
+                  static_cast<int>(n_neg), W, cols / vec / n_conc, is_distance(d->scorer) ? -1.f : 1.f, long_segs, wopt,
+                  n_conc, cols / n_conc};
         const int it = static_cast<int>(ceil_div(a.nch, 16));
         float* gs = grad_seg ? grad_seg + col0 : nullptr;
+        const unsigned grid = static_cast<unsigned>(n_conc * std::min<int64_t>(ceil_div(max_seg, 16), 256 * 16 / n_conc));
         int rc;
         if (d->dtype == BESS_F32) {
             rc = (vec == 4) ? seg_by_it<float, 4>(it, red, a, gs, tab, fused_sgd_lr, grid, st)
@@ -949,7 +979,7 @@ static int grad_segments_impl(const bess_model_desc* d, const float* query, int6
             if (wopt.xsum) wopt.xsum += col0;
             char* tab = static_cast<char*>(table) + col0 * sz;
             SegArgs a{query + col0, tab, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg,
-                      static_cast<int>(n_neg), W, cols / vec, is_distance(d->scorer) ? -1.f : 1.f, long_segs, wopt};
+                      static_cast<int>(n_neg), W, cols / vec, is_distance(d->scorer) ? -1.f : 1.f, long_segs, wopt, 1, cols};
             const int it = static_cast<int>(ceil_div(a.nch, 16));
             const unsigned lgrid = 1024;  // 16 K groups share the slices
             float* gs = grad_seg ? grad_seg + col0 : nullptr;

@@ -660,7 +660,10 @@ int bess_lookup_triples(const int32_t* triples, int64_t n_triple, const int64_t*
  *   host (torch.distributed store, MPI, a file ...), then bess_comm_init_rank on every rank
  *   (blocks until all `world` ranks have called it).
  * bess_comm_init_all: all n communicators of a single-process job at once (dev_ids NULL:
- *   devices 0..n-1); comms[i] is rank i. */
+ *   devices 0..n-1); comms[i] is rank i.
+ * bess_comm_destroy: after the stream work that uses the communicator has drained AND after every hipGraph
+ *   that recorded its collectives has been destroyed (ncclCommDestroy waits for those graphs: a host hang,
+ *   not an error, if one is still alive). */
 #define BESS_COMM_ID_BYTES 128
 typedef struct bess_comm bess_comm;
 int bess_comm_unique_id(uint8_t* id);

@@ -232,10 +232,13 @@ for k in range(3):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, torch.full_like(out, 2.0 * (k + 1))), (k, out)
+# a graph that recorded the communicator's collectives goes first: ncclCommDestroy waits for it to be destroyed
+del g, out
+torch.cuda.synchronize()
 comm.close()
 comm.close()  # idempotent
 print("ok")
 '''
     res = subprocess.run([sys.executable, "-c", code, os.path.join(os.path.dirname(HERE), "bess-kge_amd")], capture_output=True,
-                         text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+                         text=True, timeout=120, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
