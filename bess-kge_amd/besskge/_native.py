@@ -164,6 +164,8 @@ SIGNATURES = {
     "bess_assign_state_rows": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
     "bess_coalesced_update": [ctypes.POINTER(OptDesc), _i32, _i32, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_i64),
                               _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
+    "bess_coalesced_update_axpy": [ctypes.POINTER(OptDesc), _i32, _i32, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_i64),
+                                   _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _vp],
     "bess_neg_pertriple_items": [_MD, _i64, _i64, ctypes.POINTER(ctypes.c_int32)],
     "bess_neg_score_pertriple_fwd_dq": [_MD, _LD, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
     "bess_neg_score_pertriple_fwd_dq_masked": [_MD, _LD, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp,
@@ -856,9 +858,15 @@ def loss_fwd_bwd(l: LossDesc, pos: torch.Tensor, neg: torch.Tensor, weight: torc
     with _on(dev):
         stream = _stream(dev)
         # (one launch: its last workgroup sums the row terms; the counter it needs is zero between calls)
-        counter = _loss_counters.get((dev, stream))
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = (dev, "capture") if capturing else (dev, stream)
+        counter = _loss_counters.get(key)
         if counter is None:
-            counter = _loss_counters[(dev, stream)] = torch.zeros((1,), dtype=torch.int32, device=dev)
+            counter = _loss_counters[key] = torch.zeros((1,), dtype=torch.int32, device=dev)
+            if not capturing and (dev, "capture") not in _loss_counters:
+                # the counter of recorded steps exists before any recording starts (a tensor made while a
+                # stream is capturing would be cleared by a fill node at every replay: one more dispatch)
+                _loss_counters[(dev, "capture")] = torch.zeros((1,), dtype=torch.int32, device=dev)
         rc = load().bess_loss_fwd_bwd_one_launch(ctypes.byref(l), pos.data_ptr(), neg.data_ptr(), S, N, N,
                                                  weight.data_ptr(), weight.numel(), row_loss.data_ptr(), loss.data_ptr(),
                                                  dp.data_ptr() if want_grad else 0, dn.data_ptr() if want_grad else 0, N,
@@ -1147,10 +1155,12 @@ MAX_ROW_LISTS = 8  # BESS_MAX_ROW_LISTS
 
 def coalesced_update(o: Optional[OptDesc], table: torch.Tensor, seg: SegmentIndex, grads: Sequence[torch.Tensor],
                      state1: Optional[torch.Tensor] = None, state2: Optional[torch.Tensor] = None,
-                     keep: Optional[torch.Tensor] = None, sum_only: bool = False) -> Optional[torch.Tensor]:
+                     keep: Optional[torch.Tensor] = None, sum_only: bool = False,
+                     axpy: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None) -> Optional[torch.Tensor]:
     """K9 + K10 of the small lists in one pass: `seg` indexes the concatenation of the lists' row
     ids, `grads[l]` is the f32 [n_l, W] gradient of list l.  Every unique row gets one update
-    (one rounding).  `sum_only`: return the per-unique-row sums [seg.max_seg, W] instead."""
+    (one rounding).  `sum_only`: return the per-unique-row sums [seg.max_seg, W] instead.
+    `axpy` = (table2, grad2, alpha): `table2 += alpha * grad2` (dense, same dtype as `table`) in the same launch."""
     dev = _same_device([("table", table), ("refs", seg.refs), ("state1", state1), ("state2", state2)]
                        + [(f"grads[{i}]", g) for i, g in enumerate(grads)])
     W = int(table.shape[1])
@@ -1170,12 +1180,22 @@ def coalesced_update(o: Optional[OptDesc], table: torch.Tensor, seg: SegmentInde
     ptrs = (_vp * len(grads))(*[g.data_ptr() for g in grads])
     rows = (_i64 * len(grads))(*[int(g.shape[0]) for g in grads])
     out = torch.empty((seg.max_seg, W), dtype=torch.float32, device=dev) if sum_only else None
+    x_table = x_grad = None
+    x_n, x_alpha = 0, 0.0
+    if axpy is not None:
+        x_table, x_grad, x_alpha = axpy
+        _same_device([("table", table), ("axpy table", x_table), ("axpy grad", x_grad)])
+        _f32(x_grad, "axpy grad")
+        if x_table.dtype != table.dtype or not x_table.is_contiguous() or x_grad.numel() != x_table.numel():
+            raise ValueError("coalesced_update: the axpy table must be contiguous, of the table's dtype, and match its gradient")
+        x_n = int(x_table.numel())
     with _on(dev), _Timed("bess_coalesced_update", dev):
-        rc = load().bess_coalesced_update(
+        rc = load().bess_coalesced_update_axpy(
             ctypes.byref(o) if o is not None else None, _dtype_code(table), W, table.data_ptr(), len(grads), ptrs, rows,
             seg.refs.data_ptr(), seg.seg_rows.data_ptr(), seg.seg_offsets.data_ptr(), seg.n_seg.data_ptr(), seg.max_seg,
             state1.data_ptr() if state1 is not None else None, state2.data_ptr() if state2 is not None else None,
-            keep.data_ptr() if keep is not None else None, out.data_ptr() if out is not None else None, _stream(dev))
+            keep.data_ptr() if keep is not None else None, out.data_ptr() if out is not None else None,
+            x_table.data_ptr() if x_n else None, x_grad.data_ptr() if x_n else None, x_n, float(x_alpha), _stream(dev))
     _check(rc, "bess_coalesced_update")
     return out
 

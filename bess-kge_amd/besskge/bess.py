@@ -494,7 +494,8 @@ class BessKGE(torch.nn.Module, ABC):
         return o, (s[0] if n_state > 0 else None), (s[1] if n_state > 1 else None)
 
     def _apply_optimizer(self, opt: Any, table: torch.Tensor, contributions: List[Tuple[torch.Tensor, torch.Tensor]],
-                         ahead: Optional[Tuple[List[torch.Tensor], Any]] = None) -> None:
+                         ahead: Optional[Tuple[List[torch.Tensor], Any]] = None,
+                         axpy: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None) -> None:
         """General K9 + K10: all (row, gradient row) lists of a table coalesced per unique row and one
         optimiser update per row (`bess_coalesced_update`: the sums are formed straight from the lists, in
         a fixed order; every touched row is written once).  `contributions` all index `table`.
@@ -512,7 +513,7 @@ class BessKGE(torch.nn.Module, ABC):
         self._assign_state_rows(table, seg)
         if len(grads) > nat.MAX_ROW_LISTS:
             grads = [torch.cat(grads, dim=0)]
-        nat.coalesced_update(o, table, seg, grads, s1, s2)
+        nat.coalesced_update(o, table, seg, grads, s1, s2, axpy=axpy)
 
     @staticmethod
     def _match_ahead(ahead: Tuple[List[torch.Tensor], Any], ids: List[torch.Tensor], grads: List[torch.Tensor]
@@ -751,6 +752,17 @@ class BessKGE(torch.nn.Module, ABC):
         side = self._aux_stream(rel_table.device)
         # K9 + K10.  Every gradient has been computed from the pre-update tables by now.
         main.wait_stream(side)
+        # C9: replicated relation table
+        # (single process: d_rel already holds the sum over the local replicas)
+        (d_rel,) = group.all_reduce_sum([d_rel]) if len(group.local_shards) == 1 else (d_rel,)
+        mean_over_replicas = getattr(optimizer, "replica_reduction", "sum") == "mean" and group.n_shard > 1
+        if mean_over_replicas:
+            d_rel = d_rel / group.n_shard
+        # plain SGD on the relation table rides along in the launch that updates the (one) shard hosted here
+        rel_axpy, rel_done = None, False
+        if plain and not plain_rows and len(steps) == 1 and rel_table.dtype == steps[0].table.dtype \
+                and not any(item[0] is steps[0].table for item in deferred):
+            rel_axpy = (rel_table, d_rel, -lr)
         if plain_rows:
             # per-triple negatives of the own shard: segmented reduction.  A shard with a
             # single such group gets the SGD step fused into the reduction; with two
@@ -795,14 +807,11 @@ class BessKGE(torch.nn.Module, ABC):
                         n_rows = int(seg.n_seg.item())  # one host sync per step on this path
                         contrib.append((seg.seg_rows[:n_rows], gseg[:n_rows]))
                 self._apply_optimizer(optimizer, st.table, contrib,
-                                      (getattr(self, "_small_ahead", None) or {}).get(id(st)))
-        # C9: replicated relation table
-        # (single process: d_rel already holds the sum over the local replicas)
-        (d_rel,) = group.all_reduce_sum([d_rel]) if len(group.local_shards) == 1 else (d_rel,)
-        mean_over_replicas = getattr(optimizer, "replica_reduction", "sum") == "mean" and group.n_shard > 1
-        if mean_over_replicas:
-            d_rel = d_rel / group.n_shard
-        if plain:
+                                      (getattr(self, "_small_ahead", None) or {}).get(id(st)), axpy=rel_axpy)
+                rel_done = rel_axpy is not None
+        if rel_done:
+            pass  # updated in the shard's launch
+        elif plain:
             nat.dense_sgd(rel_table, d_rel, lr)
         else:
             self._apply_optimizer_dense(optimizer, rel_table, d_rel)

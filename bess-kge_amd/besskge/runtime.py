@@ -446,11 +446,11 @@ class Runner:
             per_it = []
             for res in collected:
                 vals = [r[k] if r[k].dim() > 0 else r[k].reshape(1) for r in res]
-                x = torch.cat(vals, dim=0)
+                x = torch.cat(vals, dim=0) if len(vals) > 1 else vals[0]  # (a one-piece cat is a copy launch)
                 if self.options.gather_outputs and isinstance(self.group, _MULTI_PROCESS):
                     x = self.group.all_gather([x])[0].flatten(end_dim=1)
                 per_it.append(x)
-            out[k] = torch.cat(per_it, dim=0)
+            out[k] = torch.cat(per_it, dim=0) if len(per_it) > 1 else per_it[0]
         return out["out"] if bare else out  # type: ignore[return-value]
 
 

@@ -612,6 +612,16 @@ struct RowLists {
     int n;
 };
 
+// A dense `table2 += alpha * grad2` on a small replicated table (the relation table's plain SGD step) rides along
+// in the last workgroups of the launch: one dispatch less per notebook-size step.
+struct AxpyJob {
+    void* table;
+    const float* grad;
+    int64_t n;
+    float alpha;
+    int blocks;  // workgroups at the end of the grid that do it (0: none)
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_coalesced_update(OptArgs o, RowLists L, T* __restrict__ table, int W,
                                                           const int32_t* __restrict__ refs,
@@ -619,11 +629,19 @@ __global__ __launch_bounds__(256) void k_coalesced_update(OptArgs o, RowLists L,
                                                           const int32_t* __restrict__ seg_offsets,
                                                           const int32_t* __restrict__ n_seg,
                                                           float* __restrict__ state1, float* __restrict__ state2,
-                                                          const int32_t* __restrict__ keep, float* __restrict__ sum_out) {
+                                                          const int32_t* __restrict__ keep, float* __restrict__ sum_out,
+                                                          AxpyJob x) {
+    const int main_blocks = static_cast<int>(gridDim.x) - x.blocks;
+    if (static_cast<int>(blockIdx.x) >= main_blocks) {
+        T* t2 = static_cast<T*>(x.table);
+        for (int64_t t = (blockIdx.x - main_blocks) * 256ll + threadIdx.x; t < x.n; t += 256ll * x.blocks)
+            t2[t] = static_cast<T>(static_cast<float>(t2[t]) + x.alpha * x.grad[t]);
+        return;
+    }
     o = opt_resolve(o);
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (blockIdx.x * 256ll + threadIdx.x) >> 6;
-    const int64_t n_wave = (gridDim.x * 256ll) >> 6;
+    const int64_t n_wave = (main_blocks * 256ll) >> 6;
     const int ns = *n_seg;
     for (int64_t s = wave0; s < ns; s += n_wave) {
         if (keep && keep[s] == 0) continue;
@@ -1120,6 +1138,19 @@ extern "C" int bess_coalesced_update(const bess_opt_desc* o, int32_t dtype, int3
                                      const int32_t* seg_offsets, const int32_t* n_seg, int64_t max_seg,
                                      float* state1, float* state2, const int32_t* keep, float* sum_out,
                                      void* stream) {
+    return bess_coalesced_update_axpy(o, dtype, width, table, n_lists, list_grad, list_rows, refs_sorted, seg_rows,
+                                      seg_offsets, n_seg, max_seg, state1, state2, keep, sum_out, nullptr, nullptr, 0, 0.f,
+                                      stream);
+}
+
+extern "C" int bess_coalesced_update_axpy(const bess_opt_desc* o, int32_t dtype, int32_t width, void* table,
+                                          int32_t n_lists, const float* const* list_grad, const int64_t* list_rows,
+                                          const int32_t* refs_sorted, const int32_t* seg_rows,
+                                          const int32_t* seg_offsets, const int32_t* n_seg, int64_t max_seg,
+                                          float* state1, float* state2, const int32_t* keep, float* sum_out,
+                                          void* axpy_table, const float* axpy_grad, int64_t axpy_n, float axpy_alpha,
+                                          void* stream) {
+    BESS_REQUIRE(axpy_n >= 0 && (axpy_n == 0 || (axpy_table && axpy_grad)), "coalesced_update: axpy operands");
     if (!sum_out)
         if (int e = check_opt(o, state1, state2, "coalesced_update")) return e;
     BESS_REQUIRE(dtype == BESS_F32 || dtype == BESS_F16, "coalesced_update: unknown dtype %d", dtype);
@@ -1146,15 +1177,17 @@ extern "C" int bess_coalesced_update(const bess_opt_desc* o, int32_t dtype, int3
         s1 = o->kind == BESS_OPT_SGD && o->momentum == 0.f ? nullptr : state1;
         s2 = o->kind == BESS_OPT_ADAM ? state2 : nullptr;
     }
-    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(max_seg, 4), 256 * 16));
+    AxpyJob x{axpy_table, axpy_grad, axpy_n, axpy_alpha,
+              static_cast<int>(std::min<int64_t>(ceil_div(axpy_n, 256 * 4), 256))};
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(max_seg, 4), 256 * 16)) + x.blocks;
     if (dtype == BESS_F32)
         k_coalesced_update<float><<<grid, 256, 0, as_stream(stream)>>>(a, L, static_cast<float*>(table), width,
                                                                        refs_sorted, seg_rows, seg_offsets, n_seg, s1,
-                                                                       s2, keep, sum_out);
+                                                                       s2, keep, sum_out, x);
     else
         k_coalesced_update<half_t><<<grid, 256, 0, as_stream(stream)>>>(a, L, static_cast<half_t*>(table), width,
                                                                         refs_sorted, seg_rows, seg_offsets, n_seg, s1,
-                                                                        s2, keep, sum_out);
+                                                                        s2, keep, sum_out, x);
     return check_launch("coalesced_update");
 }
 

@@ -500,6 +500,17 @@ int bess_coalesced_update(const bess_opt_desc* o, int32_t dtype, int32_t width, 
                           float* state1, float* state2, const int32_t* keep, float* sum_out,
                           void* stream);
 
+/* The same launch, with a dense `axpy_table[i] += axpy_alpha * axpy_grad[i]` (i < axpy_n; axpy_table of the
+ * same dtype as `table`) done by extra workgroups: the plain-SGD step of the replicated relation table rides
+ * along with the shard's update (one dispatch less per notebook-size step).  The two tables must not overlap. */
+int bess_coalesced_update_axpy(const bess_opt_desc* o, int32_t dtype, int32_t width, void* table,
+                               int32_t n_lists, const float* const* list_grad, const int64_t* list_rows,
+                               const int32_t* refs_sorted, const int32_t* seg_rows,
+                               const int32_t* seg_offsets, const int32_t* n_seg, int64_t max_seg,
+                               float* state1, float* state2, const int32_t* keep, float* sum_out,
+                               void* axpy_table, const float* axpy_grad, int64_t axpy_n, float axpy_alpha,
+                               void* stream);
+
 /* Paged optimiser state (a shard of tens of GB cannot carry one or two fp32 state tables of its own size:
  * BASELINE configs[4] is 128 GB per shard): state tables of `capacity` rows, a table row gets one the first
  * time it is stepped.  For every unique row seg_rows[s], s < *n_seg (with keep[s] != 0 where keep is given)

@@ -64,6 +64,12 @@ def run(workload: str) -> None:
         runner = runtime.training_model(model, runtime.Options(device_iterations=1, use_graphs=workload == "c4g"),
                                         runtime.SGD(lr=1e-3), device=dev)
 
+        if workload == "c4g":  # inputs where the recorded step reads them: no copies in front of the replay
+            static = runner.static_inputs(**batch)
+            for k_, v_ in batch.items():
+                static[k_].copy_(v_)
+            batch = static
+
         def step(i):
             runner(**batch)
 
