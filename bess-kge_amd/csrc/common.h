@@ -127,6 +127,13 @@ __device__ __forceinline__ void load_chunk(const T* __restrict__ row, int c, int
     for (int i = 0; i < VEC; ++i) out[i] = live ? out[i] : 0.f;
 }
 
+// The same without the select: lanes past the end of the row read the row's last chunk.  For elementwise uses
+// whose results for those lanes are never stored (one v_cndmask per scalar less in the inner loops).
+template <typename T, int VEC>
+__device__ __forceinline__ void load_chunk_clamped(const T* __restrict__ row, int c, int nch, float (&out)[VEC]) {
+    VecLoad<T, VEC>::load(row + min(c, nch - 1) * VEC, out);
+}
+
 // sum over the 16 lanes of a DPP row; every lane of the row gets the total
 __device__ __forceinline__ float row16_allreduce_sum(float v) {
 #define BESS_DPP_ROR(x, n)                                                                     \

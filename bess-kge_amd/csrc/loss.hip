@@ -370,6 +370,10 @@ static int loss_impl(const bess_loss_desc* l, const float* pos, const float* neg
     if (grad) BESS_REQUIRE(d_pos && d_neg && ld_dneg >= n_neg, "loss: gradients need d_pos, d_neg and ld_dneg >= n_neg");
     hipStream_t st = as_stream(stream);
     const bool adv = l->adversarial != 0;
+    // the one-launch form costs one same-address atomic per workgroup (4 rows each): they serialise at ~30 ns a
+    // piece - 4 us for the 128 workgroups of a notebook-size micro-batch (what the second launch cost), 30 us for
+    // the 1024 of S = 4096.  Larger grids keep the second launch.
+    if (n_triple > 4 * 256) counter = nullptr;
 #define BESS_LOSS(KIND, ADV) \
     launch_loss<KIND, ADV>(grad, *l, pos, neg, n_triple, n_neg, ld_neg, weight, weight_len, row_loss, d_pos, d_neg, ld_dneg, \
                            row_norm, counter, loss, st)

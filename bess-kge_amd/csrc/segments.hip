@@ -325,12 +325,18 @@ template <int VEC, int IT, int RED>
 __device__ __forceinline__ void seg_accumulate(const SegArgs& a, int g, const float (&ev)[IT][VEC], int r0, int r1,
                                                float (&acc)[IT][VEC]) {
     auto fetch = [&](int ref, float (&qv)[IT][VEC], float& go) {
-        const int q = ref / a.n_neg;
-        const int k = ref - q * a.n_neg;
+        // (references are non-negative: the unsigned division is half the instructions of the signed one)
+        const unsigned q = static_cast<unsigned>(ref) / static_cast<unsigned>(a.n_neg);
+        const unsigned k = static_cast<unsigned>(ref) - q * static_cast<unsigned>(a.n_neg);
         go = a.sign * a.d_out[q * a.ld_dout + k];
         const float* qp = a.query + static_cast<int64_t>(q) * a.W;
+        // the p = 2 norm sums over the whole row (lanes past its end must hold zeros); the dot product and the
+        // p = 1 distance are elementwise and the results of those lanes are never stored: no select needed
 #pragma unroll
-        for (int it = 0; it < IT; ++it) load_chunk<float, VEC>(qp, g + 16 * it, a.nch, qv[it]);
+        for (int it = 0; it < IT; ++it) {
+            if (RED == RED_L2) load_chunk<float, VEC>(qp, g + 16 * it, a.nch, qv[it]);
+            else load_chunk_clamped<float, VEC>(qp, g + 16 * it, a.nch, qv[it]);
+        }
     };
     auto accumulate = [&](const float (&qv)[IT][VEC], float go) {
         if (RED == RED_L2) {

@@ -345,8 +345,9 @@ int bess_loss_fwd_bwd_norm(const bess_loss_desc* l, const float* pos, const floa
                            float* loss, float* d_pos, float* d_neg, int64_t ld_dneg,
                            float* row_norm, void* stream);
 
-/* The same in ONE launch: the workgroup that finishes last forms loss[0] from row_loss (fixed order: bitwise
- * reproducible).  counter: int32 [1] on the device, zero on entry, left zero (keep one per stream). */
+/* The same in ONE launch for micro-batches of up to 1024 triples (two launches above that: the one-launch form
+ * pays one same-address atomic per 4 rows): the workgroup that finishes last forms loss[0] from row_loss (fixed
+ * order: bitwise reproducible).  counter: int32 [1] on the device, zero on entry, left zero (keep one per stream). */
 int bess_loss_fwd_bwd_one_launch(const bess_loss_desc* l, const float* pos, const float* neg,
                                  int64_t n_triple, int64_t n_neg, int64_t ld_neg,
                                  const float* weight, int64_t weight_len, float* row_loss,
