@@ -134,6 +134,8 @@ SIGNATURES = {
     "bess_neg_score_shared_fwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
     "bess_neg_score_shared_workspace": [_MD, _i64, _i64],
     "bess_neg_score_shared_fwd_ws": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp],
+    "bess_neg_score_shared_fwd_pruned": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
+    "bess_topk_update_flagged": [_vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _vp],
     "bess_neg_score_shared_fwd_masked": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, ctypes.POINTER(KillDesc), _vp, _i64, _vp],
     "bess_neg_score_shared_bwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
     "bess_neg_score_shared_bwd_workspace": [_MD, _i64, _i64],
@@ -769,6 +771,37 @@ def neg_score_shared_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, pad_
     return out if ld == n_neg else out[:, :n_neg]
 
 
+def neg_score_shared_fwd_pruned(d: ModelDesc, query: torch.Tensor, neg: RowSource, thr: torch.Tensor
+                                ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(scores [nq, n_neg] with 16-B aligned rows, flags [nq, n_blocks] uint8) for the top-k passes: a row's block
+    of 64 consecutive candidates is written only when one of its scores is above `thr[row]` (f32 [nq]: the row's
+    current k-th best), `flags` marks the blocks that were - the rest of `scores` is uninitialised memory, which
+    `topk_update(..., flags=flags)` never reads.  (`bess_neg_score_shared_fwd_pruned`: kernels without a pruning
+    epilogue write and flag everything.)"""
+    nq, n_neg = int(query.shape[0]), len(neg)
+    dev = _neg_operands(d, query, neg, n_neg)
+    _same_device([("query", query), ("thr", thr)])
+    _f32(thr, "thr")
+    if thr.numel() != nq:
+        raise ValueError("neg_score_shared_fwd_pruned: one threshold per query")
+    if d.scorer == AFFINE:
+        neg, _, _ = _affine_candidates(d, neg)
+    ld = (n_neg + 3) // 4 * 4
+    out = torch.empty((nq, ld), dtype=torch.float32, device=dev)
+    ldf = ((n_neg + 63) // 64 + 3) // 4 * 4
+    flags = torch.empty((nq, ldf), dtype=torch.uint8, device=dev)
+    lib = load()
+    ws_bytes = int(lib.bess_neg_score_shared_workspace(ctypes.byref(d), nq, n_neg))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
+    with _on(dev), _Timed("bess_neg_score_shared_fwd", dev):
+        rc = lib.bess_neg_score_shared_fwd_pruned(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
+                                                  _idx(neg.idx, "negative idx"), n_neg, out.data_ptr(), ld,
+                                                  thr.data_ptr(), flags.data_ptr(), ldf,
+                                                  ws.data_ptr() if ws is not None else None, ws_bytes, _stream(dev))
+    _check(rc, "bess_neg_score_shared_fwd_pruned")
+    return (out if ld == n_neg else out[:, :n_neg]), flags
+
+
 def shared_bwd_buffer(d: ModelDesc, nq: int, n_neg: int, device: torch.device) -> Optional[torch.Tensor]:
     """The [nq + n_neg, W] f32 allocation that `neg_score_shared_bwd(..., prezeroed=buf)` takes for d_query and
     d_neg when a caller clears it itself (with the other fills of its step: `step_prologue`); None for scorers
@@ -1302,10 +1335,12 @@ def ranks_from_indices(truth: torch.Tensor, cand: torch.Tensor, worst_rank_infty
 
 
 def topk_update(scores: torch.Tensor, best_score: torch.Tensor, best_id: torch.Tensor,
-                ids: Optional[torch.Tensor] = None, id_base: int = 0, mask: Optional[torch.Tensor] = None) -> None:
-    """Merge `scores` [rows, L] into the running (best_score, best_id) [rows, kk] lists in place."""
+                ids: Optional[torch.Tensor] = None, id_base: int = 0, mask: Optional[torch.Tensor] = None,
+                flags: Optional[torch.Tensor] = None) -> None:
+    """Merge `scores` [rows, L] into the running (best_score, best_id) [rows, kk] lists in place.
+    `flags` (from `neg_score_shared_fwd_pruned`): only the flagged blocks of 64 columns are read."""
     dev = _same_device([("scores", scores), ("best_score", best_score), ("best_id", best_id), ("ids", ids),
-                        ("mask", mask)])
+                        ("mask", mask), ("flags", flags)])
     if scores.dtype != torch.float32 or scores.dim() != 2 or (scores.shape[1] > 1 and scores.stride(1) != 1):
         raise ValueError("topk_update: scores must be float32 [rows, L] with contiguous rows")
     _f32(best_score, "best_score")
@@ -1325,6 +1360,19 @@ def topk_update(scores: torch.Tensor, best_score: torch.Tensor, best_id: torch.T
                 or not mask.is_contiguous():
             raise ValueError("topk_update: mask must be a contiguous bool [1 | rows, L] tensor")
         mp, mr = mask.data_ptr(), int(mask.shape[0])
+    if flags is not None:
+        if ids is not None or mask is not None:
+            raise ValueError("topk_update: flagged tiles take ids from id_base and no mask")
+        if flags.dtype != torch.uint8 or flags.dim() != 2 or flags.shape[0] != R or not flags.is_contiguous() \
+                or flags.shape[1] % 4 or flags.shape[1] * 64 < L:
+            raise ValueError("topk_update: flags must be a contiguous uint8 [rows, 4 * ceil(L / 256)] tensor")
+        with _on(dev), _Timed("bess_topk_update", dev):
+            ld = int(scores.stride(0)) if R > 1 else L
+            rc = load().bess_topk_update_flagged(scores.data_ptr(), R, L, max(ld, L), flags.data_ptr(),
+                                                 int(flags.shape[1]), int(id_base), best_score.data_ptr(),
+                                                 best_id.data_ptr(), kk, _stream(dev))
+        _check(rc, "bess_topk_update_flagged")
+        return
     with _on(dev), _Timed("bess_topk_update", dev):
         ld = int(scores.stride(0)) if R > 1 else L
         rc = load().bess_topk_update(scores.data_ptr(), R, L, max(ld, L), ip, ir, int(id_base), mp, mr,

@@ -174,6 +174,10 @@ class TopKQueryBessKGE(_QueryModule):
 
     #: bytes of the fp32 score tile [n_query, tile] between the scoring kernel and the top-k kernel
     score_tile_bytes = 1 << 30
+    #: candidates of the first (unpruned) tile of an all-entities pass; the next ones double up to the tile size
+    first_tile = 2048
+    #: prune the score tiles against the running k-th best scores (False: every score is written and read)
+    prune_scores = True
 
     def _tile(self, n_query: int) -> int:
         # few, large launches (writing and re-reading the tile costs 8 B per score), at least
@@ -197,10 +201,22 @@ class TopKQueryBessKGE(_QueryModule):
             bi = torch.full((nq, kk), M, dtype=torch.int32, device=dev)
             tile = self._tile(nq)
             if b.get("negative") is None:
-                for w0 in range(0, M, tile):
-                    w1 = min(M, w0 + tile)
-                    sc = nat.neg_score_shared_fwd(desc, q, RowSource(table[w0:w1]), pad_ld=True)
-                    nat.topk_update(sc, bs, bi, id_base=w0)
+                # Every entity of the shard.  After a first small tile the rows' k-th best scores are thresholds
+                # for the scoring kernel itself: a block of 64 scores is written (and later read by the top-k
+                # pass) only if one of them can still enter its row's list - the tiles grow geometrically while
+                # the thresholds tighten, so that all but a few per cent of the score traffic is never made
+                # (the reference materialises every window: bess.py:776-812)
+                w0, step = 0, min(tile, max(self.window_size, self.first_tile))
+                while w0 < M:
+                    w1 = min(M, w0 + step)
+                    if w0 == 0 or not self.prune_scores:
+                        sc = nat.neg_score_shared_fwd(desc, q, RowSource(table[w0:w1]), pad_ld=True)
+                        nat.topk_update(sc, bs, bi, id_base=w0)
+                    else:
+                        thr = bs[:, kk - 1].contiguous()
+                        sc, flags = nat.neg_score_shared_fwd_pruned(desc, q, RowSource(table[w0:w1]), thr)
+                        nat.topk_update(sc, bs, bi, id_base=w0, flags=flags)
+                    w0, step = w1, min(tile, 2 * step)
             else:
                 if b.get("negative_mask") is None:
                     raise ValueError("candidates need their `negative_mask`")

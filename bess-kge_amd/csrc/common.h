@@ -43,8 +43,11 @@ int gemm_dot_fwd(int dtype, const float* Q, int64_t S, const void* E, const int3
 // split-fp16 MFMA variant of gemm_dot_fwd (gemm_split.hip): workspace it wants for a shape
 // (0 = leave the shape to the fp32 kernels) and the product through that workspace
 int64_t gemm_split_workspace(int64_t S, int64_t N, int W);
+// (thr / flags: pruned stores for the top-k passes - a row's 64-column block is written only when one of its
+// scores is above thr[row]; flags[row, ld_flags] (one byte per block) says which were)
 int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const int32_t* idx, int64_t N, int W,
-                   float* out, int64_t ld, void* ws, int64_t ws_bytes, hipStream_t st);
+                   float* out, int64_t ld, void* ws, int64_t ws_bytes, hipStream_t st, const float* thr = nullptr,
+                   uint8_t* flags = nullptr, int64_t ld_flags = 0);
 int64_t gemm_split_bwd_workspace(int64_t S, int64_t N, int W);
 int gemm_split_bwd(int dtype, const float* G, int64_t ldg, int64_t S, const float* Q, const void* E,
                    const int32_t* idx, int64_t N, int W, float* dQ, float* dE, void* ws, int64_t ws_bytes,
@@ -58,7 +61,7 @@ int gemm_dot_de(const float* G, int64_t ldg, int64_t S, const float* Q, int64_t 
 bool l1_pk_eligible(const bess_model_desc* d);
 int l1_pk_fwd(const bess_model_desc* d, const float* query, int64_t n_query, const void* neg_base,
               const int32_t* neg_idx, int64_t n_neg, float* out, int64_t ld_out, const bess_kill_desc* kill,
-              hipStream_t st);
+              hipStream_t st, const float* thr = nullptr, uint8_t* flags = nullptr, int64_t ld_flags = 0);
 
 // affine-in-the-candidate distance scorers (affine.hip)
 int affine_pertriple(const bess_model_desc* d, bool fwd, const float* query, int64_t n_query, const void* neg_base,

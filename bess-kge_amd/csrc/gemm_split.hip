@@ -253,7 +253,7 @@ __device__ __forceinline__ f32x16 mma16(h8 a, h8 b, f32x16 c) {
 #endif
 
 // A, B: split images of M and N rows (n_slice lines each); C[m, n] = A[m] . B[n]
-template <bool B_LO>
+template <bool B_LO, bool PRUNE>
 // Split K (the backward products have few output tiles and a long k): a "tile" index t stands for
 // output tile t / ksplit and the k range [t % ksplit, +1) * n_slice lines; part p of an output
 // tile goes to C + p * part_stride (summed in a fixed order by k_sum_parts: deterministic).
@@ -261,7 +261,8 @@ __global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__
                                                         int64_t M, int64_t N, int n_slice,
                                                         float* __restrict__ C, int64_t ldc, int tiles_x,
                                                         int n_tiles, int ksplit, int64_t part_stride,
-                                                        const int32_t* __restrict__ range_flag) {
+                                                        const int32_t* __restrict__ range_flag, const float* __restrict__ thr,
+                                                        uint8_t* __restrict__ pflags, int64_t ldf) {
     __shared__ __attribute__((aligned(16))) char lds[2][2][IMG_B];  // [buffer][operand]
     if (range_flag && *range_flag) return;  // operands out of the fp16 range: the fp32 kernels take over
     const int slot = blockIdx.x, slots = gridDim.x;
@@ -417,7 +418,28 @@ __global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__
             const int64_t n0 = static_cast<int64_t>(ot % tiles_x) * 128 + wn;
             // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
             float* c0 = C + (tile % ksplit) * part_stride + (m0 + 4 * lk) * ldc + n0 + l31;
-            if (m0 + 64 <= M && n0 + 64 <= N) {
+            if constexpr (PRUNE) {
+                // pruned stores (top-k passes): the 32 lanes with this lk hold a row's 64 columns - the row's block
+                // is written only when one of them is above the row's threshold, and flagged
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
+                        const int64_t row = m0 + 4 * lk + rr;
+                        const bool rok = row < M, ok0 = n0 + l31 < N, ok1 = n0 + l31 + 32 < N;
+                        const float v0 = accm[i][0][r] + accc[i][0][r] * (1.f / 2048.f);
+                        const float v1 = accm[i][1][r] + accc[i][1][r] * (1.f / 2048.f);
+                        const float th = rok ? thr[row] : INFINITY;
+                        const unsigned long long hits = __ballot((ok0 && v0 > th) || (ok1 && v1 > th));
+                        const bool any = (lk ? (hits >> 32) : (hits & 0xffffffffull)) != 0;
+                        if (rok && l31 == 0 && n0 < N) pflags[row * ldf + n0 / 64] = any ? 1 : 0;
+                        if (any && rok) {
+                            if (ok0) c0[rr * ldc] = v0;
+                            if (ok1) c0[rr * ldc + 32] = v1;
+                        }
+                    }
+            } else if (m0 + 64 <= M && n0 + 64 <= N) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -468,12 +490,13 @@ __global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__
 // products are never stored), so a thread's six line pointers are one base plus constants.
 constexpr int W8_A = 256, W8_B = 128, W8_IMG = (W8_A + W8_B) * ROW_B;  // 48 KiB per buffer
 
-template <bool B_LO>
+template <bool B_LO, bool PRUNE>
 __global__ __launch_bounds__(512) void k_gemm_split_w8(const char* __restrict__ A, const char* __restrict__ B,
                                                        int64_t M, int64_t N, int n_slice,
                                                        float* __restrict__ C, int64_t ldc, int tiles_x,
                                                        int n_tiles, int ksplit, int64_t part_stride,
-                                                       const int32_t* __restrict__ range_flag) {
+                                                       const int32_t* __restrict__ range_flag, const float* __restrict__ thr,
+                                                        uint8_t* __restrict__ pflags, int64_t ldf) {
     extern __shared__ __attribute__((aligned(16))) char lds8[];  // [2][A rows 0-255 | B rows 0-127]
     if (range_flag && *range_flag) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -579,7 +602,28 @@ __global__ __launch_bounds__(512) void k_gemm_split_w8(const char* __restrict__ 
             const int64_t m0 = static_cast<int64_t>(ot / tiles_x) * W8_A + wm;
             const int64_t n0 = static_cast<int64_t>(ot % tiles_x) * W8_B + wn;
             float* c0 = C + (tile % ksplit) * part_stride + (m0 + 4 * lk) * ldc + n0 + l31;
-            if (m0 + 64 <= M && n0 + 64 <= N) {
+            if constexpr (PRUNE) {
+                // pruned stores (top-k passes): the 32 lanes with this lk hold a row's 64 columns - the row's block
+                // is written only when one of them is above the row's threshold, and flagged
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
+                        const int64_t row = m0 + 4 * lk + rr;
+                        const bool rok = row < M, ok0 = n0 + l31 < N, ok1 = n0 + l31 + 32 < N;
+                        const float v0 = accm[i][0][r] + accc[i][0][r] * (1.f / 2048.f);
+                        const float v1 = accm[i][1][r] + accc[i][1][r] * (1.f / 2048.f);
+                        const float th = rok ? thr[row] : INFINITY;
+                        const unsigned long long hits = __ballot((ok0 && v0 > th) || (ok1 && v1 > th));
+                        const bool any = (lk ? (hits >> 32) : (hits & 0xffffffffull)) != 0;
+                        if (rok && l31 == 0 && n0 < N) pflags[row * ldf + n0 / 64] = any ? 1 : 0;
+                        if (any && rok) {
+                            if (ok0) c0[rr * ldc] = v0;
+                            if (ok1) c0[rr * ldc + 32] = v1;
+                        }
+                    }
+            } else if (m0 + 64 <= M && n0 + 64 <= N) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -636,7 +680,8 @@ static int64_t pad_b(int64_t rows) { return ceil_div(rows, W8_B) * W8_B; }
 // kernels meet the same wall (profiles/ubench/mfma_f16.hip: the clock the chip holds under MFMA + LDS load)
 static int launch_product(const char* A, const char* B, int64_t M, int64_t N, int n_slice, float* C, int64_t ldc,
                           int ksplit, int64_t part_stride, bool b_lo, bool padded, const int32_t* flag,
-                          hipStream_t st) {
+                          hipStream_t st, const float* thr = nullptr, uint8_t* pflags = nullptr, int64_t ldf = 0) {
+    BESS_REQUIRE(!thr || (ksplit == 1 && pflags), "gemm_split: pruned stores need an unsplit product and a flag array");
     const int cus = n_compute_units();
     const int64_t tx = ceil_div(N, 128);
     const int64_t t8 = tx * ceil_div(M, W8_A) * ksplit, t4 = tx * ceil_div(M, 128) * ksplit;
@@ -645,28 +690,42 @@ static int launch_product(const char* A, const char* B, int64_t M, int64_t N, in
     if (wide) {
         static const bool attr = [] {
             const int bytes = 2 * W8_IMG;
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_split_w8<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-                   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_split_w8<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+            bool ok = true;
+            for (const void* f : {reinterpret_cast<const void*>(&k_gemm_split_w8<true, false>),
+                                  reinterpret_cast<const void*>(&k_gemm_split_w8<false, false>),
+                                  reinterpret_cast<const void*>(&k_gemm_split_w8<true, true>),
+                                  reinterpret_cast<const void*>(&k_gemm_split_w8<false, true>)})
+                ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+            return ok;
         }();
         BESS_REQUIRE(attr, "gemm_split: cannot reserve %d bytes of LDS", 2 * W8_IMG);
         const int grid = static_cast<int>(t8 < cus ? t8 : cus);
-        if (b_lo)
-            k_gemm_split_w8<true><<<grid, 512, 2 * W8_IMG, st>>>(A, B, M, N, n_slice, C, ldc, static_cast<int>(tx),
-                                                                 static_cast<int>(t8), ksplit, part_stride, flag);
-        else
-            k_gemm_split_w8<false><<<grid, 512, 2 * W8_IMG, st>>>(A, B, M, N, n_slice, C, ldc, static_cast<int>(tx),
-                                                                  static_cast<int>(t8), ksplit, part_stride, flag);
+#define BESS_W8(LO, PR)                                                                                          \
+    k_gemm_split_w8<LO, PR><<<grid, 512, 2 * W8_IMG, st>>>(A, B, M, N, n_slice, C, ldc, static_cast<int>(tx),     \
+                                                           static_cast<int>(t8), ksplit, part_stride, flag, thr, \
+                                                           pflags, ldf)
+        if (thr) {
+            if (b_lo) BESS_W8(true, true);
+            else BESS_W8(false, true);
+        } else {
+            if (b_lo) BESS_W8(true, false);
+            else BESS_W8(false, false);
+        }
+#undef BESS_W8
         return check_launch("gemm_split_w8");
     }
     const int grid = static_cast<int>(t4 < cus ? t4 : cus);
-    if (b_lo)
-        k_gemm_split_f16<true><<<grid, 512, 0, st>>>(A, B, M, N, n_slice, C, ldc, static_cast<int>(tx),
-                                                     static_cast<int>(t4), ksplit, part_stride, flag);
-    else
-        k_gemm_split_f16<false><<<grid, 512, 0, st>>>(A, B, M, N, n_slice, C, ldc, static_cast<int>(tx),
-                                                      static_cast<int>(t4), ksplit, part_stride, flag);
+#define BESS_F16(LO, PR)                                                                                    \
+    k_gemm_split_f16<LO, PR><<<grid, 512, 0, st>>>(A, B, M, N, n_slice, C, ldc, static_cast<int>(tx),        \
+                                                   static_cast<int>(t4), ksplit, part_stride, flag, thr, pflags, ldf)
+    if (thr) {
+        if (b_lo) BESS_F16(true, true);
+        else BESS_F16(false, true);
+    } else {
+        if (b_lo) BESS_F16(true, false);
+        else BESS_F16(false, false);
+    }
+#undef BESS_F16
     return check_launch("gemm_split_f16");
 }
 
@@ -704,7 +763,8 @@ static int split_rows(const SplitSrc& a, char* dst_a, int dtype_b, const SplitSr
 
 // out[q, j] = Q[q] . E[idx[j]] through the workspace (>= gemm_split_workspace bytes, 16-B aligned)
 int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const int32_t* idx, int64_t N, int W,
-                   float* out, int64_t ld, void* ws, int64_t ws_bytes, hipStream_t st) {
+                   float* out, int64_t ld, void* ws, int64_t ws_bytes, hipStream_t st, const float* thr,
+                   uint8_t* pflags, int64_t ldf) {
     const int64_t pitch = split_pitch(W);
     BESS_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 16 == 0, "gemm_split: workspace must be 16-B aligned");
     BESS_REQUIRE(ws_bytes >= FLAG_BYTES + 256 * pitch, "gemm_split: workspace too small");
@@ -727,7 +787,9 @@ int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const in
         SplitSrc src{idx ? E : static_cast<const char*>(E) + j0 * W * sz, idx ? idx + j0 : nullptr, nc, W, flag};
         // the query rows ride along with the first chunk
         if (int e = split_rows(SplitSrc{Q, nullptr, j0 == 0 ? S : 0, W, flag}, qa, dtype, src, eb, W, st)) return e;
-        if (int e = launch_product(qa, eb, S, nc, n_slice, out + j0, ld, 1, 0, dtype == BESS_F32, true, flag, st))
+        // (pruned stores: the chunk's flags start at block j0 / 64 - chunks are multiples of 128 rows)
+        if (int e = launch_product(qa, eb, S, nc, n_slice, out + j0, ld, 1, 0, dtype == BESS_F32, true, flag, st, thr,
+                                   pflags ? pflags + j0 / 64 : nullptr, ldf))
             return e;
     }
     // an operand outside the fp16 range (or not finite) raised the flag: the split kernels returned at once and

@@ -76,13 +76,21 @@ __device__ __forceinline__ void kill_row(const KillArgs& k, int64_t s, int64_t* 
     }
 }
 
+// Pruned scoring (top-k over all entities, bess_neg_score_shared_fwd_pruned): a row's 64-column block is stored
+// only when one of its scores is above the row's threshold; flags[q, block] says which were.
+struct PruneArgs {
+    const float* thr;  // [nq] or NULL: store everything
+    uint8_t* flags;    // [nq, ldf]
+    int64_t ldf;
+};
+
 // out[q, j] = -sum_w |fp16(Q[q, w]) - E[idx[j], w]|        W % 32 == 0
 // MI: query rows per thread (4: 64 x 64 tile; 2: 32 x 64 tile for launches whose 64-row grid leaves CUs idle)
 template <int MI>
 __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, int64_t nq,
                                                    const half_t* __restrict__ E, const int32_t* __restrict__ eidx,
                                                    int64_t ne, int W, float* __restrict__ out, int64_t ld,
-                                                   KillArgs kill) {
+                                                   KillArgs kill, PruneArgs prune) {
     __shared__ __attribute__((aligned(16))) uint32_t Qs[FKH / 2][PLD];
     __shared__ __attribute__((aligned(16))) uint32_t Es[FKH / 2][PLD];
     __shared__ float rsq[PT], rse[PT];
@@ -176,6 +184,16 @@ __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, 
             v4[j] = v;
         }
         const int64_t jj0 = j0 + tx * 4;
+        if (prune.thr) {  // (wave-uniform; the 16 threads with this ty hold the row's 64 columns: one 16-lane group)
+            const float th = prune.thr[q];
+            bool hit = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hit = hit || (jj0 + j < ne && v4[j] > th);
+            const unsigned long long m = __ballot(hit);
+            const bool any = ((m >> (16 * ((t & 63) >> 4))) & 0xffffull) != 0;
+            if (tx == 0) prune.flags[q * prune.ldf + blockIdx.x] = any ? 1 : 0;
+            if (!any) continue;
+        }
         if (row16 && jj0 + 3 < ne) {  // 16-byte aligned rows: one store for the thread's four scores
             *reinterpret_cast<float4*>(o + jj0) = make_float4(v4[0], v4[1], v4[2], v4[3]);
         } else {
@@ -193,7 +211,8 @@ bool l1_pk_eligible(const bess_model_desc* d) {
 
 int l1_pk_fwd(const bess_model_desc* d, const float* query, int64_t n_query, const void* neg_base,
               const int32_t* neg_idx, int64_t n_neg, float* out, int64_t ld_out, const bess_kill_desc* k,
-              hipStream_t st) {
+              hipStream_t st, const float* thr, uint8_t* flags, int64_t ld_flags) {
+    const PruneArgs pr{thr, flags, ld_flags};
     KillArgs ka{};
     if (k) ka = KillArgs{k->diag_step, k->ht, k->ppp, k->mask, k->mask_rows, k->mask ? k->mask_cols : 0, n_neg};
     // 32-row tiles when the 64-row grid would leave most CUs without a workgroup
@@ -201,10 +220,10 @@ int l1_pk_fwd(const bess_model_desc* d, const float* query, int64_t n_query, con
     const dim3 grid(static_cast<unsigned>(ceil_div(n_neg, PT)), static_cast<unsigned>(ceil_div(n_query, small ? PT / 2 : PT)));
     if (small)
         k_l1_fwd_pk<2><<<grid, 256, 0, st>>>(query, n_query, static_cast<const half_t*>(neg_base), neg_idx, n_neg,
-                                             d->width, out, ld_out, ka);
+                                             d->width, out, ld_out, ka, pr);
     else
         k_l1_fwd_pk<4><<<grid, 256, 0, st>>>(query, n_query, static_cast<const half_t*>(neg_base), neg_idx, n_neg,
-                                             d->width, out, ld_out, ka);
+                                             d->width, out, ld_out, ka, pr);
     return check_launch("neg_score_shared_fwd (packed f16 L1)");
 }
 

@@ -537,6 +537,40 @@ extern "C" int bess_neg_score_shared_fwd_ws(const bess_model_desc* d, const floa
                            ld_out, as_stream(stream));
 }
 
+extern "C" int bess_neg_score_shared_fwd_pruned(const bess_model_desc* d, const float* query, int64_t n_query,
+                                                const void* neg_base, const int32_t* neg_idx, int64_t n_neg,
+                                                float* out, int64_t ld_out, const float* thr, uint8_t* flags,
+                                                int64_t ld_flags, void* workspace, int64_t workspace_bytes,
+                                                void* stream) {
+    if (int e = check_desc(d)) return e;
+    BESS_REQUIRE(n_query >= 0 && n_neg >= 0, "neg_score_shared_fwd_pruned: bad sizes");
+    if (n_query == 0 || n_neg == 0) return BESS_OK;
+    BESS_REQUIRE(query && neg_base && out && thr && flags, "neg_score_shared_fwd_pruned: NULL pointer");
+    BESS_REQUIRE(ld_out >= n_neg && ld_flags >= ceil_div(n_neg, 64), "neg_score_shared_fwd_pruned: leading dimensions");
+    hipStream_t st = as_stream(stream);
+    // every block starts out flagged: kernels without a pruning epilogue (and the fp32 fallback of the split
+    // product) write all scores, which is what a set flag promises
+    BESS_REQUIRE(ld_flags % 4 == 0 && reinterpret_cast<uintptr_t>(flags) % 4 == 0,
+                 "neg_score_shared_fwd_pruned: flag rows must be 4-byte aligned");
+    {
+        hipError_t e = fill_words_async(flags, 0x01010101u, n_query * ld_flags / 4, st);
+        if (e != hipSuccess) return fail(static_cast<int>(e), "fill: %s", hipGetErrorString(e));
+    }
+    if (d->scorer <= BESS_COMPLEX) {
+        if (reduce_of(d) == RED_DOT) {
+            const bool fp32 = d->reserved[0] & BESS_FLAG_FP32_MATH;
+            const int64_t want = workspace && !fp32 ? gemm_split_workspace(n_query, n_neg, d->width) : 0;
+            if (want > 0 && workspace_bytes >= want)
+                return gemm_split_fwd(d->dtype, query, n_query, neg_base, neg_idx, n_neg, d->width, out, ld_out,
+                                      workspace, workspace_bytes, st, thr, flags, ld_flags);
+        } else if (use_l1_pk(d, query, neg_base)) {
+            return l1_pk_fwd(d, query, n_query, neg_base, neg_idx, n_neg, out, ld_out, nullptr, st, thr, flags, ld_flags);
+        }
+    }
+    return bess_neg_score_shared_fwd_ws(d, query, n_query, neg_base, neg_idx, n_neg, out, ld_out, workspace,
+                                        workspace_bytes, stream);
+}
+
 extern "C" int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* query,
                                          int64_t n_query, const void* neg_base,
                                          const int32_t* neg_idx, int64_t n_neg, float* out,

@@ -191,9 +191,150 @@ __global__ __launch_bounds__(256) void k_topk_update(const float* __restrict__ s
     }
 }
 
+// The same update when the scoring kernel has pruned the tile against the rows' current k-th scores
+// (bess_neg_score_shared_fwd_pruned): flags[row, b] != 0 marks the blocks of 64 columns that hold a score above
+// the threshold the row had when the tile was scored - only those were written, only those are read.  One wave
+// per row: a dword of flags per lane names 256 blocks (16,384 columns) per step, the flagged ones are fetched
+// four at a time (four independent loads in flight) and examined in column order, so equal scores keep their
+// left-to-right order exactly as in the dense pass.  After the first tiles of a long row almost nothing is
+// flagged: the pass costs the flag bytes (1/256 of the scores).
+template <bool TWO>
+__global__ __launch_bounds__(256) void k_topk_update_flagged(const float* __restrict__ scores, int64_t n_row,
+                                                             int64_t n_col, int64_t ld,
+                                                             const uint32_t* __restrict__ flags, int64_t ldf32,
+                                                             int32_t id_base, float* __restrict__ best_score,
+                                                             int32_t* __restrict__ best_id, int kk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = blockIdx.x * 4ll + wave;
+    if (row >= n_row) return;
+    float bs = -INFINITY, bs1 = -INFINITY;
+    int32_t bi = 0, bi1 = 0;
+    const int k0 = TWO ? 64 : kk;
+    if (lane < k0) {
+        bs = best_score[row * kk + lane];
+        bi = best_id[row * kk + lane];
+    }
+    if (TWO && 64 + lane < kk) {
+        bs1 = best_score[row * kk + 64 + lane];
+        bi1 = best_id[row * kk + 64 + lane];
+    }
+    float tau = TWO ? __shfl(bs1, kk - 65, 64) : __shfl(bs, kk - 1, 64);
+    auto insert = [&](float xv, int32_t iv) {
+        const int pos0 = __popcll(__ballot(lane < k0 && bs >= xv));
+        const float up_s = __shfl_up(bs, 1, 64);
+        const int32_t up_i = __shfl_up(bi, 1, 64);
+        if (TWO) {
+            const int pos1 = __popcll(__ballot(64 + lane < kk && bs1 >= xv));
+            const float last_s = __shfl(bs, 63, 64);
+            const int32_t last_i = __shfl(bi, 63, 64);
+            float up1_s = __shfl_up(bs1, 1, 64);
+            int32_t up1_i = __shfl_up(bi1, 1, 64);
+            if (lane == 0) {
+                up1_s = last_s;
+                up1_i = last_i;
+            }
+            if (64 + lane < kk) {
+                if (pos0 < 64 || lane > pos1) {
+                    bs1 = up1_s;
+                    bi1 = up1_i;
+                } else if (lane == pos1) {
+                    bs1 = xv;
+                    bi1 = iv;
+                }
+            }
+        }
+        if (lane < k0) {
+            if (lane > pos0) {
+                bs = up_s;
+                bi = up_i;
+            } else if (lane == pos0) {
+                bs = xv;
+                bi = iv;
+            }
+        }
+        tau = TWO ? __shfl(bs1, kk - 65, 64) : __shfl(bs, kk - 1, 64);
+    };
+    auto examine = [&](float x, int32_t xi) {
+        unsigned long long m = __ballot(x > tau);
+        while (m) {
+            const int l = __ffsll(static_cast<long long>(m)) - 1;
+            insert(__shfl(x, l, 64), __shfl(xi, l, 64));
+            m &= ~(1ull << l);
+            m &= __ballot(x > tau);
+        }
+    };
+    const float* srow = scores + row * ld;
+    const int64_t n_block = (n_col + 63) / 64;
+    const int64_t n_word = (n_block + 3) / 4;
+    const uint32_t* frow = flags + row * ldf32;
+    for (int64_t w0 = 0; w0 < n_word; w0 += 64) {
+        const uint32_t f = w0 + lane < n_word ? frow[w0 + lane] : 0u;
+        unsigned long long m = __ballot(f != 0u);
+        // flagged blocks of this step, four at a time: (lane of the word, byte in it) in column order
+        int64_t blk[4];
+        int n_blk = 0;
+        auto flush = [&]() {
+            float x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t j = blk[i < n_blk ? i : 0] * 64 + lane;
+                x[i] = (i < n_blk && j < n_col) ? srow[j] : -INFINITY;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < n_blk) examine(x[i], id_base + static_cast<int32_t>(blk[i] * 64 + lane));
+            n_blk = 0;
+        };
+        while (m) {
+            const int l = __ffsll(static_cast<long long>(m)) - 1;
+            m &= ~(1ull << l);
+            const uint32_t fl = __shfl(f, l, 64);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if ((fl >> (8 * b)) & 0xffu) {  // wave-uniform
+                    const int64_t block = (w0 + l) * 4 + b;
+                    if (block < n_block) {
+                        blk[n_blk++] = block;
+                        if (n_blk == 4) flush();
+                    }
+                }
+            }
+        }
+        if (n_blk) flush();
+    }
+    if (lane < k0) {
+        best_score[row * kk + lane] = bs;
+        best_id[row * kk + lane] = bi;
+    }
+    if (TWO && 64 + lane < kk) {
+        best_score[row * kk + 64 + lane] = bs1;
+        best_id[row * kk + 64 + lane] = bi1;
+    }
+}
+
 }  // namespace bess
 
 using namespace bess;
+
+extern "C" int bess_topk_update_flagged(const float* scores, int64_t n_row, int64_t n_col, int64_t ld,
+                                        const uint8_t* flags, int64_t ld_flags, int32_t id_base, float* best_score,
+                                        int32_t* best_id, int32_t kk, void* stream) {
+    BESS_REQUIRE(n_row >= 0 && n_row < (1ll << 31) && n_col >= 0 && ld >= n_col, "topk_update_flagged: bad sizes");
+    BESS_REQUIRE(kk >= 1 && kk <= 128, "topk_update_flagged: list length %d not in [1, 128]", kk);
+    if (n_row == 0 || n_col == 0) return BESS_OK;
+    BESS_REQUIRE(scores && flags && best_score && best_id, "topk_update_flagged: NULL pointer");
+    BESS_REQUIRE(ld_flags % 4 == 0 && ld_flags >= (n_col + 63) / 64 && reinterpret_cast<uintptr_t>(flags) % 4 == 0,
+                 "topk_update_flagged: flag rows must be 4-byte aligned and hold one byte per 64 columns");
+    const unsigned grid = static_cast<unsigned>(ceil_div(n_row, 4));
+    const uint32_t* f32 = reinterpret_cast<const uint32_t*>(flags);
+    if (kk > 64)
+        k_topk_update_flagged<true><<<grid, 256, 0, as_stream(stream)>>>(scores, n_row, n_col, ld, f32, ld_flags / 4,
+                                                                         id_base, best_score, best_id, kk);
+    else
+        k_topk_update_flagged<false><<<grid, 256, 0, as_stream(stream)>>>(scores, n_row, n_col, ld, f32, ld_flags / 4,
+                                                                          id_base, best_score, best_id, kk);
+    return check_launch("topk_update_flagged");
+}
 
 extern "C" int bess_topk_update(const float* scores, int64_t n_row, int64_t n_col, int64_t ld,
                                 const int32_t* ids, int64_t ids_rows, int32_t id_base, const uint8_t* mask,

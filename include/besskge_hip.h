@@ -299,6 +299,19 @@ int bess_neg_score_shared_bwd(const bess_model_desc* d, const float* query,
  * k split over workgroups with the partial tiles summed in a fixed order (deterministic).
  * bess_neg_score_shared_bwd_workspace returns the scratch bytes, 0 when the shape or the
  * scorer does not use scratch. */
+/* K4 for the top-k passes over all entities (bess.py:771-822): scores against the rows' current k-th best.
+ * thr [n_query]: a row's block of 64 consecutive candidates (block b = columns 64 b .. 64 b + 63) is written to
+ * `out` only if one of its scores is above thr[row]; flags [n_query, ld_flags] (uint8, ld_flags >= ceil(n_neg /
+ * 64), a multiple of 4, 4-byte aligned) receives 1 for every block that was written, 0 for the others (their part of
+ * `out` is left as it was).  bess_topk_update_flagged reads only the flagged blocks.  Scorers / shapes whose
+ * kernel has no pruning epilogue write everything and flag everything (same results, no saving): the split-fp16
+ * matrix-core product (DistMult / ComplEx; workspace as for bess_neg_score_shared_fwd_ws) and the packed-fp16 L1
+ * kernel (TransE / RotatE p = 1 on f16 tables) prune. */
+int bess_neg_score_shared_fwd_pruned(const bess_model_desc* d, const float* query, int64_t n_query,
+                                     const void* neg_base, const int32_t* neg_idx, int64_t n_neg, float* out,
+                                     int64_t ld_out, const float* thr, uint8_t* flags, int64_t ld_flags,
+                                     void* workspace, int64_t workspace_bytes, void* stream);
+
 int64_t bess_neg_score_shared_bwd_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg);
 int bess_neg_score_shared_bwd_ws(const bess_model_desc* d, const float* query,
                                  int64_t n_query, const void* neg_base,
@@ -364,6 +377,12 @@ int bess_topk_update(const float* scores, int64_t n_row, int64_t n_col, int64_t 
                      const int32_t* ids, int64_t ids_rows, int32_t id_base,
                      const uint8_t* mask, int64_t mask_rows, float* best_score,
                      int32_t* best_id, int32_t kk, void* stream);
+
+/* The same update from a pruned score tile (bess_neg_score_shared_fwd_pruned): only the blocks of 64 columns
+ * with a non-zero flag are read; candidate ids are id_base + column.  ld_flags: a multiple of 4. */
+int bess_topk_update_flagged(const float* scores, int64_t n_row, int64_t n_col, int64_t ld,
+                             const uint8_t* flags, int64_t ld_flags, int32_t id_base, float* best_score,
+                             int32_t* best_id, int32_t kk, void* stream);
 
 /* next-2 - prediction ranks (reference metric.py:129-217), fp32 ranks:
  * from scores: 1 + #{cand[s, j] better than pos[s]}, mode 0 optimistic ('>'),

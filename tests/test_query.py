@@ -309,3 +309,99 @@ def test_all_scores_pipeline_vs_oracle(dev, scheme, filtered):
     agree = (out["topk_global_id"][finite] == top.indices[finite]).float().mean()
     assert float(agree) > 0.99
     assert set(out["metrics_avg"]) == {"mrr", "hits@10"} and 0 < float(out["metrics_avg"]["mrr"]) <= 1
+
+
+# ----------------------------------------------------------------- pruned score tiles (next-1 as the survey wrote it)
+@pytest.mark.parametrize("scorer,dtype,W", [("ComplEx", torch.float32, 128), ("DistMult", torch.float16, 96),
+                                            ("TransE", torch.float16, 64), ("TransE", torch.float32, 64),
+                                            ("RotatE", torch.float16, 128)])
+def test_pruned_scoring_writes_exactly_the_blocks_that_matter(dev, scorer, dtype, W):
+    """bess_neg_score_shared_fwd_pruned: a (row, 64-column block) is flagged iff one of its scores beats the row's
+    threshold (kernels with a pruning epilogue) - never unflagged when one does (all kernels); flagged blocks hold
+    the scores of the plain kernel; bess_topk_update_flagged over them equals the dense update."""
+    from besskge import _native as nat
+
+    gen = torch.Generator().manual_seed(W)
+    nq, n_ent = 300, 40_000
+    table = (torch.randn(n_ent, W, generator=gen) * 0.3).to(dtype).to(dev)
+    q = (torch.randn(nq, W, generator=gen) * 0.3).to(dev)
+    code = dict(ComplEx=nat.COMPLEX, DistMult=nat.DISTMULT, TransE=nat.TRANSE, RotatE=nat.ROTATE)[scorer]
+    d = nat.make_desc(code, 1 if scorer in ("TransE", "RotatE") else 0, table, W // 2 if scorer == "RotatE" else W)
+    src = nat.RowSource(table[: n_ent - 37])  # a ragged last block
+    n = len(src)
+    dense = nat.neg_score_shared_fwd(d, q, src, pad_ld=True)
+    kk = 11
+    thr = dense.topk(kk, dim=1).values[:, -1].contiguous() - 1e-3  # a few candidates per row beat it
+    thr[::7] = -1e30  # rows without a threshold yet: everything is written
+    thr[3::7] = 1e30  # nothing can enter
+    sc, flags = nat.neg_score_shared_fwd_pruned(d, q, src, thr)
+    torch.cuda.synchronize()
+    nb = (n + 63) // 64
+    pad = torch.full((nq, nb * 64), -float("inf"), device=dev)
+    pad[:, :n] = dense[:, :n]
+    hit = (pad.reshape(nq, nb, 64) > thr[:, None, None]).any(dim=2)
+    got = flags[:, :nb].bool()
+    assert bool((got | ~hit).all()), "a block holding a candidate was not flagged"
+    prunes = (scorer in ("ComplEx", "DistMult")) or (dtype == torch.float16 and W % 32 == 0)
+    if prunes:
+        # (the two kernels round differently only in the last bits: a score within 1e-5 of the threshold may fall on
+        # either side)
+        near = ((pad.reshape(nq, nb, 64) - thr[:, None, None]).abs() < 1e-4).any(dim=2)
+        assert bool(((got == hit) | near).all())
+        assert float(got.float().mean()) < 0.6
+    else:
+        assert bool(got.all())
+    cols = torch.arange(nb * 64, device=dev) // 64
+    written = got[:, cols][:, :n]
+    torch.testing.assert_close(sc[:, :n][written], dense[:, :n][written], rtol=1e-5, atol=1e-5)
+    # the flagged top-k update equals the dense one
+    bs0 = torch.full((nq, kk), -50000.0, device=dev)
+    bs0[:, :] = thr[:, None].clamp(min=-50000.0, max=50000.0)
+    bi0 = torch.full((nq, kk), n_ent, dtype=torch.int32, device=dev)
+    want_s, want_i = bs0.clone(), bi0.clone()
+    nat.topk_update(dense[:, :n] if False else dense, want_s, want_i, id_base=5)
+    got_s, got_i = bs0.clone(), bi0.clone()
+    nat.topk_update(sc, got_s, got_i, id_base=5, flags=flags)
+    torch.cuda.synchronize()
+    ok = thr < 1e29
+    torch.testing.assert_close(got_s[ok], want_s[ok], rtol=1e-5, atol=1e-5)
+    same = (got_i == want_i) | ((got_s - want_s).abs() < 1e-4)
+    assert bool(same[ok].all())
+
+
+@pytest.mark.parametrize("n_shard", [1, 2])
+@pytest.mark.parametrize("scorer", ["ComplEx", "TransE16"])
+def test_topk_over_all_entities_with_and_without_pruning(dev, scorer, n_shard):
+    """TopKQueryBessKGE over every entity: pruned score tiles (geometric tile schedule) give the ids and scores
+    of the unpruned pass."""
+    from besskge import runtime, scoring
+    from besskge.bess import TopKQueryBessKGE
+    from besskge.negative_sampler import PlaceholderNegativeSampler
+    from besskge.sharding import Sharding
+
+    torch.manual_seed(0)
+    n_entity, n_rel, d = 30_011, 7, 64
+    sharding = Sharding.create(n_entity, n_shard, seed=3)
+    if scorer == "ComplEx":
+        fn = scoring.ComplEx(True, sharding, n_rel, d, device=dev)
+        fn.entity_embedding.data.normal_(0, 0.5)
+    else:
+        fn = scoring.TransE(True, 1, sharding, n_rel, d, device=dev, dtype=torch.float16)
+        fn.entity_embedding.data.normal_(0, 0.5)
+    rng = np.random.default_rng(1)
+    bsz = 96
+    M = int(sharding.shard_counts.min())
+    batch = dict(relation=torch.from_numpy(rng.integers(n_rel, size=(n_shard, bsz)).astype(np.int32)),
+                 head=torch.from_numpy(rng.integers(M, size=(n_shard, bsz)).astype(np.int32)))
+    outs = {}
+    for prune in (False, True):
+        model = TopKQueryBessKGE(k=10, candidate_sampler=PlaceholderNegativeSampler("t"), score_fn=fn,
+                                 return_scores=True)
+        model.prune_scores = prune
+        model.first_tile = 512
+        runner = runtime.inference_model(model, runtime.Options(device_iterations=1), device=dev)
+        outs[prune] = runner(**batch)
+    torch.testing.assert_close(outs[True]["topk_scores"].float(), outs[False]["topk_scores"].float(), rtol=1e-4, atol=1e-4)
+    close = (outs[True]["topk_scores"].float() - outs[False]["topk_scores"].float()).abs() < 1e-4
+    same = (outs[True]["topk_global_id"] == outs[False]["topk_global_id"]) | close
+    assert float(same.float().mean()) > 0.999
