@@ -175,7 +175,7 @@ class TopKQueryBessKGE(_QueryModule):
     #: bytes of the fp32 score tile [n_query, tile] between the scoring kernel and the top-k kernel
     score_tile_bytes = 1 << 30
     #: candidates of the first (unpruned) tile of an all-entities pass; the next ones double up to the tile size
-    first_tile = 2048
+    first_tile = 8192
     #: prune the score tiles against the running k-th best scores (False: every score is written and read)
     prune_scores = True
 

@@ -420,25 +420,32 @@ __global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__
             float* c0 = C + (tile % ksplit) * part_stride + (m0 + 4 * lk) * ldc + n0 + l31;
             if constexpr (PRUNE) {
                 // pruned stores (top-k passes): the 32 lanes with this lk hold a row's 64 columns - the row's block
-                // is written only when one of them is above the row's threshold, and flagged
+                // is written only when one of them is above the row's threshold, and flagged.  The thresholds of
+                // the wave's 64 rows come in with ONE load (lane l: row m0 + l) and are read out per row with
+                // v_readlane; the rows' verdicts are collected in a scalar mask and leave as one byte store per lane
+                const int l64 = threadIdx.x & 63;
+                const int tv = __builtin_bit_cast(int, (m0 + l64 < M) ? thr[m0 + l64] : INFINITY);
+                unsigned long long rows_hit = 0;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
-                        const int64_t row = m0 + 4 * lk + rr;
-                        const bool rok = row < M, ok0 = n0 + l31 < N, ok1 = n0 + l31 + 32 < N;
+                        const int rr = i * 32 + (r & 3) + 8 * (r >> 2);  // rows rr (lk = 0) and rr + 4 (lk = 1)
+                        const float th0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tv, rr));
+                        const float th1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tv, rr + 4));
+                        const float th = lk ? th1 : th0;
+                        const bool ok0 = n0 + l31 < N, ok1 = n0 + l31 + 32 < N;
                         const float v0 = accm[i][0][r] + accc[i][0][r] * (1.f / 2048.f);
                         const float v1 = accm[i][1][r] + accc[i][1][r] * (1.f / 2048.f);
-                        const float th = rok ? thr[row] : INFINITY;
                         const unsigned long long hits = __ballot((ok0 && v0 > th) || (ok1 && v1 > th));
-                        const bool any = (lk ? (hits >> 32) : (hits & 0xffffffffull)) != 0;
-                        if (rok && l31 == 0 && n0 < N) pflags[row * ldf + n0 / 64] = any ? 1 : 0;
-                        if (any && rok) {
+                        const bool any0 = (hits & 0xffffffffull) != 0, any1 = (hits >> 32) != 0;
+                        rows_hit |= (any0 ? 1ull << rr : 0ull) | (any1 ? 1ull << (rr + 4) : 0ull);
+                        if (lk ? any1 : any0) {  // (rows past M have threshold +inf: never stored)
                             if (ok0) c0[rr * ldc] = v0;
                             if (ok1) c0[rr * ldc + 32] = v1;
                         }
                     }
+                if (m0 + l64 < M && n0 < N) pflags[(m0 + l64) * ldf + n0 / 64] = (rows_hit >> l64) & 1ull;
             } else if (m0 + 64 <= M && n0 + 64 <= N) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -604,25 +611,32 @@ __global__ __launch_bounds__(512) void k_gemm_split_w8(const char* __restrict__ 
             float* c0 = C + (tile % ksplit) * part_stride + (m0 + 4 * lk) * ldc + n0 + l31;
             if constexpr (PRUNE) {
                 // pruned stores (top-k passes): the 32 lanes with this lk hold a row's 64 columns - the row's block
-                // is written only when one of them is above the row's threshold, and flagged
+                // is written only when one of them is above the row's threshold, and flagged.  The thresholds of
+                // the wave's 64 rows come in with ONE load (lane l: row m0 + l) and are read out per row with
+                // v_readlane; the rows' verdicts are collected in a scalar mask and leave as one byte store per lane
+                const int l64 = threadIdx.x & 63;
+                const int tv = __builtin_bit_cast(int, (m0 + l64 < M) ? thr[m0 + l64] : INFINITY);
+                unsigned long long rows_hit = 0;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
-                        const int64_t row = m0 + 4 * lk + rr;
-                        const bool rok = row < M, ok0 = n0 + l31 < N, ok1 = n0 + l31 + 32 < N;
+                        const int rr = i * 32 + (r & 3) + 8 * (r >> 2);  // rows rr (lk = 0) and rr + 4 (lk = 1)
+                        const float th0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tv, rr));
+                        const float th1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tv, rr + 4));
+                        const float th = lk ? th1 : th0;
+                        const bool ok0 = n0 + l31 < N, ok1 = n0 + l31 + 32 < N;
                         const float v0 = accm[i][0][r] + accc[i][0][r] * (1.f / 2048.f);
                         const float v1 = accm[i][1][r] + accc[i][1][r] * (1.f / 2048.f);
-                        const float th = rok ? thr[row] : INFINITY;
                         const unsigned long long hits = __ballot((ok0 && v0 > th) || (ok1 && v1 > th));
-                        const bool any = (lk ? (hits >> 32) : (hits & 0xffffffffull)) != 0;
-                        if (rok && l31 == 0 && n0 < N) pflags[row * ldf + n0 / 64] = any ? 1 : 0;
-                        if (any && rok) {
+                        const bool any0 = (hits & 0xffffffffull) != 0, any1 = (hits >> 32) != 0;
+                        rows_hit |= (any0 ? 1ull << rr : 0ull) | (any1 ? 1ull << (rr + 4) : 0ull);
+                        if (lk ? any1 : any0) {  // (rows past M have threshold +inf: never stored)
                             if (ok0) c0[rr * ldc] = v0;
                             if (ok1) c0[rr * ldc + 32] = v1;
                         }
                     }
+                if (m0 + l64 < M && n0 < N) pflags[(m0 + l64) * ldf + n0 / 64] = (rows_hit >> l64) & 1ull;
             } else if (m0 + 64 <= M && n0 + 64 <= N) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)

@@ -48,6 +48,8 @@ def run(name, cls, args, n_entity, n_rel, d, n_query, dtype, k=10):
     model = TopKQueryBessKGE(k=k, candidate_sampler=PlaceholderNegativeSampler("t"), score_fn=fn, return_scores=True,
                              window_size=1000)
     model.score_tile_bytes = int(os.environ.get("BESS_TOPK_TILE_MB", "1024")) << 20
+    model.prune_scores = os.environ.get("BESS_TOPK_PRUNE", "1") == "1"
+    model.first_tile = int(os.environ.get("BESS_TOPK_FIRST_TILE", model.first_tile))
     model.attach(runtime.SingleProcessGroup(1) if hasattr(runtime, "SingleProcessGroup") else None)
     rng = np.random.default_rng(0)
     batch = dict(relation=torch.from_numpy(rng.integers(n_rel, size=(1, n_query)).astype(np.int32)).to(dev),
