@@ -21,7 +21,7 @@ from besskge import runtime
 from besskge.batch_sampler import ShardedBatchSampler
 from besskge.collectives import ReplicaGroup
 from besskge.negative_sampler import PlaceholderNegativeSampler
-from besskge.query import AllScoresBESS
+from besskge.query import AllScoresBESS, topk_merge
 from besskge.scoring import BaseScoreFunction
 from besskge.utils import get_entity_filter
 
@@ -158,7 +158,7 @@ class AllScoresPipeline(torch.nn.Module):
             if self.return_topk:
                 top_s = torch.full((sc.shape[0], self.k), -torch.inf, dtype=torch.float32, device=dev)
                 top_i = torch.zeros((sc.shape[0], self.k), dtype=torch.int32, device=dev)
-                nat.topk_update(sc.contiguous(), top_s, top_i)  # column == global entity id
+                topk_merge(sc.contiguous(), top_s, top_i)  # column == global entity id
                 topk.append(top_i.cpu().long())
         out: Dict[str, Any] = dict()
         if scores:

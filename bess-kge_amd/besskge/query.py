@@ -41,6 +41,38 @@ def _i32(x: torch.Tensor) -> torch.Tensor:
     return (x if x.dtype == torch.int32 else x.to(torch.int32)).contiguous()
 
 
+#: entries the streaming top-k kernel keeps per query (two registers per lane)
+KERNEL_LIST_MAX = 128
+
+
+def topk_merge(scores: torch.Tensor, best_s: torch.Tensor, best_i: torch.Tensor, ids: Optional[torch.Tensor] = None,
+               id_base: int = 0, mask: Optional[torch.Tensor] = None, flags: Optional[torch.Tensor] = None) -> None:
+    """`nat.topk_update` for lists of any length (the reference's `torch.topk` takes any k: bess.py:807-814).
+    Up to 128 entries per query the streaming kernel keeps the list in registers; longer lists are merged by
+    `torch.topk` over [window | running list] on the device - the reference's own formulation - in column
+    chunks that bound the temporary (equal scores: order unspecified, as in the reference)."""
+    kk = int(best_s.shape[1])
+    if kk <= KERNEL_LIST_MAX:
+        nat.topk_update(scores, best_s, best_i, ids=ids, id_base=id_base, mask=mask, flags=flags)
+        return
+    if flags is not None:
+        raise ValueError("pruned score tiles are read by the streaming kernel only (lists of up to 128 entries)")
+    R, L = int(scores.shape[0]), int(scores.shape[1])
+    chunk = max(kk, (1 << 28) // max(1, R))  # <= 1 GiB of fp32 candidates per merge
+    for c0 in range(0, L, chunk):
+        c1 = min(L, c0 + chunk)
+        sc = scores[:, c0:c1]
+        if mask is not None:
+            sc = sc + BAD_NEGATIVE_SCORE * (~mask[:, c0:c1]).to(sc.dtype)
+        if ids is not None:
+            cid = ids[:, c0:c1].expand(R, c1 - c0)
+        else:
+            cid = (id_base + torch.arange(c0, c1, dtype=torch.int32, device=scores.device))[None, :].expand(R, c1 - c0)
+        top_s, pos = torch.topk(torch.cat([best_s, sc], dim=1), kk, dim=1)  # running entries first: they win ties
+        best_i.copy_(torch.gather(torch.cat([best_i, cid], dim=1), 1, pos))
+        best_s.copy_(top_s)
+
+
 class _QueryModule(torch.nn.Module):
     """Shared plumbing: replica group, shard placement, query gathering."""
 
@@ -113,7 +145,8 @@ class TopKQueryBessKGE(_QueryModule):
         window_size: int = 100,
     ) -> None:
         """
-        :param k: number of completions returned per query (k + 1 <= 128).
+        :param k: number of completions returned per query (any; up to k + 1 = 128 the running lists live in the
+            streaming kernel's registers, beyond that they are merged with `torch.topk` on the device).
         :param candidate_sampler: `PlaceholderNegativeSampler` (score against
             every entity) or a `TripleBasedShardedNegativeSampler` built with
             `mask_on_gather=True`.
@@ -127,8 +160,6 @@ class TopKQueryBessKGE(_QueryModule):
         self.return_scores = return_scores
         self.k = k
         self.window_size = window_size
-        if k + 1 > 128:
-            raise ValueError("the streaming top-k kernel keeps k + 1 <= 128 entries per query")
         if self.negative_sampler.flat_negative_format:
             assert score_fn.negative_sample_sharing, "Using flat negative format requires negative sample sharing"
         elif score_fn.negative_sample_sharing:
@@ -209,9 +240,9 @@ class TopKQueryBessKGE(_QueryModule):
                 w0, step = 0, min(tile, max(self.window_size, self.first_tile))
                 while w0 < M:
                     w1 = min(M, w0 + step)
-                    if w0 == 0 or not self.prune_scores:
+                    if w0 == 0 or not self.prune_scores or kk > KERNEL_LIST_MAX:
                         sc = nat.neg_score_shared_fwd(desc, q, RowSource(table[w0:w1]), pad_ld=True)
-                        nat.topk_update(sc, bs, bi, id_base=w0)
+                        topk_merge(sc, bs, bi, id_base=w0)
                     else:
                         thr = bs[:, kk - 1].contiguous()
                         sc, flags = nat.neg_score_shared_fwd_pruned(desc, q, RowSource(table[w0:w1]), thr)
@@ -232,12 +263,12 @@ class TopKQueryBessKGE(_QueryModule):
                         w1 = min(L, w0 + tile)
                         ids = cand[:, w0:w1].contiguous()
                         sc = nat.neg_score_shared_fwd(desc, q, RowSource(table, ids.reshape(-1)), pad_ld=True)
-                        nat.topk_update(sc, bs, bi, ids=ids, mask=mask[:, w0:w1].contiguous())
+                        topk_merge(sc, bs, bi, ids=ids, mask=mask[:, w0:w1].contiguous())
                 else:
                     if cand.shape[0] != nq:
                         raise ValueError(f"{cand.shape[0]} candidate lists for {nq} gathered queries")
                     sc = nat.neg_score_pertriple_fwd(desc, q, RowSource(table, cand.reshape(-1)), L)
-                    nat.topk_update(sc, bs, bi, ids=cand, mask=mask)
+                    topk_merge(sc, bs, bi, ids=cand, mask=mask)
             best_s.append(bs.reshape(n, -1, kk))
             best_i.append(bi.reshape(n, -1, kk))
         # per-query lists back to the query's shard (C6)
@@ -257,7 +288,7 @@ class TopKQueryBessKGE(_QueryModule):
             flat_g = gid.transpose(0, 1).reshape(shard_bs, n * kk).contiguous()
             top_s = torch.full((shard_bs, self.k), -float("inf"), dtype=torch.float32, device=dev)
             top_g = torch.zeros((shard_bs, self.k), dtype=torch.int32, device=dev)
-            nat.topk_update(flat_s, top_s, top_g, ids=flat_g)
+            topk_merge(flat_s, top_s, top_g, ids=flat_g)
             out: Dict[str, Any] = dict(topk_global_id=top_g)
             if self.return_scores:
                 out["topk_scores"] = top_s.to(fn.relation_embedding.dtype)

@@ -405,3 +405,43 @@ def test_topk_over_all_entities_with_and_without_pruning(dev, scorer, n_shard):
     close = (outs[True]["topk_scores"].float() - outs[False]["topk_scores"].float()).abs() < 1e-4
     same = (outs[True]["topk_global_id"] == outs[False]["topk_global_id"]) | close
     assert float(same.float().mean()) > 0.999
+
+
+@pytest.mark.parametrize("k", [127, 200, 500])
+def test_topk_lists_longer_than_the_kernel_keeps(dev, k):
+    """The reference's `torch.topk` takes any k (bess.py:807-814): TopKQueryBessKGE with k + 1 > 128 merges its
+    lists with torch.topk on the device; ids and scores equal a direct top-k over all entities."""
+    from besskge import runtime, scoring
+    from besskge.bess import TopKQueryBessKGE
+    from besskge.negative_sampler import PlaceholderNegativeSampler
+    from besskge.sharding import Sharding
+
+    torch.manual_seed(1)
+    n_entity, n_rel, d, n_shard, bsz = 5003, 5, 32, 2, 40
+    sharding = Sharding.create(n_entity, n_shard, seed=3)
+    fn = scoring.DistMult(True, sharding, n_rel, d, device=dev)
+    fn.entity_embedding.data.normal_(0, 1.0)
+    fn.relation_embedding.data.normal_(0, 1.0)
+    rng = np.random.default_rng(1)
+    M = int(sharding.shard_counts.min())
+    head = rng.integers(M, size=(n_shard, bsz)).astype(np.int32)
+    rel = rng.integers(n_rel, size=(n_shard, bsz)).astype(np.int32)
+    model = TopKQueryBessKGE(k=k, candidate_sampler=PlaceholderNegativeSampler("t"), score_fn=fn, return_scores=True)
+    model.score_tile_bytes = 1 << 18  # several tiles
+    runner = runtime.inference_model(model, runtime.Options(device_iterations=1), device=dev)
+    out = runner(relation=torch.from_numpy(rel), head=torch.from_numpy(head))
+    # direct: every entity's score against the queries, unsharded
+    table = fn.entity_embedding.detach().float().cpu()  # [n, M, W]
+    relt = fn.relation_embedding.detach().float().cpu()
+    glob = torch.zeros(n_entity, d)
+    s2e = torch.from_numpy(np.asarray(sharding.shard_and_idx_to_entity))
+    for sh in range(n_shard):
+        cnt = int(sharding.shard_counts[sh])
+        glob[s2e[sh, :cnt].long()] = table[sh, :cnt]
+    for sh in range(n_shard):
+        q = table[sh][torch.from_numpy(head[sh]).long()] * relt[torch.from_numpy(rel[sh]).long()]
+        want_s, want_i = torch.topk(q @ glob.T, k, dim=1)
+        got_s = out["topk_scores"][sh * bsz:(sh + 1) * bsz].float().cpu()
+        got_i = out["topk_global_id"][sh * bsz:(sh + 1) * bsz].cpu().long()
+        torch.testing.assert_close(got_s, want_s, rtol=1e-4, atol=1e-4)
+        assert float(((got_i == want_i) | ((got_s - want_s).abs() < 1e-4)).float().mean()) > 0.999
