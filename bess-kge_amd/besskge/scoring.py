@@ -269,16 +269,22 @@ class BaseScoreFunction(torch.nn.Module, ABC):
 class DistanceBasedScoreFunction(BaseScoreFunction, ABC):
     """Scorers of the form -||query - entity||_p."""
 
+    #: norms the scorer's kernels implement; None = any integer p >= 1 (TransE, RotatE: p = 1 and p = 2 have their
+    #: own instruction sequences, every other p goes through powf - reference scoring.py:174 takes any p)
+    supported_norms: Optional[Tuple[int, ...]] = None
+
     def __init__(self, negative_sample_sharing: bool, scoring_norm: int) -> None:
         """
         :param negative_sample_sharing: see :class:`BaseScoreFunction`.
-        :param scoring_norm: p of the p-norm (1 or 2 on the HIP path).
+        :param scoring_norm: p of the p-norm.
         """
         super().__init__()
-        if scoring_norm not in (1, 2):
-            raise ValueError("the HIP kernels implement scoring_norm 1 and 2")
+        if int(scoring_norm) != scoring_norm or scoring_norm < 1:
+            raise ValueError(f"scoring_norm must be an integer p >= 1, got {scoring_norm!r}")
+        if self.supported_norms is not None and scoring_norm not in self.supported_norms:
+            raise ValueError(f"the HIP kernels of {type(self).__name__} implement scoring_norm in {self.supported_norms}")
         self.negative_sample_sharing = negative_sample_sharing
-        self.scoring_norm = scoring_norm
+        self.scoring_norm = int(scoring_norm)
 
     def reduce_embedding(self, v: torch.Tensor) -> torch.Tensor:
         """p-norm over the embedding dimension (reference scoring.py:163-174)."""
@@ -490,6 +496,7 @@ class _AffineScoreFunction(_TorchQueryHooks, DistanceBasedScoreFunction, ABC):
     """`-|| U * c1 + V * c2 + R ||_p` scorers; see the module docstring."""
 
     _scorer_id = nat.AFFINE
+    supported_norms = (1, 2)
     supports_fused_segments = True  # csrc/affine.hip: k_aff_grad_segments
     #: d-wide parts of an entity row (1 | 2)
     _n_part: int = 1
@@ -892,6 +899,8 @@ class BoxE(_TorchQueryHooks, DistanceBasedScoreFunction):
     """BoxE (reference scoring.py:1149-1415): entities are [base | bump]; the head is
     bumped by the tail's bump and vice versa, and each bumped point is scored by a
     piecewise distance to its relation box."""
+
+    supported_norms = (1, 2)
 
     _scorer_id = nat.BOXE
 

@@ -30,7 +30,7 @@ inline bool is_distance(int scorer) {
 int check_desc(const bess_model_desc* d);
 
 // reductions used by the negative-scoring kernels
-enum Reduce : int { RED_DOT = 0, RED_L1 = 1, RED_L2 = 2 };
+enum Reduce : int { RED_DOT = 0, RED_L1 = 1, RED_L2 = 2 };  // RED_L2: every p != 1 (p is a run-time argument)
 inline int reduce_of(const bess_model_desc* d) {
     if (!is_distance(d->scorer)) return RED_DOT;
     return d->norm_p == 1 ? RED_L1 : RED_L2;
@@ -188,6 +188,19 @@ inline hipError_t fill_words_async(void* p, uint32_t v, int64_t n_words, hipStre
     blocks = blocks > 2048 ? 2048 : blocks;
     k_fill_words<<<static_cast<unsigned>(blocks), 256, 0, st>>>(static_cast<uint32_t*>(p), v, n_words);
     return hipGetLastError();
+}
+
+// Pieces of the p-norm of the distance scorers for any p >= 1 (reference scoring.py:174: `torch.norm(x,
+// p=scoring_norm)`).  The kernels' RED_L2 branch carries p at run time: p = 2 keeps its multiply / sqrt (a
+// wave-uniform test), every other p goes through powf.   norm = (sum |d|^p)^(1/p);   d norm / d d_w =
+// sgn(d_w) |d_w|^(p-1) * norm^(1-p).
+__device__ __forceinline__ float lp_term(float d, float p) { return p == 2.f ? d * d : powf(fabsf(d), p); }
+__device__ __forceinline__ float lp_root(float acc, float p) { return p == 2.f ? sqrtf(acc) : powf(acc, 1.f / p); }
+__device__ __forceinline__ float lp_dterm(float d, float p) {
+    return p == 2.f ? d : copysignf(powf(fabsf(d), p - 1.f), d);
+}
+__device__ __forceinline__ float lp_inv(float norm, float p) {  // norm^(1-p); 0 at the kink norm == 0
+    return norm > 0.f ? (p == 2.f ? 1.f / norm : powf(norm, 1.f - p)) : 0.f;
 }
 
 template <typename T>

@@ -36,6 +36,7 @@ struct NegPtArgs {
     int items_per_query;
     float sign;
     int accum = 0;  // forward: add to the scores already there (a later column window of a wide row)
+    float p = 2.f;  // the norm of the RED_L2 kernels (any p != 1)
 };
 
 // Fused training forward (FUSE): besides the scores, accumulate the loss gradient wrt the query,
@@ -126,13 +127,12 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_fwd(NegPtArgs a, float* _
                     } else if (RED == RED_L1) {
                         acc += fabsf(qv[it][v] - ev[u][it][v]);
                     } else {
-                        const float dlt = qv[it][v] - ev[u][it][v];
-                        acc = fmaf(dlt, dlt, acc);
+                        acc += lp_term(qv[it][v] - ev[u][it][v], a.p);
                     }
                 }
             }
             acc = row16_allreduce_sum(acc);
-            if (RED == RED_L2) acc = sqrtf(acc);
+            if (RED == RED_L2) acc = lp_root(acc, a.p);
             float sc = a.sign * acc;
             if (FUSE && f.mask && valid[u]) {
                 // K7 inside the pass (the padding mask of triple-specific negatives): a masked-out candidate gets
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_fwd(NegPtArgs a, float* _
                 const float p = e * gs;
                 fl = fmaf(fl, corr, e);
                 fm = m_new;
-                const float inv_norm = (RED == RED_L2 && acc > 0.f) ? 1.f / acc : 0.f;
+                const float inv_norm = RED == RED_L2 ? lp_inv(acc, a.p) : 0.f;
 #pragma unroll
                 for (int it = 0; it < IT; ++it)
 #pragma unroll
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_fwd(NegPtArgs a, float* _
                         float dsdq;  // d score / d query_w
                         if (RED == RED_DOT) dsdq = ev[u][it][v];
                         else if (RED == RED_L1) dsdq = -sgnf(qv[it][v] - ev[u][it][v]);
-                        else dsdq = -(qv[it][v] - ev[u][it][v]) * inv_norm;
+                        else dsdq = -lp_dterm(qv[it][v] - ev[u][it][v], a.p) * inv_norm;
                         facc[it][v] = fmaf(facc[it][v], corr, p * dsdq);
                     }
             }
@@ -324,11 +324,10 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_bwd(NegPtArgs a,
                 for (int it = 0; it < IT; ++it)
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
-                        const float dlt = qv[it][v] - ev[u][it][v];
-                        ss = fmaf(dlt, dlt, ss);
+                        ss += lp_term(qv[it][v] - ev[u][it][v], a.p);
                     }
                 ss = row16_allreduce_sum(ss);
-                gg = ss > 0.f ? gg / sqrtf(ss) : 0.f;
+                gg *= lp_inv(lp_root(ss, a.p), a.p);
             }
             float* dn = d_neg + (q * a.n_neg + ks[u]) * a.W;
 #pragma unroll
@@ -345,7 +344,7 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_bwd(NegPtArgs a,
                         dqe = gg * sgnf(qv[it][v] - ev[u][it][v]);
                         de[v] = -dqe;
                     } else {
-                        dqe = gg * (qv[it][v] - ev[u][it][v]);
+                        dqe = gg * lp_dterm(qv[it][v] - ev[u][it][v], a.p);
                         de[v] = -dqe;
                     }
                     dq[it][v] += dqe;
@@ -471,6 +470,7 @@ static int run(const bess_model_desc* d, bool fwd, const float* query, int64_t n
     a.nb = negatives_per_item(n_query, n_neg, static_cast<int64_t>(W) * (d->dtype == BESS_F32 ? 4 : 2));  // == row_bytes_of(d)
     a.items_per_query = static_cast<int>(ceil_div(n_neg, a.nb));
     a.sign = is_distance(d->scorer) ? -1.f : 1.f;
+    a.p = static_cast<float>(d->norm_p);
     const int red = reduce_of(d);
     hipStream_t st = as_stream(stream);
     if (!fwd && a.items_per_query > 1) {

@@ -81,7 +81,7 @@ __device__ __forceinline__ void stage_store(float (*tile)[LDP], int kc, int m, c
 template <typename T, int RED, bool ALIGNED, int MI>
 __global__ __launch_bounds__(256) void k_neg_shared_fwd(RowSrc<float> Q, RowSrc<T> E, int W,
                                                         float sign, float* __restrict__ out,
-                                                        int64_t ld_out) {
+                                                        int64_t ld_out, float p) {
     __shared__ __attribute__((aligned(16))) float Qs[KT][LDP];
     __shared__ __attribute__((aligned(16))) float Es[KT][LDP];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -115,8 +115,7 @@ __global__ __launch_bounds__(256) void k_neg_shared_fwd(RowSrc<float> Q, RowSrc<
                     } else if (RED == RED_L1) {
                         acc[i][j] += fabsf(a[i] - b[j]);
                     } else {
-                        const float dlt = a[i] - b[j];
-                        acc[i][j] = fmaf(dlt, dlt, acc[i][j]);
+                        acc[i][j] += lp_term(a[i] - b[j], p);
                     }
                 }
         }
@@ -159,7 +158,7 @@ __global__ __launch_bounds__(256) void k_neg_shared_fwd(RowSrc<float> Q, RowSrc<
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v = acc[i][j];
-            if (RED == RED_L2) v = sqrtf(v);
+            if (RED == RED_L2) v = lp_root(v, p);
             v4[j] = sign * v;
         }
         const int64_t jj0 = j0 + tx * 4;
@@ -198,7 +197,7 @@ template <typename TX, typename TY, int RED, bool VEC4, bool ROUND16, int MI>
 __device__ __forceinline__ void neg_shared_bwd_tile(const BwdSide<TX, TY>& S, int W, float sign,
                                                     const float* __restrict__ d_out,
                                                     const float* __restrict__ out, int block,
-                                                    float (*Cs)[LDP], float (*Ys)[LDP]) {
+                                                    float (*Cs)[LDP], float (*Ys)[LDP], float p) {
     const RowSrc<TX> X = S.X;
     const RowSrc<TY> Y = S.Y;
     const int64_t sa = S.sa, sb = S.sb, oa = S.oa, ob = S.ob, b_chunk = S.b_chunk;
@@ -265,8 +264,8 @@ __device__ __forceinline__ void neg_shared_bwd_tile(const BwdSide<TX, TY>& S, in
             const float g = d_out[ac * sa + bc * sb];
             float c;
             if (RED == RED_L2) {
-                const float o = out[ac * oa + bc * ob];
-                c = (o != 0.f) ? g / o : 0.f;
+                const float o = out[ac * oa + bc * ob];  // o = -norm: d(-norm) / d x_w = -sgn |x_w - y_w|^(p-1) norm^(1-p)
+                c = -g * lp_inv(-o, p);
             } else {
                 c = sign * g;
             }
@@ -320,7 +319,7 @@ __device__ __forceinline__ void neg_shared_bwd_tile(const BwdSide<TX, TY>& S, in
                 for (int j = 0; j < 4; ++j) {
                     if (RED == RED_DOT) acc[i][j] = fmaf(c[i], y[j], acc[i][j]);
                     else if (RED == RED_L1) acc[i][j] = fmaf(c[i], sgn_prescaled(xv[i][j] - y[j]), acc[i][j]);
-                    else acc[i][j] = fmaf(c[i], xv[i][j] - y[j], acc[i][j]);
+                    else acc[i][j] = fmaf(c[i], lp_dterm(xv[i][j] - y[j], p), acc[i][j]);
                 }
         }
         __syncthreads();
@@ -346,12 +345,12 @@ __device__ __forceinline__ void neg_shared_bwd_tile(const BwdSide<TX, TY>& S, in
 template <typename TE, int RED, bool VEC4, bool ROUND16, int MIA, int MIB>
 __global__ __launch_bounds__(256) void k_neg_shared_bwd(BwdSide<float, TE> A, BwdSide<TE, float> B, int W,
                                                         float sign, const float* __restrict__ d_out,
-                                                        const float* __restrict__ out, int blocks_a) {
+                                                        const float* __restrict__ out, int blocks_a, float p) {
     __shared__ __attribute__((aligned(16))) float Cs[KT][LDP];  // [b][a]
     __shared__ __attribute__((aligned(16))) float Ys[KT][LDP];  // [b][w]
     const int block = blockIdx.x;
-    if (block < blocks_a) neg_shared_bwd_tile<float, TE, RED, VEC4, ROUND16, MIA>(A, W, sign, d_out, out, block, Cs, Ys);
-    else neg_shared_bwd_tile<TE, float, RED, VEC4, ROUND16, MIB>(B, W, sign, d_out, out, block - blocks_a, Cs, Ys);
+    if (block < blocks_a) neg_shared_bwd_tile<float, TE, RED, VEC4, ROUND16, MIA>(A, W, sign, d_out, out, block, Cs, Ys, p);
+    else neg_shared_bwd_tile<TE, float, RED, VEC4, ROUND16, MIB>(B, W, sign, d_out, out, block - blocks_a, Cs, Ys, p);
 }
 
 template <typename T>
@@ -362,7 +361,7 @@ static int run_fwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<T> E, float
     const dim3 grid(static_cast<unsigned>(ceil_div(E.n, TN)), static_cast<unsigned>(ceil_div(Q.n, small ? TM / 2 : TM)));
     const float sign = is_distance(d->scorer) ? -1.f : 1.f;
     const bool aligned = d->width % KT == 0;
-#define BESS_FWD_ARGS <<<grid, 256, 0, st>>>(Q, E, d->width, sign, out, ld)
+#define BESS_FWD_ARGS <<<grid, 256, 0, st>>>(Q, E, d->width, sign, out, ld, static_cast<float>(d->norm_p))
 #define BESS_FWD(RED)                                                         \
     do {                                                                      \
         if (aligned && small) k_neg_shared_fwd<T, RED, true, 2> BESS_FWD_ARGS;  \
@@ -439,7 +438,7 @@ static int run_bwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<TE> E, cons
     const int ba = static_cast<int>(blocks_a);
     const float sign = is_distance(d->scorer) ? -1.f : 1.f;
     const bool vec4 = W % 4 == 0;
-#define BESS_BWD_ARGS <<<grid, 256, 0, st>>>(A, B, W, sign, d_out, out, ba)
+#define BESS_BWD_ARGS <<<grid, 256, 0, st>>>(A, B, W, sign, d_out, out, ba, static_cast<float>(d->norm_p))
 #define BESS_BWD_MI(RED, V, R16)                                                   \
     do {                                                                           \
         if (small_a && small_b) k_neg_shared_bwd<TE, RED, V, R16, 2, 2> BESS_BWD_ARGS; \
@@ -612,7 +611,7 @@ extern "C" int bess_neg_score_shared_bwd_ws(const bess_model_desc* d, const floa
                               d_query, d_neg, st);
     if (d->scorer == BESS_AFFINE) {
         BESS_REQUIRE(!neg_idx, "neg_score_shared_bwd: affine scorers take dense f32 candidates (bess_normalize_rows)");
-        BESS_REQUIRE(d->norm_p != 2 || out, "neg_score_shared_bwd: p=2 needs the forward scores");
+        BESS_REQUIRE(d->norm_p == 1 || out, "neg_score_shared_bwd: p != 1 needs the forward scores");
         return affine_shared_bwd(d, query, n_query, static_cast<const float*>(neg_base), n_neg, out, ld_out, d_out,
                                  ld_dout, d_query, d_neg, st);
     }

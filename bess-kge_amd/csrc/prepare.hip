@@ -39,7 +39,7 @@ __device__ __forceinline__ void triple_fwd_body(const TripleArgs& a, int64_t s, 
     if (SCORER == BESS_TRANSE) {
         for (int e = lane; e < a.W; e += 64) {
             const float x = to_f32(h[e]) + to_f32(r[e]) - to_f32(t[e]);
-            acc += (a.norm_p == 1) ? fabsf(x) : x * x;
+            acc += (a.norm_p == 1) ? fabsf(x) : lp_term(x, static_cast<float>(a.norm_p));
         }
     } else if (SCORER == BESS_DISTMULT) {
         for (int e = lane; e < a.W; e += 64) acc += to_f32(h[e]) * to_f32(r[e]) * to_f32(t[e]);
@@ -61,14 +61,16 @@ __device__ __forceinline__ void triple_fwd_body(const TripleArgs& a, int64_t s, 
             const float qi = hr * ri + hi * rr;
             if (SCORER == BESS_ROTATE) {
                 const float xr = qr - tr, xi = qi - ti;
-                acc += (a.norm_p == 1) ? (fabsf(xr) + fabsf(xi)) : (xr * xr + xi * xi);
+                acc += (a.norm_p == 1) ? (fabsf(xr) + fabsf(xi))
+                                       : (lp_term(xr, static_cast<float>(a.norm_p)) + lp_term(xi, static_cast<float>(a.norm_p)));
             } else {
                 acc += qr * tr + qi * ti;
             }
         }
     }
     acc = wave_allreduce_sum(acc);
-    if (SCORER == BESS_TRANSE || SCORER == BESS_ROTATE) acc = -((a.norm_p == 1) ? acc : sqrtf(acc));
+    if (SCORER == BESS_TRANSE || SCORER == BESS_ROTATE)
+        acc = -((a.norm_p == 1) ? acc : lp_root(acc, static_cast<float>(a.norm_p)));
     if (lane == 0) out[s] = acc;
 }
 
@@ -165,18 +167,19 @@ __device__ __forceinline__ void triple_bwd_body(const TripleArgs& a, int64_t s, 
 
     if (SCORER == BESS_TRANSE) {
         float inv = 0.f;
-        if (a.norm_p == 2) {
+        const float pf = static_cast<float>(a.norm_p);
+        if (a.norm_p != 1) {
             float ss = 0.f;
             for (int e = lane; e < a.W; e += 64) {
                 const float x = to_f32(h[e]) + to_f32(r[e]) - to_f32(t[e]);
-                ss += x * x;
+                ss += lp_term(x, pf);
             }
             ss = wave_allreduce_sum(ss);
-            inv = ss > 0.f ? 1.f / sqrtf(ss) : 0.f;
+            inv = lp_inv(lp_root(ss, pf), pf);
         }
         for (int e = lane; e < a.W; e += 64) {
             const float x = to_f32(h[e]) + to_f32(r[e]) - to_f32(t[e]);
-            const float dx = -g * ((a.norm_p == 1) ? sgnf(x) : x * inv);
+            const float dx = -g * ((a.norm_p == 1) ? sgnf(x) : lp_dterm(x, pf) * inv);
             dh[e] = dx;
             dt[e] = -dx;
             if (dx != 0.f) unsafeAtomicAdd(dr + e, dx);
@@ -191,7 +194,8 @@ __device__ __forceinline__ void triple_bwd_body(const TripleArgs& a, int64_t s, 
     } else {
         const int d = a.W / 2;
         float inv = 0.f;
-        if (SCORER == BESS_ROTATE && a.norm_p == 2) {
+        const float pf = static_cast<float>(a.norm_p);
+        if (SCORER == BESS_ROTATE && a.norm_p != 1) {
             float ss = 0.f;
             for (int e = lane; e < d; e += 64) {
                 const float hr = to_f32(h[e]), hi = to_f32(h[d + e]);
@@ -199,10 +203,10 @@ __device__ __forceinline__ void triple_bwd_body(const TripleArgs& a, int64_t s, 
                 const float c = cosf(ph), sn = sinf(ph);
                 const float xr = hr * c - hi * sn - to_f32(t[e]);
                 const float xi = hr * sn + hi * c - to_f32(t[d + e]);
-                ss += xr * xr + xi * xi;
+                ss += lp_term(xr, pf) + lp_term(xi, pf);
             }
             ss = wave_allreduce_sum(ss);
-            inv = ss > 0.f ? 1.f / sqrtf(ss) : 0.f;
+            inv = lp_inv(lp_root(ss, pf), pf);
         }
         for (int e = lane; e < d; e += 64) {
             const float hr = to_f32(h[e]), hi = to_f32(h[d + e]);
@@ -212,8 +216,8 @@ __device__ __forceinline__ void triple_bwd_body(const TripleArgs& a, int64_t s, 
                 const float c = cosf(ph), sn = sinf(ph);
                 const float xr = hr * c - hi * sn - tr;
                 const float xi = hr * sn + hi * c - ti;
-                const float dxr = -g * ((a.norm_p == 1) ? sgnf(xr) : xr * inv);
-                const float dxi = -g * ((a.norm_p == 1) ? sgnf(xi) : xi * inv);
+                const float dxr = -g * ((a.norm_p == 1) ? sgnf(xr) : lp_dterm(xr, pf) * inv);
+                const float dxi = -g * ((a.norm_p == 1) ? sgnf(xi) : lp_dterm(xi, pf) * inv);
                 dh[e] = dxr * c + dxi * sn;
                 dh[d + e] = -dxr * sn + dxi * c;
                 dt[e] = -dxr;

@@ -50,8 +50,8 @@ int check_desc(const bess_model_desc* d) {
     }
     if (d->width <= 0 || d->rel_width <= 0)
         return fail(BESS_EINVAL, "non-positive width %d / %d", d->width, d->rel_width);
-    if (is_distance(d->scorer) && d->norm_p != 1 && d->norm_p != 2)
-        return fail(BESS_EINVAL, "scoring norm %d not in {1, 2}", d->norm_p);
+    if (is_distance(d->scorer) && d->norm_p < 1)
+        return fail(BESS_EINVAL, "scoring norm %d is not a p >= 1", d->norm_p);
     const bool cplx = is_complex_entity(d->scorer);
     if (cplx && (d->width % 2)) return fail(BESS_EINVAL, "complex scorer needs even width");
     int want_rel = d->width;

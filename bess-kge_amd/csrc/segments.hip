@@ -289,6 +289,7 @@ struct SegArgs {
     float sign;
     const int32_t* long_segs;    // optional: [0] = number of segments longer than SEG_CAP, [1..] = their ids
     SegOpt opt;
+    float p;  // the norm of the RED_L2 kernels (any p != 1)
     // column windows that run side by side in ONE launch: workgroup b works on window b % n_win (workgroups go
     // to the XCDs round-robin, so with n_win dividing 8 an XCD only ever sees the windows b % n_win == xcd %
     // n_win and its L2 keeps just their slices of the query matrix), on segment groups b / n_win
@@ -345,11 +346,10 @@ __device__ __forceinline__ void seg_accumulate(const SegArgs& a, int g, const fl
             for (int it = 0; it < IT; ++it)
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
-                    const float dlt = qv[it][v] - ev[it][v];
-                    ss = fmaf(dlt, dlt, ss);
+                    ss += lp_term(qv[it][v] - ev[it][v], a.p);
                 }
             ss = row16_allreduce_sum(ss);
-            go = ss > 0.f ? go / sqrtf(ss) : 0.f;
+            go *= lp_inv(lp_root(ss, a.p), a.p);
         }
 #pragma unroll
         for (int it = 0; it < IT; ++it)
@@ -357,7 +357,7 @@ __device__ __forceinline__ void seg_accumulate(const SegArgs& a, int g, const fl
             for (int v = 0; v < VEC; ++v) {
                 if (RED == RED_DOT) acc[it][v] = fmaf(go, qv[it][v], acc[it][v]);
                 else if (RED == RED_L1) acc[it][v] -= go * sgnf(qv[it][v] - ev[it][v]);
-                else acc[it][v] = fmaf(-go, qv[it][v] - ev[it][v], acc[it][v]);
+                else acc[it][v] = fmaf(-go, lp_dterm(qv[it][v] - ev[it][v], a.p), acc[it][v]);
             }
     };
     if (r0 >= r1) return;
@@ -975,7 +975,7 @@ static int grad_segments_impl(const bess_model_desc* d, const float* query, int6
         if (wopt.xsum) wopt.xsum += col0;
         SegArgs a{query + col0, tab, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg,
                   static_cast<int>(n_neg), W, cols / vec / n_conc, is_distance(d->scorer) ? -1.f : 1.f, long_segs, wopt,
-                  n_conc, cols / n_conc};
+                  static_cast<float>(d->norm_p), n_conc, cols / n_conc};
         const int it = static_cast<int>(ceil_div(a.nch, 16));
         float* gs = grad_seg ? grad_seg + col0 : nullptr;
         const unsigned grid = static_cast<unsigned>(n_conc * std::min<int64_t>(ceil_div(max_seg, 16), 256 * 16 / n_conc));
@@ -1003,7 +1003,8 @@ static int grad_segments_impl(const bess_model_desc* d, const float* query, int6
             if (wopt.xsum) wopt.xsum += col0;
             char* tab = static_cast<char*>(table) + col0 * sz;
             SegArgs a{query + col0, tab, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg,
-                      static_cast<int>(n_neg), W, cols / vec, is_distance(d->scorer) ? -1.f : 1.f, long_segs, wopt, 1, cols};
+                      static_cast<int>(n_neg), W, cols / vec, is_distance(d->scorer) ? -1.f : 1.f, long_segs, wopt,
+                      static_cast<float>(d->norm_p), 1, cols};
             const int it = static_cast<int>(ceil_div(a.nch, 16));
             const unsigned lgrid = 1024;  // 16 K groups share the slices
             float* gs = grad_seg ? grad_seg + col0 : nullptr;

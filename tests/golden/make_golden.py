@@ -575,6 +575,32 @@ def gen_scoring_affine() -> None:
     _gen_scoring("scoring_affine", AFFINE_SCORERS, 2)
 
 
+#: p-norms beyond 1 and 2 (the reference takes any p through torch.norm: scoring.py:174)
+LP_SCORERS = [("TransE", 3), ("RotatE", 3), ("TransE", 4)]
+
+
+def gen_scoring_lp() -> None:
+    _gen_scoring("scoring_lp", LP_SCORERS, 7)
+
+
+def gen_bess_lp() -> None:
+    """BessKGE.forward + autograd with scoring_norm 3 / 4: shared and per-triple negatives, both schemes."""
+    EM, SM = EmbeddingMovingBessKGE, ScoreMovingBessKGE
+    cases = [
+        ("tr_EM_TransE3_t_flat_n1", EM, "TransE", 3, 1, "t", "random_flat", "logsigmoid", False, True),
+        ("tr_EM_TransE3_h_pt_n1", EM, "TransE", 3, 1, "h", "random_pt", "logsigmoid", False, False),
+        ("tr_EM_RotatE3_ht_pt_n2", EM, "RotatE", 3, 2, "ht", "random_pt", "ssce", False, False),
+        ("tr_EM_RotatE3_aug_t_flat_n2", EM, "RotatE", 3, 2, "t", "random_flat", "ssce", True, True),
+        ("tr_SM_TransE4_t_pt_n2", SM, "TransE", 4, 2, "t", "random_pt", "logsigmoid", False, False),
+        ("tr_SM_TransE3_ht_flat_n2", SM, "TransE", 3, 2, "ht", "random_flat", "margin", False, True),
+    ]
+    names = []
+    for name, mcls, scorer, p, n, scheme, nk, loss, aug, sharing in cases:
+        run_bess_case(name, mcls, scorer, p, n, scheme, nk, loss, aug, sharing, fix="bess_lp")
+        names.append(name)
+    put("bess_lp", "cases", np.array(names))
+
+
 def _gen_scoring(fix: str, scorers: Any, seed: int) -> None:
     torch.manual_seed(seed)
     S, N, d, n_rel, n_ent = 10, 7, 12, 5, 40
@@ -1089,6 +1115,8 @@ def main() -> None:
         bess_conve=gen_bess_conve,
         bess_local=gen_bess_local,
         bess_half=gen_bess_half,
+        scoring_lp=gen_scoring_lp,
+        bess_lp=gen_bess_lp,
     )
     for name, g in gens.items():
         if only and name not in only:

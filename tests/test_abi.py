@@ -89,9 +89,13 @@ def test_invalid_arguments_return_error_codes():
     d.scorer, d.norm_p, d.dtype, d.width, d.rel_width = 9, 1, 0, 8, 8
     assert lib.bess_query_fwd(ctypes.byref(d), 0, 0, 0, 0, 0, 0, 0, 0) == -1
     assert "unknown scorer" in last_error(lib)
-    d.scorer, d.norm_p = _native.TRANSE, 3
+    d.scorer, d.norm_p = _native.TRANSE, 0  # (any p >= 1 is a norm: TransE / RotatE take it)
     assert lib.bess_score_triple_fwd(ctypes.byref(d), 0, 0, 0, 0, 0, 0, 0, 0, 0) == -1
     assert "norm" in last_error(lib)
+    d.scorer, d.norm_p, d.reserved[0] = _native.AFFINE, 3, 1  # the affine family: p in {1, 2}
+    assert lib.bess_score_triple_fwd(ctypes.byref(d), 0, 0, 0, 0, 0, 0, 0, 0, 0) == -1
+    assert "norm" in last_error(lib)
+    d.reserved[0] = 0
     d.scorer, d.norm_p, d.width, d.rel_width = _native.ROTATE, 1, 8, 8  # RotatE needs Wr = W/2
     assert lib.bess_query_fwd(ctypes.byref(d), 0, 0, 0, 0, 0, 0, 0, 0) == -1
     assert "rel_width" in last_error(lib)

@@ -114,8 +114,13 @@ def test_scorer_constructors_allocate_like_the_reference():
     fn.update_sharding(new)
     after = fn.entity_embedding.data[torch.from_numpy(new.entity_to_shard), torch.from_numpy(new.entity_to_idx)]
     assert fn.sharding is new and torch.equal(before, after)
+    assert TransE(True, 3, s, 5, 16).kernel_desc().norm_p == 3  # any p >= 1, like the reference's torch.norm
     with pytest.raises(ValueError):
-        TransE(True, 3, s, 5, 16)
+        TransE(True, 0, s, 5, 16)
+    from besskge.scoring import PairRE
+
+    with pytest.raises(ValueError):  # the affine family's kernels: p in {1, 2}
+        PairRE(True, 3, s, 5, 16)
 
 
 def test_scorer_constructors_place_only_the_hosted_shards():

@@ -135,7 +135,7 @@ def test_cpu_tensors_are_refused():
 @pytest.mark.parametrize("B", [1, 10])
 def test_scoring_golden(dev, name, p, sharing, B):
     """score_triple / score_heads / score_tails + gradients vs the reference's outputs."""
-    g = scoring_fixture(name)
+    g = scoring_fixture(name, p)
     S, N, d, n_rel, n_ent = (int(x) for x in g["args"])
     k = f"{name}_p{p}_"
     c = k + f"s{int(sharing)}_B{B}_"
