@@ -79,7 +79,11 @@ def _from_initializers(
         raise ValueError("Different number of embedding splits and initializers provided")
     if dtype is not None and dtype != torch.float32:
         # the table is born in its final dtype (a 160 MB - 128 GB shard must not exist twice, once as
-        # fp32): rows are initialised in fp32 blocks and converted on the way in
+        # fp32): rows are initialised in fp32 blocks and converted on the way in.  Seed parity with the fp32
+        # path (`table.half()` of the table the same seed gives in fp32) holds for tables of up to
+        # _INIT_CHUNK_SCALARS scalars with a single initialiser: beyond one block, or with several column
+        # pieces, the random stream is consumed block by block and piece by piece inside a block, not
+        # piece by piece over the whole table as the reference does (embedding.py:173-188)
         W = int(sum(row_size))
         out = torch.empty(size=(*lead_shape, W), dtype=dtype, device=device)
         flat = out.view(-1, W)
