@@ -149,6 +149,7 @@ SIGNATURES = {
     "bess_dense_sgd": [_i32, _vp, _vp, _i64, _f32, _vp],
     "bess_segment_index_workspace": [_i64, ctypes.POINTER(ctypes.c_size_t)],
     "bess_build_segment_index": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, ctypes.c_size_t, _vp],
+    "bess_pad_segments": [_vp, _vp, _i64, _vp, _i32, _vp],
     "bess_step_prologue": [_i32, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint32),
                            ctypes.POINTER(_i64), _i32, ctypes.POINTER(_vp), ctypes.POINTER(_i64), _i32, _vp, _vp, _vp, _vp,
                            _vp, _i64, _vp],
@@ -1132,6 +1133,20 @@ def neg_pertriple_grad_segments(d: ModelDesc, query: torch.Tensor, table: torch.
                                                      seg.long_count.data_ptr() if native else None, _stream(dev))
     _check(rc, "bess_neg_pertriple_grad_segments")
     return grad
+
+
+def pad_segments(seg: SegmentIndex, grad_seg: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(row ids [max_seg], gradient rows [max_seg, W]) of a segment list with its unused tail neutralised (copies
+    of the last real row, zero gradients): an ordinary row list of host-known length - no read-back of n_seg."""
+    dev = _same_device([("grad_seg", grad_seg), ("seg_rows", seg.seg_rows)])
+    _f32(grad_seg, "grad_seg")
+    if grad_seg.dim() != 2 or grad_seg.shape[0] != seg.max_seg or not grad_seg.is_contiguous():
+        raise ValueError("pad_segments: grad_seg must be a contiguous [seg.max_seg, W] tensor")
+    with _on(dev):
+        rc = load().bess_pad_segments(seg.seg_rows.data_ptr(), seg.n_seg.data_ptr(), seg.max_seg, grad_seg.data_ptr(),
+                                      int(grad_seg.shape[1]), _stream(dev))
+    _check(rc, "bess_pad_segments")
+    return seg.seg_rows[: seg.max_seg], grad_seg
 
 
 def apply_segments_sgd(table: torch.Tensor, seg: SegmentIndex, grad_seg: torch.Tensor, lr: float) -> None:

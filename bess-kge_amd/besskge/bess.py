@@ -800,12 +800,10 @@ class BessKGE(torch.nn.Module, ABC):
                     if table is st.table:
                         seg = seg_index[id(g)]
                         gseg = nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go, seg)
-                        if torch.cuda.is_current_stream_capturing():
-                            raise NotImplementedError(
-                                "use_graphs with a stateful optimiser needs the fused optimiser step (TransE / RotatE / "
-                                "DistMult / ComplEx / ConvE with one per-triple group per shard) or shared negatives")
-                        n_rows = int(seg.n_seg.item())  # one host sync per step on this path
-                        contrib.append((seg.seg_rows[:n_rows], gseg[:n_rows]))
+                        # the group's unique rows with their summed gradients become one more row list; the unused
+                        # tail of the segment arrays is neutralised on the device (no read-back of the row
+                        # count: no host sync, and the step can be recorded into a hipGraph)
+                        contrib.append(nat.pad_segments(seg, gseg))
                 self._apply_optimizer(optimizer, st.table, contrib,
                                       (getattr(self, "_small_ahead", None) or {}).get(id(st)), axpy=rel_axpy)
                 rel_done = rel_axpy is not None

@@ -852,6 +852,32 @@ extern "C" int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int3
     return check_launch("build_segment_index");
 }
 
+// Entries [n_seg, max_seg) of a segment list become copies of its last real row with a zero gradient: the list
+// then has a length the host knows (max_seg) and can be handed on as an ordinary (row ids, gradient rows) list -
+// a duplicate with a zero contribution changes no row's total - without reading n_seg back (no host
+// synchronisation, recordable into a hipGraph).
+__global__ __launch_bounds__(256) void k_pad_segments(int32_t* __restrict__ seg_rows, const int32_t* __restrict__ n_seg,
+                                                      int64_t max_seg, float* __restrict__ grad, int W) {
+    const int64_t ns = *n_seg;
+    if (ns >= max_seg || ns <= 0) return;
+    const int32_t last = seg_rows[ns - 1];
+    const int64_t total = (max_seg - ns) * W;
+    for (int64_t t = blockIdx.x * 256ll + threadIdx.x; t < total; t += 256ll * gridDim.x) {
+        const int64_t s = ns + t / W;
+        grad[s * W + t % W] = 0.f;
+        if (t % W == 0) seg_rows[s] = last;
+    }
+}
+
+extern "C" int bess_pad_segments(int32_t* seg_rows, const int32_t* n_seg, int64_t max_seg, float* grad_seg,
+                                 int32_t width, void* stream) {
+    BESS_REQUIRE(seg_rows && n_seg && grad_seg, "pad_segments: NULL pointer");
+    BESS_REQUIRE(max_seg > 0 && width > 0, "pad_segments: bad sizes");
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(max_seg * width, 256 * 8), 2048));
+    k_pad_segments<<<grid < 1 ? 1 : grid, 256, 0, as_stream(stream)>>>(seg_rows, n_seg, max_seg, grad_seg, width);
+    return check_launch("pad_segments");
+}
+
 extern "C" int bess_step_prologue(int32_t n_jobs, void* const* job_dst, const void* const* job_src,
                                   const uint32_t* job_value, const int64_t* job_words, int32_t n_lists,
                                   const int32_t* const* id_lists, const int64_t* id_lens, int32_t row_bits,

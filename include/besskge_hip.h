@@ -437,6 +437,12 @@ int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int32_t row_bit
                              int64_t long_cap, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* Rows [*n_seg, max_seg) of (seg_rows, grad_seg [max_seg, width]) become copies of the last real row with zero
+ * gradient rows: the segment list can then be passed on with its host-known length max_seg (e.g. as one of the
+ * lists of bess_coalesced_update) without reading *n_seg back. */
+int bess_pad_segments(int32_t* seg_rows, const int32_t* n_seg, int64_t max_seg, float* grad_seg, int32_t width,
+                      void* stream);
+
 /* Prologue of a notebook-size step in ONE launch (the step is launch-bound there: reference micro-batch
  * S = 512, K = 32 of notebooks/3_wikikg2_fp16.ipynb:251-256):
  *   - up to BESS_MAX_WORD_JOBS copy / fill jobs over 32-bit words: job j writes job_words[j] words at

@@ -193,7 +193,12 @@ def test_fused_optimizer_step_in_the_segmented_reduction(dev, kind, scorer, p, d
 
 
 @pytest.mark.parametrize("opt_name", ["adam", "sgdm", "adagrad"])
-@pytest.mark.parametrize("case", ["tr_EM_TransE1_t_flat_n1", "tr_EM_ComplEx0_h_pt_n1"])
+@pytest.mark.parametrize("case", ["tr_EM_TransE1_t_flat_n1", "tr_EM_ComplEx0_h_pt_n1",
+                                  # the general coalescing path (no fused optimiser step): two per-triple groups per
+                                  # shard, the affine family, BoxE - their unique-row lists are handed on without
+                                  # reading the row count back (bess_pad_segments), so they record too
+                                  "tr_EM_RotatE2_ht_pt_n2", "tr_EM_PairRE1_h_pt_n1", "tr_EM_BoxE1_ht_pt_n2",
+                                  "tr_SM_TransE1_t_pt_n2"])
 def test_graph_replay_with_stateful_optimizers(dev, opt_name, case):
     """Options.use_graphs with Adagrad / SGD-momentum / Adam: four recorded-and-replayed steps move the
     tables like four eager steps (Adam's bias correction follows the device-side step count)."""
@@ -223,8 +228,15 @@ def test_graph_replay_with_stateful_optimizers(dev, opt_name, case):
     (l0, e0, r0), (l1, e1, r1) = out
     assert float(l0[3].sum()) != float(l0[0].sum())  # the steps do change the model
     torch.testing.assert_close(l1, l0, rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(e1, e0, rtol=1e-4, atol=2e-5)
-    torch.testing.assert_close(r1, r0, rtol=1e-4, atol=2e-5)
+    if n > 1 and opt_name in ("adam", "adagrad"):
+        # exchanged rows come back through fp32 atomics: where a gradient entry cancels to ~0 its sign - and with a
+        # sign-normalising optimiser a whole +-lr step - depends on their order (tests/test_accumulation.py)
+        for a, b in ((e1, e0), (r1, r0)):
+            off = (a - b).abs()
+            assert float((off > 1e-4).float().mean()) < 0.02 and float(off.max()) <= 4 * 0.1 * 1.01
+    else:
+        torch.testing.assert_close(e1, e0, rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(r1, r0, rtol=1e-4, atol=2e-5)
 
 
 @pytest.mark.parametrize("opt_name", ["adam", "sgdm"])
