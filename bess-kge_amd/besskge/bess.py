@@ -118,6 +118,7 @@ class _ReplicaStep:
         # training: copy / fill jobs (dst, src | None, fill word) run by ONE launch in front of the step's kernels
         # (`nat.step_prologue`), together with the index of the step's small update lists
         self.jobs: Optional[List[Tuple[torch.Tensor, Optional[torch.Tensor], int]]] = None
+        self.d_recv: Optional[torch.Tensor] = None  # [rows of recv, W] f32, cleared by the prologue (n_shard > 1)
 
 
 class _PendingUpdate:
@@ -621,6 +622,10 @@ class BessKGE(torch.nn.Module, ABC):
                     jobs.append((g.bwd_buf, None, 0))
         if d_rel is not None:
             jobs.append((d_rel, None, 0))
+        if st.n > 1 and st.recv is not None and len(jobs) < nat.MAX_WORD_JOBS:
+            # the gradients of the rows that came through the all-to-all are summed into this (C8 sends it back)
+            st.d_recv = torch.empty((st.recv.shape[0], st.recv.shape[1]), dtype=torch.float32, device=st.table.device)
+            jobs.append((st.d_recv, None, 0))
         plan = self._small_plan(st, optimizer)
         if plan is not None and sum(int(x.numel()) for x in plan) > nat.SMALL_INDEX_MAX:
             plan = None
@@ -760,9 +765,9 @@ class BessKGE(torch.nn.Module, ABC):
             d_rel = d_rel / group.n_shard
         # plain SGD on the relation table rides along in the launch that updates the (one) shard hosted here
         rel_axpy, rel_done = None, False
-        if plain and not plain_rows and len(steps) == 1 and rel_table.dtype == steps[0].table.dtype \
-                and not any(item[0] is steps[0].table for item in deferred):
-            rel_axpy = (rel_table, d_rel, -lr)
+        if plain and not plain_rows and rel_table.dtype == steps[-1].table.dtype \
+                and not any(item[0] is steps[-1].table for item in deferred):
+            rel_axpy = (rel_table, d_rel, -lr)  # (with the last shard hosted here)
         if plain_rows:
             # per-triple negatives of the own shard: segmented reduction.  A shard with a
             # single such group gets the SGD step fused into the reduction; with two
@@ -804,9 +809,11 @@ class BessKGE(torch.nn.Module, ABC):
                         # tail of the segment arrays is neutralised on the device (no read-back of the row
                         # count: no host sync, and the step can be recorded into a hipGraph)
                         contrib.append(nat.pad_segments(seg, gseg))
+                last = st is steps[-1]
                 self._apply_optimizer(optimizer, st.table, contrib,
-                                      (getattr(self, "_small_ahead", None) or {}).get(id(st)), axpy=rel_axpy)
-                rel_done = rel_axpy is not None
+                                      (getattr(self, "_small_ahead", None) or {}).get(id(st)),
+                                      axpy=rel_axpy if last else None)
+                rel_done = rel_done or (last and rel_axpy is not None)
         if rel_done:
             pass  # updated in the shard's launch
         elif plain:
@@ -1172,7 +1179,9 @@ class EmbeddingMovingBessKGE(BessKGE):
             upd: List[Tuple[torch.Tensor, torch.Tensor]] = []  # (rows of my shard, gradient rows)
             d_recv = None
             if n > 1:
-                d_recv = torch.zeros((st.recv.shape[0], W), dtype=torch.float32, device=dev)
+                d_recv = st.d_recv  # cleared by the step's prologue launch
+                if d_recv is None:
+                    d_recv = torch.zeros((st.recv.shape[0], W), dtype=torch.float32, device=dev)
 
             into_recv: List[Tuple[torch.Tensor, torch.Tensor]] = []  # gradients of rows that came from other shards
 

@@ -75,6 +75,9 @@ if steps:
 # index of the other logs kept for this round (each is the stdout of the script named in its first column)
 INDEX = [
     ("bench_default.json", "python bench.py", "the driver's line: value, roofline, train_step (SGD and AdamW), cpu_baseline"),
+    ("bench_c4_4096x256.json", "python bench.py --workload c4", "north_star's scaling workload as the line itself (S = 4096, K = 256 per shard pair)"),
+    ("bench_c4_512x32.json", "python bench.py --workload c4 --c4-point 512,32 --steps 256 --warmup 32", "the same at the notebook's micro-batch"),
+    ("pmc_k9_r03.txt", "profiles/pmc_k9.sh", "counters of the K9 segmented reduction inside the C2 training step (L2 hit rate, fetch bytes, VALU / wait cycles)"),
     ("microbench_final.log", "profiles/microbench.py", "every hot entry point on the BASELINE shapes (GB/s, TFLOP/s, T lane-ops/s)"),
     ("bench_gemm_split.log", "profiles/bench_gemm_split.py", "split-fp16 matrix-core products: accuracy vs float64 and rate, forward + backward"),
     ("bench_topk.log", "profiles/bench_topk.py", "top-k over all entities (YAGO3-10, wikikg2, biokg shapes)"),
