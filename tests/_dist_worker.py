@@ -88,6 +88,16 @@ def bess(out_dir: str) -> None:
             out[f"{case}_train_loss"] = res["loss"].float().cpu().numpy()
             out[f"{case}_train_entity"] = model.score_fn.entity_embedding.detach().float().cpu().numpy()
             out[f"{case}_train_relation"] = model.score_fn.relation_embedding.detach().float().cpu().numpy()
+            if os.environ.get("BESS_ACCUMULATE"):
+                # gradient accumulation, one process per shard: two micro-batches, one update
+                model = build_model(c, dev)
+                opt = runtime.Adam(lr=0.01) if os.environ["BESS_ACCUMULATE"] == "adam" else runtime.SGD(lr=lr)
+                runner = runtime.training_model(model, runtime.Options(device_iterations=1, gradient_accumulation=2,
+                                                                       output_mode="all"), opt, group=g, device=dev)
+                res = runner(**batch)  # bps = 2 micro-batches
+                out[f"{case}_acc_loss"] = res["loss"].float().cpu().numpy()
+                out[f"{case}_acc_entity"] = model.score_fn.entity_embedding.detach().float().cpu().numpy()
+                out[f"{case}_acc_relation"] = model.score_fn.relation_embedding.detach().float().cpu().numpy()
     np.savez(os.path.join(out_dir, f"bess_{r}.npz"), **out)
 
 

@@ -242,3 +242,38 @@ print("ok")
     res = subprocess.run([sys.executable, "-c", code, os.path.join(os.path.dirname(HERE), "bess-kge_amd")], capture_output=True,
                          text=True, timeout=120, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opt_name", ["sgd", "adam"])
+def test_gradient_accumulation_one_process_per_shard(opt_name):
+    """Options.gradient_accumulation with one process per shard (gloo, ranks sharing the GPU): two micro-batches, one
+    update - the relation gradient all-reduced once, every shard's rows updated once - equals the oracle's step on
+    the summed loss, like the single-process form (tests/test_accumulation.py)."""
+    from oracle import kge
+    from test_oracle import load_bess_case, step_batch
+
+    cases = ["tr_EM_TransE1_ht_flat_n2", "tr_EM_ComplEx0_ht_pt_n2", "tr_SM_TransE1_t_pt_n2"]
+    out = launch("bess", 2, {"BESS_CASES": ",".join(cases), "BESS_DIST_BACKEND": "gloo", "BESS_ACCUMULATE": opt_name},
+                 timeout=900)
+    per_rank = [np.load(os.path.join(out, f"bess_{r}.npz")) for r in range(2)]
+    for case in cases:
+        c = load_bess_case(case)
+        t0 = c["table"].clone().requires_grad_(True)
+        r0 = c["rel"].clone().requires_grad_(True)
+        total = 0.0
+        for it in range(2):
+            res = kge.bess_step(c["spec"], c["model_cls"], t0, r0, step_batch(c["batch"], it), c["loss"])
+            total = total + torch.stack(res["loss"]).sum()
+        total.backward()
+        opt = torch.optim.Adam([t0, r0], lr=0.01) if opt_name == "adam" else torch.optim.SGD([t0, r0], lr=0.125)
+        opt.step()
+        for r in range(2):
+            got = torch.from_numpy(per_rank[r][f"{case}_acc_entity"])[0]
+            grad = t0.grad[r]
+            solid = grad.abs() > 1e-4 if opt_name == "adam" else torch.ones_like(grad, dtype=torch.bool)
+            tol = dict(rtol=2e-3, atol=5e-5) if opt_name == "adam" else dict(rtol=1e-4, atol=2e-5)
+            torch.testing.assert_close(got[solid], t0.detach()[r][solid], **tol)
+            got_rel = torch.from_numpy(per_rank[r][f"{case}_acc_relation"])
+            solid = r0.grad.abs() > 1e-4 if opt_name == "adam" else torch.ones_like(r0.grad, dtype=torch.bool)
+            torch.testing.assert_close(got_rel[solid], r0.detach()[solid], **tol)
