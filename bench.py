@@ -596,7 +596,9 @@ def main() -> None:
     # step i+1 overlap the gather+score kernel of step i.  Training steps
     # depend on each other (table updates) and stay on one stream.
     if args.streams <= 0:
-        args.streams = 2 if distributed else 1
+        # (native collectives: ONE stream - two collectives of the one RCCL communicator in flight on different
+        # streams could start in different orders on different ranks; c10d serialises on its own stream)
+        args.streams = 2 if (distributed and not comm_name.startswith("native")) else 1
     main_stream = torch.cuda.current_stream(dev)
     streams = [main_stream] if args.mode == "train" or args.streams == 1 else \
         [torch.cuda.Stream(device=dev) for _ in range(args.streams)]

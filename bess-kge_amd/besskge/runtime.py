@@ -404,6 +404,13 @@ class Runner:
             return self._call_with_graphs(batch, iters)
         collected: List[List[Dict[str, Any]]] = []
         n_streams = 1 if (self.optimizer is not None or iters == 1) else max(1, self.options.pipeline_streams)
+        if isinstance(self.group, NativeGroup):
+            # ONE stream for the collectives of the one RCCL communicator: two of its collectives in flight on
+            # different streams may be started in different orders on different ranks (each waits for all ranks).
+            # c10d serialises its collectives on its own stream; the library's run where they are issued - so all
+            # micro-batches of a call are issued on the current stream (their gathers are still queued one
+            # micro-batch ahead of the scoring: forward_begin / forward_finish)
+            n_streams = 1
         main = torch.cuda.current_stream(self.device)
         streams = [main] if n_streams == 1 else self._side_streams(n_streams)
         for st in streams:
