@@ -374,12 +374,16 @@ def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, c
                 # VALU work of the L1 distance matrix per GPU and step: forward |q - e| accumulate and the two
                 # backward products, S x N x W elements each (csrc/neg_shared.hip states the ops per element)
                 elems = S_ * n_neg * C4_D
-                # lane-instructions per element: forward 1 (a packed max + a packed dot per 2 elements), each
-                # backward product 3 (sub, sign, multiply-add); whole step / step time -> fraction of the issue peak
-                lane_ops = 7 * elems / (best * 1e-3) / 1e12
+                # lane-instructions per element: forward 1 (a packed max + a packed dot per 2 elements); backward 4
+                # where both products come from one evaluation of sgn(q - e) (k_l1_bwd_both: sub, sign, two
+                # multiply-adds; S, N >= 1024, N % 32 == 0, S % 8 == 0), else 3 per product (sub, sign, multiply-add);
+                # whole step / step time -> fraction of the issue peak
+                both = S_ >= 1024 and n_neg >= 1024 and n_neg % 32 == 0 and S_ % 8 == 0
+                per_elem = 5 if both else 7
+                lane_ops = per_elem * elems / (best * 1e-3) / 1e12
                 point["valu"] = dict(bound="valu", elements_per_product=elems,
                                      achieved=3 * elems / (best * 1e-3) / 1e12, unit="T element-updates/s (3 products/step)",
-                                     lane_ops_per_element=7, achieved_lane_ops=lane_ops,
+                                     lane_ops_per_element=per_elem, achieved_lane_ops=lane_ops,
                                      peak=VALU_PEAK_TLOPS, peak_unit="T lane-ops/s", frac=lane_ops / VALU_PEAK_TLOPS)
     return c4_summary(state, world, comm_name)
 
@@ -818,8 +822,9 @@ def main_c4(args, world: int, rank: int, dev, group, distributed: bool, comm_nam
     valu = dict(point["valu"])
     valu.update(kernel="k_l1_fwd_pk + k_neg_shared_bwd (both products), whole step", peak=VALU_PEAK_TLOPS,
                 achieved=valu["achieved_lane_ops"], unit="T lane-ops/s", traffic=None,
-                note="the L1 distance matrix has no matrix-core form: 7 VALU lane-instructions per (query, candidate, "
-                     "column) over forward + two backward products; achieved = that count / whole step time")
+                note="the L1 distance matrix has no matrix-core form: `lane_ops_per_element` VALU lane-instructions per "
+                     "(query, candidate, column) over forward + two backward products (5 when both products share one "
+                     "evaluation of sgn(q - e), else 7); achieved = that count / whole step time")
     out = {
         "metric": "positive+negative triples scored/sec",
         "value": point["value"], "unit": "triples/s", "n_gpus": world,

@@ -608,6 +608,9 @@ class BessKGE(torch.nn.Module, ABC):
                                                       scratch=self.__dict__.setdefault("_seg_scratch", {})))
         return out
 
+    #: row ids the step prologue's single workgroup indexes; longer lists go to the side stream
+    prologue_index_max = 4096
+
     def _launch_prologue(self, st: _ReplicaStep, optimizer: Any, d_rel: Optional[torch.Tensor]) -> Optional[Any]:
         """ONE launch in front of a training step's kernels (`bess_step_prologue`): the concatenated candidate
         list of an augmented step, the cleared relation gradient and backward targets, and - when the update
@@ -627,7 +630,10 @@ class BessKGE(torch.nn.Module, ABC):
             st.d_recv = torch.empty((st.recv.shape[0], st.recv.shape[1]), dtype=torch.float32, device=st.table.device)
             jobs.append((st.d_recv, None, 0))
         plan = self._small_plan(st, optimizer)
-        if plan is not None and sum(int(x.numel()) for x in plan) > nat.SMALL_INDEX_MAX:
+        # one workgroup indexes up to 4096 ids in ~12-15 us (notebook-size steps: cheaper than any fork / join);
+        # longer lists are indexed by the device-wide pipeline on the side stream, under the forward kernels
+        # (`_small_index_ahead`) - 12.5 k ids in the prologue's one workgroup were 58 us on the critical path
+        if plan is not None and sum(int(x.numel()) for x in plan) > self.prologue_index_max:
             plan = None
         if plan is not None and len(plan) > nat.MAX_ROW_LISTS:
             plan = None

@@ -353,6 +353,145 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(BwdSide<float, TE> A, Bw
     else neg_shared_bwd_tile<TE, float, RED, VEC4, ROUND16, MIB>(B, W, sign, d_out, out, block - blocks_a, Cs, Ys, p);
 }
 
+// ---- p = 1, both products from ONE evaluation of sgn(q - e) -----------------------------------------------
+// The two products of the L1 backward,
+//     d_query[i, w] =  sum_j c[i, j] sgn(q[i, w] - e[j, w]),      d_neg[j, w] = -sum_i c[i, j] sgn(q[i, w] - e[j, w]),
+// share their expensive part: the subtraction and the sign (v_sub + v_med3, the half-rate one) of every
+// (i, j, w).  The tile kernel above evaluates it once per product - 3 VALU instructions per element and product,
+// 9.5 issue cycles.  Here a thread owns one column w and 32 candidates j (their e[j, w] and their d_neg
+// accumulators stay in registers for the workgroup's whole range of queries) and walks over the queries: per
+// (i, j, w) one v_sub, one v_med3 and two v_fma (one into the query's partial, one into the candidate's
+// accumulator) - 4 instructions, 12.1 issue cycles for BOTH products (36 % fewer).  Workgroup: 256 candidates x
+// 32 columns x a slice of the queries; the coefficients of 8 queries x 256 candidates are staged through LDS
+// (read as broadcast b128: the 32 lanes of a column group read the same 16 bytes); the queries' partials of the
+// workgroup's 8 candidate groups meet in LDS and leave as one fp32 atomic per (i, w) and step; the candidates'
+// accumulators leave as atomics at the end (one per (j, w) and query slice).  Both outputs are zero on entry.
+constexpr int FB_NW = 8;  // waves (= groups of 32 candidates) per workgroup
+constexpr int FB_TJ = 32 * FB_NW, FB_TW = 64, FB_IS = 8;
+
+template <typename TE, bool ROUND16>
+__global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, RowSrc<TE> E, int W, float sign,
+                                                        const float* __restrict__ d_out, int64_t ld,
+                                                        float* __restrict__ dq, float* __restrict__ de, int i_chunk) {
+    // A wave = 64 columns x ONE group of 32 candidates: the coefficient of (query, candidate) is the same for all
+    // its lanes - a wave-uniform address, i.e. scalar loads (s_load_dwordx8 into SGPRs that the v_fma reads
+    // directly): no LDS staging of the coefficients, no barrier for them.  Eight waves = 256 candidates; their
+    // partial sums of d_query meet in LDS every FB_IS queries.
+    __shared__ float Rs[FB_NW][FB_IS][FB_TW];
+    const int t = threadIdx.x;
+    const int w = t & 63;
+    const int jg = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t j0 = static_cast<int64_t>(blockIdx.x) * FB_TJ;
+    const int w0 = blockIdx.y * FB_TW;
+    const int64_t i_lo = static_cast<int64_t>(blockIdx.z) * i_chunk;
+    const int64_t i_hi = min(i_lo + i_chunk, Q.n);
+    if (i_lo >= i_hi) return;
+    const int wc = min(w0 + w, W - 1);  // (columns past the end: clamped, dropped at the stores)
+    const bool w_ok = w0 + w < W;
+    const int64_t jbase = j0 + jg * 32;  // wave-uniform
+
+    // this wave's 32 candidates at the lane's column, pre-scaled for the one-instruction sign
+    // (row ids first, all 32 loads together, then the 32 row loads together: written with E.row() the compiler
+    // put every load behind its own branch on `idx` - 32 round trips in a row at the start of every workgroup)
+    float e[32], acc[32];
+    {
+        int32_t rows[32];  // (row ids are int32 everywhere in the library)
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) rows[jj] = static_cast<int32_t>(min(jbase + jj, E.n - 1));
+        if (E.idx) {
+#pragma unroll
+            for (int jj = 0; jj < 32; ++jj) rows[jj] = E.idx[rows[jj]];
+        }
+        const TE* col = E.base + wc;
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) {
+            e[jj] = to_f32(col[static_cast<int64_t>(rows[jj]) * W]) * SGN_PRESCALE;
+            acc[jj] = 0.f;
+        }
+        // the scaled f32 value is what the loop subtracts (left to itself the compiler keeps the f16 value and folds
+        // conversion and scale into a v_fma_mix_f32 per element: a VOP3P instruction, 0.6 of the plain issue rate)
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) asm volatile("" : "+v"(e[jj]));
+    }
+    // (launched only with n_neg % 32 == 0 and whole steps of queries: no masks in the inner loop; `sign` is
+    // applied to the sums at the stores)
+    const float* qcol = Q.base + wc;  // (the query matrix is dense f32: Q.idx == NULL by construction)
+    float qnext = qcol[i_lo * W];    // the query value is fetched one query ahead of its use
+    for (int64_t i0 = i_lo; i0 < i_hi; i0 += FB_IS) {
+#pragma unroll 1
+        for (int ii = 0; ii < FB_IS; ++ii) {
+            const int64_t i = i0 + ii;
+            const float* __restrict__ crow = d_out + i * ld + jbase;  // wave-uniform: scalar loads
+            float qv = qnext;
+            qnext = qcol[min(i + 1, i_hi - 1) * W];
+            if (ROUND16) qv = static_cast<float>(static_cast<_Float16>(qv));
+            qv *= SGN_PRESCALE;
+            asm volatile("" : "+v"(qv));  // (else the rounding and the scale are folded into 32 v_fma_mix_f32: VOP3P rate)
+            float pq = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 32; ++jj) {
+                const float c = crow[jj];
+                const float sg = sgn_prescaled(qv - e[jj]);
+                pq = fmaf(c, sg, pq);
+                acc[jj] = fmaf(-c, sg, acc[jj]);
+            }
+            Rs[jg][ii][w] = pq;
+        }
+        __syncthreads();
+        // FB_NW waves x 64 columns: sum the candidate groups, one atomic per (i, w)
+#pragma unroll
+        for (int ii = t >> 6; ii < FB_IS; ii += FB_NW) {
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < FB_NW; ++g) sum += Rs[g][ii][w];
+            const int64_t i = i0 + ii;
+            if (i < i_hi && w_ok && sum != 0.f) unsafeAtomicAdd(dq + i * W + w0 + w, sign * sum);
+        }
+        __syncthreads();  // Rs is rewritten by the next step
+    }
+    if (w_ok) {
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) {
+            const int64_t j = jbase + jj;
+            if (j < E.n && acc[jj] != 0.f) unsafeAtomicAdd(de + j * W + w0 + w, sign * acc[jj]);
+        }
+    }
+}
+
+// worth it when the 256-candidate x 32-column tiles are mostly full and there is enough of them (with the
+// query slices) to fill the chip a few times over
+static bool use_l1_bwd_both(const bess_model_desc* d, int64_t S, int64_t N) {
+    return reduce_of(d) == RED_L1 && S >= 1024 && N >= 1024 && N % 32 == 0 && S % FB_IS == 0 && d->width >= FB_TW;
+}
+
+template <typename TE>
+static int run_l1_bwd_both(const bess_model_desc* d, RowSrc<float> Q, RowSrc<TE> E, const float* d_out,
+                           int64_t ld_dout, float* d_query, float* d_neg, hipStream_t st, bool round16) {
+    const int W = d->width;
+    const int64_t jt = ceil_div(E.n, FB_TJ), wt = ceil_div(W, FB_TW);
+    // Query slices.  512 workgroups are resident at once (103 VGPRs: 4 waves per SIMD = two 8-wave workgroups per
+    // CU; four-wave workgroups were 3 % slower where the tiles divide evenly and 2 % faster where they do not): the grid should fill them in whole rounds - 1564 workgroups are 4 rounds of which the last is almost
+    // empty, 1496 are 3.  Cost of a plan = rounds x (queries per slice + ~24 queries' worth of loading the
+    // candidates' registers and storing their sums).
+    const int64_t resident = 256 * 16 / FB_NW, tiles = jt * wt;
+    int64_t i_chunk = Q.n, slices = 1;
+    double best = 1e300;
+    for (int64_t sl = 1; sl <= ceil_div(Q.n, 64); ++sl) {
+        const int64_t ch = ceil_div(ceil_div(Q.n, sl), FB_IS) * FB_IS;
+        const int64_t actual = ceil_div(Q.n, ch);
+        const double cost = static_cast<double>(ceil_div(tiles * actual, resident)) * (ch + 24);
+        if (cost < best) best = cost, i_chunk = ch, slices = actual;
+    }
+    BESS_REQUIRE(jt < (1ll << 31) && wt < 65536 && slices < 65536, "neg_score_shared_bwd: problem too large for one launch");
+    const dim3 grid(static_cast<unsigned>(jt), static_cast<unsigned>(wt), static_cast<unsigned>(slices));
+    const float sign = is_distance(d->scorer) ? -1.f : 1.f;
+    if (round16)
+        k_l1_bwd_both<TE, true><<<grid, 64 * FB_NW, 0, st>>>(Q, E, W, sign, d_out, ld_dout, d_query, d_neg, static_cast<int>(i_chunk));
+    else
+        k_l1_bwd_both<TE, false><<<grid, 64 * FB_NW, 0, st>>>(Q, E, W, sign, d_out, ld_dout, d_query, d_neg, static_cast<int>(i_chunk));
+    return check_launch("neg_score_shared_bwd (p = 1, both products)");
+}
+
 template <typename T>
 static int run_fwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<T> E, float* out, int64_t ld,
                    hipStream_t st) {
@@ -413,6 +552,18 @@ template <typename TE>
 static int run_bwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<TE> E, const float* d_out, int64_t ld_dout,
                    const float* out, int64_t ld_out, float* d_query, float* d_neg, hipStream_t st, bool round16) {
     const int W = d->width;
+    if (use_l1_bwd_both(d, Q.n, E.n)) {
+        if (!(d->reserved[0] & BESS_FLAG_PREZEROED)) {  // its outputs are sums of atomics
+            hipError_t e = hipSuccess;
+            if (d_neg == d_query + Q.n * W) e = fill_words_async(d_query, 0u, (Q.n + E.n) * W, st);
+            else {
+                e = fill_words_async(d_query, 0u, Q.n * W, st);
+                if (e == hipSuccess) e = fill_words_async(d_neg, 0u, E.n * W, st);
+            }
+            if (e != hipSuccess) return fail(static_cast<int>(e), "fill: %s", hipGetErrorString(e));
+        }
+        return run_l1_bwd_both<TE>(d, Q, E, d_out, ld_dout, d_query, d_neg, st, round16);
+    }
     BwdSide<float, TE> A{Q, E, ld_dout, 1, ld_out, 1, d_query, 0, 0, 0, 0};
     BwdSide<TE, float> B{E, Q, 1, ld_dout, 1, ld_out, d_neg, 0, 0, 0, 0};
     const bool small_a = plan_bwd_side(W, A), small_b = plan_bwd_side(W, B);

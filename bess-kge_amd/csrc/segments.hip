@@ -978,14 +978,13 @@ static int grad_segments_impl(const bess_model_desc* d, const float* query, int6
     if (red != RED_L2 && n_query * static_cast<int64_t>(W) * 4 > (4ll << 20)) {
         const int64_t fit = (4ll << 20) / (n_query * 4);
         if (fit >= unit) win = static_cast<int>(fit / unit) * unit;
-        // side by side instead of one after the other, when W splits evenly into 2, 4 or 8 windows of whole units
-        // whose query slices (n_query x cols x 4 B) leave an XCD's 4 MiB L2 half free for rows, ids and state
-        const char* force = getenv("BESS_K9_WIN");
-        for (int nw = force ? atoi(force) : 0; nw >= 2; nw = 0) {
-            if (W % (nw * unit) == 0 && W / nw <= 16 * unit) {
-                n_conc = nw;
-                win = W;
-            }
+        // two windows: side by side in ONE launch (workgroup b works on window b % 2: an XCD's L2 then holds only
+        // its own window's query slice) - 1 % faster than one after the other (0.637 vs 0.644 ms per C2 training
+        // step); four or eight concurrent windows are no better / slower (0.643 / 0.752: the ids and score
+        // gradients are re-read per window, the rows per reference get short)
+        if (win * 2 == W && W % (2 * unit) == 0) {
+            n_conc = 2;
+            win = W;
         }
     }
     // ... and a window is at most what a 16-lane group keeps in registers (16 iterations): rows wider than that
