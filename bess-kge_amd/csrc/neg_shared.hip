@@ -427,14 +427,15 @@ __global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, 
             if (ROUND16) qv = static_cast<float>(static_cast<_Float16>(qv));
             qv *= SGN_PRESCALE;
             asm volatile("" : "+v"(qv));  // (else the rounding and the scale are folded into 32 v_fma_mix_f32: VOP3P rate)
-            float pq = 0.f;
+            float pq4[4] = {0.f, 0.f, 0.f, 0.f};  // (four chains: one accumulator would serialise 32 dependent v_fma)
 #pragma unroll
             for (int jj = 0; jj < 32; ++jj) {
                 const float c = crow[jj];
                 const float sg = sgn_prescaled(qv - e[jj]);
-                pq = fmaf(c, sg, pq);
+                pq4[jj & 3] = fmaf(c, sg, pq4[jj & 3]);
                 acc[jj] = fmaf(-c, sg, acc[jj]);
             }
+            const float pq = (pq4[0] + pq4[1]) + (pq4[2] + pq4[3]);
             Rs[jg][ii][w] = pq;
         }
         __syncthreads();
