@@ -459,10 +459,13 @@ __global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, 
     }
 }
 
-// worth it when the 256-candidate x 32-column tiles are mostly full and there is enough of them (with the
-// query slices) to fill the chip a few times over
+// Worth it when the 256-candidate x 64-column tiles are mostly full, and up to micro-batches of 8192 queries: the
+// candidates' sums leave as one atomic per (j, w) and QUERY SLICE, and filling the chip in whole rounds takes
+// more slices the larger the problem - at S = 16,384 / 65,536 (63+ slices: 1 GB of atomics per step and more) the
+// two-product tile kernel is 8 - 14 % faster again (c4 sweep: 11.6 vs 12.6 ms, 175 vs 201 ms).
 static bool use_l1_bwd_both(const bess_model_desc* d, int64_t S, int64_t N) {
-    return reduce_of(d) == RED_L1 && S >= 1024 && N >= 1024 && N % 32 == 0 && S % FB_IS == 0 && d->width >= FB_TW;
+    return reduce_of(d) == RED_L1 && S >= 1024 && S <= 8192 && N >= 1024 && N % 32 == 0 && S % FB_IS == 0 &&
+           d->width >= FB_TW;
 }
 
 template <typename TE>
@@ -553,7 +556,7 @@ template <typename TE>
 static int run_bwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<TE> E, const float* d_out, int64_t ld_dout,
                    const float* out, int64_t ld_out, float* d_query, float* d_neg, hipStream_t st, bool round16) {
     const int W = d->width;
-    if (use_l1_bwd_both(d, Q.n, E.n)) {
+    if (use_l1_bwd_both(d, Q.n, E.n) && Q.idx == nullptr) {  // (the kernel reads the dense f32 query matrix)
         if (!(d->reserved[0] & BESS_FLAG_PREZEROED)) {  // its outputs are sums of atomics
             hipError_t e = hipSuccess;
             if (d_neg == d_query + Q.n * W) e = fill_words_async(d_query, 0u, (Q.n + E.n) * W, st);
