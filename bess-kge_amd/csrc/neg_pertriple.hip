@@ -350,8 +350,20 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_bwd(NegPtArgs a,
                     dq[it][v] += dqe;
                 }
                 if (d_neg && valid[u] && c < a.nch) {  // d_neg == NULL: only d_query is wanted
+                    // written once, read much later (by C8 / the update): streamed past the caches - for fp32 tables
+                    // (one 16-byte piece per lane and chunk: 645 vs 665 us at C2, 533 vs 658 at C3, 119 vs 155 at C1;
+                    // the two pieces per lane of fp16 rows came out 12-16 % slower non-temporal)
+                    if constexpr (VEC == 4) {
+                        typedef float f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) dn[c * VEC + v] = de[v];
+                        for (int v = 0; v < VEC; v += 4) {
+                            f4 o = {de[v], de[v + 1], de[v + 2], de[v + 3]};
+                            __builtin_nontemporal_store(o, reinterpret_cast<f4*>(dn + c * VEC + v));
+                        }
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) dn[c * VEC + v] = de[v];
+                    }
                 }
             }
         }
