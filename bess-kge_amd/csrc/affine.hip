@@ -451,10 +451,20 @@ __global__ __launch_bounds__(256) void k_aff_pertriple_bwd(AffArgs a, const floa
                 for (int it = 0; it < IT; ++it) {
                     const int c = g + 16 * it;
                     if (valid && c < a.nch) {
+                        float o[VEC];
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
                             const float hat = ev[p][it][v] * inv[p];
-                            dn[p * a.d + c * VEC + v] = a.normalize ? inv[p] * (dc[p][it][v] - hat * dot) : dc[p][it][v];
+                            o[v] = a.normalize ? inv[p] * (dc[p][it][v] - hat * dot) : dc[p][it][v];
+                        }
+                        // (fp32 tables: one 16-byte piece per lane, streamed past the caches - as in neg_pertriple.hip)
+                        if constexpr (VEC == 4) {
+                            typedef float f4 __attribute__((ext_vector_type(4)));
+                            f4 o4 = {o[0], o[1], o[2], o[3]};
+                            __builtin_nontemporal_store(o4, reinterpret_cast<f4*>(dn + p * a.d + c * VEC));
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) dn[p * a.d + c * VEC + v] = o[v];
                         }
                     }
                 }
