@@ -376,9 +376,9 @@ def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, c
                 elems = S_ * n_neg * C4_D
                 # lane-instructions per element: forward 1 (a packed max + a packed dot per 2 elements); backward 4
                 # where both products come from one evaluation of sgn(q - e) (k_l1_bwd_both: sub, sign, two
-                # multiply-adds; 1024 <= S <= 8192, N >= 1024, N % 32 == 0, S % 8 == 0), else 3 per product (sub, sign, multiply-add);
+                # multiply-adds; 256 <= S <= 8192, N >= 256, N % 32 == 0, S % 8 == 0), else 3 per product (sub, sign, multiply-add);
                 # whole step / step time -> fraction of the issue peak
-                both = 1024 <= S_ <= 8192 and n_neg >= 1024 and n_neg % 32 == 0 and S_ % 8 == 0
+                both = 256 <= S_ <= 8192 and n_neg >= 256 and n_neg % 32 == 0 and S_ % 8 == 0
                 per_elem = 5 if both else 7
                 lane_ops = per_elem * elems / (best * 1e-3) / 1e12
                 point["valu"] = dict(bound="valu", elements_per_product=elems,

@@ -366,10 +366,9 @@ __global__ __launch_bounds__(256) void k_neg_shared_bwd(BwdSide<float, TE> A, Bw
 // (read as broadcast b128: the 32 lanes of a column group read the same 16 bytes); the queries' partials of the
 // workgroup's 8 candidate groups meet in LDS and leave as one fp32 atomic per (i, w) and step; the candidates'
 // accumulators leave as atomics at the end (one per (j, w) and query slice).  Both outputs are zero on entry.
-constexpr int FB_NW = 8;  // waves (= groups of 32 candidates) per workgroup
-constexpr int FB_TJ = 32 * FB_NW, FB_TW = 64, FB_IS = 8;
+constexpr int FB_TW = 64, FB_IS = 8;  // (FB_NW waves = groups of 32 candidates per workgroup: template parameter)
 
-template <typename TE, bool ROUND16>
+template <typename TE, bool ROUND16, int FB_NW>
 __global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, RowSrc<TE> E, int W, float sign,
                                                         const float* __restrict__ d_out, int64_t ld,
                                                         float* __restrict__ dq, float* __restrict__ de, int i_chunk) {
@@ -381,7 +380,7 @@ __global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, 
     const int t = threadIdx.x;
     const int w = t & 63;
     const int jg = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int64_t j0 = static_cast<int64_t>(blockIdx.x) * FB_TJ;
+    const int64_t j0 = static_cast<int64_t>(blockIdx.x) * (32 * FB_NW);
     const int w0 = blockIdx.y * FB_TW;
     const int64_t i_lo = static_cast<int64_t>(blockIdx.z) * i_chunk;
     const int64_t i_hi = min(i_lo + i_chunk, Q.n);
@@ -389,6 +388,9 @@ __global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, 
     const int wc = min(w0 + w, W - 1);  // (columns past the end: clamped, dropped at the stores)
     const bool w_ok = w0 + w < W;
     const int64_t jbase = j0 + jg * 32;  // wave-uniform
+    // (n_neg % 32 == 0: a wave's 32 candidates are all there or none is - waves of the last tile past the end
+    // load and compute nothing, they only keep the workgroup's barriers company)
+    const bool active = jbase < E.n;
 
     // this wave's 32 candidates at the lane's column, pre-scaled for the one-instruction sign
     // (row ids first, all 32 loads together, then the 32 row loads together: written with E.row() the compiler
@@ -417,26 +419,48 @@ __global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, 
     // applied to the sums at the stores)
     const float* qcol = Q.base + wc;  // (the query matrix is dense f32: Q.idx == NULL by construction)
     float qnext = qcol[i_lo * W];    // the query value is fetched one query ahead of its use
-    for (int64_t i0 = i_lo; i0 < i_hi; i0 += FB_IS) {
-#pragma unroll 1
-        for (int ii = 0; ii < FB_IS; ++ii) {
-            const int64_t i = i0 + ii;
-            const float* __restrict__ crow = d_out + i * ld + jbase;  // wave-uniform: scalar loads
-            float qv = qnext;
-            qnext = qcol[min(i + 1, i_hi - 1) * W];
-            if (ROUND16) qv = static_cast<float>(static_cast<_Float16>(qv));
-            qv *= SGN_PRESCALE;
-            asm volatile("" : "+v"(qv));  // (else the rounding and the scale are folded into 32 v_fma_mix_f32: VOP3P rate)
-            float pq4[4] = {0.f, 0.f, 0.f, 0.f};  // (four chains: one accumulator would serialise 32 dependent v_fma)
+    // The coefficients too are fetched one query ahead: two sets of 32 SGPRs take turns.  (Fetched where they are
+    // used, a wave waits ~0.4 us for its scalar loads on every query: hidden when four waves share the SIMD, but
+    // the whole kernel time of a notebook-size micro-batch whose grid is one wave per SIMD.)  Scalar loads return
+    // out of order, so a wait on them is a wait for all: the next set is requested AFTER the first use of the
+    // current one (the only place the compiler has to wait), not before.
+    const float* __restrict__ cbase = d_out + (active ? jbase : 0);  // wave-uniform
+    float cA[32], cB[32];
 #pragma unroll
-            for (int jj = 0; jj < 32; ++jj) {
-                const float c = crow[jj];
-                const float sg = sgn_prescaled(qv - e[jj]);
-                pq4[jj & 3] = fmaf(c, sg, pq4[jj & 3]);
-                acc[jj] = fmaf(-c, sg, acc[jj]);
-            }
-            const float pq = (pq4[0] + pq4[1]) + (pq4[2] + pq4[3]);
-            Rs[jg][ii][w] = pq;
+    for (int jj = 0; jj < 32; ++jj) cA[jj] = cbase[i_lo * ld + jj];
+    auto one_query = [&](const float (&cur)[32], float (&nxt)[32], int64_t i, int ii) {
+        float qv = qnext;
+        qnext = qcol[min(i + 1, i_hi - 1) * W];
+        if (ROUND16) qv = static_cast<float>(static_cast<_Float16>(qv));
+        qv *= SGN_PRESCALE;
+        asm volatile("" : "+v"(qv));  // (else the rounding and the scale are folded into 32 v_fma_mix_f32: VOP3P rate)
+        float pq4[4] = {0.f, 0.f, 0.f, 0.f};  // (four chains: one accumulator would serialise 32 dependent v_fma)
+        {
+            const float sg = sgn_prescaled(qv - e[0]);
+            pq4[0] = fmaf(cur[0], sg, pq4[0]);
+            acc[0] = fmaf(-cur[0], sg, acc[0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float* __restrict__ crow = cbase + min(i + 1, i_hi - 1) * ld;
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) nxt[jj] = crow[jj];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 1; jj < 32; ++jj) {
+            const float c = cur[jj];
+            const float sg = sgn_prescaled(qv - e[jj]);
+            pq4[jj & 3] = fmaf(c, sg, pq4[jj & 3]);
+            acc[jj] = fmaf(-c, sg, acc[jj]);
+        }
+        Rs[jg][ii][w] = active ? (pq4[0] + pq4[1]) + (pq4[2] + pq4[3]) : 0.f;
+    };
+    for (int64_t i0 = i_lo; i0 < i_hi; i0 += FB_IS) {
+        // (inactive waves - candidates past the end in the last tile - run the same loop on the first candidates'
+        // coefficients and drop everything at the stores: no branch around 128 instructions per query)
+#pragma unroll 1
+        for (int ii = 0; ii < FB_IS; ii += 2) {
+            one_query(cA, cB, i0 + ii, ii);
+            one_query(cB, cA, i0 + ii + 1, ii + 1);
         }
         __syncthreads();
         // FB_NW waves x 64 columns: sum the candidate groups, one atomic per (i, w)
@@ -464,7 +488,7 @@ __global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, 
 // more slices the larger the problem - at S = 16,384 / 65,536 (63+ slices: 1 GB of atomics per step and more) the
 // two-product tile kernel is 8 - 14 % faster again (c4 sweep: 11.6 vs 12.6 ms, 175 vs 201 ms).
 static bool use_l1_bwd_both(const bess_model_desc* d, int64_t S, int64_t N) {
-    return reduce_of(d) == RED_L1 && S >= 1024 && S <= 8192 && N >= 1024 && N % 32 == 0 && S % FB_IS == 0 &&
+    return reduce_of(d) == RED_L1 && S >= 256 && S <= 8192 && N >= 256 && N % 32 == 0 && S % FB_IS == 0 &&
            d->width >= FB_TW;
 }
 
@@ -472,27 +496,39 @@ template <typename TE>
 static int run_l1_bwd_both(const bess_model_desc* d, RowSrc<float> Q, RowSrc<TE> E, const float* d_out,
                            int64_t ld_dout, float* d_query, float* d_neg, hipStream_t st, bool round16) {
     const int W = d->width;
-    const int64_t jt = ceil_div(E.n, FB_TJ), wt = ceil_div(W, FB_TW);
-    // Query slices.  512 workgroups are resident at once (103 VGPRs: 4 waves per SIMD = two 8-wave workgroups per
-    // CU; four-wave workgroups were 3 % slower where the tiles divide evenly and 2 % faster where they do not): the grid should fill them in whole rounds - 1564 workgroups are 4 rounds of which the last is almost
-    // empty, 1496 are 3.  Cost of a plan = rounds x (queries per slice + ~24 queries' worth of loading the
-    // candidates' registers and storing their sums).
-    const int64_t resident = 256 * 16 / FB_NW, tiles = jt * wt;
+    // eight waves (256 candidates) per workgroup; four where the candidates are few (finer tiles: 544 candidates
+    // are 4.25 tiles of 128 but 2.1 of 256).  Measured (profiles/sweep_l1_bwd.py, us, 4 / 8 waves): 512 x 544
+    // 25.2 / 29.5, 1024 x 1088 49.3 / 52.8, 2048 x 2176 123.7 / 123.4, 4096 x 4352 451 / 409
+    const int nw = E.n < 2048 ? 4 : 8;
+    const int64_t jt = ceil_div(E.n, 32 * nw), wt = ceil_div(W, FB_TW);
+    // Query slices.  16 waves per CU are resident (103 VGPRs: 4 per SIMD): the grid should fill them in whole
+    // rounds - 1564 eight-wave workgroups are 4 rounds of 512 of which the last is almost empty, 1496 are 3.  Cost of
+    // a plan = rounds x (queries per slice + ~24 queries' worth of loading the candidates' registers and storing
+    // their sums) + 1 per slice (every slice adds one atomic per element of d_neg: at 512 x 544, 22 slices of 24
+    // queries take 23.8 us, 32 of 16 take 27.5).
+    const int64_t resident = 256 * 16 / nw, tiles = jt * wt;
     int64_t i_chunk = Q.n, slices = 1;
     double best = 1e300;
-    for (int64_t sl = 1; sl <= ceil_div(Q.n, 64); ++sl) {
+    for (int64_t sl = 1; sl <= ceil_div(Q.n, 16); ++sl) {
         const int64_t ch = ceil_div(ceil_div(Q.n, sl), FB_IS) * FB_IS;
         const int64_t actual = ceil_div(Q.n, ch);
-        const double cost = static_cast<double>(ceil_div(tiles * actual, resident)) * (ch + 24);
+        const double cost = static_cast<double>(ceil_div(tiles * actual, resident)) * (ch + 24) + actual;
         if (cost < best) best = cost, i_chunk = ch, slices = actual;
     }
     BESS_REQUIRE(jt < (1ll << 31) && wt < 65536 && slices < 65536, "neg_score_shared_bwd: problem too large for one launch");
     const dim3 grid(static_cast<unsigned>(jt), static_cast<unsigned>(wt), static_cast<unsigned>(slices));
     const float sign = is_distance(d->scorer) ? -1.f : 1.f;
-    if (round16)
-        k_l1_bwd_both<TE, true><<<grid, 64 * FB_NW, 0, st>>>(Q, E, W, sign, d_out, ld_dout, d_query, d_neg, static_cast<int>(i_chunk));
-    else
-        k_l1_bwd_both<TE, false><<<grid, 64 * FB_NW, 0, st>>>(Q, E, W, sign, d_out, ld_dout, d_query, d_neg, static_cast<int>(i_chunk));
+    const int ic = static_cast<int>(i_chunk);
+#define BESS_FB(R16, NW) \
+    k_l1_bwd_both<TE, R16, NW><<<grid, 64 * NW, 0, st>>>(Q, E, W, sign, d_out, ld_dout, d_query, d_neg, ic)
+    if (nw == 8) {
+        if (round16) BESS_FB(true, 8);
+        else BESS_FB(false, 8);
+    } else {
+        if (round16) BESS_FB(true, 4);
+        else BESS_FB(false, 4);
+    }
+#undef BESS_FB
     return check_launch("neg_score_shared_bwd (p = 1, both products)");
 }
 

@@ -108,7 +108,11 @@ def exact_backward(Q, E, idx, g):
 
 
 @pytest.mark.parametrize("S,N,W,scale,ties", [(64, 64, 32, 1.0, False), (70, 130, 96, 1.0, True),
-                                             (200, 1100, 256, 0.01, False), (512, 96, 64, 1.0, True)])
+                                             (200, 1100, 256, 0.01, False), (512, 96, 64, 1.0, True),
+                                             # one launch for both products (k_l1_bwd_both): four-wave workgroups with
+                                             # a last tile of one wave, columns past the end, eight-wave workgroups
+                                             (256, 288, 64, 1.0, True), (512, 544, 256, 0.01, False),
+                                             (264, 800, 96, 1.0, True), (1024, 2080, 128, 1.0, False)])
 def test_backward_differentiates_the_rounded_query_function(dev, S, N, W, scale, ties):
     """The backward of the packed forward (fp32 kernel, query rounded to fp16 as it is loaded):
     sgn(fp16(q) - e) exactly, 0 at ties; fp32 coefficients and accumulation."""
