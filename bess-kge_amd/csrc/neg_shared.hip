@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, 
         {
             const float sg = sgn_prescaled(qv - e[0]);
             pq4[0] = fmaf(cur[0], sg, pq4[0]);
-            acc[0] = fmaf(-cur[0], sg, acc[0]);
+            acc[0] = fmaf(cur[0], sg, acc[0]);
         }
         __builtin_amdgcn_sched_barrier(0);
         const float* __restrict__ crow = cbase + min(i + 1, i_hi - 1) * ld;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, 
             const float c = cur[jj];
             const float sg = sgn_prescaled(qv - e[jj]);
             pq4[jj & 3] = fmaf(c, sg, pq4[jj & 3]);
-            acc[jj] = fmaf(-c, sg, acc[jj]);
+            acc[jj] = fmaf(c, sg, acc[jj]);  // (d_neg is minus this sum: the sign is flipped once, at the store)
         }
         Rs[jg][ii][w] = active ? (pq4[0] + pq4[1]) + (pq4[2] + pq4[3]) : 0.f;
     };
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, 
 #pragma unroll
         for (int jj = 0; jj < 32; ++jj) {
             const int64_t j = jbase + jj;
-            if (j < E.n && acc[jj] != 0.f) unsafeAtomicAdd(de + j * W + w0 + w, sign * acc[jj]);
+            if (j < E.n && acc[jj] != 0.f) unsafeAtomicAdd(de + j * W + w0 + w, -sign * acc[jj]);
         }
     }
 }
