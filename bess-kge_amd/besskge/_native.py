@@ -31,7 +31,8 @@ _c_f32p = ctypes.POINTER(ctypes.c_float)
 _c_u8p = ctypes.POINTER(ctypes.c_uint8)
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
-_RETURNS_I64 = ("bess_neg_score_shared_workspace", "bess_neg_score_shared_bwd_workspace")  # every other entry returns an int status
+_RETURNS_I64 = ("bess_neg_score_shared_workspace", "bess_neg_score_shared_bwd_workspace",
+                "bess_neg_score_shared_fwd_counts_workspace")  # every other entry returns an int status
 _i32 = ctypes.c_int32
 _f32 = ctypes.c_float
 
@@ -135,6 +136,8 @@ SIGNATURES = {
     "bess_neg_score_shared_workspace": [_MD, _i64, _i64],
     "bess_neg_score_shared_fwd_ws": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp],
     "bess_neg_score_shared_fwd_pruned": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
+    "bess_neg_score_shared_fwd_counts_workspace": [_MD, _i64, _i64],
+    "bess_neg_score_shared_fwd_counts": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
     "bess_topk_update_flagged": [_vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _vp],
     "bess_neg_score_shared_fwd_masked": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, ctypes.POINTER(KillDesc), _vp, _i64, _vp],
     "bess_neg_score_shared_bwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
@@ -801,6 +804,39 @@ def neg_score_shared_fwd_pruned(d: ModelDesc, query: torch.Tensor, neg: RowSourc
                                                   ws.data_ptr() if ws is not None else None, ws_bytes, _stream(dev))
     _check(rc, "bess_neg_score_shared_fwd_pruned")
     return (out if ld == n_neg else out[:, :n_neg]), flags
+
+
+def neg_score_shared_counts(d: ModelDesc, query: torch.Tensor, neg: RowSource, thr: torch.Tensor,
+                            excl: torch.Tensor, counts: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Ranks without the score matrix (`bess_neg_score_shared_fwd_counts`): adds to `counts` [nq, 2] int32 (made
+    and cleared when None) the number of candidates scoring above / exactly `thr[q]` (f32 [nq]: the score of the
+    row's true completion), leaving out candidate `excl[q]` (int32 [nq]: its position in `neg`, -1: not among
+    them).  Negative counts afterwards: an operand was outside the fp16 range of the matrix-core product - score
+    that batch through `neg_score_shared_fwd` instead."""
+    nq, n_neg = int(query.shape[0]), len(neg)
+    dev = _neg_operands(d, query, neg, n_neg)
+    _same_device([("query", query), ("thr", thr), ("excl", excl), ("counts", counts)])
+    _f32(thr, "thr")
+    if thr.numel() != nq or excl.numel() != nq or excl.dtype != torch.int32:
+        raise ValueError("neg_score_shared_counts: one threshold and one excluded position (int32) per query")
+    if not thr.is_contiguous() or not excl.is_contiguous():
+        raise ValueError("neg_score_shared_counts: thr / excl must be contiguous")
+    if counts is None:
+        counts = torch.zeros((nq, 2), dtype=torch.int32, device=dev)
+    elif tuple(counts.shape) != (nq, 2) or counts.dtype != torch.int32 or not counts.is_contiguous():
+        raise ValueError("neg_score_shared_counts: counts must be a contiguous [nq, 2] int32 tensor")
+    if d.scorer == AFFINE:
+        neg, _, _ = _affine_candidates(d, neg)
+    lib = load()
+    ws_bytes = int(lib.bess_neg_score_shared_fwd_counts_workspace(ctypes.byref(d), nq, n_neg))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
+    with _on(dev), _Timed("bess_neg_score_shared_fwd_counts", dev):
+        rc = lib.bess_neg_score_shared_fwd_counts(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
+                                                  _idx(neg.idx, "negative idx"), n_neg, thr.data_ptr(),
+                                                  excl.data_ptr(), counts.data_ptr(),
+                                                  ws.data_ptr() if ws is not None else None, ws_bytes, _stream(dev))
+    _check(rc, "bess_neg_score_shared_fwd_counts")
+    return counts
 
 
 def shared_bwd_buffer(d: ModelDesc, nq: int, n_neg: int, device: torch.device) -> Optional[torch.Tensor]:

@@ -40,6 +40,14 @@ inline int reduce_of(const bess_model_desc* d) {
 // (run_if: optional device word; the kernels return at once while it is 0 - the conditional fallback of the split path)
 int gemm_dot_fwd(int dtype, const float* Q, int64_t S, const void* E, const int32_t* idx, int64_t N, int W,
                  float* out, int64_t ld, hipStream_t st, const int32_t* run_if = nullptr);
+// Counting epilogue of the all-entity scoring kernels (ranks without the score matrix: bess_neg_score_shared_fwd_counts):
+// counts[row, 0] += #{columns: score > thr[row]}, counts[row, 1] += #{score == thr[row]}; column excl[row] (an index
+// into the whole candidate list, -1: none) is left out; col0 = list index of the launch's first column.
+struct CountArgs {
+    const int32_t* excl;
+    int32_t* counts;
+    int64_t col0;
+};
 // split-fp16 MFMA variant of gemm_dot_fwd (gemm_split.hip): workspace it wants for a shape
 // (0 = leave the shape to the fp32 kernels) and the product through that workspace
 int64_t gemm_split_workspace(int64_t S, int64_t N, int W);
@@ -47,7 +55,7 @@ int64_t gemm_split_workspace(int64_t S, int64_t N, int W);
 // scores is above thr[row]; flags[row, ld_flags] (one byte per block) says which were)
 int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const int32_t* idx, int64_t N, int W,
                    float* out, int64_t ld, void* ws, int64_t ws_bytes, hipStream_t st, const float* thr = nullptr,
-                   uint8_t* flags = nullptr, int64_t ld_flags = 0);
+                   uint8_t* flags = nullptr, int64_t ld_flags = 0, const CountArgs* count = nullptr);
 int64_t gemm_split_bwd_workspace(int64_t S, int64_t N, int W);
 int gemm_split_bwd(int dtype, const float* G, int64_t ldg, int64_t S, const float* Q, const void* E,
                    const int32_t* idx, int64_t N, int W, float* dQ, float* dE, void* ws, int64_t ws_bytes,
@@ -61,7 +69,8 @@ int gemm_dot_de(const float* G, int64_t ldg, int64_t S, const float* Q, int64_t 
 bool l1_pk_eligible(const bess_model_desc* d);
 int l1_pk_fwd(const bess_model_desc* d, const float* query, int64_t n_query, const void* neg_base,
               const int32_t* neg_idx, int64_t n_neg, float* out, int64_t ld_out, const bess_kill_desc* kill,
-              hipStream_t st, const float* thr = nullptr, uint8_t* flags = nullptr, int64_t ld_flags = 0);
+              hipStream_t st, const float* thr = nullptr, uint8_t* flags = nullptr, int64_t ld_flags = 0,
+              const CountArgs* count = nullptr);
 
 // affine-in-the-candidate distance scorers (affine.hip)
 int affine_pertriple(const bess_model_desc* d, bool fwd, const float* query, int64_t n_query, const void* neg_base,

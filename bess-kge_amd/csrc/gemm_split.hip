@@ -253,7 +253,7 @@ __device__ __forceinline__ f32x16 mma16(h8 a, h8 b, f32x16 c) {
 #endif
 
 // A, B: split images of M and N rows (n_slice lines each); C[m, n] = A[m] . B[n]
-template <bool B_LO, bool PRUNE>
+template <bool B_LO, int EPI>  // EPI: 0 stores, 1 pruned stores (top-k passes), 2 counts (ranks; nothing is stored)
 // Split K (the backward products have few output tiles and a long k): a "tile" index t stands for
 // output tile t / ksplit and the k range [t % ksplit, +1) * n_slice lines; part p of an output
 // tile goes to C + p * part_stride (summed in a fixed order by k_sum_parts: deterministic).
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__
                                                         float* __restrict__ C, int64_t ldc, int tiles_x,
                                                         int n_tiles, int ksplit, int64_t part_stride,
                                                         const int32_t* __restrict__ range_flag, const float* __restrict__ thr,
-                                                        uint8_t* __restrict__ pflags, int64_t ldf) {
+                                                        uint8_t* __restrict__ pflags, int64_t ldf, CountArgs cnt) {
     __shared__ __attribute__((aligned(16))) char lds[2][2][IMG_B];  // [buffer][operand]
     if (range_flag && *range_flag) return;  // operands out of the fp16 range: the fp32 kernels take over
     const int slot = blockIdx.x, slots = gridDim.x;
@@ -418,7 +418,46 @@ __global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__
             const int64_t n0 = static_cast<int64_t>(ot % tiles_x) * 128 + wn;
             // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
             float* c0 = C + (tile % ksplit) * part_stride + (m0 + 4 * lk) * ldc + n0 + l31;
-            if constexpr (PRUNE) {
+            if constexpr (EPI == 2) {
+                // counting epilogue (ranks): nothing is stored.  Lane l of the wave keeps the two counts of row
+                // m0 + l: a row's 64 scores sit in the 32 lanes of one lk, so one ballot per comparison holds two
+                // rows' verdicts (low half: row rr, high half: rr + 4), counted with s_bcnt1 and kept by the
+                // row's lane; one pair of atomics per row and tile at the end
+                const int l64 = threadIdx.x & 63;
+                const bool rok = m0 + l64 < M;
+                const int tv = __builtin_bit_cast(int, rok ? thr[m0 + l64] : INFINITY);
+                // the row's excluded column, relative to this wave's first one (anything outside 0 .. 63: none here)
+                int64_t exl = rok ? static_cast<int64_t>(cnt.excl[m0 + l64]) - (cnt.col0 + n0) : -1;
+                const int ex = (exl >= 0 && exl < 64) ? static_cast<int>(exl) : -1;
+                int cgt = 0, ceq = 0;
+                const bool ok0 = n0 + l31 < N, ok1 = n0 + l31 + 32 < N;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = i * 32 + (r & 3) + 8 * (r >> 2);  // rows rr (lk = 0) and rr + 4 (lk = 1)
+                        const float th0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tv, rr));
+                        const float th1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tv, rr + 4));
+                        const int e0 = __builtin_amdgcn_readlane(ex, rr), e1 = __builtin_amdgcn_readlane(ex, rr + 4);
+                        const float th = lk ? th1 : th0;
+                        const int e = lk ? e1 : e0;
+                        const float v0 = accm[i][0][r] + accc[i][0][r] * (1.f / 2048.f);
+                        const float v1 = accm[i][1][r] + accc[i][1][r] * (1.f / 2048.f);
+                        const bool in0 = ok0 && l31 != e, in1 = ok1 && l31 + 32 != e;
+                        const unsigned long long g0 = __ballot(in0 && v0 > th), g1 = __ballot(in1 && v1 > th);
+                        const unsigned long long q0 = __ballot(in0 && v0 == th), q1 = __ballot(in1 && v1 == th);
+                        const int gt_lo = __builtin_popcount(static_cast<unsigned>(g0)) + __builtin_popcount(static_cast<unsigned>(g1));
+                        const int gt_hi = __builtin_popcount(static_cast<unsigned>(g0 >> 32)) + __builtin_popcount(static_cast<unsigned>(g1 >> 32));
+                        const int eq_lo = __builtin_popcount(static_cast<unsigned>(q0)) + __builtin_popcount(static_cast<unsigned>(q1));
+                        const int eq_hi = __builtin_popcount(static_cast<unsigned>(q0 >> 32)) + __builtin_popcount(static_cast<unsigned>(q1 >> 32));
+                        if (l64 == rr) cgt = gt_lo, ceq = eq_lo;  // (every row of the wave is met exactly once)
+                        if (l64 == rr + 4) cgt = gt_hi, ceq = eq_hi;
+                    }
+                if (rok && n0 < N) {
+                    if (cgt) atomicAdd(cnt.counts + 2 * (m0 + l64), cgt);
+                    if (ceq) atomicAdd(cnt.counts + 2 * (m0 + l64) + 1, ceq);
+                }
+            } else if constexpr (EPI == 1) {
                 // pruned stores (top-k passes): the 32 lanes with this lk hold a row's 64 columns - the row's block
                 // is written only when one of them is above the row's threshold, and flagged.  The thresholds of
                 // the wave's 64 rows come in with ONE load (lane l: row m0 + l) and are read out per row with
@@ -497,13 +536,13 @@ __global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__
 // products are never stored), so a thread's six line pointers are one base plus constants.
 constexpr int W8_A = 256, W8_B = 128, W8_IMG = (W8_A + W8_B) * ROW_B;  // 48 KiB per buffer
 
-template <bool B_LO, bool PRUNE>
+template <bool B_LO, int EPI>  // EPI: 0 stores, 1 pruned stores (top-k passes), 2 counts (ranks; nothing is stored)
 __global__ __launch_bounds__(512) void k_gemm_split_w8(const char* __restrict__ A, const char* __restrict__ B,
                                                        int64_t M, int64_t N, int n_slice,
                                                        float* __restrict__ C, int64_t ldc, int tiles_x,
                                                        int n_tiles, int ksplit, int64_t part_stride,
                                                        const int32_t* __restrict__ range_flag, const float* __restrict__ thr,
-                                                        uint8_t* __restrict__ pflags, int64_t ldf) {
+                                                        uint8_t* __restrict__ pflags, int64_t ldf, CountArgs cnt) {
     extern __shared__ __attribute__((aligned(16))) char lds8[];  // [2][A rows 0-255 | B rows 0-127]
     if (range_flag && *range_flag) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -609,7 +648,46 @@ __global__ __launch_bounds__(512) void k_gemm_split_w8(const char* __restrict__ 
             const int64_t m0 = static_cast<int64_t>(ot / tiles_x) * W8_A + wm;
             const int64_t n0 = static_cast<int64_t>(ot % tiles_x) * W8_B + wn;
             float* c0 = C + (tile % ksplit) * part_stride + (m0 + 4 * lk) * ldc + n0 + l31;
-            if constexpr (PRUNE) {
+            if constexpr (EPI == 2) {
+                // counting epilogue (ranks): nothing is stored.  Lane l of the wave keeps the two counts of row
+                // m0 + l: a row's 64 scores sit in the 32 lanes of one lk, so one ballot per comparison holds two
+                // rows' verdicts (low half: row rr, high half: rr + 4), counted with s_bcnt1 and kept by the
+                // row's lane; one pair of atomics per row and tile at the end
+                const int l64 = threadIdx.x & 63;
+                const bool rok = m0 + l64 < M;
+                const int tv = __builtin_bit_cast(int, rok ? thr[m0 + l64] : INFINITY);
+                // the row's excluded column, relative to this wave's first one (anything outside 0 .. 63: none here)
+                int64_t exl = rok ? static_cast<int64_t>(cnt.excl[m0 + l64]) - (cnt.col0 + n0) : -1;
+                const int ex = (exl >= 0 && exl < 64) ? static_cast<int>(exl) : -1;
+                int cgt = 0, ceq = 0;
+                const bool ok0 = n0 + l31 < N, ok1 = n0 + l31 + 32 < N;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = i * 32 + (r & 3) + 8 * (r >> 2);  // rows rr (lk = 0) and rr + 4 (lk = 1)
+                        const float th0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tv, rr));
+                        const float th1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tv, rr + 4));
+                        const int e0 = __builtin_amdgcn_readlane(ex, rr), e1 = __builtin_amdgcn_readlane(ex, rr + 4);
+                        const float th = lk ? th1 : th0;
+                        const int e = lk ? e1 : e0;
+                        const float v0 = accm[i][0][r] + accc[i][0][r] * (1.f / 2048.f);
+                        const float v1 = accm[i][1][r] + accc[i][1][r] * (1.f / 2048.f);
+                        const bool in0 = ok0 && l31 != e, in1 = ok1 && l31 + 32 != e;
+                        const unsigned long long g0 = __ballot(in0 && v0 > th), g1 = __ballot(in1 && v1 > th);
+                        const unsigned long long q0 = __ballot(in0 && v0 == th), q1 = __ballot(in1 && v1 == th);
+                        const int gt_lo = __builtin_popcount(static_cast<unsigned>(g0)) + __builtin_popcount(static_cast<unsigned>(g1));
+                        const int gt_hi = __builtin_popcount(static_cast<unsigned>(g0 >> 32)) + __builtin_popcount(static_cast<unsigned>(g1 >> 32));
+                        const int eq_lo = __builtin_popcount(static_cast<unsigned>(q0)) + __builtin_popcount(static_cast<unsigned>(q1));
+                        const int eq_hi = __builtin_popcount(static_cast<unsigned>(q0 >> 32)) + __builtin_popcount(static_cast<unsigned>(q1 >> 32));
+                        if (l64 == rr) cgt = gt_lo, ceq = eq_lo;  // (every row of the wave is met exactly once)
+                        if (l64 == rr + 4) cgt = gt_hi, ceq = eq_hi;
+                    }
+                if (rok && n0 < N) {
+                    if (cgt) atomicAdd(cnt.counts + 2 * (m0 + l64), cgt);
+                    if (ceq) atomicAdd(cnt.counts + 2 * (m0 + l64) + 1, ceq);
+                }
+            } else if constexpr (EPI == 1) {
                 // pruned stores (top-k passes): the 32 lanes with this lk hold a row's 64 columns - the row's block
                 // is written only when one of them is above the row's threshold, and flagged.  The thresholds of
                 // the wave's 64 rows come in with ONE load (lane l: row m0 + l) and are read out per row with
@@ -694,8 +772,12 @@ static int64_t pad_b(int64_t rows) { return ceil_div(rows, W8_B) * W8_B; }
 // kernels meet the same wall (profiles/ubench/mfma_f16.hip: the clock the chip holds under MFMA + LDS load)
 static int launch_product(const char* A, const char* B, int64_t M, int64_t N, int n_slice, float* C, int64_t ldc,
                           int ksplit, int64_t part_stride, bool b_lo, bool padded, const int32_t* flag,
-                          hipStream_t st, const float* thr = nullptr, uint8_t* pflags = nullptr, int64_t ldf = 0) {
-    BESS_REQUIRE(!thr || (ksplit == 1 && pflags), "gemm_split: pruned stores need an unsplit product and a flag array");
+                          hipStream_t st, const float* thr = nullptr, uint8_t* pflags = nullptr, int64_t ldf = 0,
+                          const CountArgs* count = nullptr) {
+    BESS_REQUIRE(!thr || (ksplit == 1 && (pflags || count)),
+                 "gemm_split: pruned stores / counts need an unsplit product and a flag or count array");
+    const CountArgs cnt = count ? *count : CountArgs{nullptr, nullptr, 0};
+    const int epi = count ? 2 : (thr ? 1 : 0);
     const int cus = n_compute_units();
     const int64_t tx = ceil_div(N, 128);
     const int64_t t8 = tx * ceil_div(M, W8_A) * ksplit, t4 = tx * ceil_div(M, 128) * ksplit;
@@ -705,10 +787,12 @@ static int launch_product(const char* A, const char* B, int64_t M, int64_t N, in
         static const bool attr = [] {
             const int bytes = 2 * W8_IMG;
             bool ok = true;
-            for (const void* f : {reinterpret_cast<const void*>(&k_gemm_split_w8<true, false>),
-                                  reinterpret_cast<const void*>(&k_gemm_split_w8<false, false>),
-                                  reinterpret_cast<const void*>(&k_gemm_split_w8<true, true>),
-                                  reinterpret_cast<const void*>(&k_gemm_split_w8<false, true>)})
+            for (const void* f : {reinterpret_cast<const void*>(&k_gemm_split_w8<true, 0>),
+                                  reinterpret_cast<const void*>(&k_gemm_split_w8<false, 0>),
+                                  reinterpret_cast<const void*>(&k_gemm_split_w8<true, 1>),
+                                  reinterpret_cast<const void*>(&k_gemm_split_w8<false, 1>),
+                                  reinterpret_cast<const void*>(&k_gemm_split_w8<true, 2>),
+                                  reinterpret_cast<const void*>(&k_gemm_split_w8<false, 2>)})
                 ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
             return ok;
         }();
@@ -717,29 +801,36 @@ static int launch_product(const char* A, const char* B, int64_t M, int64_t N, in
 #define BESS_W8(LO, PR)                                                                                          \
     k_gemm_split_w8<LO, PR><<<grid, 512, 2 * W8_IMG, st>>>(A, B, M, N, n_slice, C, ldc, static_cast<int>(tx),     \
                                                            static_cast<int>(t8), ksplit, part_stride, flag, thr, \
-                                                           pflags, ldf)
-        if (thr) {
-            if (b_lo) BESS_W8(true, true);
-            else BESS_W8(false, true);
+                                                           pflags, ldf, cnt)
+        if (epi == 2) {
+            if (b_lo) BESS_W8(true, 2);
+            else BESS_W8(false, 2);
+        } else if (epi == 1) {
+            if (b_lo) BESS_W8(true, 1);
+            else BESS_W8(false, 1);
         } else {
-            if (b_lo) BESS_W8(true, false);
-            else BESS_W8(false, false);
+            if (b_lo) BESS_W8(true, 0);
+            else BESS_W8(false, 0);
         }
 #undef BESS_W8
         return check_launch("gemm_split_w8");
     }
     const int grid = static_cast<int>(t4 < cus ? t4 : cus);
-#define BESS_F16(LO, PR)                                                                                    \
+#define BESS_T4(LO, PR)                                                                                    \
     k_gemm_split_f16<LO, PR><<<grid, 512, 0, st>>>(A, B, M, N, n_slice, C, ldc, static_cast<int>(tx),        \
-                                                   static_cast<int>(t4), ksplit, part_stride, flag, thr, pflags, ldf)
-    if (thr) {
-        if (b_lo) BESS_F16(true, true);
-        else BESS_F16(false, true);
+                                                   static_cast<int>(t4), ksplit, part_stride, flag, thr, pflags, ldf, \
+                                                   cnt)
+    if (epi == 2) {
+        if (b_lo) BESS_T4(true, 2);
+        else BESS_T4(false, 2);
+    } else if (epi == 1) {
+        if (b_lo) BESS_T4(true, 1);
+        else BESS_T4(false, 1);
     } else {
-        if (b_lo) BESS_F16(true, false);
-        else BESS_F16(false, false);
+        if (b_lo) BESS_T4(true, 0);
+        else BESS_T4(false, 0);
     }
-#undef BESS_F16
+#undef BESS_T4
     return check_launch("gemm_split_f16");
 }
 
@@ -775,10 +866,15 @@ static int split_rows(const SplitSrc& a, char* dst_a, int dtype_b, const SplitSr
     return check_launch("split_rows");
 }
 
+__global__ void k_poison_counts(const int32_t* __restrict__ flag, int32_t* __restrict__ counts, int64_t n) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (*flag && i < n) counts[i] = INT32_MIN;
+}
+
 // out[q, j] = Q[q] . E[idx[j]] through the workspace (>= gemm_split_workspace bytes, 16-B aligned)
 int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const int32_t* idx, int64_t N, int W,
                    float* out, int64_t ld, void* ws, int64_t ws_bytes, hipStream_t st, const float* thr,
-                   uint8_t* pflags, int64_t ldf) {
+                   uint8_t* pflags, int64_t ldf, const CountArgs* count) {
     const int64_t pitch = split_pitch(W);
     BESS_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 16 == 0, "gemm_split: workspace must be 16-B aligned");
     BESS_REQUIRE(ws_bytes >= FLAG_BYTES + 256 * pitch, "gemm_split: workspace too small");
@@ -802,9 +898,17 @@ int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const in
         // the query rows ride along with the first chunk
         if (int e = split_rows(SplitSrc{Q, nullptr, j0 == 0 ? S : 0, W, flag}, qa, dtype, src, eb, W, st)) return e;
         // (pruned stores: the chunk's flags start at block j0 / 64 - chunks are multiples of 128 rows)
-        if (int e = launch_product(qa, eb, S, nc, n_slice, out + j0, ld, 1, 0, dtype == BESS_F32, true, flag, st, thr,
-                                   pflags ? pflags + j0 / 64 : nullptr, ldf))
+        CountArgs cj{nullptr, nullptr, 0};
+        if (count) cj = CountArgs{count->excl, count->counts, count->col0 + j0};
+        if (int e = launch_product(qa, eb, S, nc, n_slice, count ? nullptr : out + j0, ld, 1, 0, dtype == BESS_F32, true,
+                                   flag, st, thr, pflags ? pflags + j0 / 64 : nullptr, ldf, count ? &cj : nullptr))
             return e;
+    }
+    if (count) {
+        // (no score matrix for the fp32 kernels to fill) an operand outside the fp16 range: every count becomes
+        // negative - the caller sees it where it reads the counts and scores that batch through the matrix
+        k_poison_counts<<<static_cast<unsigned>(ceil_div(2 * S, 256)), 256, 0, st>>>(flag, count->counts, 2 * S);
+        return check_launch("poison_counts");
     }
     // an operand outside the fp16 range (or not finite) raised the flag: the split kernels returned at once and
     // the exact fp32 kernels compute the whole product now; else they are the ones that return at once

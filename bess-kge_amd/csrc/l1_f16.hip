@@ -82,6 +82,7 @@ struct PruneArgs {
     const float* thr;  // [nq] or NULL: store everything
     uint8_t* flags;    // [nq, ldf]
     int64_t ldf;
+    CountArgs cnt;     // cnt.counts != NULL: count the scores above / equal to thr instead, store nothing
 };
 
 // out[q, j] = -sum_w |fp16(Q[q, w]) - E[idx[j], w]|        W % 32 == 0
@@ -184,6 +185,27 @@ __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, 
             v4[j] = v;
         }
         const int64_t jj0 = j0 + tx * 4;
+        if (prune.cnt.counts) {  // (wave-uniform) ranks: the row's counts over these 64 columns, nothing stored
+            const float th = prune.thr[q];
+            const int64_t ex = static_cast<int64_t>(prune.cnt.excl[q]) - prune.cnt.col0;  // the row's excluded column
+            int cg = 0, ce = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = jj0 + j < ne && jj0 + j != ex;
+                cg += (in && v4[j] > th) ? 1 : 0;
+                ce += (in && v4[j] == th) ? 1 : 0;
+            }
+#pragma unroll
+            for (int o2 = 1; o2 < 16; o2 <<= 1) {  // the 16 threads with this ty hold the row
+                cg += __shfl_xor(cg, o2, 64);
+                ce += __shfl_xor(ce, o2, 64);
+            }
+            if (tx == 0) {
+                if (cg) atomicAdd(prune.cnt.counts + 2 * q, cg);
+                if (ce) atomicAdd(prune.cnt.counts + 2 * q + 1, ce);
+            }
+            continue;
+        }
         if (prune.thr) {  // (wave-uniform; the 16 threads with this ty hold the row's 64 columns: one 16-lane group)
             const float th = prune.thr[q];
             bool hit = false;
@@ -211,8 +233,8 @@ bool l1_pk_eligible(const bess_model_desc* d) {
 
 int l1_pk_fwd(const bess_model_desc* d, const float* query, int64_t n_query, const void* neg_base,
               const int32_t* neg_idx, int64_t n_neg, float* out, int64_t ld_out, const bess_kill_desc* k,
-              hipStream_t st, const float* thr, uint8_t* flags, int64_t ld_flags) {
-    const PruneArgs pr{thr, flags, ld_flags};
+              hipStream_t st, const float* thr, uint8_t* flags, int64_t ld_flags, const CountArgs* count) {
+    const PruneArgs pr{thr, flags, ld_flags, count ? *count : CountArgs{nullptr, nullptr, 0}};
     KillArgs ka{};
     if (k) ka = KillArgs{k->diag_step, k->ht, k->ppp, k->mask, k->mask_rows, k->mask ? k->mask_cols : 0, n_neg};
     // 32-row tiles when the 64-row grid would leave most CUs without a workgroup

@@ -761,6 +761,106 @@ extern "C" int bess_neg_score_shared_fwd_pruned(const bess_model_desc* d, const 
                                         workspace_bytes, stream);
 }
 
+// ---- ranks without the score matrix ---------------------------------------------------------------------
+// counts of a stored score tile (scorers / shapes whose kernel has no counting epilogue): one wave per row
+__global__ __launch_bounds__(256) void k_count_scores(const float* __restrict__ sc, int64_t ld, int64_t n_row,
+                                                      int64_t n_col, const float* __restrict__ thr,
+                                                      const int32_t* __restrict__ excl, int64_t col0,
+                                                      int32_t* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (r >= n_row) return;
+    const float th = thr[r];
+    const int64_t ex = static_cast<int64_t>(excl[r]) - col0;
+    const float* row = sc + r * ld;
+    int cg = 0, ce = 0;
+    for (int64_t j = lane; j < n_col; j += 64) {
+        const float v = row[j];
+        const bool in = j != ex;
+        cg += (in && v > th) ? 1 : 0;
+        ce += (in && v == th) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        cg += __shfl_xor(cg, o, 64);
+        ce += __shfl_xor(ce, o, 64);
+    }
+    if (lane == 0) {
+        if (cg) atomicAdd(counts + 2 * r, cg);
+        if (ce) atomicAdd(counts + 2 * r + 1, ce);
+    }
+}
+
+constexpr int64_t COUNT_TILE_BYTES = 64ll << 20;  // score tile of the scorers without a counting epilogue
+static int64_t count_tile_cols(int64_t n_query, int64_t n_neg) {
+    int64_t c = COUNT_TILE_BYTES / 4 / n_query / 64 * 64;
+    if (c < 64) c = 64;
+    return c < n_neg ? c : (n_neg + 3) / 4 * 4;
+}
+static bool counts_in_epilogue(const bess_model_desc* d, const float* query, const void* neg_base, int64_t n_query,
+                               int64_t n_neg, int64_t* ws_want) {
+    *ws_want = 0;
+    if (d->scorer > BESS_COMPLEX) return false;
+    if (reduce_of(d) == RED_DOT) {
+        if (d->reserved[0] & BESS_FLAG_FP32_MATH) return false;
+        *ws_want = gemm_split_workspace(n_query, n_neg, d->width);
+        return *ws_want > 0;
+    }
+    return !query || use_l1_pk(d, query, neg_base);
+}
+
+extern "C" int64_t bess_neg_score_shared_fwd_counts_workspace(const bess_model_desc* d, int64_t n_query,
+                                                              int64_t n_neg) {
+    if (!d || check_desc(d) || n_query <= 0 || n_neg <= 0) return 0;
+    int64_t want = 0;
+    if (counts_in_epilogue(d, nullptr, nullptr, n_query, n_neg, &want) && want > 0) return want;
+    // (the packed L1 kernel needs none, but whether it applies depends on the pointers' alignment: the tile is
+    // what the call falls back on)
+    return n_query * count_tile_cols(n_query, n_neg) * 4;
+}
+
+extern "C" int bess_neg_score_shared_fwd_counts(const bess_model_desc* d, const float* query, int64_t n_query,
+                                                const void* neg_base, const int32_t* neg_idx, int64_t n_neg,
+                                                const float* thr, const int32_t* excl, int32_t* counts,
+                                                void* workspace, int64_t workspace_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    BESS_REQUIRE(n_query >= 0 && n_neg >= 0, "neg_score_shared_fwd_counts: bad sizes");
+    if (n_query == 0 || n_neg == 0) return BESS_OK;
+    BESS_REQUIRE(query && neg_base && thr && excl && counts, "neg_score_shared_fwd_counts: NULL pointer");
+    BESS_REQUIRE(n_neg < (1ll << 31), "neg_score_shared_fwd_counts: candidate ids are int32");
+    hipStream_t st = as_stream(stream);
+    const CountArgs cnt{excl, counts, 0};
+    int64_t want = 0;
+    if (counts_in_epilogue(d, query, neg_base, n_query, n_neg, &want)) {
+        if (reduce_of(d) == RED_DOT) {
+            if (workspace && workspace_bytes >= want)
+                return gemm_split_fwd(d->dtype, query, n_query, neg_base, neg_idx, n_neg, d->width, nullptr, 0,
+                                      workspace, workspace_bytes, st, thr, nullptr, 0, &cnt);
+        } else {
+            return l1_pk_fwd(d, query, n_query, neg_base, neg_idx, n_neg, nullptr, 0, nullptr, st, thr, nullptr, 0, &cnt);
+        }
+    }
+    // no counting epilogue for this scorer / shape: score tiles through the workspace, counted by a second kernel
+    BESS_REQUIRE(d->scorer != BESS_AFFINE || !neg_idx,
+                 "neg_score_shared_fwd_counts: affine scorers take dense f32 candidates (bess_normalize_rows)");
+    const int64_t cols = count_tile_cols(n_query, n_neg);
+    BESS_REQUIRE(workspace && workspace_bytes >= n_query * cols * 4 && reinterpret_cast<uintptr_t>(workspace) % 16 == 0,
+                 "neg_score_shared_fwd_counts: workspace too small (bess_neg_score_shared_fwd_counts_workspace) or misaligned");
+    float* tile = static_cast<float*>(workspace);
+    const int64_t row_bytes = static_cast<int64_t>(d->width) * ((d->scorer == BESS_AFFINE || d->dtype == BESS_F32) ? 4 : 2);
+    for (int64_t j0 = 0; j0 < n_neg; j0 += cols) {
+        const int64_t nc = n_neg - j0 < cols ? n_neg - j0 : cols;
+        const void* base = neg_idx ? neg_base : static_cast<const char*>(neg_base) + j0 * row_bytes;
+        if (int e = bess_neg_score_shared_fwd_ws(d, query, n_query, base, neg_idx ? neg_idx + j0 : nullptr, nc, tile, cols,
+                                                 nullptr, 0, stream))
+            return e;
+        k_count_scores<<<static_cast<unsigned>(ceil_div(n_query, 4)), 256, 0, st>>>(tile, cols, n_query, nc, thr, excl,
+                                                                                    j0, counts);
+        if (int e = check_launch("count_scores")) return e;
+    }
+    return BESS_OK;
+}
+
 extern "C" int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* query,
                                          int64_t n_query, const void* neg_base,
                                          const int32_t* neg_idx, int64_t n_neg, float* out,

@@ -312,6 +312,25 @@ int bess_neg_score_shared_fwd_pruned(const bess_model_desc* d, const float* quer
                                      int64_t ld_out, const float* thr, uint8_t* flags, int64_t ld_flags,
                                      void* workspace, int64_t workspace_bytes, void* stream);
 
+/* K4 for ranks over all entities without the score matrix (replaces the reference's AllScoresBESS window loop +
+ * Evaluation.ranks_from_scores, bess.py:1005-1062 + metric.py:129-182, when only ranks / metrics are wanted):
+ *   counts[q, 0] += #{ j != excl[q] : score(q, j) >  thr[q] }
+ *   counts[q, 1] += #{ j != excl[q] : score(q, j) == thr[q] }
+ * thr [n_query] f32: the score of the row's true completion; excl [n_query] int32: the position of that completion
+ * in the candidate list (0 .. n_neg - 1), or -1 when it is not among these candidates (another shard's entity);
+ * counts [n_query, 2] int32 is accumulated into (clear it before the first shard / window).  The counting is the
+ * epilogue of the split-fp16 matrix-core product (DistMult / ComplEx) and of the packed-fp16 L1 kernel (TransE /
+ * RotatE p = 1 on f16 tables): no score is written.  Other scorers / shapes score tiles of at most 64 MiB into the
+ * workspace and count them there.  workspace: bess_neg_score_shared_fwd_counts_workspace bytes, 16-B aligned.
+ * If an operand of the matrix-core product is outside the fp16 range every count of the call is set to INT32_MIN
+ * (there is no score matrix for the fp32 kernels to fall back on): a caller that sees negative counts scores that
+ * batch through bess_neg_score_shared_fwd_ws + bess_ranks_from_scores instead. */
+int64_t bess_neg_score_shared_fwd_counts_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg);
+int bess_neg_score_shared_fwd_counts(const bess_model_desc* d, const float* query, int64_t n_query,
+                                     const void* neg_base, const int32_t* neg_idx, int64_t n_neg, const float* thr,
+                                     const int32_t* excl, int32_t* counts, void* workspace, int64_t workspace_bytes,
+                                     void* stream);
+
 int64_t bess_neg_score_shared_bwd_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg);
 int bess_neg_score_shared_bwd_ws(const bess_model_desc* d, const float* query,
                                  int64_t n_query, const void* neg_base,

@@ -445,3 +445,58 @@ def test_topk_lists_longer_than_the_kernel_keeps(dev, k):
         got_i = out["topk_global_id"][sh * bsz:(sh + 1) * bsz].cpu().long()
         torch.testing.assert_close(got_s, want_s, rtol=1e-4, atol=1e-4)
         assert float(((got_i == want_i) | ((got_s - want_s).abs() < 1e-4)).float().mean()) > 0.999
+
+
+# ------------------------------------------------- ranks in the scoring epilogue (next-2 as the survey wrote it)
+@pytest.mark.parametrize("scorer,dtype,W,indexed", [("ComplEx", torch.float32, 128, False),
+                                                    ("DistMult", torch.float16, 96, True),
+                                                    ("TransE", torch.float16, 64, False),
+                                                    ("TransE", torch.float16, 64, True),
+                                                    ("TransE", torch.float32, 64, False),
+                                                    ("RotatE", torch.float16, 128, True)])
+def test_counts_in_the_scoring_epilogue_equal_counts_of_the_stored_scores(dev, scorer, dtype, W, indexed):
+    """bess_neg_score_shared_fwd_counts: per row the number of candidates above / equal to the row's threshold,
+    the excluded position left out - exactly what counting the stored score matrix of the same kernel gives
+    (matrix-core product, packed L1 kernel, and the tile + count fallback)."""
+    from besskge import _native as nat
+
+    gen = torch.Generator().manual_seed(W + int(indexed))
+    nq, n_ent = 300, 40_000
+    table = (torch.randn(n_ent, W, generator=gen) * 0.3).to(dtype).to(dev)
+    q = (torch.randn(nq, W, generator=gen) * 0.3).to(dev)
+    code = dict(ComplEx=nat.COMPLEX, DistMult=nat.DISTMULT, TransE=nat.TRANSE, RotatE=nat.ROTATE)[scorer]
+    d = nat.make_desc(code, 1 if scorer in ("TransE", "RotatE") else 0, table, W // 2 if scorer == "RotatE" else W)
+    n_cand = n_ent - 37  # a ragged last block
+    if indexed:
+        idx = torch.randperm(n_ent, generator=gen)[:n_cand].to(torch.int32).to(dev)
+        src = nat.RowSource(table, idx)
+    else:
+        src = nat.RowSource(table[:n_cand])
+    sc = nat.neg_score_shared_fwd(d, q, src)
+    # thresholds: the score of the excluded candidate (ties with duplicates of it below), or of none of them
+    excl = torch.randint(0, n_cand, (nq,), generator=gen).to(torch.int32)
+    excl[::7] = -1
+    excl[5], excl[6] = 0, n_cand - 1  # first and last column
+    excl = excl.to(dev)
+    rows = torch.arange(nq, device=dev)
+    thr = torch.where(excl >= 0, sc[rows, excl.clamp(min=0).long()], sc[rows, 17])
+    thr[3] = float("inf")
+    thr[4] = -float("inf")
+    counts = nat.neg_score_shared_counts(d, q, src, thr.contiguous(), excl)
+    keep = torch.ones_like(sc, dtype=torch.bool)
+    keep[rows[excl >= 0], excl[excl >= 0].long()] = False
+    want_gt = ((sc > thr[:, None]) & keep).sum(-1)
+    want_eq = ((sc == thr[:, None]) & keep).sum(-1)
+    assert torch.equal(counts[:, 0].long(), want_gt)
+    assert torch.equal(counts[:, 1].long(), want_eq)
+    assert int(want_eq[excl < 0].min()) >= 1  # (rows without an exclusion tie with their column 17)
+    # accumulation over windows: two halves of the candidates into the same counters
+    half = (n_cand // 2) // 64 * 64 + 13
+    if indexed:
+        a, b = nat.RowSource(table, idx[:half].contiguous()), nat.RowSource(table, idx[half:].contiguous())
+    else:
+        a, b = nat.RowSource(table[:half]), nat.RowSource(table[half:n_cand])
+    c2 = nat.neg_score_shared_counts(d, q, a, thr, torch.where(excl < half, excl, torch.full_like(excl, -1)))
+    ex_b = torch.where(excl >= half, excl - half, torch.full_like(excl, -1))
+    c2 = nat.neg_score_shared_counts(d, q, b, thr, ex_b, counts=c2)
+    assert torch.equal(c2, counts)
