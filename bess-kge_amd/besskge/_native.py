@@ -137,7 +137,7 @@ SIGNATURES = {
     "bess_neg_score_shared_fwd_ws": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp],
     "bess_neg_score_shared_fwd_pruned": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
     "bess_neg_score_shared_fwd_counts_workspace": [_MD, _i64, _i64],
-    "bess_neg_score_shared_fwd_counts": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
+    "bess_neg_score_shared_fwd_counts": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _vp],
     "bess_topk_update_flagged": [_vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _vp],
     "bess_neg_score_shared_fwd_masked": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, ctypes.POINTER(KillDesc), _vp, _i64, _vp],
     "bess_neg_score_shared_bwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
@@ -806,12 +806,23 @@ def neg_score_shared_fwd_pruned(d: ModelDesc, query: torch.Tensor, neg: RowSourc
     return (out if ld == n_neg else out[:, :n_neg]), flags
 
 
+def shared_kernel_rounds_queries(d: ModelDesc) -> bool:
+    """Does the shared-candidate kernel of this model take the query rounded to fp16?  (The packed-fp16 L1 kernel:
+    TransE / RotatE, p = 1, f16 table, width a multiple of 32, fp32-math switch off - `l1_pk_eligible`,
+    csrc/l1_f16.hip.)  A score of the same (query, candidate) from a per-triple kernel agrees with the matrix
+    kernel's to fp32 rounding only if it is given the query rounded the same way."""
+    return (int(d.dtype) == F16 and int(d.scorer) in (TRANSE, ROTATE) and int(d.norm_p) == 1
+            and int(d.width) % 32 == 0 and not (int(d.reserved[0]) & FLAG_FP32_MATH))
+
+
 def neg_score_shared_counts(d: ModelDesc, query: torch.Tensor, neg: RowSource, thr: torch.Tensor,
-                            excl: torch.Tensor, counts: Optional[torch.Tensor] = None) -> torch.Tensor:
+                            excl: torch.Tensor, counts: Optional[torch.Tensor] = None,
+                            round_f16: bool = False) -> torch.Tensor:
     """Ranks without the score matrix (`bess_neg_score_shared_fwd_counts`): adds to `counts` [nq, 2] int32 (made
     and cleared when None) the number of candidates scoring above / exactly `thr[q]` (f32 [nq]: the score of the
     row's true completion), leaving out candidate `excl[q]` (int32 [nq]: its position in `neg`, -1: not among
-    them).  Negative counts afterwards: an operand was outside the fp16 range of the matrix-core product - score
+    them).  `round_f16`: scores are rounded to fp16 before they are compared (the ranking of a half-precision
+    model's scores).  Negative counts afterwards: an operand was outside the fp16 range of the matrix-core product - score
     that batch through `neg_score_shared_fwd` instead."""
     nq, n_neg = int(query.shape[0]), len(neg)
     dev = _neg_operands(d, query, neg, n_neg)
@@ -833,7 +844,7 @@ def neg_score_shared_counts(d: ModelDesc, query: torch.Tensor, neg: RowSource, t
     with _on(dev), _Timed("bess_neg_score_shared_fwd_counts", dev):
         rc = lib.bess_neg_score_shared_fwd_counts(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
                                                   _idx(neg.idx, "negative idx"), n_neg, thr.data_ptr(),
-                                                  excl.data_ptr(), counts.data_ptr(),
+                                                  excl.data_ptr(), counts.data_ptr(), int(bool(round_f16)),
                                                   ws.data_ptr() if ws is not None else None, ws_bytes, _stream(dev))
     _check(rc, "bess_neg_score_shared_fwd_counts")
     return counts

@@ -26,6 +26,14 @@ from besskge.scoring import BaseScoreFunction
 from besskge.utils import get_entity_filter
 
 
+def _counting_scorer(score_fn: BaseScoreFunction) -> bool:
+    """TransE / RotatE / DistMult / ComplEx: the scorers whose all-entity kernels can count ranks."""
+    try:
+        return int(score_fn.kernel_desc().scorer) <= nat.COMPLEX
+    except (AttributeError, NotImplementedError, ValueError):
+        return False
+
+
 class AllScoresPipeline(torch.nn.Module):
     """Scores (and metrics) of (h, r, ?) / (?, r, t) queries against all entities,
     with optional filtering of known triples and restriction to candidate entities."""
@@ -45,6 +53,7 @@ class AllScoresPipeline(torch.nn.Module):
         use_ipu_model: bool = False,
         group: Optional[ReplicaGroup] = None,
         device: Optional[torch.device] = None,
+        fused_ranks: bool = True,
     ) -> None:
         """
         :param batch_sampler: sampler over "h_shard" / "t_shard" partitioned queries.
@@ -59,6 +68,12 @@ class AllScoresPipeline(torch.nn.Module):
         :param use_ipu_model: accepted for call compatibility, ignored.
         :param group / device: replica group and HIP device (default: all shards
             in this process on the current device).
+        :param fused_ranks: when only metrics / ranks are asked for (no scores, no top-k, no
+            `candidate_ents`) count the entities that beat the true completion in the scoring kernel's
+            epilogue instead of assembling the `[queries, n_entity]` score matrix
+            (`AllScoresBESS.rank_counts_replicas`).  Same ranks, except where another entity's score
+            ties with the true completion's to the last bit: the positive score then comes from the
+            per-triple kernel, the candidates' from the matrix kernel.
         """
         super().__init__()
         if not (evaluation or return_scores):
@@ -96,6 +111,8 @@ class AllScoresPipeline(torch.nn.Module):
             self.triples = torch.from_numpy(glob)
             self.filter_triples = torch.concat(
                 [t if isinstance(t, torch.Tensor) else torch.from_numpy(t) for t in filter_triples], dim=0)
+        self.fused_ranks = bool(fused_ranks and evaluation and not return_scores and not return_topk
+                                and candidate_ents is None and _counting_scorer(score_fn))
         self.candidate_mask: Optional[torch.Tensor] = None
         if candidate_ents is not None:
             self.candidate_mask = torch.from_numpy(np.setdiff1d(np.arange(sharding.n_entity), candidate_ents))
@@ -106,6 +123,62 @@ class AllScoresPipeline(torch.nn.Module):
             ent_slice = np.minimum(i * ws + np.arange(ws), M - 1)
             cols.append(sharding.shard_and_idx_to_entity[:, ent_slice].flatten())
         self._first = torch.from_numpy(np.unique(np.concatenate(cols), return_index=True)[1])
+
+    def _ranks_by_counting(self, inp: Dict[str, torch.Tensor], ground_truth: torch.Tensor,
+                           triple_mask: torch.Tensor, triple_id: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """Ranks of one sampler batch from counts made in the scoring kernels' epilogues; None when the
+        matrix-core product met operands outside its fp16 range (the caller then takes the matrix path)."""
+        ev = self.evaluation
+        sharding = self.bess_module.sharding
+        n = sharding.n_shard
+        rows, shard_bs = ground_truth.flatten(end_dim=1).shape  # [micro-batches * n_shard, shard_bs]
+        keep = triple_mask.flatten()
+        truth = ground_truth.flatten()
+        extra = dict(rank_truth=ground_truth.flatten(end_dim=1).to(torch.int32))
+        n_masked = torch.ones(int(keep.sum()), dtype=torch.int64)  # entries the reference sets to -inf, per kept row
+        if self.filter_triples is not None:
+            if triple_id is None:
+                raise ValueError("filtering needs a batch sampler with return_triple_idx=True")
+            flt = get_entity_filter(self.triples[triple_id[triple_mask]], self.filter_triples,
+                                    filter_mode=self.corruption_scheme)
+            slot = keep.nonzero().reshape(-1)[flt[:, 0]]  # position in the flat [rows * shard_bs] batch
+            pairs = torch.stack([slot, flt[:, 1].to(slot.dtype)], dim=1)
+            pairs = pairs[pairs[:, 1] != truth[pairs[:, 0]].to(pairs.dtype)]  # (the truth is left out anyway)
+            pairs = torch.unique(pairs, dim=0)  # sorted by slot
+            per_kept = torch.zeros(keep.numel(), dtype=torch.int64)
+            per_kept.index_add_(0, pairs[:, 0], torch.ones(len(pairs), dtype=torch.int64))
+            n_masked += per_kept[keep]
+            row_of = pairs[:, 0] // shard_bs
+            per_row = torch.bincount(row_of, minlength=rows)
+            start = torch.cumsum(per_row, 0) - per_row
+            P = int(per_row.max()) if len(pairs) else 0
+            filt = torch.full((rows, max(P, 1), 2), -1, dtype=torch.int32)
+            if len(pairs):
+                k = torch.arange(len(pairs)) - start[row_of]
+                filt[row_of, k, 0] = (pairs[:, 0] % shard_bs).to(torch.int32)
+                filt[row_of, k, 1] = pairs[:, 1].to(torch.int32)
+            extra["rank_filter"] = filt
+        step = torch.zeros((rows, 1), dtype=torch.int32)
+        out = self.runner(step=step, **inp, **extra)
+        dev = out["counts"].device
+        counts = out["counts"].reshape(-1, 2)[keep.to(dev)]
+        if bool((counts < 0).any()):
+            return None
+        pos = out["pos_score"].reshape(-1)[keep.to(dev)]
+        gt, eq = counts[:, 0].float(), counts[:, 1].float()
+        # the reference's masked entries (-inf) are candidates too: they tie with a -inf positive
+        ge = gt + eq + torch.where(pos == -torch.inf, n_masked.to(dev).float(), torch.zeros_like(gt))
+        n_cand = float(sharding.n_entity)
+        if ev.mode == "optimistic":
+            better, worst = gt, gt == n_cand
+        elif ev.mode == "pessimistic":
+            better, worst = ge, ge == n_cand
+        else:
+            better, worst = 0.5 * (gt + ge), (gt == n_cand) | (ge == n_cand)
+        rank = 1.0 + better
+        if ev.worst_rank_infty:
+            rank = torch.where(worst, torch.full_like(rank, torch.inf), rank)
+        return rank
 
     def forward(self) -> Dict[str, Any]:
         """Run over the whole sampler."""
@@ -124,6 +197,14 @@ class AllScoresPipeline(torch.nn.Module):
                 ids.append(triple_id[triple_mask])
             n_triple += int(triple_mask.sum())
             inp = {k: v.flatten(end_dim=1) for k, v in batch.items()}
+            if self.fused_ranks:
+                assert ground_truth is not None, "Evaluation requires providing ground truth entities"
+                r = self._ranks_by_counting(inp, ground_truth, triple_mask, triple_id)
+                if r is not None:
+                    metrics.append({m: v.cpu() for m, v in ev.dict_metrics_from_ranks(r).items()})
+                    if ev.return_ranks:
+                        ranks.append(r.cpu())
+                    continue
             parts = []
             for i in range(self.bess_module.n_step):
                 step = torch.full((n * bps, 1), i, dtype=torch.int32)

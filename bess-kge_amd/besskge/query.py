@@ -327,14 +327,101 @@ class AllScoresBESS(_QueryModule):
         self.n_step = int(np.ceil(self.sharding.max_entity_per_shard / self.window_size))
 
     def forward(self, step: torch.Tensor, relation: torch.Tensor, head: Optional[torch.Tensor] = None,
-                tail: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Scores (shard_bs, n_shard * window_size) of window `step` (one replica)."""
-        b = dict(step=step, relation=relation, head=head, tail=tail)
+                tail: Optional[torch.Tensor] = None, rank_truth: Optional[torch.Tensor] = None,
+                rank_filter: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Scores (shard_bs, n_shard * window_size) of window `step` (one replica); with `rank_truth` the
+        rank counts over all entities instead (`rank_counts_replicas`; `step` is not used then)."""
+        b = dict(step=step, relation=relation, head=head, tail=tail, rank_truth=rank_truth, rank_filter=rank_filter)
         if len(self._group().local_shards) != 1:
             raise RuntimeError("forward() steps a single replica; use forward_replicas()")
         return self.forward_replicas([{k: v for k, v in b.items() if v is not None}])[0]
 
+    def _entity_maps_on(self, dev: torch.device):
+        """(entity_to_shard, entity_to_idx, shard_counts) as int32 device tensors, uploaded once."""
+        cache = self.__dict__.setdefault("_entity_map_cache", {})
+        if dev not in cache:
+            cache[dev] = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=torch.int32)
+                               for a in (self.sharding.entity_to_shard, self.sharding.entity_to_idx,
+                                         self.sharding.shard_counts))
+        return cache[dev]
+
+    def rank_counts_replicas(self, batches: List[_Batch]) -> List[Dict[str, torch.Tensor]]:
+        """Rank-counting mode (`rank_truth` in the batch): for every query of the hosted replicas the number of
+        entities (all shards) scoring above / exactly as its true completion, without a score matrix - the
+        counting is the epilogue of the scoring kernel (`bess_neg_score_shared_fwd_counts`).  What the reference
+        gets from the window loop + `Evaluation.ranks_from_scores` (`bess.py:1005-1062`, `metric.py:129-182`,
+        `pipeline.py:233-271`), for the case where only ranks / metrics are wanted.
+
+        Inputs next to the query's known entity and relation: `rank_truth` [1, shard_bs] global id of the true
+        completion; optional `rank_filter` [1, P, 2] int32 pairs (query position in the replica's micro-batch,
+        global id of an entity to leave out; -1 padding; pairs distinct, none naming the query's true
+        completion).  Returns per replica `counts` [shard_bs, 2] int32 (above, equal: over the entities that are
+        neither the true completion nor filtered) and `pos_score` [shard_bs] f32 (NaN -> -inf, infinities ->
+        the largest finite values, as `Evaluation.ranks_from_scores` does)."""
+        group = self._group()
+        n = group.n_shard
+        fn = self.score_fn
+        desc = fn.kernel_desc()
+        queries = self._gather_queries(batches)
+        devs = [self._local_table(s).device for s in group.local_shards]
+        truth_all = group.all_gather([_i32(b["rank_truth"].squeeze(0).to(d)).reshape(-1) for b, d in zip(batches, devs)])
+        with_filter = batches[0].get("rank_filter") is not None
+        if with_filter:
+            filt_all = group.all_gather([_i32(b["rank_filter"].squeeze(0).to(d)) for b, d in zip(batches, devs)])
+        # the positive scores: computed where the true completion lives, summed over the shards
+        # (single (query, entity) scores come from the per-triple kernel: hand it the query as the matrix kernel takes it)
+        if nat.shared_kernel_rounds_queries(desc):
+            queries = [q.half().float() for q in queries]
+        pos_parts, local = [], []
+        for shard, q, tr in zip(group.local_shards, queries, truth_all):
+            table = self._local_table(shard)
+            e2s, e2i, _ = self._entity_maps_on(table.device)
+            t = tr.reshape(-1).long()
+            here = e2s[t] == shard
+            row = torch.where(here, e2i[t], torch.zeros_like(e2i[t]))
+            sc = nat.neg_score_pertriple_fwd(desc, q, RowSource(table, row.contiguous()), 1).reshape(-1)
+            pos_parts.append(torch.where(here, sc, torch.zeros_like(sc)))
+            local.append((here, row))
+        thr_all = group.all_reduce_sum(pos_parts)
+        outs_c, thrs = [], []
+        filters = filt_all if with_filter else [None] * len(queries)
+        for shard, q, thr, (here, row), f in zip(group.local_shards, queries, thr_all, local, filters):
+            table = self._local_table(shard)
+            e2s, e2i, cnt = self._entity_maps_on(table.device)
+            # scores leave AllScoresBESS in the model's dtype (bess.py:1058-1062): a half-precision model ranks
+            # fp16 scores, ties included
+            half = fn.relation_embedding.dtype == torch.float16
+            if half:
+                thr = thr.half().float()
+            thr = torch.nan_to_num(thr, nan=-torch.inf).contiguous()  # (ranks_from_scores: metric.py:152)
+            excl = torch.where(here, row, torch.full_like(row, -1)).contiguous()
+            valid_rows = int(self.sharding.shard_counts[shard])  # the padding rows of the shard are no entities
+            counts = nat.neg_score_shared_counts(desc, q, RowSource(table[:valid_rows]), thr, excl, round_f16=half)
+            if f is not None:  # [n, P, 2]: the pairs of every replica
+                if int(f.shape[1]):
+                    qi, ent = f[..., 0].long(), f[..., 1].long()
+                    g = (torch.arange(n, device=f.device)[:, None] * (q.shape[0] // n) + qi.clamp(min=0)).reshape(-1)
+                    ent = ent.reshape(-1)
+                    ok = (ent >= 0) & (e2s[ent.clamp(min=0)] == shard)
+                    rows_f = torch.where(ok, e2i[ent.clamp(min=0)], torch.zeros_like(e2i[ent.clamp(min=0)]))
+                    sc = nat.neg_score_pertriple_fwd(desc, q[g].contiguous(), RowSource(table, rows_f.contiguous()),
+                                                     1).reshape(-1)
+                    if half:
+                        sc = sc.half().float()
+                    t = thr[g]
+                    sub = torch.stack([(ok & (sc > t)), (ok & (sc == t))], dim=1).to(torch.int32)
+                    counts.index_add_(0, g, -sub)
+            outs_c.append(counts.reshape(n, -1, 2))
+            thrs.append(thr.reshape(n, -1))
+        back = group.all_to_all(outs_c)  # counts of every shard's entities, back to the query's replica
+        res = []
+        for shard, c, thr in zip(group.local_shards, back, thrs):
+            res.append(dict(counts=c.sum(dim=0, dtype=torch.int32), pos_score=thr[shard].contiguous()))
+        return res
+
     def forward_replicas(self, batches: List[_Batch]) -> List[torch.Tensor]:
+        if batches and batches[0].get("rank_truth") is not None:
+            return self.rank_counts_replicas(batches)  # type: ignore[return-value]
         group = self._group()
         n = group.n_shard
         desc = self.score_fn.kernel_desc()

@@ -25,7 +25,8 @@ from besskge.collectives import DistributedGroup, NativeGroup, ReplicaGroup, Sin
 
 _MULTI_PROCESS = (DistributedGroup, NativeGroup)
 
-_BATCH_KEYS = ("head", "relation", "tail", "negative", "triple_mask", "triple_weight", "negative_mask", "step")
+_BATCH_KEYS = ("head", "relation", "tail", "negative", "triple_mask", "triple_weight", "negative_mask", "step",
+               "rank_truth", "rank_filter")  # (the last two: AllScoresBESS in rank-counting mode)
 
 
 @dataclasses.dataclass

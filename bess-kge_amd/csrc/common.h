@@ -43,11 +43,16 @@ int gemm_dot_fwd(int dtype, const float* Q, int64_t S, const void* E, const int3
 // Counting epilogue of the all-entity scoring kernels (ranks without the score matrix: bess_neg_score_shared_fwd_counts):
 // counts[row, 0] += #{columns: score > thr[row]}, counts[row, 1] += #{score == thr[row]}; column excl[row] (an index
 // into the whole candidate list, -1: none) is left out; col0 = list index of the launch's first column.
+// round16: compare the scores as rounded to fp16 (what a `model.half()` reference hands to its ranking).
 struct CountArgs {
     const int32_t* excl;
     int32_t* counts;
     int64_t col0;
+    int round16;
 };
+__device__ __forceinline__ float count_value(float v, int round16) {
+    return round16 ? static_cast<float>(static_cast<_Float16>(v)) : v;
+}
 // split-fp16 MFMA variant of gemm_dot_fwd (gemm_split.hip): workspace it wants for a shape
 // (0 = leave the shape to the fp32 kernels) and the product through that workspace
 int64_t gemm_split_workspace(int64_t S, int64_t N, int W);

@@ -441,8 +441,8 @@ __global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__
                         const int e0 = __builtin_amdgcn_readlane(ex, rr), e1 = __builtin_amdgcn_readlane(ex, rr + 4);
                         const float th = lk ? th1 : th0;
                         const int e = lk ? e1 : e0;
-                        const float v0 = accm[i][0][r] + accc[i][0][r] * (1.f / 2048.f);
-                        const float v1 = accm[i][1][r] + accc[i][1][r] * (1.f / 2048.f);
+                        const float v0 = count_value(accm[i][0][r] + accc[i][0][r] * (1.f / 2048.f), cnt.round16);
+                        const float v1 = count_value(accm[i][1][r] + accc[i][1][r] * (1.f / 2048.f), cnt.round16);
                         const bool in0 = ok0 && l31 != e, in1 = ok1 && l31 + 32 != e;
                         const unsigned long long g0 = __ballot(in0 && v0 > th), g1 = __ballot(in1 && v1 > th);
                         const unsigned long long q0 = __ballot(in0 && v0 == th), q1 = __ballot(in1 && v1 == th);
@@ -671,8 +671,8 @@ __global__ __launch_bounds__(512) void k_gemm_split_w8(const char* __restrict__ 
                         const int e0 = __builtin_amdgcn_readlane(ex, rr), e1 = __builtin_amdgcn_readlane(ex, rr + 4);
                         const float th = lk ? th1 : th0;
                         const int e = lk ? e1 : e0;
-                        const float v0 = accm[i][0][r] + accc[i][0][r] * (1.f / 2048.f);
-                        const float v1 = accm[i][1][r] + accc[i][1][r] * (1.f / 2048.f);
+                        const float v0 = count_value(accm[i][0][r] + accc[i][0][r] * (1.f / 2048.f), cnt.round16);
+                        const float v1 = count_value(accm[i][1][r] + accc[i][1][r] * (1.f / 2048.f), cnt.round16);
                         const bool in0 = ok0 && l31 != e, in1 = ok1 && l31 + 32 != e;
                         const unsigned long long g0 = __ballot(in0 && v0 > th), g1 = __ballot(in1 && v1 > th);
                         const unsigned long long q0 = __ballot(in0 && v0 == th), q1 = __ballot(in1 && v1 == th);
@@ -776,7 +776,7 @@ static int launch_product(const char* A, const char* B, int64_t M, int64_t N, in
                           const CountArgs* count = nullptr) {
     BESS_REQUIRE(!thr || (ksplit == 1 && (pflags || count)),
                  "gemm_split: pruned stores / counts need an unsplit product and a flag or count array");
-    const CountArgs cnt = count ? *count : CountArgs{nullptr, nullptr, 0};
+    const CountArgs cnt = count ? *count : CountArgs{nullptr, nullptr, 0, 0};
     const int epi = count ? 2 : (thr ? 1 : 0);
     const int cus = n_compute_units();
     const int64_t tx = ceil_div(N, 128);
@@ -898,8 +898,8 @@ int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const in
         // the query rows ride along with the first chunk
         if (int e = split_rows(SplitSrc{Q, nullptr, j0 == 0 ? S : 0, W, flag}, qa, dtype, src, eb, W, st)) return e;
         // (pruned stores: the chunk's flags start at block j0 / 64 - chunks are multiples of 128 rows)
-        CountArgs cj{nullptr, nullptr, 0};
-        if (count) cj = CountArgs{count->excl, count->counts, count->col0 + j0};
+        CountArgs cj{nullptr, nullptr, 0, 0};
+        if (count) cj = CountArgs{count->excl, count->counts, count->col0 + j0, count->round16};
         if (int e = launch_product(qa, eb, S, nc, n_slice, count ? nullptr : out + j0, ld, 1, 0, dtype == BESS_F32, true,
                                    flag, st, thr, pflags ? pflags + j0 / 64 : nullptr, ldf, count ? &cj : nullptr))
             return e;

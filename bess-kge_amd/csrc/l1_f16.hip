@@ -192,8 +192,9 @@ __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool in = jj0 + j < ne && jj0 + j != ex;
-                cg += (in && v4[j] > th) ? 1 : 0;
-                ce += (in && v4[j] == th) ? 1 : 0;
+                const float v = count_value(v4[j], prune.cnt.round16);
+                cg += (in && v > th) ? 1 : 0;
+                ce += (in && v == th) ? 1 : 0;
             }
 #pragma unroll
             for (int o2 = 1; o2 < 16; o2 <<= 1) {  // the 16 threads with this ty hold the row
@@ -234,7 +235,7 @@ bool l1_pk_eligible(const bess_model_desc* d) {
 int l1_pk_fwd(const bess_model_desc* d, const float* query, int64_t n_query, const void* neg_base,
               const int32_t* neg_idx, int64_t n_neg, float* out, int64_t ld_out, const bess_kill_desc* k,
               hipStream_t st, const float* thr, uint8_t* flags, int64_t ld_flags, const CountArgs* count) {
-    const PruneArgs pr{thr, flags, ld_flags, count ? *count : CountArgs{nullptr, nullptr, 0}};
+    const PruneArgs pr{thr, flags, ld_flags, count ? *count : CountArgs{nullptr, nullptr, 0, 0}};
     KillArgs ka{};
     if (k) ka = KillArgs{k->diag_step, k->ht, k->ppp, k->mask, k->mask_rows, k->mask ? k->mask_cols : 0, n_neg};
     // 32-row tiles when the 64-row grid would leave most CUs without a workgroup

@@ -766,7 +766,7 @@ extern "C" int bess_neg_score_shared_fwd_pruned(const bess_model_desc* d, const 
 __global__ __launch_bounds__(256) void k_count_scores(const float* __restrict__ sc, int64_t ld, int64_t n_row,
                                                       int64_t n_col, const float* __restrict__ thr,
                                                       const int32_t* __restrict__ excl, int64_t col0,
-                                                      int32_t* __restrict__ counts) {
+                                                      int32_t* __restrict__ counts, int round16) {
     const int lane = threadIdx.x & 63;
     const int64_t r = blockIdx.x * 4ll + (threadIdx.x >> 6);
     if (r >= n_row) return;
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(256) void k_count_scores(const float* __restrict__ 
     const float* row = sc + r * ld;
     int cg = 0, ce = 0;
     for (int64_t j = lane; j < n_col; j += 64) {
-        const float v = row[j];
+        const float v = count_value(row[j], round16);
         const bool in = j != ex;
         cg += (in && v > th) ? 1 : 0;
         ce += (in && v == th) ? 1 : 0;
@@ -822,14 +822,15 @@ extern "C" int64_t bess_neg_score_shared_fwd_counts_workspace(const bess_model_d
 extern "C" int bess_neg_score_shared_fwd_counts(const bess_model_desc* d, const float* query, int64_t n_query,
                                                 const void* neg_base, const int32_t* neg_idx, int64_t n_neg,
                                                 const float* thr, const int32_t* excl, int32_t* counts,
-                                                void* workspace, int64_t workspace_bytes, void* stream) {
+                                                int32_t round_f16, void* workspace, int64_t workspace_bytes,
+                                                void* stream) {
     if (int e = check_desc(d)) return e;
     BESS_REQUIRE(n_query >= 0 && n_neg >= 0, "neg_score_shared_fwd_counts: bad sizes");
     if (n_query == 0 || n_neg == 0) return BESS_OK;
     BESS_REQUIRE(query && neg_base && thr && excl && counts, "neg_score_shared_fwd_counts: NULL pointer");
     BESS_REQUIRE(n_neg < (1ll << 31), "neg_score_shared_fwd_counts: candidate ids are int32");
     hipStream_t st = as_stream(stream);
-    const CountArgs cnt{excl, counts, 0};
+    const CountArgs cnt{excl, counts, 0, round_f16 ? 1 : 0};
     int64_t want = 0;
     if (counts_in_epilogue(d, query, neg_base, n_query, n_neg, &want)) {
         if (reduce_of(d) == RED_DOT) {
@@ -855,7 +856,7 @@ extern "C" int bess_neg_score_shared_fwd_counts(const bess_model_desc* d, const 
                                                  nullptr, 0, stream))
             return e;
         k_count_scores<<<static_cast<unsigned>(ceil_div(n_query, 4)), 256, 0, st>>>(tile, cols, n_query, nc, thr, excl,
-                                                                                    j0, counts);
+                                                                                    j0, counts, cnt.round16);
         if (int e = check_launch("count_scores")) return e;
     }
     return BESS_OK;

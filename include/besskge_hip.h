@@ -322,14 +322,16 @@ int bess_neg_score_shared_fwd_pruned(const bess_model_desc* d, const float* quer
  * epilogue of the split-fp16 matrix-core product (DistMult / ComplEx) and of the packed-fp16 L1 kernel (TransE /
  * RotatE p = 1 on f16 tables): no score is written.  Other scorers / shapes score tiles of at most 64 MiB into the
  * workspace and count them there.  workspace: bess_neg_score_shared_fwd_counts_workspace bytes, 16-B aligned.
+ * round_f16 != 0: every score is rounded to fp16 before it is compared (thr is taken as given) - the ranking a
+ * reference whose model is in half precision makes of its fp16 scores, ties included.
  * If an operand of the matrix-core product is outside the fp16 range every count of the call is set to INT32_MIN
  * (there is no score matrix for the fp32 kernels to fall back on): a caller that sees negative counts scores that
  * batch through bess_neg_score_shared_fwd_ws + bess_ranks_from_scores instead. */
 int64_t bess_neg_score_shared_fwd_counts_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg);
 int bess_neg_score_shared_fwd_counts(const bess_model_desc* d, const float* query, int64_t n_query,
                                      const void* neg_base, const int32_t* neg_idx, int64_t n_neg, const float* thr,
-                                     const int32_t* excl, int32_t* counts, void* workspace, int64_t workspace_bytes,
-                                     void* stream);
+                                     const int32_t* excl, int32_t* counts, int32_t round_f16, void* workspace,
+                                     int64_t workspace_bytes, void* stream);
 
 int64_t bess_neg_score_shared_bwd_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg);
 int bess_neg_score_shared_bwd_ws(const bess_model_desc* d, const float* query,

@@ -500,3 +500,89 @@ def test_counts_in_the_scoring_epilogue_equal_counts_of_the_stored_scores(dev, s
     ex_b = torch.where(excl >= half, excl - half, torch.full_like(excl, -1))
     c2 = nat.neg_score_shared_counts(d, q, b, thr, ex_b, counts=c2)
     assert torch.equal(c2, counts)
+    # a half-precision model ranks fp16 scores: many ties
+    sc16, thr16 = sc.half().float(), thr.half().float().contiguous()
+    c16 = nat.neg_score_shared_counts(d, q, src, thr16, excl, round_f16=True)
+    assert torch.equal(c16[:, 0].long(), ((sc16 > thr16[:, None]) & keep).sum(-1))
+    assert torch.equal(c16[:, 1].long(), ((sc16 == thr16[:, None]) & keep).sum(-1))
+    assert int(c16[:, 1].sum()) > int(counts[:, 1].sum())
+
+
+@pytest.mark.parametrize("scorer,dtype,n_entity,n_shard,shard_bs", [
+    ("ComplEx", torch.float32, 60_000, 2, 160),  # split-fp16 product with the counting epilogue
+    ("TransE", torch.float16, 20_000, 2, 80),    # packed L1 kernel with the counting epilogue
+    ("RotatE", torch.float32, 6_000, 3, 40),     # score tiles + count kernel
+    ("DistMult", torch.float32, 5_000, 4, 80),   # small shards: the fp32 product, tiles + count kernel
+])
+@pytest.mark.parametrize("scheme,filtered,mode", [("t", False, "average"), ("h", True, "optimistic"),
+                                                  ("t", True, "pessimistic")])
+def test_pipeline_ranks_by_counting_equal_ranks_from_the_score_matrix(dev, scorer, dtype, n_entity, n_shard, shard_bs,
+                                                                      scheme, filtered, mode):
+    """AllScoresPipeline with only metrics / ranks asked for never assembles the score matrix
+    (`AllScoresBESS.rank_counts_replicas`): same ranks as the matrix path and as the CPU oracle."""
+    from besskge.batch_sampler import RigidShardedBatchSampler
+    from besskge.dataset import KGDataset
+    from besskge.metric import Evaluation
+    from besskge.negative_sampler import PlaceholderNegativeSampler
+    from besskge.pipeline import AllScoresPipeline
+    from besskge.sharding import PartitionedTripleSet, Sharding
+
+    seed, n_rel, d = 99, 30, 64
+    n_triple = 3 * n_shard * shard_bs - 17  # a padded last batch
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    sharding = Sharding.create(n_entity, n_shard, seed=seed)
+    ew, rw = kge.entity_width(scorer, d), kge.relation_width(scorer, d)
+    ent = torch.randn(n_shard, sharding.max_entity_per_shard, ew) * 0.3
+    rel = torch.randn(n_rel, rw) * 0.3
+    if dtype == torch.float16:
+        ent, rel = ent.half().float(), rel.half().float()
+    triples = np.stack([rng.integers(n_entity, size=n_triple), rng.integers(n_rel, size=n_triple),
+                        rng.integers(n_entity, size=n_triple)], axis=1)
+    extra = np.stack([rng.integers(n_entity, size=4000), rng.integers(n_rel, size=4000),
+                      rng.integers(n_entity, size=4000)], axis=1)
+    extra[:1500, :2] = triples[rng.integers(n_triple, size=1500), :2]  # share (h, r) with test queries
+    extra[1500:3000, 1:] = triples[rng.integers(n_triple, size=1500), 1:]  # share (r, t)
+    extra[3000:3200] = triples[:200]  # the test triples themselves (filtered and true completion at once)
+    extra[3200:3400] = extra[:200]    # duplicates in the filter set
+    ds = KGDataset(n_entity=n_entity, n_relation_type=n_rel, triples={"test": triples},
+                   original_triple_ids={"test": np.arange(n_triple)})
+    pts = PartitionedTripleSet.create_from_dataset(ds, "test", sharding,
+                                                   partition_mode="h_shard" if scheme == "t" else "t_shard")
+    p = 1 if scorer in ("TransE", "RotatE") else 0
+    fn = make_scorer(scorer, p, True, n_rel, d, ent, rel, dev, dtype=dtype, sharding=sharding)
+    bs = RigidShardedBatchSampler(pts, PlaceholderNegativeSampler(scheme), shard_bs=shard_bs, batches_per_step=2,
+                                  seed=seed, return_triple_idx=True)
+    ev = Evaluation(["mrr", "hits@10"], mode=mode, reduction="sum", return_ranks=True)
+    kw = dict(evaluation=ev, filter_triples=[extra] if filtered else None, window_size=1000, device=dev)
+    fused = AllScoresPipeline(bs, scheme, fn, **kw)
+    assert fused.fused_ranks
+    plain = AllScoresPipeline(bs, scheme, fn, fused_ranks=False, **kw)
+    assert not plain.fused_ranks
+    a, b = fused(), plain()
+    assert torch.equal(a["triple_idx"], b["triple_idx"]) and len(a["ranks"]) == n_triple
+    assert float((a["ranks"] != b["ranks"]).float().mean()) < 0.01  # (ties to the last bit between two kernels)
+    torch.testing.assert_close(a["metrics"]["mrr"], b["metrics"]["mrr"], rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(a["metrics"]["hits@10"], b["metrics"]["hits@10"], rtol=0, atol=2)
+    # and the unsharded oracle
+    order = pts.triple_sort_idx[a["triple_idx"].numpy()]
+    tr = triples[order]
+    flat = ent[sharding.entity_to_shard, sharding.entity_to_idx]
+    known, truth = (tr[:, 0], tr[:, 2]) if scheme == "t" else (tr[:, 2], tr[:, 0])
+    import contextlib
+
+    half = dtype == torch.float16  # (the fp16 mode: query rounded to fp16, fp16 scores ranked - ties included)
+    with (kge.half_queries() if half else contextlib.nullcontext()):
+        full = kge.score_candidates(scorer, p, True, scheme, flat[known], rel, T(tr[:, 1]), flat[None])
+    if half:
+        full = full.half().float()
+    rows = torch.arange(len(tr))
+    true_sc = full[rows, T(truth)].clone()
+    if filtered:
+        col, other = (0, 2) if scheme == "t" else (2, 0)
+        for i, (e_, r_) in enumerate(zip(tr[:, col], tr[:, 1])):
+            full[i, T(extra[(extra[:, col] == e_) & (extra[:, 1] == r_)][:, other])] = -torch.inf
+    full[rows, T(truth)] = -torch.inf
+    gt, ge = (full > true_sc[:, None]).sum(-1).float(), (full >= true_sc[:, None]).sum(-1).float()
+    want = 1 + dict(optimistic=gt, pessimistic=ge, average=0.5 * (gt + ge))[mode]
+    assert float((a["ranks"] != want).float().mean()) < (0.05 if half else 0.03)  # (rank flips at numerical ties: fp16 rounding boundaries; RotatE's sin / cos)
