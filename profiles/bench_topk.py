@@ -72,7 +72,63 @@ def run(name, cls, args, n_entity, n_rel, d, n_query, dtype, k=10):
     n_topk = len(km.get("bess_topk_update", [])) // reps
     print(f"{name:28s} {n_query:6d} queries x {n_entity:9,d} entities  W={W} {str(dtype)[6:]:8s}: {dt*1e3:8.2f} ms/batch"
           f"  {n_query*n_entity/dt/1e9:7.1f} G scores/s   (scoring {score_ms:7.2f} ms, top-k {topk_ms:7.2f} ms in {n_topk} launches)")
+    if os.environ.get("BESS_TOPK_RANKS", "1") == "1":
+        run_ranks(name, fn, sharding, n_entity, n_rel, n_query, batch)
     return out
+
+
+def run_ranks(name, fn, sharding, n_entity, n_rel, n_query, batch):
+    """next-2: full ranks of the same queries (true completion = a random entity), by counting in the scoring
+    kernel's epilogue (AllScoresBESS.rank_counts_replicas) against scoring every entity into a matrix +
+    bess_ranks_from_scores (what AllScoresPipeline does when scores are asked for too)."""
+    from besskge import _native as nat
+    from besskge._native import RowSource
+    from besskge.bess import AllScoresBESS
+
+    mod = AllScoresBESS(PlaceholderNegativeSampler("t"), fn, window_size=1000)
+    mod.attach(runtime.SingleProcessGroup(1))
+    rng = np.random.default_rng(1)
+    truth = torch.from_numpy(rng.integers(n_entity, size=(1, n_query)).astype(np.int32)).to(dev)
+    b = dict(batch, rank_truth=truth)
+
+    def counted():
+        return mod.rank_counts_replicas([b])[0]
+
+    def matrix():
+        q = mod._gather_queries([batch])[0]
+        table = mod._local_table(0)
+        desc = fn.kernel_desc()
+        rows = sharding.entity_to_idx[truth.reshape(-1).cpu().numpy()]
+        rows_t = torch.from_numpy(np.ascontiguousarray(rows)).to(device=dev, dtype=torch.int64)
+        ranks = []
+        tile = max(64, (1 << 30) // 4 // n_entity)  # 1 GiB score tiles, as the top-k passes
+        for q0 in range(0, n_query, tile):
+            qq = q[q0:q0 + tile]
+            sc = nat.neg_score_shared_fwd(desc, qq, RowSource(table))
+            if fn.relation_embedding.dtype == torch.float16:  # (scores leave AllScoresBESS in the model's dtype)
+                sc = sc.half().float()
+            r = torch.arange(qq.shape[0], device=dev)
+            pos = sc[r, rows_t[q0:q0 + tile]].clone()
+            sc[r, rows_t[q0:q0 + tile]] = -torch.inf
+            ranks.append(nat.ranks_from_scores(pos, sc, 2, False))
+        return torch.cat(ranks)
+
+    res = {}
+    for label, f in (("counted", counted), ("matrix", matrix)):
+        for _ in range(2):
+            f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            out = f()
+        torch.cuda.synchronize()
+        res[label] = ((time.perf_counter() - t0) / 5, out)
+    c = res["counted"][1]["counts"].float()
+    r_counted = 1 + c[:, 0] + 0.5 * c[:, 1]
+    agree = float((r_counted == res["matrix"][1]).float().mean())
+    tc, tm = res["counted"][0], res["matrix"][0]
+    print(f"{'  ranks, same queries':28s} counted in the epilogue {tc*1e3:8.2f} ms ({n_query*n_entity/tc/1e9:6.1f} G scores/s)"
+          f"   score matrix + ranks_from_scores {tm*1e3:8.2f} ms ({n_query*n_entity/tm/1e9:6.1f} G)   ranks equal {agree:.4f}")
 
 
 if __name__ == "__main__":

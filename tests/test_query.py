@@ -561,7 +561,10 @@ def test_pipeline_ranks_by_counting_equal_ranks_from_the_score_matrix(dev, score
     assert not plain.fused_ranks
     a, b = fused(), plain()
     assert torch.equal(a["triple_idx"], b["triple_idx"]) and len(a["ranks"]) == n_triple
-    assert float((a["ranks"] != b["ranks"]).float().mean()) < 0.01  # (ties to the last bit between two kernels)
+    # (the true completion's score comes from the per-triple kernel here, from the matrix kernel there: a
+    # candidate within a rounding error of it moves the rank by one)
+    diff = (a["ranks"] - b["ranks"]).abs()
+    assert float((diff > 0).float().mean()) < 0.03 and float(diff.max()) <= 2
     torch.testing.assert_close(a["metrics"]["mrr"], b["metrics"]["mrr"], rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(a["metrics"]["hits@10"], b["metrics"]["hits@10"], rtol=0, atol=2)
     # and the unsharded oracle
