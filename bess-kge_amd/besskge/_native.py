@@ -32,7 +32,7 @@ _c_u8p = ctypes.POINTER(ctypes.c_uint8)
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
 _RETURNS_I64 = ("bess_neg_score_shared_workspace", "bess_neg_score_shared_bwd_workspace",
-                "bess_neg_score_shared_fwd_counts_workspace")  # every other entry returns an int status
+                "bess_neg_score_shared_fwd_counts_workspace", "bess_neg_score_shared_fwd_pairs_workspace")  # every other entry returns an int status
 _i32 = ctypes.c_int32
 _f32 = ctypes.c_float
 
@@ -138,6 +138,8 @@ SIGNATURES = {
     "bess_neg_score_shared_fwd_pruned": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
     "bess_neg_score_shared_fwd_counts_workspace": [_MD, _i64, _i64],
     "bess_neg_score_shared_fwd_counts": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _vp],
+    "bess_neg_score_shared_fwd_pairs_workspace": [_MD, _i64, _i64],
+    "bess_neg_score_shared_fwd_pairs": [_MD, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp],
     "bess_topk_update_flagged": [_vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _vp],
     "bess_neg_score_shared_fwd_masked": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, ctypes.POINTER(KillDesc), _vp, _i64, _vp],
     "bess_neg_score_shared_bwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
@@ -804,6 +806,29 @@ def neg_score_shared_fwd_pruned(d: ModelDesc, query: torch.Tensor, neg: RowSourc
                                                   ws.data_ptr() if ws is not None else None, ws_bytes, _stream(dev))
     _check(rc, "bess_neg_score_shared_fwd_pruned")
     return (out if ld == n_neg else out[:, :n_neg]), flags
+
+
+def neg_score_shared_pairs(d: ModelDesc, query: torch.Tensor, neg: RowSource, like_n_query: int,
+                           like_n_neg: int) -> torch.Tensor:
+    """out[i] = score(query[i], candidate i of `neg`) in the arithmetic of the all-entity pass over a
+    (like_n_query x like_n_neg) problem (`bess_neg_score_shared_fwd_pairs`): what `neg_score_shared_counts` compares
+    against, to the last bit."""
+    n = int(query.shape[0])
+    if len(neg) != n or neg.idx is None:
+        raise ValueError("neg_score_shared_pairs: one indexed candidate per query")
+    dev = _neg_operands(d, query, neg, n)
+    out = torch.empty((n,), dtype=torch.float32, device=dev)
+    if n == 0:
+        return out
+    lib = load()
+    ws_bytes = int(lib.bess_neg_score_shared_fwd_pairs_workspace(ctypes.byref(d), int(like_n_query), int(like_n_neg)))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    with _on(dev), _Timed("bess_neg_score_shared_fwd_pairs", dev):
+        rc = lib.bess_neg_score_shared_fwd_pairs(ctypes.byref(d), query.data_ptr(), neg.base.data_ptr(),
+                                                 _idx(neg.idx, "negative idx"), n, int(like_n_query), int(like_n_neg),
+                                                 out.data_ptr(), ws.data_ptr(), ws_bytes, _stream(dev))
+    _check(rc, "bess_neg_score_shared_fwd_pairs")
+    return out
 
 
 def shared_kernel_rounds_queries(d: ModelDesc) -> bool:

@@ -71,9 +71,12 @@ class AllScoresPipeline(torch.nn.Module):
         :param fused_ranks: when only metrics / ranks are asked for (no scores, no top-k, no
             `candidate_ents`) count the entities that beat the true completion in the scoring kernel's
             epilogue instead of assembling the `[queries, n_entity]` score matrix
-            (`AllScoresBESS.rank_counts_replicas`).  Same ranks, except where another entity's score
-            ties with the true completion's to the last bit: the positive score then comes from the
-            per-triple kernel, the candidates' from the matrix kernel.
+            (`AllScoresBESS.rank_counts_replicas`).  The same ranks to the last bit as the matrix path
+            whenever that scores its windows with the same kernel as the all-entity pass (the positives'
+            and the filtered completions' scores are taken in that kernel's arithmetic too:
+            `bess_neg_score_shared_fwd_pairs`); where `window_size` makes the matrix path take another
+            kernel (the split-fp16 product needs 256 output tiles) ranks may differ by one at scores that
+            agree to a rounding error.
         """
         super().__init__()
         if not (evaluation or return_scores):

@@ -356,7 +356,8 @@ class AllScoresBESS(_QueryModule):
         completion; optional `rank_filter` [1, P, 2] int32 pairs (query position in the replica's micro-batch,
         global id of an entity to leave out; -1 padding; pairs distinct, none naming the query's true
         completion).  Returns per replica `counts` [shard_bs, 2] int32 (above, equal: over the entities that are
-        neither the true completion nor filtered) and `pos_score` [shard_bs] f32 (NaN -> -inf, infinities ->
+        neither the true completion nor filtered; every score involved - candidates, positives, filtered
+        completions - in the arithmetic of the all-entity kernel) and `pos_score` [shard_bs] f32 (NaN -> -inf, infinities ->
         the largest finite values, as `Evaluation.ranks_from_scores` does)."""
         group = self._group()
         n = group.n_shard
@@ -369,9 +370,8 @@ class AllScoresBESS(_QueryModule):
         if with_filter:
             filt_all = group.all_gather([_i32(b["rank_filter"].squeeze(0).to(d)) for b, d in zip(batches, devs)])
         # the positive scores: computed where the true completion lives, summed over the shards
-        # (single (query, entity) scores come from the per-triple kernel: hand it the query as the matrix kernel takes it)
-        if nat.shared_kernel_rounds_queries(desc):
-            queries = [q.half().float() for q in queries]
+        # (single (query, entity) scores - the positives, the filtered completions - in the arithmetic of the
+        # all-entity pass they are compared with: bess_neg_score_shared_fwd_pairs)
         pos_parts, local = [], []
         for shard, q, tr in zip(group.local_shards, queries, truth_all):
             table = self._local_table(shard)
@@ -379,7 +379,8 @@ class AllScoresBESS(_QueryModule):
             t = tr.reshape(-1).long()
             here = e2s[t] == shard
             row = torch.where(here, e2i[t], torch.zeros_like(e2i[t]))
-            sc = nat.neg_score_pertriple_fwd(desc, q, RowSource(table, row.contiguous()), 1).reshape(-1)
+            sc = nat.neg_score_shared_pairs(desc, q, RowSource(table, row.contiguous()), int(q.shape[0]),
+                                            int(self.sharding.shard_counts[shard]))
             pos_parts.append(torch.where(here, sc, torch.zeros_like(sc)))
             local.append((here, row))
         thr_all = group.all_reduce_sum(pos_parts)
@@ -404,8 +405,8 @@ class AllScoresBESS(_QueryModule):
                     ent = ent.reshape(-1)
                     ok = (ent >= 0) & (e2s[ent.clamp(min=0)] == shard)
                     rows_f = torch.where(ok, e2i[ent.clamp(min=0)], torch.zeros_like(e2i[ent.clamp(min=0)]))
-                    sc = nat.neg_score_pertriple_fwd(desc, q[g].contiguous(), RowSource(table, rows_f.contiguous()),
-                                                     1).reshape(-1)
+                    sc = nat.neg_score_shared_pairs(desc, q[g].contiguous(), RowSource(table, rows_f.contiguous()),
+                                                    int(q.shape[0]), valid_rows)
                     if half:
                         sc = sc.half().float()
                     t = thr[g]

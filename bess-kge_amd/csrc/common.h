@@ -56,6 +56,7 @@ __device__ __forceinline__ float count_value(float v, int round16) {
 // split-fp16 MFMA variant of gemm_dot_fwd (gemm_split.hip): workspace it wants for a shape
 // (0 = leave the shape to the fp32 kernels) and the product through that workspace
 int64_t gemm_split_workspace(int64_t S, int64_t N, int W);
+int64_t gemm_split_workspace_any(int64_t S, int64_t N, int W);  // (bytes for a shape, eligible or not)
 // (thr / flags: pruned stores for the top-k passes - a row's 64-column block is written only when one of its
 // scores is above thr[row]; flags[row, ld_flags] (one byte per block) says which were)
 int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const int32_t* idx, int64_t N, int W,

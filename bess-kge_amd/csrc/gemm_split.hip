@@ -846,6 +846,11 @@ int64_t gemm_split_workspace(int64_t S, int64_t N, int W) {
     return (pad_a(S) + pad_b(N < SPLIT_CHUNK ? N : SPLIT_CHUNK)) * split_pitch(W) + FLAG_BYTES;
 }
 
+// the same for a caller that takes the split path whatever the shape (pair scores in the arithmetic of a larger product)
+int64_t gemm_split_workspace_any(int64_t S, int64_t N, int W) {
+    return (pad_a(S) + pad_b(N < SPLIT_CHUNK ? N : SPLIT_CHUNK)) * split_pitch(W) + FLAG_BYTES;
+}
+
 // splits `a` (f32 rows; skipped when a.rows == 0) and `b` (table dtype) in one launch
 static int split_rows(const SplitSrc& a, char* dst_a, int dtype_b, const SplitSrc& b, char* dst_b, int W,
                       hipStream_t st) {
@@ -885,8 +890,8 @@ int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const in
         if (e != hipSuccess) return fail(static_cast<int>(e), "memset: %s", hipGetErrorString(e));
     }
     int64_t chunk = (ws_bytes / pitch - pad_a(S)) / 128 * 128;  // candidate rows per pass
-    if (chunk >= N) chunk = N;
     BESS_REQUIRE(chunk >= 128, "gemm_split: workspace too small");
+    if (chunk >= N) chunk = N;
     char* qa = static_cast<char*>(ws);
     char* eb = qa + pad_a(S) * pitch;
     const int n_slice = static_cast<int>(ceil_div(W, SK));

@@ -862,6 +862,62 @@ extern "C" int bess_neg_score_shared_fwd_counts(const bess_model_desc* d, const 
     return BESS_OK;
 }
 
+// ---- single (query, candidate) scores in the arithmetic of the all-entity kernels -------------------------
+// out[i] = score(query[i], candidate idx[i]) as bess_neg_score_shared_fwd_counts on a (like_n_query x like_n_neg)
+// problem computes it: diagonal of PAIR_CHUNK x PAIR_CHUNK blocks scored by the same kernel (the per-element
+// arithmetic of these kernels does not depend on where in the matrix an element sits).
+constexpr int64_t PAIR_CHUNK = 1024;
+__global__ void k_take_diagonal(const float* __restrict__ tile, int64_t ld, int64_t n, float* __restrict__ out) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) out[i] = tile[i * ld + i];
+}
+
+extern "C" int64_t bess_neg_score_shared_fwd_pairs_workspace(const bess_model_desc* d, int64_t like_n_query,
+                                                             int64_t like_n_neg) {
+    if (!d || check_desc(d) || like_n_query <= 0 || like_n_neg <= 0) return 0;
+    int64_t want = 0, gemm = 0;
+    if (counts_in_epilogue(d, nullptr, nullptr, like_n_query, like_n_neg, &want) && want > 0)
+        gemm = gemm_split_workspace_any(PAIR_CHUNK, PAIR_CHUNK, d->width);
+    return PAIR_CHUNK * PAIR_CHUNK * 4 + gemm;
+}
+
+extern "C" int bess_neg_score_shared_fwd_pairs(const bess_model_desc* d, const float* query, const void* neg_base,
+                                               const int32_t* neg_idx, int64_t n_pair, int64_t like_n_query,
+                                               int64_t like_n_neg, float* out, void* workspace,
+                                               int64_t workspace_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    BESS_REQUIRE(n_pair >= 0 && like_n_query > 0 && like_n_neg > 0, "neg_score_shared_fwd_pairs: bad sizes");
+    if (n_pair == 0) return BESS_OK;
+    BESS_REQUIRE(query && neg_base && neg_idx && out, "neg_score_shared_fwd_pairs: NULL pointer");
+    BESS_REQUIRE(d->scorer <= BESS_COMPLEX, "neg_score_shared_fwd_pairs: TransE / RotatE / DistMult / ComplEx only");
+    const int64_t tile_bytes = PAIR_CHUNK * PAIR_CHUNK * 4;
+    BESS_REQUIRE(workspace && workspace_bytes >= bess_neg_score_shared_fwd_pairs_workspace(d, like_n_query, like_n_neg) &&
+                     reinterpret_cast<uintptr_t>(workspace) % 16 == 0,
+                 "neg_score_shared_fwd_pairs: workspace too small (bess_neg_score_shared_fwd_pairs_workspace) or misaligned");
+    hipStream_t st = as_stream(stream);
+    float* tile = static_cast<float*>(workspace);
+    void* gws = static_cast<char*>(workspace) + tile_bytes;
+    const int64_t gws_bytes = workspace_bytes - tile_bytes;
+    int64_t want = 0;
+    const bool epi = counts_in_epilogue(d, query, neg_base, like_n_query, like_n_neg, &want);
+    const int64_t qw = d->width;  // (the four native scorers: query rows as wide as entity rows)
+    for (int64_t p0 = 0; p0 < n_pair; p0 += PAIR_CHUNK) {
+        const int64_t np = n_pair - p0 < PAIR_CHUNK ? n_pair - p0 : PAIR_CHUNK;
+        const float* q = query + p0 * qw;
+        int rc;
+        if (epi && reduce_of(d) == RED_DOT)
+            rc = gemm_split_fwd(d->dtype, q, np, neg_base, neg_idx + p0, np, d->width, tile, PAIR_CHUNK, gws, gws_bytes, st);
+        else if (epi)
+            rc = l1_pk_fwd(d, q, np, neg_base, neg_idx + p0, np, tile, PAIR_CHUNK, nullptr, st);
+        else
+            rc = bess_neg_score_shared_fwd_ws(d, q, np, neg_base, neg_idx + p0, np, tile, PAIR_CHUNK, nullptr, 0, stream);
+        if (rc) return rc;
+        k_take_diagonal<<<static_cast<unsigned>(ceil_div(np, 256)), 256, 0, st>>>(tile, PAIR_CHUNK, np, out + p0);
+        if (int e = check_launch("take_diagonal")) return e;
+    }
+    return BESS_OK;
+}
+
 extern "C" int bess_neg_score_shared_fwd(const bess_model_desc* d, const float* query,
                                          int64_t n_query, const void* neg_base,
                                          const int32_t* neg_idx, int64_t n_neg, float* out,

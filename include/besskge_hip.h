@@ -333,6 +333,18 @@ int bess_neg_score_shared_fwd_counts(const bess_model_desc* d, const float* quer
                                      const int32_t* excl, int32_t* counts, int32_t round_f16, void* workspace,
                                      int64_t workspace_bytes, void* stream);
 
+/* Single (query, candidate) scores in the arithmetic of the all-entity pass: out[i] = score(query[i], row
+ * neg_idx[i] of neg_base) exactly as bess_neg_score_shared_fwd_counts / _fwd_ws computes that element inside a
+ * (like_n_query x like_n_neg) problem - the same kernel run on 1024 x 1024 blocks whose diagonal is kept (the
+ * kernels' per-element arithmetic does not depend on the element's place in the matrix).  For the positive scores
+ * and the filtered completions that a rank count is corrected with (pipeline.py:233-271): a per-triple kernel
+ * would round differently and move ranks by one at near-ties.  TransE / RotatE / DistMult / ComplEx.
+ * workspace: bess_neg_score_shared_fwd_pairs_workspace bytes, 16-B aligned. */
+int64_t bess_neg_score_shared_fwd_pairs_workspace(const bess_model_desc* d, int64_t like_n_query, int64_t like_n_neg);
+int bess_neg_score_shared_fwd_pairs(const bess_model_desc* d, const float* query, const void* neg_base,
+                                    const int32_t* neg_idx, int64_t n_pair, int64_t like_n_query, int64_t like_n_neg,
+                                    float* out, void* workspace, int64_t workspace_bytes, void* stream);
+
 int64_t bess_neg_score_shared_bwd_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg);
 int bess_neg_score_shared_bwd_ws(const bess_model_desc* d, const float* query,
                                  int64_t n_query, const void* neg_base,

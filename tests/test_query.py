@@ -554,17 +554,19 @@ def test_pipeline_ranks_by_counting_equal_ranks_from_the_score_matrix(dev, score
     bs = RigidShardedBatchSampler(pts, PlaceholderNegativeSampler(scheme), shard_bs=shard_bs, batches_per_step=2,
                                   seed=seed, return_triple_idx=True)
     ev = Evaluation(["mrr", "hits@10"], mode=mode, reduction="sum", return_ranks=True)
-    kw = dict(evaluation=ev, filter_triples=[extra] if filtered else None, window_size=1000, device=dev)
+    # (the matrix path scores window by window: give it windows that take the same kernel as the all-entity pass -
+    # the split-fp16 product needs 256 output tiles - so that the two paths can be compared to the last bit)
+    window = sharding.max_entity_per_shard if scorer == "ComplEx" else 1000
+    kw = dict(evaluation=ev, filter_triples=[extra] if filtered else None, window_size=window, device=dev)
     fused = AllScoresPipeline(bs, scheme, fn, **kw)
     assert fused.fused_ranks
     plain = AllScoresPipeline(bs, scheme, fn, fused_ranks=False, **kw)
     assert not plain.fused_ranks
     a, b = fused(), plain()
     assert torch.equal(a["triple_idx"], b["triple_idx"]) and len(a["ranks"]) == n_triple
-    # (the true completion's score comes from the per-triple kernel here, from the matrix kernel there: a
-    # candidate within a rounding error of it moves the rank by one)
-    diff = (a["ranks"] - b["ranks"]).abs()
-    assert float((diff > 0).float().mean()) < 0.03 and float(diff.max()) <= 2
+    # (the positives' and the filtered completions' scores come from the matrix kernel's arithmetic on both paths:
+    # bess_neg_score_shared_fwd_pairs - the same ranks to the last bit)
+    assert torch.equal(a["ranks"], b["ranks"])
     torch.testing.assert_close(a["metrics"]["mrr"], b["metrics"]["mrr"], rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(a["metrics"]["hits@10"], b["metrics"]["hits@10"], rtol=0, atol=2)
     # and the unsharded oracle
@@ -589,3 +591,25 @@ def test_pipeline_ranks_by_counting_equal_ranks_from_the_score_matrix(dev, score
     gt, ge = (full > true_sc[:, None]).sum(-1).float(), (full >= true_sc[:, None]).sum(-1).float()
     want = 1 + dict(optimistic=gt, pessimistic=ge, average=0.5 * (gt + ge))[mode]
     assert float((a["ranks"] != want).float().mean()) < (0.05 if half else 0.03)  # (rank flips at numerical ties: fp16 rounding boundaries; RotatE's sin / cos)
+
+
+@pytest.mark.parametrize("scorer,dtype,W,n_cand", [("ComplEx", torch.float32, 128, 40_000), ("DistMult", torch.float16, 96, 40_000),
+                                                   ("TransE", torch.float16, 64, 40_000), ("TransE", torch.float32, 64, 3_000),
+                                                   ("RotatE", torch.float16, 128, 2_000), ("ComplEx", torch.float32, 64, 900)])
+def test_pair_scores_equal_the_matrix_kernels_elements(dev, scorer, dtype, W, n_cand):
+    """bess_neg_score_shared_fwd_pairs: score(query i, candidate c_i) bit-for-bit the element [i, c_i] of the
+    all-entity pass (every kernel family: split-fp16 product, packed L1, fp32 product, generic tiles)."""
+    from besskge import _native as nat
+
+    gen = torch.Generator().manual_seed(W)
+    nq = 300
+    table = (torch.randn(n_cand + 50, W, generator=gen) * 0.3).to(dtype).to(dev)
+    q = (torch.randn(nq, W, generator=gen) * 0.3).to(dev)
+    code = dict(ComplEx=nat.COMPLEX, DistMult=nat.DISTMULT, TransE=nat.TRANSE, RotatE=nat.ROTATE)[scorer]
+    d = nat.make_desc(code, 1 if scorer in ("TransE", "RotatE") else 0, table, W // 2 if scorer == "RotatE" else W)
+    sc = nat.neg_score_shared_fwd(d, q, nat.RowSource(table[:n_cand]))
+    n_pair = 2500  # (more than two blocks of 1024, a ragged last one)
+    rows = torch.randint(0, nq, (n_pair,), generator=gen).to(dev)
+    cols = torch.randint(0, n_cand, (n_pair,), generator=gen).to(torch.int32).to(dev)
+    got = nat.neg_score_shared_pairs(d, q[rows].contiguous(), nat.RowSource(table, cols), nq, n_cand)
+    assert torch.equal(got, sc[rows, cols.long()])
