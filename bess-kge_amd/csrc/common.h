@@ -61,7 +61,8 @@ int64_t gemm_split_workspace_any(int64_t S, int64_t N, int W);  // (bytes for a 
 // scores is above thr[row]; flags[row, ld_flags] (one byte per block) says which were)
 int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const int32_t* idx, int64_t N, int W,
                    float* out, int64_t ld, void* ws, int64_t ws_bytes, hipStream_t st, const float* thr = nullptr,
-                   uint8_t* flags = nullptr, int64_t ld_flags = 0, const CountArgs* count = nullptr);
+                   uint8_t* flags = nullptr, int64_t ld_flags = 0, const CountArgs* count = nullptr,
+                   bool diag = false);  // diag: S == N, out [S, 128] receives the diagonal 128 x 128 tiles only
 int64_t gemm_split_bwd_workspace(int64_t S, int64_t N, int W);
 int gemm_split_bwd(int dtype, const float* G, int64_t ldg, int64_t S, const float* Q, const void* E,
                    const int32_t* idx, int64_t N, int W, float* dQ, float* dE, void* ws, int64_t ws_bytes,
@@ -76,7 +77,7 @@ bool l1_pk_eligible(const bess_model_desc* d);
 int l1_pk_fwd(const bess_model_desc* d, const float* query, int64_t n_query, const void* neg_base,
               const int32_t* neg_idx, int64_t n_neg, float* out, int64_t ld_out, const bess_kill_desc* kill,
               hipStream_t st, const float* thr = nullptr, uint8_t* flags = nullptr, int64_t ld_flags = 0,
-              const CountArgs* count = nullptr);
+              const CountArgs* count = nullptr, bool diag = false);  // diag: out [n, 64] = the diagonal 64 x 64 tiles
 
 // affine-in-the-candidate distance scorers (affine.hip)
 int affine_pertriple(const bess_model_desc* d, bool fwd, const float* query, int64_t n_query, const void* neg_base,

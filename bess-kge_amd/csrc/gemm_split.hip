@@ -288,8 +288,10 @@ __global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__
             if (sl == 0) {
                 const int ot = tl / ksplit;
                 const int64_t k_off = static_cast<int64_t>(tl % ksplit) * n_slice * ROW_B;
-                la.init(A + k_off, M, pitch, static_cast<int64_t>(ot / tiles_x) * 128);
-                lb.init(B + k_off, N, pitch, static_cast<int64_t>(ot % tiles_x) * 128);
+                // (tiles_x == 0: only the diagonal tiles ot x ot, stored side by side as a [M, 128] matrix -
+                // single (query, candidate) scores, bess_neg_score_shared_fwd_pairs)
+                la.init(A + k_off, M, pitch, static_cast<int64_t>(tiles_x ? ot / tiles_x : ot) * 128);
+                lb.init(B + k_off, N, pitch, static_cast<int64_t>(tiles_x ? ot % tiles_x : ot) * 128);
             }
             la.load(sl, xa);
             lb.load(sl, xb);
@@ -414,10 +416,10 @@ __global__ __launch_bounds__(512) void k_gemm_split_f16(const char* __restrict__
         __builtin_amdgcn_sched_barrier(0);
         if (++s == n_slice) {  // tile done: main + corr / 2048 -> C
             const int ot = tile / ksplit;
-            const int64_t m0 = static_cast<int64_t>(ot / tiles_x) * 128 + wm;
-            const int64_t n0 = static_cast<int64_t>(ot % tiles_x) * 128 + wn;
+            const int64_t m0 = static_cast<int64_t>(tiles_x ? ot / tiles_x : ot) * 128 + wm;
+            const int64_t n0 = static_cast<int64_t>(tiles_x ? ot % tiles_x : ot) * 128 + wn;
             // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-            float* c0 = C + (tile % ksplit) * part_stride + (m0 + 4 * lk) * ldc + n0 + l31;
+            float* c0 = C + (tile % ksplit) * part_stride + (m0 + 4 * lk) * ldc + (tiles_x ? n0 : wn) + l31;
             if constexpr (EPI == 2) {
                 // counting epilogue (ranks): nothing is stored.  Lane l of the wave keeps the two counts of row
                 // m0 + l: a row's 64 scores sit in the 32 lanes of one lk, so one ballot per comparison holds two
@@ -773,7 +775,7 @@ static int64_t pad_b(int64_t rows) { return ceil_div(rows, W8_B) * W8_B; }
 static int launch_product(const char* A, const char* B, int64_t M, int64_t N, int n_slice, float* C, int64_t ldc,
                           int ksplit, int64_t part_stride, bool b_lo, bool padded, const int32_t* flag,
                           hipStream_t st, const float* thr = nullptr, uint8_t* pflags = nullptr, int64_t ldf = 0,
-                          const CountArgs* count = nullptr) {
+                          const CountArgs* count = nullptr, bool diag = false) {
     BESS_REQUIRE(!thr || (ksplit == 1 && (pflags || count)),
                  "gemm_split: pruned stores / counts need an unsplit product and a flag or count array");
     const CountArgs cnt = count ? *count : CountArgs{nullptr, nullptr, 0, 0};
@@ -782,6 +784,18 @@ static int launch_product(const char* A, const char* B, int64_t M, int64_t N, in
     const int64_t tx = ceil_div(N, 128);
     const int64_t t8 = tx * ceil_div(M, W8_A) * ksplit, t4 = tx * ceil_div(M, 128) * ksplit;
     BESS_REQUIRE(t4 < (1ll << 31), "gemm_split: too many tiles");
+    if (diag) {  // the diagonal 128 x 128 tiles only (M == N), C is [M, 128]
+        BESS_REQUIRE(M == N && ksplit == 1 && !thr && !count && ldc == 128, "gemm_split: bad diagonal product");
+        const int64_t td = ceil_div(M, 128);
+        const int grid = static_cast<int>(td < cus ? td : cus);
+        if (b_lo)
+            k_gemm_split_f16<true, 0><<<grid, 512, 0, st>>>(A, B, M, N, n_slice, C, ldc, 0, static_cast<int>(td), 1, 0, flag,
+                                                            nullptr, nullptr, 0, cnt);
+        else
+            k_gemm_split_f16<false, 0><<<grid, 512, 0, st>>>(A, B, M, N, n_slice, C, ldc, 0, static_cast<int>(td), 1, 0, flag,
+                                                             nullptr, nullptr, 0, cnt);
+        return check_launch("gemm_split_f16 (diagonal tiles)");
+    }
     const bool wide = padded && t8 >= cus;
     if (wide) {
         static const bool attr = [] {
@@ -879,8 +893,9 @@ __global__ void k_poison_counts(const int32_t* __restrict__ flag, int32_t* __res
 // out[q, j] = Q[q] . E[idx[j]] through the workspace (>= gemm_split_workspace bytes, 16-B aligned)
 int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const int32_t* idx, int64_t N, int W,
                    float* out, int64_t ld, void* ws, int64_t ws_bytes, hipStream_t st, const float* thr,
-                   uint8_t* pflags, int64_t ldf, const CountArgs* count) {
+                   uint8_t* pflags, int64_t ldf, const CountArgs* count, bool diag) {
     const int64_t pitch = split_pitch(W);
+    BESS_REQUIRE(!diag || (S == N && idx && !thr && !count && ld == 128), "gemm_split: bad diagonal product");
     BESS_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 16 == 0, "gemm_split: workspace must be 16-B aligned");
     BESS_REQUIRE(ws_bytes >= FLAG_BYTES + 256 * pitch, "gemm_split: workspace too small");
     ws_bytes -= FLAG_BYTES;
@@ -905,8 +920,10 @@ int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const in
         // (pruned stores: the chunk's flags start at block j0 / 64 - chunks are multiples of 128 rows)
         CountArgs cj{nullptr, nullptr, 0, 0};
         if (count) cj = CountArgs{count->excl, count->counts, count->col0 + j0, count->round16};
-        if (int e = launch_product(qa, eb, S, nc, n_slice, count ? nullptr : out + j0, ld, 1, 0, dtype == BESS_F32, true,
-                                   flag, st, thr, pflags ? pflags + j0 / 64 : nullptr, ldf, count ? &cj : nullptr))
+        BESS_REQUIRE(!diag || nc == N, "gemm_split: the diagonal product wants its operands in one pass");
+        if (int e = launch_product(qa, eb, S, nc, n_slice, count ? nullptr : out + (diag ? 0 : j0), ld, 1, 0,
+                                   dtype == BESS_F32, true, flag, st, thr, pflags ? pflags + j0 / 64 : nullptr, ldf,
+                                   count ? &cj : nullptr, diag))
             return e;
     }
     if (count) {
@@ -917,6 +934,9 @@ int gemm_split_fwd(int dtype, const float* Q, int64_t S, const void* E, const in
     }
     // an operand outside the fp16 range (or not finite) raised the flag: the split kernels returned at once and
     // the exact fp32 kernels compute the whole product now; else they are the ones that return at once
+    // (diagonal form: no fp32 fallback - an operand outside the fp16 range leaves `out` unwritten; the counting pass
+    // over the same rows meets the same operand and poisons its counts, which is what the caller acts on)
+    if (diag) return BESS_OK;
     return gemm_dot_fwd(dtype, Q, S, E, idx, N, W, out, ld, st, flag);
 }
 

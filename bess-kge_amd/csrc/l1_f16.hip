@@ -83,6 +83,7 @@ struct PruneArgs {
     uint8_t* flags;    // [nq, ldf]
     int64_t ldf;
     CountArgs cnt;     // cnt.counts != NULL: count the scores above / equal to thr instead, store nothing
+    int diag;          // only the diagonal 64 x 64 tiles (nq == ne), stored side by side: out is [nq, 64]
 };
 
 // out[q, j] = -sum_w |fp16(Q[q, w]) - E[idx[j], w]|        W % 32 == 0
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, 
     const int t = threadIdx.x;
     const int tx = t & 15, ty = t >> 4;
     constexpr int QT = 16 * MI;  // query rows of the tile
-    const int64_t q0 = static_cast<int64_t>(blockIdx.y) * QT;
+    const int64_t q0 = static_cast<int64_t>(prune.diag ? blockIdx.x : blockIdx.y) * QT;
     const int64_t j0 = static_cast<int64_t>(blockIdx.x) * PT;
     float acc[MI][4];
 #pragma unroll
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, 
             v4[j] = v;
         }
         const int64_t jj0 = j0 + tx * 4;
+        const int64_t oc = jj0 - (prune.diag ? j0 : 0);  // column of the thread's first score in `out`
         if (prune.cnt.counts) {  // (wave-uniform) ranks: the row's counts over these 64 columns, nothing stored
             const float th = prune.thr[q];
             const int64_t ex = static_cast<int64_t>(prune.cnt.excl[q]) - prune.cnt.col0;  // the row's excluded column
@@ -196,11 +198,9 @@ __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, 
                 cg += (in && v > th) ? 1 : 0;
                 ce += (in && v == th) ? 1 : 0;
             }
-#pragma unroll
-            for (int o2 = 1; o2 < 16; o2 <<= 1) {  // the 16 threads with this ty hold the row
-                cg += __shfl_xor(cg, o2, 64);
-                ce += __shfl_xor(ce, o2, 64);
-            }
+            // the 16 threads with this ty hold the row: one DPP row reduction for both counts (each <= 64)
+            const int both = static_cast<int>(row16_allreduce_sum(static_cast<float>(cg + (ce << 12))));
+            cg = both & 4095, ce = both >> 12;
             if (tx == 0) {
                 if (cg) atomicAdd(prune.cnt.counts + 2 * q, cg);
                 if (ce) atomicAdd(prune.cnt.counts + 2 * q + 1, ce);
@@ -218,11 +218,11 @@ __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, 
             if (!any) continue;
         }
         if (row16 && jj0 + 3 < ne) {  // 16-byte aligned rows: one store for the thread's four scores
-            *reinterpret_cast<float4*>(o + jj0) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+            *reinterpret_cast<float4*>(o + oc) = make_float4(v4[0], v4[1], v4[2], v4[3]);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (jj0 + j < ne) o[jj0 + j] = v4[j];
+                if (jj0 + j < ne) o[oc + j] = v4[j];
         }
     }
 }
@@ -234,8 +234,14 @@ bool l1_pk_eligible(const bess_model_desc* d) {
 
 int l1_pk_fwd(const bess_model_desc* d, const float* query, int64_t n_query, const void* neg_base,
               const int32_t* neg_idx, int64_t n_neg, float* out, int64_t ld_out, const bess_kill_desc* k,
-              hipStream_t st, const float* thr, uint8_t* flags, int64_t ld_flags, const CountArgs* count) {
-    const PruneArgs pr{thr, flags, ld_flags, count ? *count : CountArgs{nullptr, nullptr, 0, 0}};
+              hipStream_t st, const float* thr, uint8_t* flags, int64_t ld_flags, const CountArgs* count, bool diag) {
+    const PruneArgs pr{thr, flags, ld_flags, count ? *count : CountArgs{nullptr, nullptr, 0, 0}, diag ? 1 : 0};
+    if (diag) {  // pair scores: 64 x 64 tiles on the diagonal, out [n, 64]
+        BESS_REQUIRE(n_query == n_neg && ld_out == PT && !thr && !count && !k, "l1_pk_fwd: bad diagonal problem");
+        k_l1_fwd_pk<4><<<dim3(static_cast<unsigned>(ceil_div(n_neg, PT)), 1), 256, 0, st>>>(
+            query, n_query, static_cast<const half_t*>(neg_base), neg_idx, n_neg, d->width, out, ld_out, KillArgs{}, pr);
+        return check_launch("neg_score_shared_fwd (packed f16 L1, diagonal tiles)");
+    }
     KillArgs ka{};
     if (k) ka = KillArgs{k->diag_step, k->ht, k->ppp, k->mask, k->mask_rows, k->mask ? k->mask_cols : 0, n_neg};
     // 32-row tiles when the 64-row grid would leave most CUs without a workgroup

@@ -838,7 +838,19 @@ extern "C" int bess_neg_score_shared_fwd_counts(const bess_model_desc* d, const 
                 return gemm_split_fwd(d->dtype, query, n_query, neg_base, neg_idx, n_neg, d->width, nullptr, 0,
                                       workspace, workspace_bytes, st, thr, nullptr, 0, &cnt);
         } else {
-            return l1_pk_fwd(d, query, n_query, neg_base, neg_idx, n_neg, nullptr, 0, nullptr, st, thr, nullptr, 0, &cnt);
+            // one launch per 65,536 candidates (32 MiB of fp16 rows at W = 256): the launch's rows stay in the
+            // Infinity Cache while its query tiles pass over them - over all 2.5 M rows of a wikikg2 shard in one
+            // launch every row tile would stream the table from HBM again
+            constexpr int64_t L1_COUNT_CHUNK = 65536;
+            for (int64_t j0 = 0; j0 < n_neg; j0 += L1_COUNT_CHUNK) {
+                const int64_t nc = n_neg - j0 < L1_COUNT_CHUNK ? n_neg - j0 : L1_COUNT_CHUNK;
+                const CountArgs cj{excl, counts, j0, cnt.round16};
+                const void* base = neg_idx ? neg_base : static_cast<const char*>(neg_base) + j0 * d->width * 2;
+                if (int e = l1_pk_fwd(d, query, n_query, base, neg_idx ? neg_idx + j0 : nullptr, nc, nullptr, 0, nullptr,
+                                      st, thr, nullptr, 0, &cj))
+                    return e;
+            }
+            return BESS_OK;
         }
     }
     // no counting epilogue for this scorer / shape: score tiles through the workspace, counted by a second kernel
@@ -864,21 +876,25 @@ extern "C" int bess_neg_score_shared_fwd_counts(const bess_model_desc* d, const 
 
 // ---- single (query, candidate) scores in the arithmetic of the all-entity kernels -------------------------
 // out[i] = score(query[i], candidate idx[i]) as bess_neg_score_shared_fwd_counts on a (like_n_query x like_n_neg)
-// problem computes it: diagonal of PAIR_CHUNK x PAIR_CHUNK blocks scored by the same kernel (the per-element
-// arithmetic of these kernels does not depend on where in the matrix an element sits).
-constexpr int64_t PAIR_CHUNK = 1024;
-__global__ void k_take_diagonal(const float* __restrict__ tile, int64_t ld, int64_t n, float* __restrict__ out) {
+// problem computes it: the SAME kernel on the diagonal tiles of the (pairs x pairs) problem - 128 x 128 tiles of the
+// split-fp16 product, 64 x 64 of the packed L1 kernel - or, for the kernels without a diagonal form, on
+// 1024 x 1024 blocks whose diagonal is kept (the per-element arithmetic of these kernels does not depend on where
+// in the matrix an element sits).
+constexpr int64_t PAIR_CHUNK = 1024, PAIR_DIAG_CHUNK = 8192;
+__global__ void k_take_diagonal(const float* __restrict__ tile, int64_t ld, int64_t n, int64_t block,
+                                float* __restrict__ out) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    if (i < n) out[i] = tile[i * ld + i];
+    if (i < n) out[i] = tile[i * ld + i % block];  // (block >= n: the plain diagonal; else tiles stored side by side)
 }
 
 extern "C" int64_t bess_neg_score_shared_fwd_pairs_workspace(const bess_model_desc* d, int64_t like_n_query,
                                                              int64_t like_n_neg) {
     if (!d || check_desc(d) || like_n_query <= 0 || like_n_neg <= 0) return 0;
-    int64_t want = 0, gemm = 0;
+    int64_t want = 0;
     if (counts_in_epilogue(d, nullptr, nullptr, like_n_query, like_n_neg, &want) && want > 0)
-        gemm = gemm_split_workspace_any(PAIR_CHUNK, PAIR_CHUNK, d->width);
-    return PAIR_CHUNK * PAIR_CHUNK * 4 + gemm;
+        return PAIR_DIAG_CHUNK * 128 * 4 + gemm_split_workspace_any(PAIR_DIAG_CHUNK, PAIR_DIAG_CHUNK, d->width);
+    const int64_t blocks = PAIR_CHUNK * PAIR_CHUNK * 4, diag = PAIR_DIAG_CHUNK * 64 * 4;
+    return blocks > diag ? blocks : diag;
 }
 
 extern "C" int bess_neg_score_shared_fwd_pairs(const bess_model_desc* d, const float* query, const void* neg_base,
@@ -890,29 +906,32 @@ extern "C" int bess_neg_score_shared_fwd_pairs(const bess_model_desc* d, const f
     if (n_pair == 0) return BESS_OK;
     BESS_REQUIRE(query && neg_base && neg_idx && out, "neg_score_shared_fwd_pairs: NULL pointer");
     BESS_REQUIRE(d->scorer <= BESS_COMPLEX, "neg_score_shared_fwd_pairs: TransE / RotatE / DistMult / ComplEx only");
-    const int64_t tile_bytes = PAIR_CHUNK * PAIR_CHUNK * 4;
     BESS_REQUIRE(workspace && workspace_bytes >= bess_neg_score_shared_fwd_pairs_workspace(d, like_n_query, like_n_neg) &&
                      reinterpret_cast<uintptr_t>(workspace) % 16 == 0,
                  "neg_score_shared_fwd_pairs: workspace too small (bess_neg_score_shared_fwd_pairs_workspace) or misaligned");
     hipStream_t st = as_stream(stream);
     float* tile = static_cast<float*>(workspace);
-    void* gws = static_cast<char*>(workspace) + tile_bytes;
-    const int64_t gws_bytes = workspace_bytes - tile_bytes;
     int64_t want = 0;
     const bool epi = counts_in_epilogue(d, query, neg_base, like_n_query, like_n_neg, &want);
+    const bool gemm = epi && reduce_of(d) == RED_DOT;
     const int64_t qw = d->width;  // (the four native scorers: query rows as wide as entity rows)
-    for (int64_t p0 = 0; p0 < n_pair; p0 += PAIR_CHUNK) {
-        const int64_t np = n_pair - p0 < PAIR_CHUNK ? n_pair - p0 : PAIR_CHUNK;
+    const int64_t chunk = epi ? PAIR_DIAG_CHUNK : PAIR_CHUNK;
+    const int64_t block = gemm ? 128 : (epi ? 64 : PAIR_CHUNK);  // columns of `tile`
+    void* gws = static_cast<char*>(workspace) + PAIR_DIAG_CHUNK * 128 * 4;
+    const int64_t gws_bytes = workspace_bytes - PAIR_DIAG_CHUNK * 128 * 4;
+    for (int64_t p0 = 0; p0 < n_pair; p0 += chunk) {
+        const int64_t np = n_pair - p0 < chunk ? n_pair - p0 : chunk;
         const float* q = query + p0 * qw;
         int rc;
-        if (epi && reduce_of(d) == RED_DOT)
-            rc = gemm_split_fwd(d->dtype, q, np, neg_base, neg_idx + p0, np, d->width, tile, PAIR_CHUNK, gws, gws_bytes, st);
+        if (gemm)
+            rc = gemm_split_fwd(d->dtype, q, np, neg_base, neg_idx + p0, np, d->width, tile, 128, gws, gws_bytes, st,
+                                nullptr, nullptr, 0, nullptr, true);
         else if (epi)
-            rc = l1_pk_fwd(d, q, np, neg_base, neg_idx + p0, np, tile, PAIR_CHUNK, nullptr, st);
+            rc = l1_pk_fwd(d, q, np, neg_base, neg_idx + p0, np, tile, 64, nullptr, st, nullptr, nullptr, 0, nullptr, true);
         else
             rc = bess_neg_score_shared_fwd_ws(d, q, np, neg_base, neg_idx + p0, np, tile, PAIR_CHUNK, nullptr, 0, stream);
         if (rc) return rc;
-        k_take_diagonal<<<static_cast<unsigned>(ceil_div(np, 256)), 256, 0, st>>>(tile, PAIR_CHUNK, np, out + p0);
+        k_take_diagonal<<<static_cast<unsigned>(ceil_div(np, 256)), 256, 0, st>>>(tile, block, np, block, out + p0);
         if (int e = check_launch("take_diagonal")) return e;
     }
     return BESS_OK;

@@ -335,8 +335,9 @@ int bess_neg_score_shared_fwd_counts(const bess_model_desc* d, const float* quer
 
 /* Single (query, candidate) scores in the arithmetic of the all-entity pass: out[i] = score(query[i], row
  * neg_idx[i] of neg_base) exactly as bess_neg_score_shared_fwd_counts / _fwd_ws computes that element inside a
- * (like_n_query x like_n_neg) problem - the same kernel run on 1024 x 1024 blocks whose diagonal is kept (the
- * kernels' per-element arithmetic does not depend on the element's place in the matrix).  For the positive scores
+ * (like_n_query x like_n_neg) problem - the same kernel run on the diagonal tiles of the (pairs x pairs) problem
+ * (split-fp16 product, packed L1 kernel) or on 1024 x 1024 blocks whose diagonal is kept (the other kernels); the
+ * kernels' per-element arithmetic does not depend on the element's place in the matrix.  For the positive scores
  * and the filtered completions that a rank count is corrected with (pipeline.py:233-271): a per-triple kernel
  * would round differently and move ranks by one at near-ties.  TransE / RotatE / DistMult / ComplEx.
  * workspace: bess_neg_score_shared_fwd_pairs_workspace bytes, 16-B aligned. */
