@@ -136,6 +136,14 @@ def topk(out_dir: str) -> None:
             steps = [runner(step=torch.full((bps * n, 1), s, dtype=torch.int32), **inp).float().cpu().numpy()
                      for s in range(model.n_step)]
             out[f"{case}_scores"] = np.stack(steps)
+            # rank-counting mode: positives scored on their shard and summed, counts from every shard back to the
+            # query's (all_gather + all_reduce + all_to_all of the group)
+            from test_query import rank_inputs
+
+            truth, filt = rank_inputs(c, bps * n, int(inp["relation"].shape[1]))
+            res = runner(step=torch.zeros((bps * n, 1), dtype=torch.int32), **inp, rank_truth=truth, rank_filter=filt)
+            out[f"{case}_rank_counts"] = res["counts"].cpu().numpy()
+            out[f"{case}_rank_pos"] = res["pos_score"].float().cpu().numpy()
     np.savez(os.path.join(out_dir, f"topk_{r}.npz"), **out)
 
 

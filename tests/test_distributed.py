@@ -157,6 +157,38 @@ def test_distributed_queries_golden(world, backend):
                 got = z[f"{case}_scores"]  # [n_step, bps * shard_bs, n * ws]
                 got = got.reshape(want.shape[1], want.shape[0], *want.shape[2:]).transpose(1, 0, 2, 3)
                 np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+        if fix == "allscores":
+            # rank-counting mode, one process per shard == all shards in this process (same kernels, same shapes)
+            counts, pos = _single_process_rank_counts(c, world)
+            for r in range(world):
+                assert np.array_equal(per_rank[r][f"{case}_rank_counts"], counts[r]), f"{case}: rank counts of shard {r}"
+                np.testing.assert_array_equal(per_rank[r][f"{case}_rank_pos"], pos[r])
+            assert sum(int(x[:, 0].sum()) for x in counts) > 0
+
+
+def _single_process_rank_counts(c, n):
+    import torch
+    from besskge import runtime
+    from besskge.bess import AllScoresBESS
+    from besskge.sharding import Sharding
+    from test_hip_parity import make_scorer
+    from test_query import candidate_sampler, rank_inputs
+
+    m = c["meta"]
+    bps = m["bps"]
+    dev = torch.device("cuda", 0)
+    fn = make_scorer(c["scorer"], m["norm"], bool(m["flat"]), m["n_rel"], m["d"], c["table"], c["rel"], dev,
+                     sharding=Sharding.create(m["n_entity"], n, seed=1234))
+    model = AllScoresBESS(candidate_sampler(c), fn, window_size=m["window"])
+    runner = runtime.inference_model(model, runtime.Options(device_iterations=bps), device=dev)
+    known = "tail" if c["scheme"] == "h" else "head"
+    inp = {k: c["batch"][k].flatten(end_dim=1) for k in ("relation", known)}
+    truth, filt = rank_inputs(c, bps * n, int(inp["relation"].shape[1]))
+    res = runner(step=torch.zeros((bps * n, 1), dtype=torch.int32), **inp, rank_truth=truth, rank_filter=filt)
+    bs = int(inp["relation"].shape[1])
+    counts = res["counts"].cpu().numpy().reshape(bps, n, bs, 2)
+    pos = res["pos_score"].float().cpu().numpy().reshape(bps, n, bs)
+    return ([counts[:, r].reshape(-1, 2) for r in range(n)], [pos[:, r].reshape(-1) for r in range(n)])
 
 
 @pytest.mark.gpu

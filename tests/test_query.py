@@ -161,6 +161,19 @@ def query_cases(fix):
     return [str(c) for c in load_golden(fix)["cases"]]
 
 
+def rank_inputs(c, rows, shard_bs):
+    """Seeded `rank_truth` [rows, shard_bs] and `rank_filter` [rows, 5, 2] for an allscores golden case (rows =
+    micro-batches x shards): the rank-counting mode of AllScoresBESS, single-process and one process per shard."""
+    gen = torch.Generator().manual_seed(7)
+    n_entity = c["meta"]["n_entity"]
+    truth = torch.randint(0, n_entity, (rows, shard_bs), generator=gen, dtype=torch.int32)
+    qi = torch.stack([torch.randperm(shard_bs, generator=gen)[:5] for _ in range(rows)]).to(torch.int32)
+    ent = torch.randint(0, n_entity, (rows, 5), generator=gen, dtype=torch.int32)
+    ent = torch.where(ent == torch.gather(truth, 1, qi.long()), torch.full_like(ent, -1), ent)
+    ent[:, 4] = -1  # padding
+    return truth, torch.stack([torch.where(ent < 0, torch.full_like(qi, -1), qi), ent], dim=-1).contiguous()
+
+
 def candidate_sampler(c):
     from besskge.negative_sampler import PlaceholderNegativeSampler, TripleBasedShardedNegativeSampler
 
