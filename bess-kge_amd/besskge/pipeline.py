@@ -68,8 +68,7 @@ class AllScoresPipeline(torch.nn.Module):
         :param use_ipu_model: accepted for call compatibility, ignored.
         :param group / device: replica group and HIP device (default: all shards
             in this process on the current device).
-        :param fused_ranks: when only metrics / ranks are asked for (no scores, no top-k, no
-            `candidate_ents`) count the entities that beat the true completion in the scoring kernel's
+        :param fused_ranks: when only metrics / ranks are asked for (no scores, no top-k) count the entities that beat the true completion in the scoring kernel's
             epilogue instead of assembling the `[queries, n_entity]` score matrix
             (`AllScoresBESS.rank_counts_replicas`).  The same ranks to the last bit as the matrix path
             whenever that scores its windows with the same kernel as the all-entity pass (the positives'
@@ -115,7 +114,9 @@ class AllScoresPipeline(torch.nn.Module):
             self.filter_triples = torch.concat(
                 [t if isinstance(t, torch.Tensor) else torch.from_numpy(t) for t in filter_triples], dim=0)
         self.fused_ranks = bool(fused_ranks and evaluation and not return_scores and not return_topk
-                                and candidate_ents is None and _counting_scorer(score_fn))
+                                and _counting_scorer(score_fn))
+        if self.fused_ranks:
+            self.bess_module.set_rank_candidates(candidate_ents)
         self.candidate_mask: Optional[torch.Tensor] = None
         if candidate_ents is not None:
             self.candidate_mask = torch.from_numpy(np.setdiff1d(np.arange(sharding.n_entity), candidate_ents))

@@ -345,6 +345,24 @@ class AllScoresBESS(_QueryModule):
                                          self.sharding.shard_counts))
         return cache[dev]
 
+    def set_rank_candidates(self, candidate_ents: Optional[Any]) -> None:
+        """Restrict the rank-counting mode to these entities (global ids; None: all) - `candidate_ents` of
+        `AllScoresPipeline` (pipeline.py:101-111): every other entity counts as scoring -inf."""
+        self.__dict__.pop("_rank_cand_cache", None)
+        self.rank_candidates = None if candidate_ents is None else np.unique(np.asarray(candidate_ents).reshape(-1))
+
+    def _rank_candidates_on(self, shard: int, dev: torch.device):
+        """(local rows of the shard's candidate entities, ascending; local row -> position in that list or -1)."""
+        cache = self.__dict__.setdefault("_rank_cand_cache", {})
+        if (shard, dev) not in cache:
+            sh = self.sharding
+            ents = self.rank_candidates
+            rows = np.sort(sh.entity_to_idx[ents[sh.entity_to_shard[ents] == shard]]).astype(np.int32)
+            pos = np.full(sh.max_entity_per_shard, -1, dtype=np.int32)
+            pos[rows] = np.arange(len(rows), dtype=np.int32)
+            cache[(shard, dev)] = (torch.from_numpy(rows).to(dev), torch.from_numpy(pos).to(dev))
+        return cache[(shard, dev)]
+
     def rank_counts_replicas(self, batches: List[_Batch]) -> List[Dict[str, torch.Tensor]]:
         """Rank-counting mode (`rank_truth` in the batch): for every query of the hosted replicas the number of
         entities (all shards) scoring above / exactly as its true completion, without a score matrix - the
@@ -372,6 +390,7 @@ class AllScoresBESS(_QueryModule):
         # the positive scores: computed where the true completion lives, summed over the shards
         # (single (query, entity) scores - the positives, the filtered completions - in the arithmetic of the
         # all-entity pass they are compared with: bess_neg_score_shared_fwd_pairs)
+        subset = getattr(self, "rank_candidates", None) is not None
         pos_parts, local = [], []
         for shard, q, tr in zip(group.local_shards, queries, truth_all):
             table = self._local_table(shard)
@@ -379,25 +398,44 @@ class AllScoresBESS(_QueryModule):
             t = tr.reshape(-1).long()
             here = e2s[t] == shard
             row = torch.where(here, e2i[t], torch.zeros_like(e2i[t]))
-            sc = nat.neg_score_shared_pairs(desc, q, RowSource(table, row.contiguous()), int(q.shape[0]),
-                                            int(self.sharding.shard_counts[shard]))
-            pos_parts.append(torch.where(here, sc, torch.zeros_like(sc)))
-            local.append((here, row))
+            # what the all-entity pass of this shard runs over: its entities, or its candidate entities
+            cand_rows = cand_pos = None
+            n_count = int(self.sharding.shard_counts[shard])  # (the padding rows of a shard are no entities)
+            if subset:
+                cand_rows, cand_pos = self._rank_candidates_on(shard, table.device)
+                n_count = int(cand_rows.numel())
+                here = here & (cand_pos[row.long()] >= 0)  # a true completion outside the candidates scores -inf
+            sc = nat.neg_score_shared_pairs(desc, q, RowSource(table, row.contiguous()), int(q.shape[0]), max(1, n_count))
+            # (second row: is the true completion a candidate at all - on whichever shard it lives)
+            pos_parts.append(torch.stack([torch.where(here, sc, torch.zeros_like(sc)), here.to(sc.dtype)]))
+            local.append((here, row, cand_rows, cand_pos, n_count))
         thr_all = group.all_reduce_sum(pos_parts)
         outs_c, thrs = [], []
         filters = filt_all if with_filter else [None] * len(queries)
-        for shard, q, thr, (here, row), f in zip(group.local_shards, queries, thr_all, local, filters):
+        for shard, q, thr2, (here, row, cand_rows, cand_pos, n_count), f in zip(group.local_shards, queries, thr_all,
+                                                                                local, filters):
             table = self._local_table(shard)
             e2s, e2i, cnt = self._entity_maps_on(table.device)
+            thr, is_cand = thr2[0], thr2[1] > 0
             # scores leave AllScoresBESS in the model's dtype (bess.py:1058-1062): a half-precision model ranks
             # fp16 scores, ties included
             half = fn.relation_embedding.dtype == torch.float16
             if half:
                 thr = thr.half().float()
-            thr = torch.nan_to_num(thr, nan=-torch.inf).contiguous()  # (ranks_from_scores: metric.py:152)
-            excl = torch.where(here, row, torch.full_like(row, -1)).contiguous()
-            valid_rows = int(self.sharding.shard_counts[shard])  # the padding rows of the shard are no entities
-            counts = nat.neg_score_shared_counts(desc, q, RowSource(table[:valid_rows]), thr, excl, round_f16=half)
+            thr = torch.nan_to_num(thr, nan=-torch.inf)  # (ranks_from_scores: metric.py:152)
+            # (a true completion outside the candidates: -inf there, which the same nan_to_num_ turns into the
+            # lowest finite float)
+            thr = torch.where(is_cand, thr, torch.full_like(thr, torch.finfo(torch.float32).min)).contiguous()
+            if cand_rows is None:
+                excl = torch.where(here, row, torch.full_like(row, -1)).contiguous()
+                src = RowSource(table[:n_count])
+            else:
+                excl = torch.where(here, cand_pos[row.long()], torch.full_like(row, -1)).contiguous()
+                src = RowSource(table, cand_rows)
+            if n_count:
+                counts = nat.neg_score_shared_counts(desc, q, src, thr, excl, round_f16=half)
+            else:
+                counts = torch.zeros((q.shape[0], 2), dtype=torch.int32, device=q.device)
             if f is not None:  # [n, P, 2]: the pairs of every replica
                 if int(f.shape[1]):
                     qi, ent = f[..., 0].long(), f[..., 1].long()
@@ -405,8 +443,10 @@ class AllScoresBESS(_QueryModule):
                     ent = ent.reshape(-1)
                     ok = (ent >= 0) & (e2s[ent.clamp(min=0)] == shard)
                     rows_f = torch.where(ok, e2i[ent.clamp(min=0)], torch.zeros_like(e2i[ent.clamp(min=0)]))
+                    if cand_pos is not None:
+                        ok = ok & (cand_pos[rows_f.long()] >= 0)  # (not a candidate: not counted in the first place)
                     sc = nat.neg_score_shared_pairs(desc, q[g].contiguous(), RowSource(table, rows_f.contiguous()),
-                                                    int(q.shape[0]), valid_rows)
+                                                    int(q.shape[0]), max(1, n_count))
                     if half:
                         sc = sc.half().float()
                     t = thr[g]

@@ -570,7 +570,10 @@ def test_pipeline_ranks_by_counting_equal_ranks_from_the_score_matrix(dev, score
     # (the matrix path scores window by window: give it windows that take the same kernel as the all-entity pass -
     # the split-fp16 product needs 256 output tiles - so that the two paths can be compared to the last bit)
     window = sharding.max_entity_per_shard if scorer == "ComplEx" else 1000
-    kw = dict(evaluation=ev, filter_triples=[extra] if filtered else None, window_size=window, device=dev)
+    # (filtered runs also rank against a subset of the entities: `candidate_ents`)
+    cand_ents = np.sort(rng.choice(n_entity, size=int(0.8 * n_entity), replace=False)) if filtered else None
+    kw = dict(evaluation=ev, filter_triples=[extra] if filtered else None, candidate_ents=cand_ents, window_size=window,
+              device=dev)
     fused = AllScoresPipeline(bs, scheme, fn, **kw)
     assert fused.fused_ranks
     plain = AllScoresPipeline(bs, scheme, fn, fused_ranks=False, **kw)
@@ -595,7 +598,10 @@ def test_pipeline_ranks_by_counting_equal_ranks_from_the_score_matrix(dev, score
     if half:
         full = full.half().float()
     rows = torch.arange(len(tr))
-    true_sc = full[rows, T(truth)].clone()
+    if filtered:
+        full[:, T(np.setdiff1d(np.arange(n_entity), cand_ents))] = -torch.inf
+    # (reference quirk: a -inf positive - a true completion outside the candidates - becomes the lowest finite float)
+    true_sc = torch.nan_to_num(full[rows, T(truth)].clone(), neginf=torch.finfo(torch.float32).min)
     if filtered:
         col, other = (0, 2) if scheme == "t" else (2, 0)
         for i, (e_, r_) in enumerate(zip(tr[:, col], tr[:, 1])):
