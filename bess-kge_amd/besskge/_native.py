@@ -831,15 +831,6 @@ def neg_score_shared_pairs(d: ModelDesc, query: torch.Tensor, neg: RowSource, li
     return out
 
 
-def shared_kernel_rounds_queries(d: ModelDesc) -> bool:
-    """Does the shared-candidate kernel of this model take the query rounded to fp16?  (The packed-fp16 L1 kernel:
-    TransE / RotatE, p = 1, f16 table, width a multiple of 32, fp32-math switch off - `l1_pk_eligible`,
-    csrc/l1_f16.hip.)  A score of the same (query, candidate) from a per-triple kernel agrees with the matrix
-    kernel's to fp32 rounding only if it is given the query rounded the same way."""
-    return (int(d.dtype) == F16 and int(d.scorer) in (TRANSE, ROTATE) and int(d.norm_p) == 1
-            and int(d.width) % 32 == 0 and not (int(d.reserved[0]) & FLAG_FP32_MATH))
-
-
 def neg_score_shared_counts(d: ModelDesc, query: torch.Tensor, neg: RowSource, thr: torch.Tensor,
                             excl: torch.Tensor, counts: Optional[torch.Tensor] = None,
                             round_f16: bool = False) -> torch.Tensor:
