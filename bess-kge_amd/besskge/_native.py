@@ -680,21 +680,25 @@ def combine_dq_partials(state: Tuple[torch.Tensor, torch.Tensor], norm: torch.Te
 
 
 def neg_score_pertriple_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n_neg: int,
-                            d_out: torch.Tensor, want_d_neg: bool = True
-                            ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """Returns (d_query [nq, W], d_neg [nq*n_neg, W] or None)."""
+                            d_out: torch.Tensor, want_d_neg: bool = True, want_d_query: bool = True
+                            ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """Returns (d_query [nq, W] or None, d_neg [nq*n_neg, W] or None).  `want_d_query=False` (TransE / RotatE /
+    DistMult / ComplEx; d_query came out of the fused forward): DistMult / ComplEx then do not read the candidate
+    rows at all - their d_neg rows are coefficient x query."""
     nq = int(query.shape[0])
     dev = _neg_operands(d, query, neg, nq * n_neg)
     _same_device([("d_out", d_out), ("query", query)])
     _f32(d_out, "d_out")
     if tuple(d_out.shape) != (nq, n_neg):
         raise ValueError("neg_score_pertriple_bwd: bad `d_out` shape")
-    dq = torch.empty((nq, query_width(d)), dtype=torch.float32, device=dev)
+    if not want_d_query and (int(d.scorer) > COMPLEX or not want_d_neg):
+        raise ValueError("neg_score_pertriple_bwd: want_d_query=False is for the four native scorers, with d_neg")
+    dq = torch.empty((nq, query_width(d)), dtype=torch.float32, device=dev) if want_d_query else None
     dn = torch.empty((nq * n_neg, d.width), dtype=torch.float32, device=dev) if want_d_neg else None
     ip, keep = _neg_idx_ptr(neg, dev)
     with _on(dev), _Timed("bess_neg_score_pertriple_bwd", dev):
         rc = load().bess_neg_score_pertriple_bwd(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(), ip,
-                                                 n_neg, d_out.data_ptr(), n_neg, dq.data_ptr(),
+                                                 n_neg, d_out.data_ptr(), n_neg, dq.data_ptr() if want_d_query else 0,
                                                  dn.data_ptr() if want_d_neg else 0, _stream(dev))
     _check(rc, "bess_neg_score_pertriple_bwd")
     del keep

@@ -855,9 +855,12 @@ class BessKGE(torch.nn.Module, ABC):
             g.query, g.query_ctx = self.score_fn.query_fwd(g.side, g.ent, g.rel_idx)
         if g.shared:
             g.out = nat.neg_score_shared_fwd(desc, g.query, g.neg, kill=g.kill)
-        elif fuse is not None and st is not None and g.neg.base is st.table:
+        elif fuse is not None and st is not None and (
+                g.neg.base is st.table or (g.neg.base is st.recv and self.score_fn.bilinear_candidates)):
             # training, nothing masked afterwards: scores and d loss / d query in one pass (the
-            # backward then never re-reads the negative rows)
+            # backward then never re-reads the negative rows: shard rows through the segmented reduction K9;
+            # rows that arrived through the all-to-all - EmbeddingMoving, n > 1 - for the bilinear scorers, whose
+            # d_neg rows are coefficient x query)
             pos, w = st.positive_score, fuse["weight"]
             if g.sel is not None:
                 pos = pos[g.sel].contiguous()
@@ -1227,6 +1230,10 @@ class EmbeddingMovingBessKGE(BessKGE):
                         dq, _ = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go,
                                                             want_d_neg=False)
                     deferred.append((st.table, g, go))
+                elif g.dq is not None:  # fused forward over rows of the receive buffer (bilinear scorers)
+                    dq = g.dq
+                    _, dn = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go, want_d_query=False)
+                    sink(g.neg, dn)
                 else:
                     dq, dn = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go)
                     sink(g.neg, dn)

@@ -117,6 +117,9 @@ class BaseScoreFunction(torch.nn.Module, ABC):
     #: the training forward can accumulate d loss / d query next to the scores
     #: (`bess_neg_score_pertriple_fwd_dq`)
     supports_fused_forward = True
+    #: the score is bilinear in (query, candidate row): d score / d candidate = query, whatever the candidate
+    #: (DistMult, ComplEx) - a backward that already has d_query never reads the candidate rows again
+    bilinear_candidates = False
     #: query_fwd + triple_fwd, and their backwards, also exist as ONE launch each
     #: (`bess_query_triple_fwd / _bwd`: TransE / RotatE / DistMult / ComplEx)
     supports_fused_query_triple = True
@@ -386,6 +389,7 @@ class DistMult(MatrixDecompositionScoreFunction):
     """DistMult: sum(h * r * t)  (reference scoring.py:746-837)."""
 
     _scorer_id = nat.DISTMULT
+    bilinear_candidates = True
 
     def __init__(
         self,
@@ -413,6 +417,7 @@ class ComplEx(MatrixDecompositionScoreFunction):
     """ComplEx: Re<h * r, conj t> on [re | im] rows (reference scoring.py:840-946)."""
 
     _scorer_id = nat.COMPLEX
+    bilinear_candidates = True
 
     def __init__(
         self,

@@ -298,6 +298,9 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_bwd(NegPtArgs a,
         nrow[u] = idx[kk];
         ngo[u] = grow[kk];
     }
+    // d_query == NULL (it came out of the fused forward) and a bilinear scorer: d f / d e = g * q does not involve
+    // the candidate rows - they are not read at all, the kernel only writes d_neg
+    const bool need_rows = !(RED == RED_DOT && d_query == nullptr);
     for (int kb = k0; kb < k1; kb += 4 * UNROLL) {  // kb is wave-uniform
         float ev[UNROLL][IT][VEC], go[UNROLL];
         int ks[UNROLL];
@@ -312,8 +315,15 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_bwd(NegPtArgs a,
             const int kn = min(k + 4 * UNROLL, k1 - 1);
             nrow[u] = idx[kn];
             ngo[u] = grow[kn];
+            if (need_rows) {
 #pragma unroll
-            for (int it = 0; it < IT; ++it) load_chunk<T, VEC>(rp, g + 16 * it, a.nch, ev[u][it]);
+                for (int it = 0; it < IT; ++it) load_chunk<T, VEC>(rp, g + 16 * it, a.nch, ev[u][it]);
+            } else {
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) ev[u][it][v] = 0.f;
+            }
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -368,6 +378,7 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_bwd(NegPtArgs a,
             }
         }
     }
+    if (!d_query) return;
     // combine the four DPP rows, then one atomic per scalar per work item
     float* dqp = d_query + q * a.W;
 #pragma unroll
@@ -485,7 +496,7 @@ static int run(const bess_model_desc* d, bool fwd, const float* query, int64_t n
     a.p = static_cast<float>(d->norm_p);
     const int red = reduce_of(d);
     hipStream_t st = as_stream(stream);
-    if (!fwd && a.items_per_query > 1) {
+    if (!fwd && a.items_per_query > 1 && dq) {
         hipError_t e = fill_words_async(dq, 0u, n_query * W, st);
         if (e != hipSuccess) return fail(static_cast<int>(e), "memset d_query: %s", hipGetErrorString(e));
     }
@@ -543,8 +554,10 @@ extern "C" int bess_neg_score_pertriple_bwd(const bess_model_desc* d, const floa
                                             const int32_t* neg_idx, int64_t n_neg,
                                             const float* d_out, int64_t ld_dout, float* d_query,
                                             float* d_neg, void* stream) {
-    if (n_query > 0 && n_neg > 0 && !(d_out && d_query))
+    if (n_query > 0 && n_neg > 0 && !(d_out && (d_query || d_neg)))
         return bess::fail(BESS_EINVAL, "neg_score_pertriple_bwd: NULL pointer");
+    // (d_query == NULL: only d_neg is wanted - d_query came out of bess_neg_score_pertriple_fwd_dq; DistMult /
+    // ComplEx then never read the candidate rows)
     return bess::run(d, false, query, n_query, neg_base, neg_idx, n_neg, nullptr, d_out, ld_dout,
                      d_query, d_neg, stream);
 }

@@ -223,7 +223,10 @@ int bess_neg_score_pertriple_fwd(const bess_model_desc* d, const float* query,
 /* backward of K5.  d_out read with ld_dout.  d_query [n_query, W] f32 is
  * overwritten; d_neg [n_query*n_neg, W] f32 (gradient w.r.t. every gathered
  * row, same order as neg_idx) is overwritten - or pass d_neg = NULL when the
- * row gradients are produced by bess_neg_pertriple_grad_segments instead. */
+ * row gradients are produced by bess_neg_pertriple_grad_segments instead.
+ * d_query = NULL (with d_neg; TransE / RotatE / DistMult / ComplEx): only d_neg is wanted - d_query came out of
+ * bess_neg_score_pertriple_fwd_dq.  DistMult / ComplEx then do not read the candidate rows at all (d_neg =
+ * coefficient x query): the one pass over rows that arrived through the all-to-all was the fused forward. */
 int bess_neg_score_pertriple_bwd(const bess_model_desc* d, const float* query,
                                  int64_t n_query, const void* neg_base,
                                  const int32_t* neg_idx, int64_t n_neg,

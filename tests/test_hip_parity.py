@@ -489,6 +489,9 @@ def test_grad_segments_match_scatter_of_row_gradients(dev, name, p, dtype):
     dq, none = nat.neg_score_pertriple_bwd(desc, q, RowSource(table, idx), N, go, want_d_neg=False)
     assert none is None
     close(dq, dq_ref, rtol=1e-5, atol=1e-5)  # partial sums over negative blocks are combined atomically
+    # d_neg alone (d_query came out of the fused forward): the same rows - DistMult / ComplEx without reading a candidate
+    none, dn_only = nat.neg_score_pertriple_bwd(desc, q, RowSource(table, idx), N, go, want_d_query=False)
+    assert none is None and torch.equal(dn_only, dn)
     seg = nat.SegmentIndex(idx, M)
     n_seg = int(seg.n_seg.item())
     uniq, counts = torch.unique(idx.cpu().long(), return_counts=True)
@@ -1106,6 +1109,35 @@ def test_score_moving_training_forward_keeps_its_partials(dev, case, fused):
         assert calls.get("bess_neg_score_pertriple_bwd", 0) == 0 and calls.get("bess_neg_score_pertriple_fwd", 0) == 0, calls
     else:
         assert calls.get("bess_neg_score_pertriple_fwd_partials", 0) == 0, calls
+    close(model.score_fn.entity_embedding, c["table"] - lr * c["grads"]["entity"], rtol=1e-4, atol=2e-5)
+    close(model.score_fn.relation_embedding, c["rel"] - lr * c["grads"]["relation"].sum(0), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("case,fused", [("tr_EM_ComplEx0_ht_pt_n2", True), ("tr_EM_DistMult0_ht_pt_n2", True),
+                                        ("tr_EM_TransE1_ht_pt_n2", False)])
+def test_embedding_moving_fused_forward_over_received_rows(dev, case, fused):
+    """EmbeddingMoving on two shards, per-triple negatives that arrived through the all-to-all: the bilinear scorers
+    take scores and d loss / d query from ONE pass over the received rows (`bess_neg_score_pertriple_fwd_dq`) and
+    their backward writes d_neg = coefficient x query without reading a candidate row; the distance scorers keep
+    the two-pass form (sgn(q - e) needs the rows again).  Tables move by the reference's gradients either way
+    (reference bess.py:340-468 + autograd)."""
+    from besskge import _native as nat
+    from besskge import runtime
+
+    c = load_bess_case(case)
+    lr = 0.125
+    model = build_model(c, dev)
+    runner = runtime.training_model(model, runtime.Options(device_iterations=1), runtime.SGD(lr=lr), device=dev)
+    keys = ("head", "relation", "tail", "negative", "negative_mask")
+    watched = ["bess_neg_score_pertriple_fwd_dq", "bess_neg_score_pertriple_fwd", "bess_neg_score_pertriple_bwd"]
+    nat.start_kernel_timing(watched)
+    runner(**{k: c["batch"][k][0] for k in keys if k in c["batch"]})
+    calls = {k: len(v) for k, v in nat.stop_kernel_timing().items()}
+    if fused:
+        assert calls.get("bess_neg_score_pertriple_fwd_dq", 0) > 0 and calls.get("bess_neg_score_pertriple_fwd", 0) == 0, calls
+    else:
+        assert calls.get("bess_neg_score_pertriple_fwd_dq", 0) == 0 and calls.get("bess_neg_score_pertriple_fwd", 0) > 0, calls
+    assert calls.get("bess_neg_score_pertriple_bwd", 0) > 0, calls
     close(model.score_fn.entity_embedding, c["table"] - lr * c["grads"]["entity"], rtol=1e-4, atol=2e-5)
     close(model.score_fn.relation_embedding, c["rel"] - lr * c["grads"]["relation"].sum(0), rtol=1e-4, atol=2e-5)
 
