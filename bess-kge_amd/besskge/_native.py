@@ -84,6 +84,7 @@ class OptDesc(ctypes.Structure):
 OPT_SGD, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
 FLAG_FP32_MATH = 1  # BESS_FLAG_FP32_MATH (ModelDesc.reserved[0] of the four native scorers)
 FLAG_PREZEROED = 2  # BESS_FLAG_PREZEROED: the targets of bess_neg_score_shared_bwd are zero on entry
+FLAG_DNEG_BY_ROW = 4  # BESS_FLAG_DNEG_BY_ROW: bess_neg_score_pertriple_bwd stores d_neg at row neg_idx[k] of a row-space matrix
 
 
 class KillDesc(ctypes.Structure):
@@ -680,11 +681,14 @@ def combine_dq_partials(state: Tuple[torch.Tensor, torch.Tensor], norm: torch.Te
 
 
 def neg_score_pertriple_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n_neg: int,
-                            d_out: torch.Tensor, want_d_neg: bool = True, want_d_query: bool = True
+                            d_out: torch.Tensor, want_d_neg: bool = True, want_d_query: bool = True,
+                            d_neg_rows: Optional[torch.Tensor] = None
                             ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
     """Returns (d_query [nq, W] or None, d_neg [nq*n_neg, W] or None).  `want_d_query=False` (TransE / RotatE /
     DistMult / ComplEx; d_query came out of the fused forward): DistMult / ComplEx then do not read the candidate
-    rows at all - their d_neg rows are coefficient x query."""
+    rows at all - their d_neg rows are coefficient x query.  `d_neg_rows` ([rows of neg.base, W] f32; the four
+    native scorers): the gradient of reference k is STORED at row neg.idx[k] of it (BESS_FLAG_DNEG_BY_ROW) - only for
+    lists that name a row at most once; d_neg is not returned then."""
     nq = int(query.shape[0])
     dev = _neg_operands(d, query, neg, nq * n_neg)
     _same_device([("d_out", d_out), ("query", query)])
@@ -695,6 +699,14 @@ def neg_score_pertriple_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n
         raise ValueError("neg_score_pertriple_bwd: want_d_query=False is for the four native scorers, with d_neg")
     dq = torch.empty((nq, query_width(d)), dtype=torch.float32, device=dev) if want_d_query else None
     dn = torch.empty((nq * n_neg, d.width), dtype=torch.float32, device=dev) if want_d_neg else None
+    if d_neg_rows is not None:
+        if (int(d.scorer) > COMPLEX or not want_d_neg or d_neg_rows.dtype != torch.float32 or not d_neg_rows.is_contiguous()
+                or tuple(d_neg_rows.shape) != (int(neg.base.shape[0]), int(d.width)) or d_neg_rows.device != dev):
+            raise ValueError("neg_score_pertriple_bwd: `d_neg_rows` must be a contiguous f32 [rows of neg.base, W] "
+                             "tensor (native scorers)")
+        d = copy_desc(d)
+        d.reserved[0] |= FLAG_DNEG_BY_ROW
+        dn = d_neg_rows
     ip, keep = _neg_idx_ptr(neg, dev)
     with _on(dev), _Timed("bess_neg_score_pertriple_bwd", dev):
         rc = load().bess_neg_score_pertriple_bwd(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(), ip,
@@ -702,7 +714,7 @@ def neg_score_pertriple_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n
                                                  dn.data_ptr() if want_d_neg else 0, _stream(dev))
     _check(rc, "bess_neg_score_pertriple_bwd")
     del keep
-    return dq, dn
+    return dq, (None if d_neg_rows is not None else dn)
 
 
 def normalize_rows(neg: RowSource, n_part: int, normalize: bool) -> Tuple[torch.Tensor, torch.Tensor]:

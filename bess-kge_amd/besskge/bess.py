@@ -1230,13 +1230,21 @@ class EmbeddingMovingBessKGE(BessKGE):
                         dq, _ = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go,
                                                             want_d_neg=False)
                     deferred.append((st.table, g, go))
-                elif g.dq is not None:  # fused forward over rows of the receive buffer (bilinear scorers)
-                    dq = g.dq
-                    _, dn = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go, want_d_query=False)
-                    sink(g.neg, dn)
                 else:
-                    dq, dn = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go)
-                    sink(g.neg, dn)
+                    # Negatives that arrived through the all-to-all are named once each by the static index map
+                    # (`_run_groups`) and nothing else contributes to their rows of the receive-buffer gradient:
+                    # the native scorers' backward stores them there directly - no [S * N, W] copy, no scatter pass
+                    in_place = (d_recv is not None and g.neg.base is st.recv and not self.augment_negative
+                                and st.ext_src is None and 0 <= fn._scorer_id <= nat.COMPLEX
+                                and d_recv.shape[0] == st.recv.shape[0])
+                    fused_dq = g.dq is not None  # fused forward over received rows (bilinear scorers)
+                    dq, dn = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go,
+                                                         want_d_query=not fused_dq,
+                                                         d_neg_rows=d_recv if in_place else None)
+                    if fused_dq:
+                        dq = g.dq
+                    if not in_place:
+                        sink(g.neg, dn)
                 if st.fused_qt:
                     dh, dt = fn.query_triple_bwd(g.side, RowSource(st.table, st.head_idx), st.tail, st.rel_idx, d_pos,
                                                  dq, d_rel)

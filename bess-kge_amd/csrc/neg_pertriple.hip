@@ -37,6 +37,7 @@ struct NegPtArgs {
     float sign;
     int accum = 0;  // forward: add to the scores already there (a later column window of a wide row)
     float p = 2.f;  // the norm of the RED_L2 kernels (any p != 1)
+    int dn_by_row = 0;  // backward: d_neg row of reference k is neg_idx[k] (BESS_FLAG_DNEG_BY_ROW), not q * n_neg + k
 };
 
 // Fused training forward (FUSE): besides the scores, accumulate the loss gradient wrt the query,
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_bwd(NegPtArgs a,
     for (int kb = k0; kb < k1; kb += 4 * UNROLL) {  // kb is wave-uniform
         float ev[UNROLL][IT][VEC], go[UNROLL];
         int ks[UNROLL];
+        int32_t row_now[UNROLL];
         bool valid[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -311,6 +313,7 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_bwd(NegPtArgs a,
             valid[u] = k < k1;
             ks[u] = min(k, k1 - 1);
             const T* rp = base + static_cast<int64_t>(nrow[u]) * a.W;
+            row_now[u] = nrow[u];
             go[u] = valid[u] ? a.sign * ngo[u] : 0.f;
             const int kn = min(k + 4 * UNROLL, k1 - 1);
             nrow[u] = idx[kn];
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_bwd(NegPtArgs a,
                 ss = row16_allreduce_sum(ss);
                 gg *= lp_inv(lp_root(ss, a.p), a.p);
             }
-            float* dn = d_neg + (q * a.n_neg + ks[u]) * a.W;
+            float* dn = d_neg + (a.dn_by_row ? static_cast<int64_t>(row_now[u]) : q * a.n_neg + ks[u]) * a.W;
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 const int c = g + 16 * it;
@@ -494,6 +497,7 @@ static int run(const bess_model_desc* d, bool fwd, const float* query, int64_t n
     a.items_per_query = static_cast<int>(ceil_div(n_neg, a.nb));
     a.sign = is_distance(d->scorer) ? -1.f : 1.f;
     a.p = static_cast<float>(d->norm_p);
+    a.dn_by_row = (!fwd && (d->reserved[0] & BESS_FLAG_DNEG_BY_ROW)) ? 1 : 0;
     const int red = reduce_of(d);
     hipStream_t st = as_stream(stream);
     if (!fwd && a.items_per_query > 1 && dq) {

@@ -93,6 +93,10 @@ extern "C" {
 /* bess_model_desc.reserved[0] of TransE / RotatE / DistMult / ComplEx: flags */
 #define BESS_FLAG_PREZEROED 2 /* bess_neg_score_shared_bwd(_ws): d_query and d_neg are zero on entry (e.g. cleared by
                                * bess_step_prologue): the call does not clear them itself */
+#define BESS_FLAG_DNEG_BY_ROW 4 /* bess_neg_score_pertriple_bwd: d_neg is a matrix over the ROW SPACE of neg_base and the
+                                  * gradient of reference k is stored at row neg_idx[k] (plain stores) - for lists that
+                                  * name every row at most once (negatives that arrived through the all-to-all: the
+                                  * receive-buffer gradient is written in place, no [n_query * n_neg, W] copy) */
 #define BESS_FLAG_FP32_MATH 1 /* shared negatives with the plain fp32 kernels only: no packed-fp16 L1 forward
                                  (TransE / RotatE on f16 tables), no split-fp16 matrix-core products (DistMult /
                                  ComplEx) */

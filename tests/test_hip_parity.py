@@ -492,6 +492,16 @@ def test_grad_segments_match_scatter_of_row_gradients(dev, name, p, dtype):
     # d_neg alone (d_query came out of the fused forward): the same rows - DistMult / ComplEx without reading a candidate
     none, dn_only = nat.neg_score_pertriple_bwd(desc, q, RowSource(table, idx), N, go, want_d_query=False)
     assert none is None and torch.equal(dn_only, dn)
+    # lists that name a row at most once: the gradient rows stored straight into a row-space matrix
+    perm = torch.randperm(S * N + 50, generator=gen)[: S * N].to(torch.int32).to(dev)
+    big = torch.randn(S * N + 50, W, generator=gen).to(dtype).to(dev)
+    _, dn_p = nat.neg_score_pertriple_bwd(desc, q, RowSource(big, perm), N, go)
+    by_row = torch.zeros((big.shape[0], W), dtype=torch.float32, device=dev)
+    dq_p, none = nat.neg_score_pertriple_bwd(desc, q, RowSource(big, perm), N, go, d_neg_rows=by_row)
+    assert none is None and torch.equal(by_row[perm.long()], dn_p)
+    untouched = torch.ones(big.shape[0], dtype=torch.bool, device=dev)
+    untouched[perm.long()] = False
+    assert float(by_row[untouched].abs().max()) == 0.0
     seg = nat.SegmentIndex(idx, M)
     n_seg = int(seg.n_seg.item())
     uniq, counts = torch.unique(idx.cpu().long(), return_counts=True)
