@@ -628,7 +628,13 @@ class BessKGE(torch.nn.Module, ABC):
         if st.n > 1 and st.recv is not None and len(jobs) < nat.MAX_WORD_JOBS:
             # the gradients of the rows that came through the all-to-all are summed into this (C8 sends it back)
             st.d_recv = torch.empty((st.recv.shape[0], st.recv.shape[1]), dtype=torch.float32, device=st.table.device)
-            jobs.append((st.d_recv, None, 0))
+            if self._recv_negatives_in_place(st):
+                # the backward STORES the rows of the received negatives (every one exactly once): only the tails'
+                # rows - the first ppp of each block - are sums and start from zero (1 GB less to clear per step at
+                # C2's per-triple shape)
+                st.d_recv.view(st.n, -1, st.d_recv.shape[1])[:, : st.ppp].zero_()
+            else:
+                jobs.append((st.d_recv, None, 0))
         plan = self._small_plan(st, optimizer)
         # one workgroup indexes up to 4096 ids in ~12-15 us (notebook-size steps: cheaper than any fork / join);
         # longer lists are indexed by the device-wide pipeline on the side stream, under the forward kernels
@@ -641,6 +647,18 @@ class BessKGE(torch.nn.Module, ABC):
                                 self.__dict__.setdefault("_seg_scratch", {}))
         st.jobs = None
         return (plan, seg) if plan is not None else None
+
+    def _recv_negatives_in_place(self, st: _ReplicaStep) -> bool:
+        """Do the backward kernels of this step store the gradient rows of the received negatives straight into
+        the receive-buffer gradient (`BESS_FLAG_DNEG_BY_ROW`)?  Per-triple negatives that all came through the
+        all-to-all - the static index map names each of them once, nothing else adds to their rows - of a native
+        scorer, no augmentation (which appends rows and makes positives candidates)."""
+        fn = self.score_fn
+        return bool(st.n > 1 and st.recv is not None and st.groups and not self.augment_negative and st.ext_src is None
+                    and 0 <= fn._scorer_id <= nat.COMPLEX
+                    and all((not g.shared) and g.neg.base is st.recv for g in st.groups)
+                    and st.recv.shape[0] == st.n * (st.recv.shape[0] // st.n)
+                    and sum(len(g.neg) for g in st.groups) == st.recv.shape[0] - st.n * st.ppp)
 
     def _apply_optimizer_dense(self, opt: Any, table: torch.Tensor, grad: torch.Tensor) -> None:
         """Optimiser step on every row of a small replicated table (relation table, dense parameters):
@@ -792,6 +810,8 @@ class BessKGE(torch.nn.Module, ABC):
                     for (table, g, _), gseg in zip(items, grads):
                         nat.apply_segments_sgd(table, seg_index[id(g)], gseg, lr)
             # everything else: sparse atomic SGD on the shard (duplicates accumulate), one launch per shard
+            # (measured for the half-million 2 KB gradient rows that C8 returns at C2's per-triple shape: 1.17 ms of
+            # atomics; sorting the ids and summing per unique row through `bess_coalesced_update` took 0.1 + 1.2 ms)
             for st, upd in zip(steps, local_updates):
                 lists = [(idx.contiguous(), g.contiguous()) for idx, g in upd]
                 for i in range(0, len(lists), nat.MAX_ROW_LISTS):
@@ -1189,7 +1209,10 @@ class EmbeddingMovingBessKGE(BessKGE):
             d_recv = None
             if n > 1:
                 d_recv = st.d_recv  # cleared by the step's prologue launch
-                if d_recv is None:
+                if d_recv is None and self._recv_negatives_in_place(st):
+                    d_recv = torch.empty((st.recv.shape[0], W), dtype=torch.float32, device=dev)
+                    d_recv.view(n, -1, W)[:, : st.ppp].zero_()  # (the negatives' rows are stored, not summed)
+                elif d_recv is None:
                     d_recv = torch.zeros((st.recv.shape[0], W), dtype=torch.float32, device=dev)
 
             into_recv: List[Tuple[torch.Tensor, torch.Tensor]] = []  # gradients of rows that came from other shards
@@ -1234,9 +1257,7 @@ class EmbeddingMovingBessKGE(BessKGE):
                     # Negatives that arrived through the all-to-all are named once each by the static index map
                     # (`_run_groups`) and nothing else contributes to their rows of the receive-buffer gradient:
                     # the native scorers' backward stores them there directly - no [S * N, W] copy, no scatter pass
-                    in_place = (d_recv is not None and g.neg.base is st.recv and not self.augment_negative
-                                and st.ext_src is None and 0 <= fn._scorer_id <= nat.COMPLEX
-                                and d_recv.shape[0] == st.recv.shape[0])
+                    in_place = d_recv is not None and self._recv_negatives_in_place(st)
                     fused_dq = g.dq is not None  # fused forward over received rows (bilinear scorers)
                     dq, dn = nat.neg_score_pertriple_bwd(desc, g.query, g.neg, g.n_per_query, go,
                                                          want_d_query=not fused_dq,

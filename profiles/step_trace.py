@@ -8,7 +8,7 @@
 tensor: `FillFunctor<long>`); `show` lists the dispatches of the last marked step in start order with their
 duration and the idle gap in front of each (all streams), and the totals.  Workloads: c2score (the bench headline: gather + score + loss), c2 (the same as a
 training step), c2sm (that step in its multi-GPU form, ScoreMovingBessKGE, on one shard), c2adam, c4s (S=512, K=32: the notebook's micro-batch), c4 (S=4096, K=256), c4g (c4s replayed
-from a hipGraph).
+from a hipGraph), c2em2 (C2's scorer in the EmbeddingMoving form on two shards in lock-step: per-triple negatives through the all-to-all).
 """
 import csv
 import glob
@@ -29,7 +29,34 @@ def run(workload: str) -> None:
 
     dev = torch.device("cuda", 0)
     marker = torch.zeros(1, dtype=torch.int64, device=dev)
-    if workload.startswith("c2"):
+    if workload == "c2em2":
+        # C2's scorer and negatives in the EmbeddingMoving form on TWO shards stepped in lock-step on this GPU: the
+        # per-triple negatives arrive through the all-to-all (fused forward over the received rows, backward stores
+        # d_neg = coefficient x query straight into the receive-buffer gradient)
+        from besskge.bess import EmbeddingMovingBessKGE
+        from besskge.loss import LogSigmoidLoss
+        from besskge.negative_sampler import RandomShardedNegativeSampler
+        from besskge.scoring import ComplEx
+        from besskge.sharding import Sharding
+
+        nsh, S_, K_ = 2, 2048, 128  # per shard: 2048 positives x (2 x 128) negatives
+        sharding = Sharding.create(bench.N_ENTITY_C2 * nsh, nsh, seed=1234)
+        fn = ComplEx(False, sharding, bench.N_REL, bench.D, device=dev, shards=list(range(nsh)))
+        ns = RandomShardedNegativeSampler(K_, sharding, 1234, "t", local_sampling=False, flat_negative_format=False)
+        model = EmbeddingMovingBessKGE(negative_sampler=ns, score_fn=fn,
+                                       loss_fn=LogSigmoidLoss(margin=12.0, negative_adversarial_sampling=True))
+        for p_ in (fn.entity_embedding, fn.relation_embedding):
+            p_.requires_grad_(False)
+        rng = np.random.default_rng(0)
+        M, pp = bench.N_ENTITY_C2, S_ // nsh
+        batch = dict(head=rng.integers(M, size=(nsh, nsh, pp)), relation=rng.integers(bench.N_REL, size=(nsh, nsh, pp)),
+                     tail=rng.integers(M, size=(nsh, nsh, pp)), negative=rng.integers(M, size=(nsh, nsh, S_, K_)))
+        batch = {k: torch.from_numpy(v.astype(np.int32)).to(dev) for k, v in batch.items()}
+        runner = runtime.training_model(model, runtime.Options(device_iterations=1), runtime.SGD(lr=1e-3), device=dev)
+
+        def step(i):
+            runner(**batch)
+    elif workload.startswith("c2"):
         # c2sm: the multi-GPU form of the step (ScoreMoving) on one shard
         model, sharding, k_pair = bench.build_c2(bench.N_ENTITY_C2, 1, 0, dev, SingleProcessGroup(1), workload == "c2sm")
         batches = bench.make_batches_c2(1, 0, sharding, k_pair, pool=4, dev=dev)
