@@ -597,6 +597,27 @@ __global__ __launch_bounds__(256) void k_segment_sum_rows(const float* __restric
     const int ns = *n_seg;
     for (int64_t s = wave0; s < ns; s += n_wave) {
         const int r0 = seg_offsets[s], r1 = seg_offsets[s + 1];
+        if ((W & 3) == 0) {  // 16 B per lane and load, four references in flight; summed in reference order
+            for (int c = lane * 4; c < W; c += 256) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int r = r0; r < r1; r += 4) {
+                    float4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        v[u] = *reinterpret_cast<const float4*>(src + static_cast<int64_t>(refs[min(r + u, r1 - 1)]) * W + c);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (r + u < r1) {
+                            acc[0] += v[u].x;
+                            acc[1] += v[u].y;
+                            acc[2] += v[u].z;
+                            acc[3] += v[u].w;
+                        }
+                }
+                *reinterpret_cast<float4*>(out + s * W + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            }
+            continue;
+        }
         for (int c = lane; c < W; c += 64) {
             float acc = 0.f;
             for (int r = r0; r < r1; ++r) acc += src[static_cast<int64_t>(refs[r]) * W + c];
@@ -653,6 +674,49 @@ __global__ __launch_bounds__(256) void k_coalesced_update(OptArgs o, RowLists L,
         if (keep && keep[s] == 0) continue;
         const int r0 = seg_offsets[s], r1 = seg_offsets[s + 1];
         const int64_t row = seg_rows[s];
+        if ((W & 3) == 0) {
+            // four scalars per lane and load, the rows of four references in flight (their pointers are wave-uniform:
+            // resolved once per reference, not once per column pass); summed in reference order as before
+            for (int c = lane * 4; c < W; c += 256) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int r = r0; r < r1; r += 4) {
+                    float4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ref = refs[min(r + u, r1 - 1)];
+                        int l = 0;
+#pragma unroll
+                        for (int k = 1; k < BESS_MAX_ROW_LISTS; ++k) l += (k < L.n && ref >= L.first[k]) ? 1 : 0;
+                        v[u] = *reinterpret_cast<const float4*>(L.grad[l] + static_cast<int64_t>(ref - L.first[l]) * W + c);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (r + u < r1) {
+                            acc[0] += v[u].x;
+                            acc[1] += v[u].y;
+                            acc[2] += v[u].z;
+                            acc[3] += v[u].w;
+                        }
+                }
+                if (sum_out) {
+                    *reinterpret_cast<float4*>(sum_out + s * W + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                    continue;
+                }
+                const int64_t srow = state_row(o, row);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t at = row * W + c + j;
+                    const int64_t sat = srow * W + c + j;
+                    float p = static_cast<float>(table[at]);
+                    float s1 = (state1 && srow >= 0) ? state1[sat] : 0.f, s2 = (state2 && srow >= 0) ? state2[sat] : 0.f;
+                    opt_step(o, p, acc[j], s1, s2);
+                    if (state1 && srow >= 0) state1[sat] = s1;
+                    if (state2 && srow >= 0) state2[sat] = s2;
+                    table[at] = static_cast<T>(p);
+                }
+            }
+            continue;
+        }
         for (int c = lane; c < W; c += 64) {
             float acc = 0.f;
             for (int r = r0; r < r1; ++r) {
