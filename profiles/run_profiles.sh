@@ -22,5 +22,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_
 find $OUT -name "*.csv" | head -50
 # 4. one traced training step per workload (kernel by kernel, in start order): C2 (SGD, AdamW), C4 (S=512 eager /
 #    hipGraph, S=4096), the headline scoring step and the ScoreMoving form of the C2 training step
-bash profiles/run_step_traces.sh $TAG "c2score c2 c2adam c2sm c4s c4g c4" || exit 1
+bash profiles/run_step_traces.sh $TAG "c2score c2 c2adam c2sm c2em2 c4s c4g c4n2 c4" || exit 1
 cp gpurun_out/step_${TAG}_*.txt $OUT/ 2>/dev/null

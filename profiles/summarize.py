@@ -63,7 +63,8 @@ if steps:
             "c2sm": "C2 training step in its multi-GPU form (ScoreMovingBessKGE, fused forward with partials), one shard",
             "c4s": "C4 TransE d=256 fp16, S=512, K=32, eager",
             "c4n2": "C4, two shards of S=512 stepped in lock-step on one GPU (the n > 1 code path: pack, exchange, C8), eager", "c4g": "C4 TransE d=256 fp16, S=512, K=32, hipGraph replay",
-            "c4": "C4 TransE d=256 fp16, S=4096, K=256, eager"}
+            "c4": "C4 TransE d=256 fp16, S=4096, K=256, eager",
+            "c2em2": "C2's scorer and per-triple negatives in the EmbeddingMoving form on TWO shards stepped in lock-step on one GPU (S = 2048, 2 x 128 negatives per triple and shard; the n > 1 code path: pack, exchange - simulated by copies here -, fused forward over the received rows, in-place negative gradients, C8, coalesced update), SGD"}
     for f in steps:
         txt = open(f).read().splitlines()
         key = os.path.basename(f)[len(f"step_{tag}_"):-4]
@@ -80,7 +81,9 @@ INDEX = [
     ("pmc_k9_r03.txt", "profiles/pmc_k9.sh", "counters of the K9 segmented reduction inside the C2 training step (L2 hit rate, fetch bytes, VALU / wait cycles)"),
     ("microbench_final.log", "profiles/microbench.py", "every hot entry point on the BASELINE shapes (GB/s, TFLOP/s, T lane-ops/s)"),
     ("bench_gemm_split.log", "profiles/bench_gemm_split.py", "split-fp16 matrix-core products: accuracy vs float64 and rate, forward + backward"),
-    ("bench_topk.log", "profiles/bench_topk.py", "top-k over all entities (YAGO3-10, wikikg2, biokg shapes)"),
+    ("bench_topk.log", "profiles/bench_topk.py", "top-k over all entities (YAGO3-10, wikikg2, biokg shapes) and full ranks of the same queries: counted in the scoring epilogue vs score matrix + `bess_ranks_from_scores`"),
+    ("sweep_l1_bwd.log", "profiles/sweep_l1_bwd.py", "`k_l1_bwd_both` alone (hipGraph of back-to-back launches) from 256 x 288 to 8192 x 8448"),
+    ("pmc_l1_kernels.txt", "profiles/pmc_l1_bwd.sh", "SQ counters of the shared-negative L1 kernels at 4096 x 4352"),
     ("bench_c4.log", "profiles/bench_c4.py", "BASELINE configs[3] regime through runtime.Runner, hipGraph replay, SGD and AdamW"),
     ("bench_graphs.log", "profiles/bench_graphs.py", "hipGraph replay in the launch-bound regime (configs[0] shape)"),
     ("bench_optim.log", "profiles/bench_optim.py", "training step of the bench workload per optimiser"),
