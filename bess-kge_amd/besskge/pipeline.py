@@ -34,6 +34,55 @@ def _counting_scorer(score_fn: BaseScoreFunction) -> bool:
         return False
 
 
+def rank_filter_pairs(flt: torch.Tensor, keep: torch.Tensor, truth: torch.Tensor, rows: int, shard_bs: int
+                      ) -> "tuple[torch.Tensor, torch.Tensor]":
+    """The `rank_filter` input of `AllScoresBESS.rank_counts_replicas` for one sampler batch.
+
+    :param flt: (z, 2) rows (i, e) of `get_entity_filter`: entity e is filtered for the i-th KEPT triple.
+    :param keep: flat [rows * shard_bs] triple mask (rows = micro-batches x shards).
+    :param truth: flat [rows * shard_bs] global id of every slot's true completion.
+    :return: (`rank_filter` [rows, P, 2] int32 - (position in the row's micro-batch, entity), -1 padding, every
+        pair once, none naming its query's true completion -, number of such pairs per kept triple [n_kept]).
+    """
+    slot = keep.nonzero().reshape(-1)[flt[:, 0]]  # position in the flat [rows * shard_bs] batch
+    pairs = torch.stack([slot, flt[:, 1].to(slot.dtype)], dim=1)
+    pairs = pairs[pairs[:, 1] != truth[pairs[:, 0]].to(pairs.dtype)]  # (the truth is left out anyway)
+    pairs = torch.unique(pairs, dim=0)  # sorted by slot
+    per_slot = torch.zeros(keep.numel(), dtype=torch.int64)
+    per_slot.index_add_(0, pairs[:, 0], torch.ones(len(pairs), dtype=torch.int64))
+    row_of = pairs[:, 0] // shard_bs
+    per_row = torch.bincount(row_of, minlength=rows)
+    start = torch.cumsum(per_row, 0) - per_row
+    P = int(per_row.max()) if len(pairs) else 0
+    filt = torch.full((rows, max(P, 1), 2), -1, dtype=torch.int32)
+    if len(pairs):
+        k = torch.arange(len(pairs)) - start[row_of]
+        filt[row_of, k, 0] = (pairs[:, 0] % shard_bs).to(torch.int32)
+        filt[row_of, k, 1] = pairs[:, 1].to(torch.int32)
+    return filt, per_slot[keep]
+
+
+def ranks_from_counts(counts: torch.Tensor, pos: torch.Tensor, n_masked: torch.Tensor, n_entity: int, mode: str,
+                      worst_rank_infty: bool) -> torch.Tensor:
+    """`Evaluation.ranks_from_scores` (reference metric.py:129-182) from the counts of the entities scoring above
+    (`counts[:, 0]`) / exactly (`counts[:, 1]`) as the true completion, taken over the entities that the reference
+    does NOT set to -inf; `n_masked` of them per query are (the true completion, filtered completions): they only
+    ever tie with a -inf positive score (a NaN one, `metric.py:152`)."""
+    gt, eq = counts[:, 0].float(), counts[:, 1].float()
+    ge = gt + eq + torch.where(pos == -torch.inf, n_masked.float(), torch.zeros_like(gt))
+    n_cand = float(n_entity)
+    if mode == "optimistic":
+        better, worst = gt, gt == n_cand
+    elif mode == "pessimistic":
+        better, worst = ge, ge == n_cand
+    else:
+        better, worst = 0.5 * (gt + ge), (gt == n_cand) | (ge == n_cand)
+    rank = 1.0 + better
+    if worst_rank_infty:
+        rank = torch.where(worst, torch.full_like(rank, torch.inf), rank)
+    return rank
+
+
 class AllScoresPipeline(torch.nn.Module):
     """Scores (and metrics) of (h, r, ?) / (?, r, t) queries against all entities,
     with optional filtering of known triples and restriction to candidate entities."""
@@ -145,22 +194,8 @@ class AllScoresPipeline(torch.nn.Module):
                 raise ValueError("filtering needs a batch sampler with return_triple_idx=True")
             flt = get_entity_filter(self.triples[triple_id[triple_mask]], self.filter_triples,
                                     filter_mode=self.corruption_scheme)
-            slot = keep.nonzero().reshape(-1)[flt[:, 0]]  # position in the flat [rows * shard_bs] batch
-            pairs = torch.stack([slot, flt[:, 1].to(slot.dtype)], dim=1)
-            pairs = pairs[pairs[:, 1] != truth[pairs[:, 0]].to(pairs.dtype)]  # (the truth is left out anyway)
-            pairs = torch.unique(pairs, dim=0)  # sorted by slot
-            per_kept = torch.zeros(keep.numel(), dtype=torch.int64)
-            per_kept.index_add_(0, pairs[:, 0], torch.ones(len(pairs), dtype=torch.int64))
-            n_masked += per_kept[keep]
-            row_of = pairs[:, 0] // shard_bs
-            per_row = torch.bincount(row_of, minlength=rows)
-            start = torch.cumsum(per_row, 0) - per_row
-            P = int(per_row.max()) if len(pairs) else 0
-            filt = torch.full((rows, max(P, 1), 2), -1, dtype=torch.int32)
-            if len(pairs):
-                k = torch.arange(len(pairs)) - start[row_of]
-                filt[row_of, k, 0] = (pairs[:, 0] % shard_bs).to(torch.int32)
-                filt[row_of, k, 1] = pairs[:, 1].to(torch.int32)
+            filt, per_kept = rank_filter_pairs(flt, keep, truth, rows, shard_bs)
+            n_masked += per_kept
             extra["rank_filter"] = filt
         step = torch.zeros((rows, 1), dtype=torch.int32)
         out = self.runner(step=step, **inp, **extra)
@@ -169,20 +204,7 @@ class AllScoresPipeline(torch.nn.Module):
         if bool((counts < 0).any()):
             return None
         pos = out["pos_score"].reshape(-1)[keep.to(dev)]
-        gt, eq = counts[:, 0].float(), counts[:, 1].float()
-        # the reference's masked entries (-inf) are candidates too: they tie with a -inf positive
-        ge = gt + eq + torch.where(pos == -torch.inf, n_masked.to(dev).float(), torch.zeros_like(gt))
-        n_cand = float(sharding.n_entity)
-        if ev.mode == "optimistic":
-            better, worst = gt, gt == n_cand
-        elif ev.mode == "pessimistic":
-            better, worst = ge, ge == n_cand
-        else:
-            better, worst = 0.5 * (gt + ge), (gt == n_cand) | (ge == n_cand)
-        rank = 1.0 + better
-        if ev.worst_rank_infty:
-            rank = torch.where(worst, torch.full_like(rank, torch.inf), rank)
-        return rank
+        return ranks_from_counts(counts, pos, n_masked.to(dev), sharding.n_entity, ev.mode, ev.worst_rank_infty)
 
     def forward(self) -> Dict[str, Any]:
         """Run over the whole sampler."""
