@@ -90,15 +90,24 @@ class BaseScoreFunction(torch.nn.Module, ABC):
     _scorer_id: int = -1
 
     def kernel_desc(self) -> nat.ModelDesc:
-        """Descriptor handed to the kernels (dtype follows the tables)."""
+        """Descriptor handed to the kernels (dtype follows the tables).  Built once per (dtype, widths, norm,
+        switches) and handed out again: callers that set flags take a copy first (`nat.copy_desc`) - a training
+        step asks for it five times."""
+        rel, ent = self.relation_embedding, self.entity_embedding
+        key = (rel.dtype, int(ent.shape[-1]), int(rel.shape[-1]), int(getattr(self, "scoring_norm", 0)),
+               bool(getattr(self, "fp32_math", False)))
+        cached = self.__dict__.get("_kernel_desc_cache")
+        if cached is not None and cached[0] == key:
+            return cached[1]
         d = nat.ModelDesc()
         d.scorer = self._scorer_id
-        d.norm_p = int(getattr(self, "scoring_norm", 0))
-        d.dtype = nat._dtype_code(self.relation_embedding)
-        d.width = int(self.entity_embedding.shape[-1])
-        d.rel_width = int(self.relation_embedding.shape[-1])
-        if 0 <= self._scorer_id <= nat.COMPLEX and getattr(self, "fp32_math", False):
+        d.norm_p = key[3]
+        d.dtype = nat._dtype_code(rel)
+        d.width = key[1]
+        d.rel_width = key[2]
+        if 0 <= self._scorer_id <= nat.COMPLEX and key[4]:
             d.reserved[0] = nat.FLAG_FP32_MATH
+        self.__dict__["_kernel_desc_cache"] = (key, d)
         return d
 
     #: TransE / RotatE with p = 1 on fp16 tables score shared negatives with packed-fp16 kernels that
