@@ -787,16 +787,14 @@ def finish(line: dict, rank: int, distributed: bool, group) -> None:
     if rank == 0:
         print(json.dumps(line), flush=True)
     if distributed:
-        # the line is out.  A rank that cannot finish the teardown (a peer died) must not hang the launcher - and
-        # must not look like a clean run either: non-zero exit code.
-        bye = threading.Timer(60, lambda: os._exit(EXIT_ABANDONED))
-        bye.daemon = True
-        bye.start()
+        # the line is out.  Teardown in the one order that cannot hang: the recorded steps (hipGraphs holding the
+        # communicator's send / recv nodes) go first, then the communicator, then the process group
+        # (NativeGroup.close; round 3 needed a watchdog here because ncclCommDestroy waited for a live graph)
+        torch.cuda.synchronize()
         dist.barrier()
         if hasattr(group, "close"):
             group.close()
         dist.destroy_process_group()
-        bye.cancel()
 
 
 def main_c4(args, world: int, rank: int, dev, group, distributed: bool, comm_name: str) -> None:

@@ -13,6 +13,7 @@ on a CUDA/HIP device or if the library is missing.
 import contextlib
 import ctypes
 import pathlib
+import sys
 from typing import Any, List, Optional, Sequence, Tuple
 
 import torch
@@ -196,6 +197,7 @@ SIGNATURES = {
     "bess_allgather": [_vp, _vp, _vp, _i64, _vp],
     "bess_allreduce_sum_f32": [_vp, _vp, _vp, _i64, _vp],
     "bess_pack_exchange": [_vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp],
+    "bess_graph_node_counts": [_vp, _c_i32p, _i32],
 }
 COMM_ID_BYTES = 128
 ECOMM_BASE = 10000
@@ -1646,14 +1648,34 @@ class Communicator:
         return w.value, r.value, d.value
 
     def close(self) -> None:
-        """`bess_comm_destroy`.  hipGraphs that recorded collectives of this communicator must be destroyed first
-        (drop the `Runner` / `torch.cuda.CUDAGraph` objects): `ncclCommDestroy` waits for them."""
+        """`bess_comm_destroy`.  `ncclCommDestroy` waits for hipGraphs that recorded collectives of this
+        communicator, so they must be destroyed first: a communicator that has seen one of its collectives
+        recorded refuses to be destroyed until `graphs_released()` says they are gone (`NativeGroup.close()`
+        does both, in order) - an error instead of a process that never ends."""
         if getattr(self, "_h", None) is not None and self._h.value:
+            if getattr(self, "_recorded", False):
+                raise RuntimeError(
+                    "besskge: this communicator's collectives were recorded into a hipGraph; destroy the graphs "
+                    "(NativeGroup.close() / ReplicaGroup.release_graphs()) and call graphs_released() first - "
+                    "ncclCommDestroy would wait for them forever")
             torch.cuda.synchronize(self.device)
             h, self._h = self._h, _vp()
             _check(load().bess_comm_destroy(h), "bess_comm_destroy")
 
-    def __del__(self) -> None:  # pragma: no cover - interpreter shutdown order
+    def graphs_released(self) -> None:
+        """The caller has destroyed every hipGraph that recorded this communicator's collectives."""
+        self._recorded = False
+
+    def _note_capture(self) -> None:
+        if not getattr(self, "_recorded", False) and torch.cuda.is_current_stream_capturing():
+            self._recorded = True
+
+    def __del__(self, _finalizing: Any = sys.is_finalizing) -> None:  # pragma: no cover - shutdown order
+        # Never `ncclCommDestroy` from a finaliser that cannot know the graphs are gone: at interpreter shutdown
+        # (objects die in no useful order) or when a collective was recorded and nobody released the graphs, the
+        # handle is left to the process teardown.
+        if _finalizing() or getattr(self, "_recorded", False):
+            return
         try:
             self.close()
         except Exception:
@@ -1675,6 +1697,7 @@ class Communicator:
         elif recv.shape != send.shape or recv.dtype != send.dtype:
             raise ValueError("all_to_all: recv does not match send")
         per_peer = send[0].numel() * send.element_size()
+        self._note_capture()
         with _on(self.device), _Timed("bess_alltoall", self.device):
             rc = load().bess_alltoall(self._h, self._buf(send, "send"), self._buf(recv, "recv"), per_peer,
                                       _stream(self.device))
@@ -1684,6 +1707,7 @@ class Communicator:
     def all_gather(self, send: torch.Tensor) -> torch.Tensor:
         """recv [world, *send.shape] in rank order."""
         recv = torch.empty((self.world, *send.shape), dtype=send.dtype, device=send.device)
+        self._note_capture()
         with _on(self.device), _Timed("bess_allgather", self.device):
             rc = load().bess_allgather(self._h, self._buf(send, "send"), self._buf(recv, "recv"),
                                        send.numel() * send.element_size(), _stream(self.device))
@@ -1693,6 +1717,7 @@ class Communicator:
     def all_reduce_sum_(self, x: torch.Tensor) -> torch.Tensor:
         """In-place sum over ranks of a float32 tensor."""
         _f32(x, "x")
+        self._note_capture()
         with _on(self.device), _Timed("bess_allreduce_sum_f32", self.device):
             p = self._buf(x, "x")
             rc = load().bess_allreduce_sum_f32(self._h, p, p, x.numel(), _stream(self.device))
@@ -1708,9 +1733,27 @@ class Communicator:
         L = int(idx.shape[1])
         send = torch.empty((self.world, L, W), dtype=table.dtype, device=table.device)
         recv = torch.empty_like(send)
+        self._note_capture()
         with _on(self.device), _Timed("bess_pack_exchange", self.device):
             rc = load().bess_pack_exchange(self._h, _dtype_code(table), W, self._buf(table, "table"),
                                            self._buf(idx, "idx"), L, send.data_ptr(), recv.data_ptr(),
                                            _stream(self.device))
         _check(rc, "bess_pack_exchange")
         return send, recv
+
+
+# --------------------------------------------------------------------------- #
+# recorded steps
+GRAPH_NODE_KINDS = ("kernel", "memcpy", "memset", "host", "graph", "empty", "wait_event", "event_record",
+                    "ext_sem_signal", "ext_sem_wait", "mem_alloc", "mem_free", "memcpy_from_symbol",
+                    "memcpy_to_symbol", "batch_mem_op")
+
+
+def graph_node_counts(graph: Any) -> dict:
+    """Node types of a recorded step: `graph` is a `torch.cuda.CUDAGraph(keep_graph=True)` (its hipGraph_t is
+    `raw_cuda_graph()`) or a raw `hipGraph_t` address.  {"kernel": n, "memset": n, ...}, zero counts left out."""
+    raw = graph if isinstance(graph, int) else graph.raw_cuda_graph()
+    counts = (ctypes.c_int32 * len(GRAPH_NODE_KINDS))()
+    _check(load().bess_graph_node_counts(ctypes.c_void_p(raw), counts, len(GRAPH_NODE_KINDS)),
+           "bess_graph_node_counts")
+    return {k: int(c) for k, c in zip(GRAPH_NODE_KINDS, counts) if c}

@@ -91,6 +91,16 @@ class _NegGroup:
         self.bwd_buf: Optional[torch.Tensor] = None  # targets of the shared backward, cleared by the prologue
 
 
+class _SmallPlan(list):
+    """Row-id lists of a shard's small update lists, in hand-over order (`BessKGE._small_plan`).  `concats`:
+    {position in the plan: (address of the tensor that is the concatenation of the next k lists, k)} - the only
+    update lists `_match_ahead` accepts as "several planned lists in one"."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.concats: Dict[int, Tuple[int, int]] = {}
+
+
 class _ReplicaStep:
     """Per-replica state of one micro-batch (forward products + backward ctx)."""
 
@@ -474,7 +484,18 @@ class BessKGE(torch.nn.Module, ABC):
             n_state = 1 if opt.momentum != 0.0 else 0
         else:
             n_state = 1 if opt.kind == nat.OPT_ADAGRAD else 2
+        prev = getattr(self, "_optimizer_state", {}).get(table.data_ptr())
+        if prev is not None and prev.get("kind", opt.kind) != opt.kind:
+            # the table was stepped (or its state loaded from a checkpoint) under another optimiser: state tensors
+            # mean something else there (a momentum buffer is not Adam's first moment)
+            if prev["s"]:
+                raise RuntimeError(
+                    f"besskge: this table's optimiser state belongs to optimiser kind {prev['kind']} (0 SGD, 1 Adagrad, "
+                    f"2 Adam; e.g. loaded from a checkpoint), the step is taken with kind {opt.kind}")
+            prev["step"] = 0  # stateless so far (plain SGD): the new optimiser counts its own steps
+            prev.pop("step_dev", None)
         state = self._opt_state(table, n_state, getattr(opt, "state_rows", None))
+        state["kind"] = opt.kind
         state["step"] += 1
         o = nat.OptDesc()
         o.kind, o.step, o.lr = opt.kind, state["step"], float(opt.lr)
@@ -530,13 +551,15 @@ class BessKGE(torch.nn.Module, ABC):
                 out.append(g)
                 k += 1
                 continue
-            # a concatenation of the next planned lists?
+            # the concatenation of the next planned lists?  Only the tensor the plan itself named as one (by
+            # address: `_SmallPlan.concats`) - an unplanned list that merely has the length of the next few
+            # planned ones must not reuse their index (its gradient rows would land on other rows' ids)
             n, start = int(i.numel()), k
-            got = 0
-            while k < len(plan) and got < n:
-                got += int(plan[k].numel())
-                k += 1
-            if got != n or k - start < 2:
+            named = getattr(plan, "concats", {}).get(start)
+            if named is None or named[0] != i.data_ptr() or start + named[1] > len(plan):
+                return None, grads
+            k = start + named[1]
+            if sum(int(p_.numel()) for p_ in plan[start:k]) != n:
                 return None, grads
             at = 0
             for part in plan[start:k]:
@@ -555,10 +578,12 @@ class BessKGE(torch.nn.Module, ABC):
         if plain and self.score_fn.entity_embedding.dtype == torch.float32:
             return None
         fn = self.score_fn
-        plan: List[torch.Tensor] = []
+        plan = _SmallPlan()
 
         def add(src: RowSource, parts: Optional[List[torch.Tensor]] = None) -> None:
             if src.base is st.table and src.idx is not None:
+                if parts is not None and len(parts) > 1:
+                    plan.concats[len(plan)] = (src.idx.data_ptr(), len(parts))  # `src.idx` IS these parts, joined
                 plan.extend(parts if parts is not None else [src.idx.reshape(-1)])
 
         head = RowSource(st.table, st.head_idx)

@@ -105,6 +105,8 @@ def _save_table(model: Any, table: torch.Tensor, stem: Path, chunk_bytes: int) -
     meta: Dict[str, Any] = dict(step=0, n_state=0, paged=False)
     if st is not None:
         meta.update(step=_step_of(st), n_state=len(st["s"]), paged="slot_map" in st)
+        if "kind" in st:
+            meta["kind"] = int(st["kind"])  # BESS_OPT_*: a state tensor means different things to different optimisers
         for i, s in enumerate(st["s"]):
             save_rows(s, f"{stem}.state{i}.npy", chunk_bytes)
         if "slot_map" in st:
@@ -131,10 +133,17 @@ def _load_table(model: Any, table: torch.Tensor, stem: Path, chunk_bytes: int) -
     paged = bool(meta["paged"])
     n_state, step = int(meta["n_state"]), int(meta["step"])
     shape = (int(meta["capacity"]), table.shape[1]) if paged else tuple(table.shape)
-    if have is not None and ("slot_map" in have) == paged and len(have["s"]) >= n_state \
+    if have is not None and n_state > 0 and "kind" in have and "kind" in meta and int(have["kind"]) != int(meta["kind"]):
+        raise ValueError(
+            f"{stem}: the checkpoint's optimiser state was written by optimiser kind {meta['kind']}, the live state "
+            f"belongs to kind {have['kind']} (0 SGD, 1 Adagrad, 2 Adam): its tensors mean something else there")
+    fresh = n_state == 0 and step == 0  # a checkpoint without optimiser history: the live state starts over
+    if have is not None and ("slot_map" in have) == paged and (len(have["s"]) == n_state or fresh) \
             and all(tuple(x.shape) == shape for x in have["s"]) and (not paged or have["capacity"] == int(meta["capacity"])):
         # same layout as the live state: read into the existing tensors - a hipGraph recorded on them (tables,
-        # moments, slot map, device-side step count) stays valid
+        # moments, slot map, device-side step count) stays valid.  (Fewer state tensors in the file than live -
+        # a momentum checkpoint under Adam - is NOT the same layout: zeroed moments under the checkpoint's step
+        # count would skip Adam's bias correction, first updates ~30x too large.)
         for i, x in enumerate(have["s"]):
             if i < n_state:
                 load_rows(f"{stem}.state{i}.npy", x, chunk_bytes)
@@ -167,6 +176,8 @@ def _load_table(model: Any, table: torch.Tensor, stem: Path, chunk_bytes: int) -
         st["s"].append(load_rows(f"{stem}.state{i}.npy", torch.empty(shape, dtype=torch.float32, device=dev), chunk_bytes))
     if "step_dev" in meta:
         st["step_dev"] = torch.full((1,), step, dtype=torch.int32, device=dev)
+    if "kind" in meta:
+        st["kind"] = int(meta["kind"])
     states[table.data_ptr()] = st
     _stale_graphs(model)
 

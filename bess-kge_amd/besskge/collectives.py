@@ -28,7 +28,8 @@ removes that all-reduce with a PopART pattern,
 """
 
 from abc import ABC, abstractmethod
-from typing import List, Optional
+import sys
+from typing import Any, Dict, List, Optional
 
 import torch
 import torch.distributed as dist
@@ -56,6 +57,35 @@ class ReplicaGroup(ABC):
 
     def barrier(self) -> None:
         """Synchronise all replicas (no-op when they share a process)."""
+
+    # ------------------------------------------------------------------ recorded steps
+    # A hipGraph that recorded a collective keeps the communicator busy: `ncclCommDestroy` waits for it
+    # (round 3: a process that ended with a `Runner(use_graphs=True)` over a `NativeGroup` alive hung in
+    # `Communicator.__del__`).  The group therefore knows every graph cache recorded over it and destroys the
+    # graphs BEFORE the communicator goes.
+    def register_graph_cache(self, cache: Dict[Any, Any]) -> None:
+        """`cache` maps an input signature to `(graph, static inputs, static outputs)` (`Runner._graphs`)."""
+        held = self.__dict__.setdefault("_graph_caches", [])
+        if not any(c is cache for c in held):
+            held.append(cache)
+
+    def unregister_graph_cache(self, cache: Dict[Any, Any]) -> None:
+        held = self.__dict__.get("_graph_caches", [])
+        held[:] = [c for c in held if c is not cache]
+
+    def release_graphs(self) -> int:
+        """Destroy every hipGraph recorded over this group (their runners re-record on the next call).
+        Returns how many were destroyed."""
+        n = 0
+        for cache in self.__dict__.get("_graph_caches", []):
+            for entry in list(cache.values()):
+                graph = entry[0] if isinstance(entry, tuple) else entry
+                reset = getattr(graph, "reset", None)
+                if reset is not None:
+                    reset()
+                    n += 1
+            cache.clear()
+        return n
 
 
 class SingleProcessGroup(ReplicaGroup):
@@ -209,4 +239,17 @@ class NativeGroup(ReplicaGroup):
             torch.cuda.current_stream(self.device).synchronize()
 
     def close(self) -> None:
+        """Destroy the recorded steps that use the communicator, then the communicator (in that order:
+        `ncclCommDestroy` waits for hipGraphs that recorded its collectives)."""
+        if self.release_graphs():
+            torch.cuda.synchronize(self.device)
+        self.comm.graphs_released()
         self.comm.close()
+
+    def __del__(self, _finalizing: Any = sys.is_finalizing) -> None:  # pragma: no cover - collection order
+        if _finalizing():
+            return  # the process is going: its memory and the communicator go with it, nothing to wait for
+        try:
+            self.close()
+        except Exception:
+            pass

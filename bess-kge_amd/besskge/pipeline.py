@@ -34,19 +34,24 @@ def _counting_scorer(score_fn: BaseScoreFunction) -> bool:
         return False
 
 
-def rank_filter_pairs(flt: torch.Tensor, keep: torch.Tensor, truth: torch.Tensor, rows: int, shard_bs: int
-                      ) -> "tuple[torch.Tensor, torch.Tensor]":
+def rank_filter_pairs(flt: torch.Tensor, keep: torch.Tensor, truth: torch.Tensor, rows: int, shard_bs: int,
+                      candidate: Optional[torch.Tensor] = None) -> "tuple[torch.Tensor, torch.Tensor]":
     """The `rank_filter` input of `AllScoresBESS.rank_counts_replicas` for one sampler batch.
 
     :param flt: (z, 2) rows (i, e) of `get_entity_filter`: entity e is filtered for the i-th KEPT triple.
     :param keep: flat [rows * shard_bs] triple mask (rows = micro-batches x shards).
     :param truth: flat [rows * shard_bs] global id of every slot's true completion.
+    :param candidate: bool [n_entity], with `candidate_ents`: pairs naming an entity outside the subset are
+        dropped - the counting pass never sees those entities (the reference sets them to -inf anyway,
+        pipeline.py:247-250), so there is nothing to subtract for them.
     :return: (`rank_filter` [rows, P, 2] int32 - (position in the row's micro-batch, entity), -1 padding, every
         pair once, none naming its query's true completion -, number of such pairs per kept triple [n_kept]).
     """
     slot = keep.nonzero().reshape(-1)[flt[:, 0]]  # position in the flat [rows * shard_bs] batch
     pairs = torch.stack([slot, flt[:, 1].to(slot.dtype)], dim=1)
     pairs = pairs[pairs[:, 1] != truth[pairs[:, 0]].to(pairs.dtype)]  # (the truth is left out anyway)
+    if candidate is not None:
+        pairs = pairs[candidate[pairs[:, 1]]]
     pairs = torch.unique(pairs, dim=0)  # sorted by slot
     per_slot = torch.zeros(keep.numel(), dtype=torch.int64)
     per_slot.index_add_(0, pairs[:, 0], torch.ones(len(pairs), dtype=torch.int64))
@@ -66,8 +71,9 @@ def ranks_from_counts(counts: torch.Tensor, pos: torch.Tensor, n_masked: torch.T
                       worst_rank_infty: bool) -> torch.Tensor:
     """`Evaluation.ranks_from_scores` (reference metric.py:129-182) from the counts of the entities scoring above
     (`counts[:, 0]`) / exactly (`counts[:, 1]`) as the true completion, taken over the entities that the reference
-    does NOT set to -inf; `n_masked` of them per query are (the true completion, filtered completions): they only
-    ever tie with a -inf positive score (a NaN one, `metric.py:152`)."""
+    does NOT set to -inf; `n_masked` entities per query are set to -inf there (the true completion, the filtered
+    completions and - with `candidate_ents` - every entity outside the subset, each counted once): they only ever
+    tie with a -inf positive score (a NaN one, `metric.py:152`)."""
     gt, eq = counts[:, 0].float(), counts[:, 1].float()
     ge = gt + eq + torch.where(pos == -torch.inf, n_masked.float(), torch.zeros_like(gt))
     n_cand = float(n_entity)
@@ -167,8 +173,11 @@ class AllScoresPipeline(torch.nn.Module):
         if self.fused_ranks:
             self.bess_module.set_rank_candidates(candidate_ents)
         self.candidate_mask: Optional[torch.Tensor] = None
+        self._is_candidate: Optional[torch.Tensor] = None
         if candidate_ents is not None:
             self.candidate_mask = torch.from_numpy(np.setdiff1d(np.arange(sharding.n_entity), candidate_ents))
+            self._is_candidate = torch.ones(sharding.n_entity, dtype=torch.bool)
+            self._is_candidate[self.candidate_mask] = False
         # column order of the assembled scores -> global entity id (first occurrence of every entity)
         ws, n_step, M = self.window_size, self.bess_module.n_step, sharding.max_entity_per_shard
         cols = []
@@ -194,15 +203,19 @@ class AllScoresPipeline(torch.nn.Module):
                 raise ValueError("filtering needs a batch sampler with return_triple_idx=True")
             flt = get_entity_filter(self.triples[triple_id[triple_mask]], self.filter_triples,
                                     filter_mode=self.corruption_scheme)
-            filt, per_kept = rank_filter_pairs(flt, keep, truth, rows, shard_bs)
+            filt, per_kept = rank_filter_pairs(flt, keep, truth, rows, shard_bs, self._is_candidate)
             n_masked += per_kept
             extra["rank_filter"] = filt
+        if self._is_candidate is not None:
+            # entities outside the subset are -inf in the reference's matrix too (pipeline.py:247-250): they tie
+            # with a NaN positive (-inf after metric.py:152) like the truth and the filtered completions do
+            n_masked += sharding.n_entity - int(self._is_candidate.sum())
         step = torch.zeros((rows, 1), dtype=torch.int32)
         out = self.runner(step=step, **inp, **extra)
         dev = out["counts"].device
         counts = out["counts"].reshape(-1, 2)[keep.to(dev)]
-        if bool((counts < 0).any()):
-            return None
+        if bool(out["out_of_range"].any()):
+            return None  # some shard's matrix-core product met operands outside the fp16 range: matrix path
         pos = out["pos_score"].reshape(-1)[keep.to(dev)]
         return ranks_from_counts(counts, pos, n_masked.to(dev), sharding.n_entity, ev.mode, ev.worst_rank_infty)
 

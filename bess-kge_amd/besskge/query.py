@@ -376,7 +376,9 @@ class AllScoresBESS(_QueryModule):
         completion).  Returns per replica `counts` [shard_bs, 2] int32 (above, equal: over the entities that are
         neither the true completion nor filtered; every score involved - candidates, positives, filtered
         completions - in the arithmetic of the all-entity kernel) and `pos_score` [shard_bs] f32 (NaN -> -inf, infinities ->
-        the largest finite values, as `Evaluation.ranks_from_scores` does)."""
+        the largest finite values, as `Evaluation.ranks_from_scores` does) and `out_of_range` [shard_bs] bool: some
+        shard's matrix-core product met operands outside the fp16 range (its counts are then -1: use the score
+        matrix for this batch)."""
         group = self._group()
         n = group.n_shard
         fn = self.score_fn
@@ -436,6 +438,12 @@ class AllScoresBESS(_QueryModule):
                 counts = nat.neg_score_shared_counts(desc, q, src, thr, excl, round_f16=half)
             else:
                 counts = torch.zeros((q.shape[0], 2), dtype=torch.int32, device=q.device)
+            # The split-fp16 product poisons its counts (INT32_MIN) when an operand is outside the fp16 range.
+            # The sentinel must not go through arithmetic (INT32_MIN - 1 wraps, n * INT32_MIN is 0 for even n):
+            # it becomes a flag column of its own here, the counts of a poisoned pass are zeroed, and the flag is
+            # summed over the shards next to them.
+            bad = (counts < 0).any(dim=1)
+            counts = torch.where(bad[:, None], torch.zeros_like(counts), counts)
             if f is not None:  # [n, P, 2]: the pairs of every replica
                 if int(f.shape[1]):
                     qi, ent = f[..., 0].long(), f[..., 1].long()
@@ -450,14 +458,19 @@ class AllScoresBESS(_QueryModule):
                     if half:
                         sc = sc.half().float()
                     t = thr[g]
+                    ok = ok & ~bad[g]
                     sub = torch.stack([(ok & (sc > t)), (ok & (sc == t))], dim=1).to(torch.int32)
                     counts.index_add_(0, g, -sub)
-            outs_c.append(counts.reshape(n, -1, 2))
+            outs_c.append(torch.cat([counts, bad[:, None].to(torch.int32)], dim=1).reshape(n, -1, 3))
             thrs.append(thr.reshape(n, -1))
         back = group.all_to_all(outs_c)  # counts of every shard's entities, back to the query's replica
         res = []
         for shard, c, thr in zip(group.local_shards, back, thrs):
-            res.append(dict(counts=c.sum(dim=0, dtype=torch.int32), pos_score=thr[shard].contiguous()))
+            total = c.sum(dim=0, dtype=torch.int32)
+            flagged = total[:, 2] > 0
+            # (counts of a flagged query mean nothing: -1, so that no caller can take them for ranks)
+            res.append(dict(counts=torch.where(flagged[:, None], torch.full_like(total[:, :2], -1), total[:, :2]),
+                            out_of_range=flagged, pos_score=thr[shard].contiguous()))
         return res
 
     def forward_replicas(self, batches: List[_Batch]) -> List[torch.Tensor]:

@@ -16,6 +16,7 @@ so a notebook's `poptorch.X` lines become `besskge.runtime.X`.
 """
 
 import dataclasses
+import sys
 from typing import Any, Dict, List, Optional
 
 import torch
@@ -55,18 +56,23 @@ class Options:
     #: recorded by value).  One process per GPU: with `NativeGroup` (collectives on
     #: the kernels' stream, captured with them), not with c10d's `DistributedGroup`.
     use_graphs: bool = False
+    #: `use_graphs`: keep the recorded hipGraph_t next to its executable form, so that
+    #: `Runner.graph_node_counts()` can say what a recorded step holds (kernel / memset / memcpy nodes)
+    keep_graph: bool = False
     #: training: micro-batches whose gradients are summed before ONE optimiser step (poptorch
     #: `Training.gradientAccumulation`; reference `notebooks/1_biokg_training_inference.ipynb:408-417,
     #: 470-477`, `2_yago_topk_prediction.ipynb:240-280`).  A call consumes `device_iterations *
     #: gradient_accumulation` micro-batches (`batches_per_step` of the batch sampler) and makes
     #: `device_iterations` weight updates; every micro-batch of an update sees the same tables.
     gradient_accumulation: int = 1
-    #: how the gradients of accumulated micro-batches (and, with `replicas=True` semantics of PopTorch's
-    #: `accumulationAndReplicationReductionType`, of the replicas) are combined: "sum" = gradient of the summed
-    #: loss, "mean" = divided by `gradient_accumulation` (and by n_shard for the replicated tables when the
-    #: optimiser says `replica_reduction="mean"`).  The reference never sets it and PopTorch's default is not
-    #: visible in the repository: parity unpinned, "sum" chosen.
-    accumulation_reduction: str = "sum"
+    #: how the gradients of accumulated micro-batches and of the replicas (replicated tables) are combined -
+    #: PopTorch's `Training.accumulationAndReplicationReductionType`: "sum" = gradient of the summed loss, "mean" =
+    #: divided by `gradient_accumulation` (and, for the replicated tables, by n_shard unless the optimiser names
+    #: its own `replica_reduction`).  None = not set by the caller: `training_model` then takes "sum" (the gradient
+    #: of the summed loss, what the reference-generated fixtures pin), the PopTorch-spelled `trainingModel` takes
+    #: PopTorch's own documented default, Mean - so a recipe ported line by line (`from besskge import runtime as
+    #: poptorch`) steps as far as the upstream run.  The reference never sets it: DESIGN.md section 4.
+    accumulation_reduction: Optional[str] = None
 
     def deviceIterations(self, n: int) -> "Options":  # noqa: N802 - poptorch spelling
         self.device_iterations = int(n)
@@ -133,10 +139,10 @@ class SGD:
     #: paged state: keep at most this many rows of momentum per shard (rows get one when first stepped);
     #: None = a state table of the shard's own size
     state_rows: Optional[int] = None
-    #: how replicated-parameter gradients are combined over replicas ("sum" is
-    #: d(sum of replica losses); PopTorch's choice is not visible in the
-    #: reference repo -> parity unpinned)
-    replica_reduction: str = "sum"
+    #: how replicated-parameter gradients are combined over replicas: "sum" (d of the summed replica losses),
+    #: "mean", or None = as the runner's `Options.accumulation_reduction` resolves (PopTorch has ONE setting for
+    #: both); a model stepped without a runner (`train_step_replicas`) sums
+    replica_reduction: Optional[str] = None
 
     kind = 0  # BESS_OPT_SGD
 
@@ -152,7 +158,7 @@ class Adagrad:
     lr: float = 0.01
     eps: float = 1e-10
     weight_decay: float = 0.0
-    replica_reduction: str = "sum"
+    replica_reduction: Optional[str] = None
     #: paged state (see :class:`SGD`)
     state_rows: Optional[int] = None
     kind = 1  # BESS_OPT_ADAGRAD
@@ -170,7 +176,7 @@ class Adam:
     beta2: float = 0.999
     eps: float = 1e-8
     weight_decay: float = 0.0
-    replica_reduction: str = "sum"
+    replica_reduction: Optional[str] = None
     #: paged state: the two moment tables hold at most this many rows per shard, a row gets its pair the
     #: first time it is stepped (BASELINE configs[4]: Adam state of a 128 GB shard's own size would be
     #: 256 GB); `BessKGE.optimizer_state_rows_used()` tells when the pool is exhausted.  None = full tables
@@ -211,9 +217,14 @@ class Runner:
 
     def __init__(self, model: BessKGE, options: Optional[Options], group: Optional[ReplicaGroup],
                  device: Optional[torch.device], optimizer: Optional[Any],
-                 dtype: Optional[torch.dtype] = None) -> None:
+                 dtype: Optional[torch.dtype] = None, default_reduction: str = "sum") -> None:
         self.model = model
         self.options = options or Options()
+        self.default_reduction = default_reduction
+        if self.reduction not in ("sum", "mean"):
+            raise ValueError("Options.accumulation_reduction must be 'sum' or 'mean'")
+        if optimizer is not None and getattr(optimizer, "replica_reduction", "") is None:
+            optimizer = dataclasses.replace(optimizer, replica_reduction=self.reduction)
         n = model.sharding.n_shard
         if group is None:
             group = SingleProcessGroup(n)
@@ -239,6 +250,12 @@ class Runner:
             return self.model.forward_replicas(reps)
 
     @property
+    def reduction(self) -> str:
+        """"sum" | "mean": the options' `accumulation_reduction`, or the default of the entry point that made the
+        runner (`training_model`: sum; `trainingModel`, PopTorch's spelling: PopTorch's default, mean)."""
+        return self.options.accumulation_reduction or self.default_reduction
+
+    @property
     def _accum(self) -> int:
         return max(1, int(self.options.gradient_accumulation)) if self.optimizer is not None else 1
 
@@ -249,9 +266,7 @@ class Runner:
         k = self._accum
         if k == 1:
             return [self._step(self._split(batch, it))]
-        mean = self.options.accumulation_reduction == "mean"
-        if self.options.accumulation_reduction not in ("sum", "mean"):
-            raise ValueError("Options.accumulation_reduction must be 'sum' or 'mean'")
+        mean = self.reduction == "mean"
         pending: List[Any] = []
         outs = []
         if mean:
@@ -282,6 +297,8 @@ class Runner:
         # clones were a third of the step).
         sig = (iters,) + tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()))
         cache = self.__dict__.setdefault("_graphs", {})
+        # the group destroys these graphs before its communicator goes (ReplicaGroup.release_graphs)
+        self.group.register_graph_cache(cache)
         generation = self.model.__dict__.get("_state_generation", 0)
         if self.__dict__.get("_graphs_generation", generation) != generation:
             cache.clear()  # optimiser state tensors were replaced (checkpoint load): recorded addresses are stale
@@ -303,7 +320,7 @@ class Runner:
                     self._iteration(static, 0)
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
-            graph = torch.cuda.CUDAGraph()
+            graph = torch.cuda.CUDAGraph(keep_graph=True) if self.options.keep_graph else torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 outs = [o for it in range(iters) for o in self._iteration(static, it)]
                 stacked = self._stack_outputs(outs)  # the stacking of the outputs is part of the recording too
@@ -319,6 +336,35 @@ class Runner:
         if isinstance(stacked, dict):
             return {k: v.clone() for k, v in stacked.items()}
         return stacked.clone()
+
+    def graph_node_counts(self) -> Dict[Any, Dict[str, int]]:
+        """`Options(use_graphs=True, keep_graph=True)`: node types of every recorded step, by input signature
+        (`bess_graph_node_counts`): {"kernel": n, "memset": n, "memcpy": n, ...}."""
+        from besskge import _native as nat
+
+        if not self.options.keep_graph:
+            raise RuntimeError("graph_node_counts() needs Options(use_graphs=True, keep_graph=True)")
+        return {sig: nat.graph_node_counts(entry[0]) for sig, entry in self.__dict__.get("_graphs", {}).items()}
+
+    def reset_graphs(self) -> None:
+        """Destroy this runner's recorded steps (the next call records again)."""
+        cache = self.__dict__.get("_graphs")
+        if cache:
+            for entry in list(cache.values()):
+                entry[0].reset()
+            cache.clear()
+
+    def __del__(self, _finalizing: Any = sys.is_finalizing) -> None:  # pragma: no cover - collection order
+        cache = self.__dict__.get("_graphs")
+        if cache is None or _finalizing():
+            return
+        try:
+            # the graphs go before anything else of the runner does (a communicator they recorded waits for them),
+            # and the group stops holding the cache
+            self.reset_graphs()
+            self.group.unregister_graph_cache(cache)
+        except Exception:
+            pass
 
     def static_inputs(self, **batch: torch.Tensor) -> Dict[str, torch.Tensor]:
         """`use_graphs`: the device-resident input buffers the recorded step reads for inputs of these shapes
@@ -480,5 +526,15 @@ def training_model(model: BessKGE, options: Optional[Options] = None, optimizer:
 # PopTorch's spellings, so that `from besskge import runtime as poptorch` keeps a notebook's lines
 # (`poptorch.trainingModel(model, options=options, optimizer=opt)`; the `replicaGrouping` call that follows
 # in the notebooks has no counterpart: shard r always lives with replica r)
-trainingModel = training_model  # noqa: N816
+def trainingModel(model: BessKGE, options: Optional[Options] = None, optimizer: Optional[Any] = None,  # noqa: N802
+                  group: Optional[ReplicaGroup] = None, device: Optional[torch.device] = None,
+                  dtype: Optional[torch.dtype] = None) -> Runner:
+    """`poptorch.trainingModel` under its own name AND with its own default reduction: gradients of accumulated
+    micro-batches and of the replicas are averaged (PopTorch's documented default for
+    `accumulationAndReplicationReductionType` is Mean; the notebooks rely on it with `gradientAccumulation(6)` and
+    four replicas) unless the options / the optimiser say otherwise."""
+    model.train()
+    return Runner(model, options, group, device, optimizer or SGD(), dtype, default_reduction="mean")
+
+
 inferenceModel = inference_model  # noqa: N816

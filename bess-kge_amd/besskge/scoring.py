@@ -524,6 +524,17 @@ class _AffineScoreFunction(_TorchQueryHooks, DistanceBasedScoreFunction, ABC):
         """The model's additive constant (TripleRE: u, InterHT / TranS: offset)."""
         return 0.0
 
+    def _host_constant(self, buf: torch.Tensor) -> float:
+        """Value of a one-element constant buffer as a Python float, read from the device ONCE per version of the
+        buffer: `float(device tensor)` is a host sync on every step - and an error inside a hipGraph capture
+        (`tests/test_multi_gpu.py`, recorded TripleRE / InterHT / TranS steps)."""
+        key = (buf.data_ptr(), buf._version, buf.device)
+        cached = self.__dict__.get("_host_constant_cache")
+        if cached is None or cached[0] != key:
+            cached = (key, float(buf))
+            self.__dict__["_host_constant_cache"] = cached
+        return cached[1]
+
     def kernel_desc(self) -> nat.ModelDesc:
         d = super().kernel_desc()
         d.reserved[0] = self._n_part
@@ -650,7 +661,7 @@ class TripleRE(_AffineScoreFunction):
     _member = 1
 
     def _constant(self) -> float:
-        return float(self.rel_u) if self.use_v2 else 0.0
+        return self._host_constant(self.rel_u) if self.use_v2 else 0.0
 
     def __init__(
         self,
@@ -708,7 +719,7 @@ class InterHT(_AffineScoreFunction):
     _member = 2
 
     def _constant(self) -> float:
-        return float(self.offset)
+        return self._host_constant(self.offset)
 
     def __init__(
         self,
@@ -759,7 +770,7 @@ class TranS(_AffineScoreFunction):
     _member = 3
 
     def _constant(self) -> float:
-        return float(self.offset)
+        return self._host_constant(self.offset)
 
     def __init__(
         self,

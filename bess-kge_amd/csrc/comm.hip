@@ -181,3 +181,32 @@ extern "C" int bess_pack_exchange(bess_comm* c, int32_t dtype, int32_t width, co
     if (int e = check_launch("pack_exchange")) return e;
     return alltoall(c, send, recv, rows_per_peer * row_bytes, st);
 }
+
+// ---- recorded steps ------------------------------------------------------------------------------------------
+// Which node types a recorded step holds (child graphs included): the library's fills are kernels, so a step
+// recorded over it holds kernel nodes (+ RCCL's) - tests/test_graph_nodes.py asserts that no memset node is left.
+static int count_nodes(hipGraph_t g, int32_t* counts, int32_t n_kinds, int depth) {
+    size_t n = 0;
+    BESS_HIP(hipGraphGetNodes(g, nullptr, &n), "graph_node_counts: hipGraphGetNodes");
+    if (n == 0) return BESS_OK;
+    std::vector<hipGraphNode_t> nodes(n);
+    BESS_HIP(hipGraphGetNodes(g, nodes.data(), &n), "graph_node_counts: hipGraphGetNodes");
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType t;
+        BESS_HIP(hipGraphNodeGetType(nodes[i], &t), "graph_node_counts: hipGraphNodeGetType");
+        const int k = static_cast<int>(t);
+        if (k >= 0 && k < n_kinds) counts[k] += 1;
+        if (t == hipGraphNodeTypeGraph && depth < 8) {
+            hipGraph_t child = nullptr;
+            BESS_HIP(hipGraphChildGraphNodeGetGraph(nodes[i], &child), "graph_node_counts: child graph");
+            if (int e = count_nodes(child, counts, n_kinds, depth + 1)) return e;
+        }
+    }
+    return BESS_OK;
+}
+
+extern "C" int bess_graph_node_counts(void* graph, int32_t* counts, int32_t n_kinds) {
+    BESS_REQUIRE(graph && counts && n_kinds > 0, "graph_node_counts: NULL graph / counts");
+    for (int i = 0; i < n_kinds; ++i) counts[i] = 0;
+    return count_nodes(static_cast<hipGraph_t>(graph), counts, n_kinds, 0);
+}

@@ -200,6 +200,11 @@ static __global__ __launch_bounds__(256) void k_fill_words(uint32_t* __restrict_
 }
 inline hipError_t fill_words_async(void* p, uint32_t v, int64_t n_words, hipStream_t st) {
     if (n_words <= 0) return hipSuccess;
+#ifdef BESS_PROBE_MEMSET_NODES
+    // probe build only (make PROBE_MEMSET=1 -> profiles/ubench/bin/libbesskge_hip_memset.so, read by
+    // profiles/graph_memset_probe.py): the round-2 form of the fills, to settle what a recorded memset node does
+    if (v == 0u || v == 0xffffffffu) return hipMemsetAsync(p, static_cast<int>(v & 0xffu), sizeof(uint32_t) * n_words, st);
+#endif
     int64_t blocks = (n_words + 255) / 256;
     blocks = blocks > 2048 ? 2048 : blocks;
     k_fill_words<<<static_cast<unsigned>(blocks), 256, 0, st>>>(static_cast<uint32_t*>(p), v, n_words);

@@ -765,6 +765,16 @@ int bess_pack_exchange(bess_comm* comm, int32_t dtype, int32_t width, const void
                        const int32_t* idx, int64_t rows_per_peer, void* send, void* recv,
                        void* stream);
 
+/* ---- recorded steps -----------------------------------------------------------
+ * A step of this library can be captured into a hipGraph as a whole (every call is asynchronous on the
+ * caller's stream, every clear is a kernel).  bess_graph_node_counts tells what a captured graph holds:
+ * counts[t] = nodes of hipGraphNodeType t (0 kernel, 1 memcpy, 2 memset, 3 host, 4 child graph, 5 empty ...;
+ * t < n_kinds; nodes of child graphs are counted too).  Host-side inspection, no stream work. */
+#define BESS_GRAPH_NODE_KERNEL 0
+#define BESS_GRAPH_NODE_MEMCPY 1
+#define BESS_GRAPH_NODE_MEMSET 2
+int bess_graph_node_counts(void* graph, int32_t* counts, int32_t n_kinds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,21 +23,39 @@ for p in (os.path.join(REPO, "bess-kge_amd"), REPO, HERE):
         sys.path.insert(0, p)
 
 
+_GROUPS = []
+
+
+def device() -> torch.device:
+    """The GPU of this rank: the box's one GPU shared by all ranks (default), or - BESS_DIST_DEVICE=local_rank,
+    the real layout, tests/test_multi_gpu.py - one GPU per rank."""
+    if os.environ.get("BESS_DIST_DEVICE", "shared") == "local_rank":
+        return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    return torch.device("cuda", 0)
+
+
 def make_group():
     """DistributedGroup (c10d: gloo / nccl), or - BESS_DIST_BACKEND=native - NativeGroup: the library's
     own RCCL entry points (bess_comm_*), the RCCL id handed round over a gloo process group."""
     from besskge.collectives import DistributedGroup, NativeGroup
 
-    if os.environ.get("BESS_DIST_BACKEND", "gloo") == "native":
-        return NativeGroup(torch.device("cuda", 0))
-    return DistributedGroup()
+    g = NativeGroup(device()) if os.environ.get("BESS_DIST_BACKEND", "gloo") == "native" else DistributedGroup()
+    _GROUPS.append(g)
+    return g
+
+
+def options(**kw):
+    """runtime.Options of a worker run; BESS_USE_GRAPHS=1 records the steps (collectives included) into hipGraphs."""
+    from besskge import runtime
+
+    return runtime.Options(use_graphs=os.environ.get("BESS_USE_GRAPHS", "0") == "1", **kw)
 
 
 def routing(out_dir: str) -> None:
     g = make_group()
     n, r = g.n_shard, g.rank
     native = os.environ.get("BESS_DIST_BACKEND", "gloo") == "native"
-    dev = torch.device("cuda", 0) if native else torch.device("cpu")
+    dev = device() if native else torch.device("cpu")
     # block j of rank r carries the value 100*r + j
     x = torch.stack([torch.full((3, 2), 100.0 * r + j) for j in range(n)]).to(dev)
     (a2a,) = g.all_to_all([x])
@@ -64,7 +82,7 @@ def bess(out_dir: str) -> None:
 
     g = make_group()
     n, r = g.n_shard, g.rank
-    dev = torch.device("cuda", 0)
+    dev = device()
     cases = [c for c in os.environ["BESS_CASES"].split(",") if c]
     out = {}
     for case in cases:
@@ -74,7 +92,7 @@ def bess(out_dir: str) -> None:
         keys = ("head", "relation", "tail", "negative", "negative_mask")
         batch = {k: c["batch"][k].flatten(end_dim=1) for k in keys if k in c["batch"]}
         model = build_model(c, dev)
-        runner = runtime.inference_model(model, runtime.Options(device_iterations=bps), group=g, device=dev)
+        runner = runtime.inference_model(model, options(device_iterations=bps), group=g, device=dev)
         if c["net"] is not None:
             model.train()  # ConvE fixtures: train mode (batch statistics), no dropout
         res = runner(**batch)
@@ -83,8 +101,20 @@ def bess(out_dir: str) -> None:
         if case.startswith("tr_"):
             model = build_model(c, dev)
             lr = 0.125
-            runner = runtime.training_model(model, runtime.Options(device_iterations=1), runtime.SGD(lr=lr), group=g, device=dev)
+            runner = runtime.training_model(model, options(device_iterations=1), runtime.SGD(lr=lr), group=g, device=dev)
             res = runner(**{k: v[: n] for k, v in batch.items()})
+            if os.environ.get("BESS_USE_GRAPHS", "0") == "1":
+                # recorded steps: the first call recorded AND took the step; a replay on restored tables must take
+                # the same one (the collectives of the graph re-run with the peers' new data)
+                first = model.score_fn.entity_embedding.detach().clone()
+                c2 = load_bess_case(case)
+                model.score_fn.entity_embedding.data.copy_(c2["table"][r: r + 1].to(dev))
+                model.score_fn.relation_embedding.data.copy_(c2["rel"].to(dev))
+                res = runner(**{k: v[: n] for k, v in batch.items()})
+                torch.cuda.synchronize()
+                # (fp32 atomics of the plain-SGD scatter: equal up to the order of the additions)
+                torch.testing.assert_close(model.score_fn.entity_embedding.detach(), first, rtol=1e-5, atol=1e-6,
+                                           msg=f"{case}: replay != recording step")
             out[f"{case}_train_loss"] = res["loss"].float().cpu().numpy()
             out[f"{case}_train_entity"] = model.score_fn.entity_embedding.detach().float().cpu().numpy()
             out[f"{case}_train_relation"] = model.score_fn.relation_embedding.detach().float().cpu().numpy()
@@ -111,7 +141,7 @@ def topk(out_dir: str) -> None:
 
     g = make_group()
     n, r = g.n_shard, g.rank
-    dev = torch.device("cuda", 0)
+    dev = device()
     out = {}
     for spec in [c for c in os.environ["BESS_CASES"].split(",") if c]:
         fix, case = spec.split(":")
@@ -123,7 +153,7 @@ def topk(out_dir: str) -> None:
         if fix == "topk":
             model = TopKQueryBessKGE(k=m["k"], candidate_sampler=candidate_sampler(c), score_fn=fn, return_scores=True,
                                      window_size=m["window"])
-            runner = runtime.inference_model(model, runtime.Options(device_iterations=bps), group=g, device=dev)
+            runner = runtime.inference_model(model, options(device_iterations=bps), group=g, device=dev)
             keys = ("relation", "head", "tail", "negative", "triple_mask", "negative_mask")
             res = runner(**{k: c["batch"][k].flatten(end_dim=1) for k in keys if k in c["batch"]})
             out[f"{case}_ids"] = res["topk_global_id"].cpu().numpy()
@@ -239,10 +269,10 @@ def main() -> None:
     # per GPU - with a single GPU that is world_size 1, which still sends every collective through RCCL
     backend = os.environ.get("BESS_DIST_BACKEND", "gloo")
     if backend == "nccl":
-        torch.cuda.set_device(0)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        torch.cuda.set_device(device())
+        dist.init_process_group("nccl", device_id=device())
     elif backend == "native":
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(device())
         dist.init_process_group("gloo")
     else:
         dist.init_process_group("gloo")
@@ -250,6 +280,9 @@ def main() -> None:
         {"routing": routing, "bess": bess, "topk": topk, "sampler": sampler, "checkpoint": checkpoint}[mode](out_dir)
         dist.barrier()
     finally:
+        for g in _GROUPS:
+            if hasattr(g, "close"):
+                g.close()  # recorded steps first, then the communicator (NativeGroup.close)
         dist.destroy_process_group()
 
 

@@ -205,15 +205,45 @@ def test_mean_reduction_is_sum_with_a_scaled_rate(dev):
     order = [0, 1]
     batch = {k: torch.stack([c["batch"][k][it] for it in order]).flatten(end_dim=1) for k in KEYS if k in c["batch"]}
     out = []
-    for reduction, lr in (("sum", 0.025), ("mean", 0.05)):
+    # (the last row: PopTorch's spelling of the entry point brings PopTorch's default - Mean - with it)
+    for reduction, lr, make in (("sum", 0.025, runtime.training_model), ("mean", 0.05, runtime.training_model),
+                                (None, 0.025, runtime.training_model), (None, 0.05, runtime.trainingModel)):
         model = build_model(c, dev)
         options = runtime.Options(device_iterations=1, gradient_accumulation=2, accumulation_reduction=reduction)
-        runner = runtime.training_model(model, options, runtime.SGD(lr=lr), device=dev)
+        runner = make(model, options, runtime.SGD(lr=lr), device=dev)
         res = runner(**batch)
         out.append((model.score_fn.entity_embedding.detach().cpu(), model.score_fn.relation_embedding.detach().cpu(),
                     res["loss"].cpu()))
-    for a, b in zip(out[0], out[1]):
-        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_reduction_defaults_follow_the_entry_point():
+    """`accumulationAndReplicationReductionType` is one PopTorch setting for accumulated micro-batches and replicas;
+    unset, `training_model` sums (the fixtures' convention) and the PopTorch-spelled `trainingModel` averages
+    (PopTorch's documented default); an optimiser without its own `replica_reduction` follows the runner."""
+    import dataclasses
+
+    from besskge import runtime
+
+    def resolved(options, default, opt):
+        r = runtime.Runner.__new__(runtime.Runner)  # (the constructor places shards on a GPU: host logic only here)
+        r.options, r.default_reduction = options, default
+        if getattr(opt, "replica_reduction", "") is None:
+            opt = dataclasses.replace(opt, replica_reduction=r.reduction)
+        return r.reduction, opt.replica_reduction
+
+    assert resolved(runtime.Options(), "sum", runtime.SGD()) == ("sum", "sum")
+    assert resolved(runtime.Options(), "mean", runtime.Adam()) == ("mean", "mean")
+    assert resolved(runtime.Options(accumulation_reduction="sum"), "mean", runtime.Adagrad()) == ("sum", "sum")
+    assert resolved(runtime.Options(), "mean", runtime.SGD(replica_reduction="sum")) == ("mean", "sum")
+    o = runtime.Options()
+    o.Training.accumulationAndReplicationReductionType("Sum")
+    assert resolved(o, "mean", runtime.SGD()) == ("sum", "sum")
+    import inspect
+
+    assert inspect.signature(runtime.trainingModel).parameters.keys() == inspect.signature(runtime.training_model).parameters.keys()
 
 
 @pytest.mark.gpu

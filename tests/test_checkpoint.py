@@ -138,3 +138,44 @@ def test_rollback_in_a_live_process_under_graph_replay(tmp_path, warm):
         off = (a - b).abs()
         assert float((off > 1e-5).float().mean()) < 0.01 and float(off.max()) <= 2 * 0.01 * 1.01
     torch.testing.assert_close(results[False][2], results[True][2], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_state_of_another_optimiser_is_not_merged(tmp_path):
+    """a momentum-SGD checkpoint (one state tensor) loaded into a model that is live under Adam (two)
+    used to be read in place - first moment = momentum buffer, second moment zeroed, the checkpoint's step count
+    kept: no bias correction, first updates ~30x too large.  Now the file's optimiser kind is compared and the
+    load refuses; a checkpoint WITHOUT optimiser history resets the live state in place."""
+    from besskge import checkpoint, runtime
+
+    dev = torch.device("cuda", 0)
+    model, sharding = _model(dev)
+    batches = [_batch(sharding, 2, 16, 6, s) for s in range(3)]
+    fresh_dir = tmp_path / "fresh"
+    checkpoint.save_checkpoint(model, fresh_dir, chunk_bytes=4096)  # no optimiser history yet
+    runner = runtime.training_model(model, optimizer=runtime.SGD(lr=0.05, momentum=0.9), device=dev)
+    runner(**batches[0])
+    checkpoint.save_checkpoint(model, tmp_path / "sgdm", chunk_bytes=4096)
+
+    live, _ = _model(dev)
+    adam = runtime.training_model(live, optimizer=runtime.Adam(lr=0.01), device=dev)
+    adam(**batches[0])
+    with pytest.raises(ValueError, match="optimiser kind"):
+        checkpoint.load_checkpoint(live, tmp_path / "sgdm", chunk_bytes=4096)
+    # into a model without live state the file's state comes in as it is - and stepping it with Adam is refused
+    cold, _ = _model(dev)
+    cold_runner = runtime.training_model(cold, optimizer=runtime.Adam(lr=0.01), device=dev)
+    checkpoint.load_checkpoint(cold, tmp_path / "sgdm", chunk_bytes=4096)
+    with pytest.raises(RuntimeError, match="optimiser kind"):
+        cold_runner(**batches[1])
+    # a history-free checkpoint under live Adam: tables back, moments zero, step count 0 (bias correction restarts)
+    st = live._optimizer_state[live._local_table(0).data_ptr()]
+    ptrs = [x.data_ptr() for x in st["s"]]
+    checkpoint.load_checkpoint(live, fresh_dir, chunk_bytes=4096)
+    st = live._optimizer_state[live._local_table(0).data_ptr()]
+    assert [x.data_ptr() for x in st["s"]] == ptrs and checkpoint._step_of(st) == 0
+    assert all(float(x.abs().max()) == 0.0 for x in st["s"])
+    before = live.score_fn.entity_embedding.detach().clone()
+    adam(**batches[1])
+    step = (live.score_fn.entity_embedding.detach() - before).abs().max()
+    assert 0 < float(step) <= 0.01 * 1.01  # one bias-corrected Adam step is at most lr

@@ -264,15 +264,78 @@ for k in range(3):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, torch.full_like(out, 2.0 * (k + 1))), (k, out)
-# a graph that recorded the communicator's collectives goes first: ncclCommDestroy waits for it to be destroyed
+# a graph that recorded the communicator's collectives goes first: ncclCommDestroy waits for it to be destroyed -
+# the communicator knows it was recorded and refuses (an error, not a process that never ends)
+try:
+    comm.close()
+    raise SystemExit("close() with a recorded graph alive must refuse")
+except RuntimeError as e:
+    assert "hipGraph" in str(e), e
+g.reset()
 del g, out
 torch.cuda.synchronize()
+comm.graphs_released()
 comm.close()
 comm.close()  # idempotent
 print("ok")
 '''
     res = subprocess.run([sys.executable, "-c", code, os.path.join(os.path.dirname(HERE), "bess-kge_amd")], capture_output=True,
                          text=True, timeout=120, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+_RECORDED_RUNNER = r'''
+import sys, torch
+sys.path[:0] = [sys.argv[1], sys.argv[2]]
+import numpy as np
+from besskge import _native as nat, runtime
+from besskge.bess import EmbeddingMovingBessKGE
+from besskge.collectives import NativeGroup
+from besskge.loss import LogSigmoidLoss
+from besskge.negative_sampler import RandomShardedNegativeSampler
+from besskge.scoring import TransE
+from besskge.sharding import Sharding
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+group = NativeGroup(dev, unique_id=nat.comm_unique_id(), world=1, rank=0)
+sharding = Sharding.create(500, 1, seed=3)
+fn = TransE(True, 1, sharding, 5, 32)
+ns = RandomShardedNegativeSampler(16, sharding, 1, "t", local_sampling=False, flat_negative_format=True)
+model = EmbeddingMovingBessKGE(ns, fn, LogSigmoidLoss(margin=3.0, negative_adversarial_sampling=True))
+runner = runtime.training_model(model, runtime.Options(use_graphs=True), runtime.SGD(lr=0.01), group=group, device=dev)
+rng = np.random.default_rng(0)
+batch = dict(head=torch.from_numpy(rng.integers(500, size=(1, 1, 64)).astype(np.int32)),
+             relation=torch.from_numpy(rng.integers(5, size=(1, 1, 64)).astype(np.int32)),
+             tail=torch.from_numpy(rng.integers(500, size=(1, 1, 64)).astype(np.int32)),
+             negative=torch.from_numpy(rng.integers(500, size=(1, 1, 1, 16)).astype(np.int32)))
+losses = [float(runner(**batch)["loss"]) for _ in range(4)]   # record + three replays
+torch.cuda.synchronize()
+assert group.comm._recorded, "the step's all-reduce was recorded with the communicator"
+assert all(np.isfinite(losses)) and losses[3] != losses[0], losses
+MODE = sys.argv[3]
+if MODE == "close":
+    group.close()          # destroys the runner's graphs, then the communicator
+    assert not runner._graphs
+    group2 = None
+elif MODE == "drop":
+    del runner, model, group   # any order the collector likes
+print("ok", flush=True)
+# MODE == "exit": leave with runner, graphs, group and communicator all alive
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["exit", "close", "drop"])
+def test_process_ends_with_recorded_collectives_alive(mode):
+    """Round 3's hang: `ncclCommDestroy` waits for hipGraphs that recorded the communicator's collectives, and
+    `Communicator.__del__` called it at interpreter exit with a `Runner(use_graphs=True)` still alive.  Now the
+    group knows the graphs recorded over it (`ReplicaGroup.register_graph_cache`), `NativeGroup.close()` destroys
+    them first, and no finaliser destroys a communicator it cannot know to be free.  A NativeGroup of one rank,
+    a recorded training step (the relation gradient's all-reduce is a collective), three replays, then the
+    process ends WITHOUT deleting anything ("exit"), after `group.close()`, or by dropping the objects."""
+    repo = os.path.dirname(HERE)
+    res = subprocess.run([sys.executable, "-c", _RECORDED_RUNNER, os.path.join(repo, "bess-kge_amd"), repo, mode],
+                         capture_output=True, text=True, timeout=60, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
 
 

@@ -612,6 +612,64 @@ def test_pipeline_ranks_by_counting_equal_ranks_from_the_score_matrix(dev, score
     assert float((a["ranks"] != want).float().mean()) < (0.05 if half else 0.03)  # (rank flips at numerical ties: fp16 rounding boundaries; RotatE's sin / cos)
 
 
+@pytest.mark.parametrize("n_shard", [2, 3])
+def test_counting_falls_back_when_an_operand_leaves_the_fp16_range(dev, n_shard):
+    """the split-fp16 product poisons a shard's counts with INT32_MIN when an operand is
+    outside the fp16 range.  A query row goes into EVERY shard's product, so all n shards are poisoned at once and
+    n * INT32_MIN wraps to 0 for even n (and INT32_MIN - 1 wraps in the filter correction): the sentinel used to
+    vanish in the sum and every rank came out as 1.  Now the flag travels next to the counts (`out_of_range`) and
+    the pipeline takes the matrix path for that batch: same ranks as the pipeline that never counts."""
+    from besskge.batch_sampler import RigidShardedBatchSampler
+    from besskge.dataset import KGDataset
+    from besskge.metric import Evaluation
+    from besskge.negative_sampler import PlaceholderNegativeSampler
+    from besskge.pipeline import AllScoresPipeline
+    from besskge.sharding import PartitionedTripleSet, Sharding
+
+    seed, n_rel, d, n_entity, shard_bs = 5, 11, 64, 60_000, 160
+    n_triple = 2 * n_shard * shard_bs
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    sharding = Sharding.create(n_entity, n_shard, seed=seed)
+    ent = torch.randn(n_shard, sharding.max_entity_per_shard, 2 * d) * 0.3
+    rel = torch.randn(n_rel, 2 * d) * 0.3
+    triples = np.stack([rng.integers(n_entity, size=n_triple), rng.integers(n_rel, size=n_triple),
+                        rng.integers(n_entity, size=n_triple)], axis=1)
+    h0 = int(triples[7, 0])  # the head of one query: its row makes that query's row of the product huge
+    ent[sharding.entity_to_shard[h0], sharding.entity_to_idx[h0], :4] = 3.0e5
+    extra = np.stack([rng.integers(n_entity, size=2000), rng.integers(n_rel, size=2000),
+                      rng.integers(n_entity, size=2000)], axis=1)
+    extra[:1500, :2] = triples[rng.integers(n_triple, size=1500), :2]
+    ds = KGDataset(n_entity=n_entity, n_relation_type=n_rel, triples={"test": triples},
+                   original_triple_ids={"test": np.arange(n_triple)})
+    pts = PartitionedTripleSet.create_from_dataset(ds, "test", sharding, partition_mode="h_shard")
+    fn = make_scorer("ComplEx", 0, True, n_rel, d, ent, rel, dev, sharding=sharding)
+    bs = RigidShardedBatchSampler(pts, PlaceholderNegativeSampler("t"), shard_bs=shard_bs, batches_per_step=1,
+                                  seed=seed, return_triple_idx=True)
+    ev = Evaluation(["mrr"], mode="average", reduction="sum", return_ranks=True)
+    kw = dict(evaluation=ev, filter_triples=[extra], window_size=sharding.max_entity_per_shard, device=dev)
+    fused = AllScoresPipeline(bs, "t", fn, **kw)
+    assert fused.fused_ranks
+    seen = []
+    inner = fused._ranks_by_counting
+    fused._ranks_by_counting = lambda *a, **k: (seen.append(inner(*a, **k)), seen[-1])[1]
+    a = fused()
+    b = AllScoresPipeline(bs, "t", fn, fused_ranks=False, **kw)()
+    assert any(r is None for r in seen), "the out-of-range flag was lost: no batch fell back to the score matrix"
+    assert torch.equal(a["ranks"], b["ranks"])
+    assert float((a["ranks"] == 1).float().mean()) < 0.5  # (the lost sentinel made every rank 1)
+    # and the module's own outputs say which queries were flagged
+    mod = fused.bess_module
+    batch = next(iter(fused.dl))
+    rows = batch["head"].flatten(end_dim=1)
+    res = fused.runner(step=torch.zeros((rows.shape[0], 1), dtype=torch.int32), head=rows,
+                       relation=batch["relation"].flatten(end_dim=1),
+                       rank_truth=batch["tail"].flatten(end_dim=1).to(torch.int32))
+    assert bool(res["out_of_range"].any()) and bool((res["counts"][res["out_of_range"]] == -1).all())
+    assert not bool((res["counts"][~res["out_of_range"]] < 0).any())
+    del mod
+
+
 @pytest.mark.parametrize("scorer,dtype,W,n_cand", [("ComplEx", torch.float32, 128, 40_000), ("DistMult", torch.float16, 96, 40_000),
                                                    ("TransE", torch.float16, 64, 40_000), ("TransE", torch.float32, 64, 3_000),
                                                    ("RotatE", torch.float16, 128, 2_000), ("ComplEx", torch.float32, 64, 900)])

@@ -31,7 +31,8 @@ def reference_ranks(pos, cand, mode, worst_inf):
 @pytest.mark.parametrize("mode", ["optimistic", "pessimistic", "average"])
 @pytest.mark.parametrize("worst_inf", [False, True])
 @pytest.mark.parametrize("scheme", ["t", "h"])
-def test_ranks_from_epilogue_counts_equal_ranks_of_the_masked_matrix(mode, worst_inf, scheme):
+@pytest.mark.parametrize("subset", [False, True])
+def test_ranks_from_epilogue_counts_equal_ranks_of_the_masked_matrix(mode, worst_inf, scheme, subset):
     rng = np.random.default_rng(3)
     gen = torch.Generator().manual_seed(3)
     n_entity, n_rel, rows, shard_bs = 200, 5, 6, 8  # rows = micro-batches x shards
@@ -73,10 +74,20 @@ def test_ranks_from_epilogue_counts_equal_ranks_of_the_masked_matrix(mode, worst
     scores[3, int(truth[3])] = float("nan")
     scores[5, int(truth[5])] = -float("inf")
     keep[3] = keep[5] = True  # (those two are looked at whether or not the draw kept them)
+    # `candidate_ents`: only a subset of the entities competes (pipeline.py:247-250 sets the others to -inf BEFORE
+    # the true scores are read); the NaN positive's truth is a candidate, some truths and filter entities are not
+    candidate = None
+    n_outside = 0
+    if subset:
+        candidate = torch.rand(n_entity, generator=gen) > 0.3
+        candidate[int(truth[3])] = True
+        n_outside = int((~candidate).sum())
+        scores[:, ~candidate] = -torch.inf
+        scores[3, int(truth[3])] = float("nan")
     # recompute what depends on keep
     kept = triples[keep]
     flt = get_entity_filter(kept, extra, filter_mode=scheme)
-    filt, per_kept = rank_filter_pairs(flt, keep, truth, rows, shard_bs)
+    filt, per_kept = rank_filter_pairs(flt, keep, truth, rows, shard_bs, candidate)
     kept_slots = keep.nonzero().reshape(-1)
     pos = scores[kept_slots, truth[kept_slots]].clone()
     masked = scores[kept_slots].clone()
@@ -86,7 +97,9 @@ def test_ranks_from_epilogue_counts_equal_ranks_of_the_masked_matrix(mode, worst
     # what the kernels hand back: counts over the entities that are not masked, against the nan_to_num'ed positive
     thr = torch.nan_to_num(pos.clone(), nan=-torch.inf)
     open_ = torch.isfinite(masked) | (masked == torch.inf)
+    if subset:
+        open_ &= candidate[None, :]  # the counting pass runs over the candidate rows only
     counts = torch.stack([((scores[kept_slots] > thr[:, None]) & open_).sum(-1),
                           ((scores[kept_slots] == thr[:, None]) & open_).sum(-1)], dim=1).to(torch.int32)
-    got = ranks_from_counts(counts, thr, 1 + per_kept, n_entity, mode, worst_inf)
+    got = ranks_from_counts(counts, thr, 1 + per_kept + n_outside, n_entity, mode, worst_inf)
     assert torch.equal(got, want)
