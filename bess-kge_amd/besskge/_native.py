@@ -198,6 +198,8 @@ SIGNATURES = {
     "bess_allreduce_sum_f32": [_vp, _vp, _vp, _i64, _vp],
     "bess_pack_exchange": [_vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp],
     "bess_graph_node_counts": [_vp, _c_i32p, _i32],
+    "bess_neg_score_shared_fwd_loss": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, ctypes.POINTER(KillDesc), _LD, _vp, _vp, _i64,
+                                       _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp],
 }
 COMM_ID_BYTES = 128
 ECOMM_BASE = 10000
@@ -990,6 +992,77 @@ def loss_fwd_bwd(l: LossDesc, pos: torch.Tensor, neg: torch.Tensor, weight: torc
     if want_norm:
         return loss.reshape(()), dp, dn, norm
     return loss.reshape(()), dp, dn
+
+
+_tail_counters: dict = {}  # (device, raw stream | "capture", slots) -> int32 [slots], zero between calls
+
+
+def _counters(dev: torch.device, stream: int, slots: int) -> torch.Tensor:
+    """Zeroed int32 counters that kernels of one stream leave zero again (one array per stream; recorded steps
+    share one that exists before any recording starts - a tensor made while a stream is capturing would be
+    cleared by a fill node at every replay)."""
+    slots = max(64, 1 << (slots - 1).bit_length())
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (dev, "capture" if capturing else stream, slots)
+    c = _tail_counters.get(key)
+    if c is None:
+        if capturing:
+            raise RuntimeError("besskge: the counters of a recorded step must exist before the recording starts "
+                               "(run the step once eagerly first - Runner does)")
+        c = _tail_counters[key] = torch.zeros((slots,), dtype=torch.int32, device=dev)
+        _tail_counters.setdefault((dev, "capture", slots), torch.zeros((slots,), dtype=torch.int32, device=dev))
+    return c
+
+
+def neg_score_shared_fwd_loss(d: ModelDesc, l: LossDesc, query: torch.Tensor, neg: RowSource, pos: torch.Tensor,
+                              weight: torch.Tensor, kill: Optional[Tuple[int, bool, int, Optional[torch.Tensor]]] = None
+                              ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """K4 + K7 + K8 of a training step with shared negatives (`bess_neg_score_shared_fwd_loss`): scores [nq, n_neg]
+    (K7 applied), loss [], d_pos [nq], d_neg [nq, n_neg].  One launch where the scoring kernel can finish the loss
+    rows itself (packed L1 kernel, rows of up to 1024 scores), else the scoring launch + the loss launch(es)."""
+    nq, n_neg = int(query.shape[0]), len(neg)
+    dev = _neg_operands(d, query, neg, n_neg)
+    _same_device([("query", query), ("positive_score", pos), ("triple_weight", weight)])
+    _f32(pos, "positive_score")
+    _f32(weight, "triple_weight")
+    if pos.numel() != nq or weight.numel() not in (1, nq):
+        raise ValueError("neg_score_shared_fwd_loss: shapes of positive_score / triple_weight do not match the queries")
+    if d.scorer == AFFINE:
+        neg, _, _ = _affine_candidates(d, neg)
+    # ONE allocation: scores, score gradients, row terms, d_pos, loss (every piece starts on a 16-byte boundary;
+    # dense rows: the backward kernels take contiguous [nq, n_neg] matrices)
+    ld = n_neg
+    mat = (nq * ld + 3) // 4 * 4
+    nq4 = (nq + 3) // 4 * 4
+    buf = torch.empty((2 * mat + 2 * nq4 + 4,), dtype=torch.float32, device=dev)
+    out = buf[: nq * ld].view(nq, ld)
+    dn = buf[mat: mat + nq * ld].view(nq, ld)
+    row_loss = buf[2 * mat: 2 * mat + nq]
+    dp = buf[2 * mat + nq4: 2 * mat + nq4 + nq]
+    loss = buf[2 * mat + 2 * nq4: 2 * mat + 2 * nq4 + 1]
+    lib = load()
+    ws_bytes = int(lib.bess_neg_score_shared_workspace(ctypes.byref(d), nq, n_neg))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
+    kd = None
+    if kill is not None:
+        diag_step, ht, ppp, mask = kill
+        kd = KillDesc()
+        kd.diag_step, kd.ht, kd.ppp = int(diag_step), int(bool(ht)), int(ppp)
+        if mask is not None:
+            _same_device([("negative_mask", mask), ("query", query)])
+            if mask.dtype != torch.bool or mask.dim() != 2 or not mask.is_contiguous():
+                raise ValueError("negative_mask must be a contiguous 2-D bool tensor")
+            kd.mask, kd.mask_rows, kd.mask_cols = mask.data_ptr(), int(mask.shape[0]), int(mask.shape[1])
+    with _on(dev), _Timed("bess_neg_score_shared_fwd_loss", dev):
+        stream = _stream(dev)
+        counters = _counters(dev, stream, (nq + 15) // 16 + 1)
+        rc = lib.bess_neg_score_shared_fwd_loss(
+            ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(), _idx(neg.idx, "negative idx"), n_neg,
+            out.data_ptr(), ld, ctypes.byref(kd) if kd is not None else None, ctypes.byref(l), pos.data_ptr(),
+            weight.data_ptr(), weight.numel(), row_loss.data_ptr(), loss.data_ptr(), dp.data_ptr(), dn.data_ptr(), ld,
+            counters.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes, stream)
+    _check(rc, "bess_neg_score_shared_fwd_loss")
+    return out, loss.reshape(()), dp, dn
 
 
 def scatter_add_rows(dst: torch.Tensor, idx: torch.Tensor, src: torch.Tensor, scale: float = 1.0) -> None:

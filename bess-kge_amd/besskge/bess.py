@@ -129,6 +129,9 @@ class _ReplicaStep:
         # (`nat.step_prologue`), together with the index of the step's small update lists
         self.jobs: Optional[List[Tuple[torch.Tensor, Optional[torch.Tensor], int]]] = None
         self.d_recv: Optional[torch.Tensor] = None  # [rows of recv, W] f32, cleared by the prologue (n_shard > 1)
+        # training, shared negatives: (loss, d_pos, d_neg) that came out of the scoring call (K4 + K7 + K8 behind
+        # `bess_neg_score_shared_fwd_loss`: one launch where the scoring kernel finishes the loss rows itself)
+        self.loss_pre: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
 
 
 class _PendingUpdate:
@@ -395,7 +398,9 @@ class BessKGE(torch.nn.Module, ABC):
         if self.loss_fn:
             w = self._triple_weight(batch, dev)
             ld = self.loss_fn.kernel_desc(int(neg.shape[1]))
-            if want_norm:  # ScoreMoving's fused training forward: the softmax normalisation goes back to the shards
+            if st.loss_pre is not None and not want_norm:  # the scoring call has done K8 already
+                loss, d_pos, d_neg = st.loss_pre
+            elif want_norm:  # ScoreMoving's fused training forward: the softmax normalisation goes back to the shards
                 loss, d_pos, d_neg, st.loss_norm = nat.loss_fwd_bwd(ld, pos, neg, w, want_grad, want_norm=True)
             else:
                 loss, d_pos, d_neg = nat.loss_fwd_bwd(ld, pos, neg, w, want_grad)
@@ -906,7 +911,16 @@ class BessKGE(torch.nn.Module, ABC):
             ahead[id(g)] = self._segment_index_on_side(g, st)
         if g.query is None:
             g.query, g.query_ctx = self.score_fn.query_fwd(g.side, g.ent, g.rel_idx)
-        if g.shared:
+        with_loss = getattr(self, "_train_loss_in_scoring", None)
+        if g.shared and with_loss is not None and st is not None and len(st.groups) == 1 and g.sel is None \
+                and (st.kill_applied or with_loss.get("no_kill")):
+            # training: K4 + K7 + K8 behind one call (one launch for the packed L1 kernel at notebook sizes)
+            b = with_loss["batch"]
+            w = self._triple_weight(b, g.query.device)
+            g.out, loss, d_pos, d_neg = nat.neg_score_shared_fwd_loss(
+                desc, self.loss_fn.kernel_desc(len(g.neg)), g.query, g.neg, st.positive_score, w, kill=g.kill)
+            st.loss_pre = (loss, d_pos, d_neg)
+        elif g.shared:
             g.out = nat.neg_score_shared_fwd(desc, g.query, g.neg, kill=g.kill)
         elif fuse is not None and st is not None and (
                 g.neg.base is st.table or (g.neg.base is st.recv and self.score_fn.bilinear_candidates)):
@@ -1047,7 +1061,17 @@ class EmbeddingMovingBessKGE(BessKGE):
                     st.kill_applied = True
                 else:
                     fz = None  # two-pass path: scores, K7, loss, backward
-            outs = self._run_groups(st, desc, fz)
+            in_scoring = self.__dict__.get("_train_loss_in_scoring_on")
+            if in_scoring and self.loss_fn is not None and hasattr(self.loss_fn, "kernel_desc") and not self.evaluation:
+                src_b = b.get("_kill_from")
+                if src_b is not None:
+                    no_kill = (not st.kill_applied
+                               and self._kill_spec(src_b, st.n, st.ppp, st.n * st.ppp, st.table.device) is None)
+                    self.__dict__["_train_loss_in_scoring"] = dict(batch=src_b, no_kill=no_kill)
+            try:
+                outs = self._run_groups(st, desc, fz)
+            finally:
+                self.__dict__["_train_loss_in_scoring"] = None
             done.append(st)
             if len(outs) == 1:
                 st.negative_score = outs[0]
@@ -1210,6 +1234,7 @@ class EmbeddingMovingBessKGE(BessKGE):
         self.__dict__["_seg_ahead"] = None if accumulating else {}
         self.__dict__["_small_early"] = None if accumulating else {}
         self.__dict__["_ahead_optimizer"] = optimizer
+        self.__dict__["_train_loss_in_scoring_on"] = True
         try:
             steps = self._score_replicas(batches)
             seg_index = {} if accumulating else self._prefetch_segment_indices(steps)
@@ -1219,6 +1244,7 @@ class EmbeddingMovingBessKGE(BessKGE):
             self.__dict__["_seg_ahead"] = None
             self.__dict__["_small_early"] = None
             self.__dict__["_ahead_optimizer"] = None
+            self.__dict__["_train_loss_in_scoring_on"] = False
         if not accumulating:
             self._small_ahead.update(self._small_index_ahead([st for st in steps if id(st) not in self._small_ahead],
                                                              optimizer))

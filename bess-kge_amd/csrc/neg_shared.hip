@@ -684,6 +684,42 @@ extern "C" int bess_neg_score_shared_fwd_masked(const bess_model_desc* d, const 
                             kill->mask_rows, kill->mask_cols, stream);
 }
 
+extern "C" int bess_neg_score_shared_fwd_loss(const bess_model_desc* d, const float* query, int64_t n_query,
+                                              const void* neg_base, const int32_t* neg_idx, int64_t n_neg,
+                                              float* out, int64_t ld_out, const bess_kill_desc* kill,
+                                              const bess_loss_desc* l, const float* pos, const float* weight,
+                                              int64_t weight_len, float* row_loss, float* loss, float* d_pos,
+                                              float* d_neg, int64_t ld_dneg, int32_t* counters, void* workspace,
+                                              int64_t workspace_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    BESS_REQUIRE(l && pos && weight && row_loss && loss && d_pos && d_neg && counters, "neg_score_shared_fwd_loss: NULL pointer");
+    BESS_REQUIRE(n_query > 0 && n_neg > 0 && query && neg_base && out && ld_out >= n_neg && ld_dneg >= n_neg,
+                 "neg_score_shared_fwd_loss: bad sizes / NULL pointer");
+    BESS_REQUIRE(l->kind >= BESS_LOSS_LOGSIGMOID && l->kind <= BESS_LOSS_SSCE, "neg_score_shared_fwd_loss: unknown loss %d", l->kind);
+    BESS_REQUIRE(weight_len == 1 || weight_len == n_query, "neg_score_shared_fwd_loss: weight_len must be 1 or n_query");
+    if (d->scorer <= BESS_COMPLEX && use_l1_pk(d, query, neg_base) && l1_pk_loss_in_launch(n_neg, out, ld_out, d_neg, ld_dneg)) {
+        if (kill) {
+            BESS_REQUIRE(kill->diag_step >= 0, "neg_score_shared_fwd_loss: negative diag_step");
+            if (kill->mask) {
+                BESS_REQUIRE(kill->mask_cols > 0 && kill->mask_cols <= n_neg, "neg_score_shared_fwd_loss: mask_cols");
+                BESS_REQUIRE(kill->mask_rows == 1 || kill->mask_rows == 2 || kill->mask_rows == n_query,
+                             "neg_score_shared_fwd_loss: mask_rows %lld not 1, 2 or n_query", (long long)kill->mask_rows);
+            }
+            if (kill->ht || (kill->mask && kill->mask_rows == 2))
+                BESS_REQUIRE(kill->ppp >= 2 && (kill->ppp % 2) == 0 && (n_query % kill->ppp) == 0,
+                             "neg_score_shared_fwd_loss: 'ht' needs an even block size dividing n_query");
+        }
+        return l1_pk_fwd_loss(d, query, n_query, neg_base, neg_idx, n_neg, out, ld_out, kill, l, pos, weight, weight_len,
+                              row_loss, loss, d_pos, d_neg, ld_dneg, counters, as_stream(stream));
+    }
+    // the other kernel families: the scoring launch (+ K7), then the loss launch(es)
+    if (int e = bess_neg_score_shared_fwd_masked(d, query, n_query, neg_base, neg_idx, n_neg, out, ld_out, kill, workspace,
+                                                 workspace_bytes, stream))
+        return e;
+    return bess_loss_fwd_bwd_one_launch(l, pos, out, n_query, n_neg, ld_out, weight, weight_len, row_loss, loss, d_pos,
+                                        d_neg, ld_dneg, nullptr, counters, stream);
+}
+
 extern "C" int64_t bess_neg_score_shared_workspace(const bess_model_desc* d, int64_t n_query, int64_t n_neg) {
     if (!d || check_desc(d) || n_query <= 0 || n_neg <= 0) return 0;
     if (d->scorer == BESS_BOXE || d->scorer == BESS_AFFINE || reduce_of(d) != RED_DOT) return 0;

@@ -22,22 +22,204 @@
 
 #include "common.h"
 
-#ifndef BESS_SORT_RADIX_BITS
-#define BESS_SORT_RADIX_BITS 9
-#endif
-
 namespace bess {
 
 static inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 
-// rocPRIM's default sorts up to 2^20 items with ~10 merge passes; the row ids have
-// few significant bits, so the Onesweep LSD radix sort (stable) is 3 passes instead.
-// 9 bits per place instead of rocPRIM's 8: the 17 significant bits of a 93,773-row shard (BASELINE
-// configs[1]), and the 18-19 of a 312,576-row one, then take two passes over the references instead of three.
-using OnesweepConfig = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>,
-                                                           rocprim::kernel_config<1024, 8>, BESS_SORT_RADIX_BITS,
-                                                           rocprim::block_radix_rank_algorithm::match>;
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, OnesweepConfig, 32768>;
+// ---- device-wide stable LSD radix sort of (row id, reference) pairs: kernels only ------------------------------
+// rocPRIM's radix sort clears its histograms / look-back state with hipMemsetAsync.  Recorded into a hipGraph those
+// become MEMSET nodes, and on this ROCm a recorded training step whose side branch interleaves memset nodes with
+// the sort's kernels is not safe to replay: round 3 saw buffers that a recorded clear should have zeroed keep what
+// the previous replay left (Adam moments of 1e20), round 4 a memory-aperture fault inside the Onesweep kernel
+// that reads the look-back state those nodes clear (profiles/r04/graph_memset_probe.md).  Simple graphs replay
+// their memset nodes correctly (same probe, experiment A) - the failure needs the step's topology - so nothing of
+// this library puts a memset node into a graph any more: every clear is a kernel (common.h: fill_words_async) and
+// the sort below is our own.  tests/test_graph_nodes.py pins "no memset node in any recorded step".
+//
+// One pass per RB-bit place (RB = ceil(row_bits / passes) <= 9: two passes for the 17-19 bits of BASELINE's
+// shards).  A WAVE owns a contiguous tile of the input and walks it 64 keys at a time; the lanes that share a
+// digit find each other with RB ballots (wave multisplit), so ranks inside a wave's 64 keys cost no atomics and
+// keep input order - the sort is stable, equal rows keep reference order, sums stay bitwise reproducible.
+//   k_rsort_hist     per-wave digit histograms                                  H[digit][wave]
+//   k_rsort_rowscan  one workgroup per digit: exclusive scan over the waves, the digit's total
+//   k_rsort_scatter  base of every digit (scan of the totals, per workgroup in LDS) + the wave's running
+//                    offsets in LDS; keys / references written to their places
+constexpr int RS_WAVES = 4;  // waves per workgroup (each with its own 2 KiB of counters)
+constexpr int RS_MAX_BITS = 9;
+constexpr int RS_MAX_WAVES = 2048;
+
+struct RSortArgs {
+    const int32_t* keys_in;
+    const int32_t* vals_in;  // NULL: the value is the position (first pass)
+    int32_t* keys_out;
+    int32_t* vals_out;
+    int32_t* hist;    // [1 << rb][n_wave]
+    int32_t* totals;  // [1 << rb]
+    int64_t n;
+    int64_t tile;  // keys per wave (multiple of 64)
+    int n_wave;
+    int shift, rb;
+};
+
+__device__ __forceinline__ uint64_t rsort_peers(int digit, int rb, bool valid) {
+    uint64_t peers = __ballot(valid);
+    for (int b = 0; b < rb; ++b) {
+        const bool bit = (digit >> b) & 1;
+        const uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    return valid ? peers : 0ull;
+}
+
+__global__ __launch_bounds__(64 * RS_WAVES) void k_rsort_hist(RSortArgs a) {
+    __shared__ int32_t cnt[RS_WAVES][1 << RS_MAX_BITS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int w = blockIdx.x * RS_WAVES + wv;
+    const int nd = 1 << a.rb;
+    if (w >= a.n_wave) return;  // (whole waves, no barrier in this kernel)
+    for (int d = lane; d < nd; d += 64) cnt[wv][d] = 0;
+    const int64_t lo = w * a.tile, hi = min(lo + a.tile, a.n);
+    const uint64_t below = (1ull << lane) - 1ull;
+    int32_t knext = lo + lane < hi ? a.keys_in[lo + lane] : 0;  // one chunk of keys ahead
+    for (int64_t i0 = lo; i0 < hi; i0 += 64) {
+        const bool valid = i0 + lane < hi;
+        const int32_t key = knext;
+        if (i0 + 64 + lane < hi) knext = a.keys_in[i0 + 64 + lane];
+        const int digit = (static_cast<uint32_t>(key) >> a.shift) & (nd - 1);
+        const uint64_t peers = rsort_peers(digit, a.rb, valid);
+        if (valid && (peers & below) == 0) cnt[wv][digit] += __popcll(peers);  // the lowest lane of each digit
+    }
+    for (int d = lane; d < nd; d += 64) a.hist[static_cast<int64_t>(d) * a.n_wave + w] = cnt[wv][d];
+}
+
+// workgroup d: H[d][0 .. n_wave) becomes its exclusive scan, totals[d] its sum
+__global__ __launch_bounds__(256) void k_rsort_rowscan(int32_t* __restrict__ hist, int32_t* __restrict__ totals, int n_wave) {
+    __shared__ int32_t wsum[4];
+    __shared__ int32_t carry_s;
+    int32_t* row = hist + static_cast<int64_t>(blockIdx.x) * n_wave;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n_wave; i0 += 256) {
+        const int i = i0 + t;
+        const int32_t v = i < n_wave ? row[i] : 0;
+        int32_t inc = v;  // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t u = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += u;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int32_t before = carry_s;
+        for (int k = 0; k < wv; ++k) before += wsum[k];
+        if (i < n_wave) row[i] = before + inc - v;
+        __syncthreads();
+        if (t == 255) carry_s = before + inc;
+        __syncthreads();
+    }
+    if (t == 0) totals[blockIdx.x] = carry_s;
+}
+
+__global__ __launch_bounds__(64 * RS_WAVES) void k_rsort_scatter(RSortArgs a) {
+    __shared__ int32_t off[RS_WAVES][1 << RS_MAX_BITS];
+    __shared__ int32_t base[1 << RS_MAX_BITS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int w = blockIdx.x * RS_WAVES + wv;
+    const int nd = 1 << a.rb;
+    if (wv == 0) {  // first place of every digit: exclusive scan of the digits' totals (nd <= 512: 8 per lane)
+        int32_t v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int d = lane * 8 + k;
+            v[k] = d < nd ? a.totals[d] : 0;
+            sum += v[k];
+        }
+        int32_t inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t u = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += u;
+        }
+        int32_t run = inc - sum;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int d = lane * 8 + k;
+            if (d < nd) base[d] = run;
+            run += v[k];
+        }
+    }
+    __syncthreads();
+    if (w >= a.n_wave) return;
+    for (int d = lane; d < nd; d += 64) off[wv][d] = base[d] + a.hist[static_cast<int64_t>(d) * a.n_wave + w];
+    const int64_t lo = w * a.tile, hi = min(lo + a.tile, a.n);
+    const uint64_t below = (1ull << lane) - 1ull;
+    int32_t knext = lo + lane < hi ? a.keys_in[lo + lane] : 0;
+    int32_t vnext = (a.vals_in && lo + lane < hi) ? a.vals_in[lo + lane] : 0;
+    for (int64_t i0 = lo; i0 < hi; i0 += 64) {
+        const bool valid = i0 + lane < hi;
+        const int32_t key = knext;
+        const int32_t val = a.vals_in ? vnext : static_cast<int32_t>(i0 + lane);
+        if (i0 + 64 + lane < hi) {
+            knext = a.keys_in[i0 + 64 + lane];
+            if (a.vals_in) vnext = a.vals_in[i0 + 64 + lane];
+        }
+        const int digit = (static_cast<uint32_t>(key) >> a.shift) & (nd - 1);
+        const uint64_t peers = rsort_peers(digit, a.rb, valid);
+        // (a wave's LDS accesses execute in program order: every lane of a digit reads the running offset before
+        // the digit's lowest lane advances it)
+        const int32_t at = valid ? off[wv][digit] : 0;
+        const int rank = __popcll(peers & below);
+        if (valid) {
+            a.keys_out[at + rank] = key;
+            a.vals_out[at + rank] = val;
+            if (rank == 0) off[wv][digit] = at + __popcll(peers);
+        }
+    }
+}
+
+// waves (= tiles) of a sort of n keys: tiles of at least 512 keys, at most RS_MAX_WAVES waves
+static void rsort_plan(int64_t n, int* n_wave, int64_t* tile) {
+    int64_t t = std::max<int64_t>(512, (n + RS_MAX_WAVES - 1) / RS_MAX_WAVES);
+    t = (t + 63) / 64 * 64;
+    *tile = t;
+    *n_wave = static_cast<int>((n + t - 1) / t);
+}
+static int rsort_passes(int bits) { return (bits + RS_MAX_BITS - 1) / RS_MAX_BITS; }
+static size_t rsort_hist_bytes(int64_t n) {  // histograms + totals
+    int nw;
+    int64_t tile;
+    rsort_plan(n, &nw, &tile);
+    return sizeof(int32_t) * (size_t(1) << RS_MAX_BITS) * (static_cast<size_t>(nw) + 1);
+}
+
+// keys[n] (row ids < 2^bits) -> keys_sorted, refs_sorted (positions 0 .. n-1 in sorted order, stable).
+// tmp_k / tmp_v: n int32 each; hist: rsort_hist_bytes(n).
+static int radix_sort_refs(const int32_t* keys, int64_t n, int bits, int32_t* keys_sorted, int32_t* refs_sorted,
+                           int32_t* tmp_k, int32_t* tmp_v, int32_t* hist, hipStream_t st) {
+    const int passes = rsort_passes(bits);
+    const int rb = (bits + passes - 1) / passes;
+    RSortArgs a{};
+    a.n = n;
+    a.hist = hist;
+    a.rb = rb;
+    rsort_plan(n, &a.n_wave, &a.tile);
+    a.totals = hist + (size_t(1) << RS_MAX_BITS) * static_cast<size_t>(a.n_wave);
+    const unsigned grid = static_cast<unsigned>((a.n_wave + RS_WAVES - 1) / RS_WAVES);
+    // the last pass writes (keys_sorted, refs_sorted); the passes before alternate so that it does
+    for (int p = 0; p < passes; ++p) {
+        const bool to_final = ((passes - 1 - p) % 2) == 0;
+        a.keys_in = p == 0 ? keys : (to_final ? tmp_k : keys_sorted);
+        a.vals_in = p == 0 ? nullptr : (to_final ? tmp_v : refs_sorted);
+        a.keys_out = to_final ? keys_sorted : tmp_k;
+        a.vals_out = to_final ? refs_sorted : tmp_v;
+        a.shift = p * rb;
+        k_rsort_hist<<<grid, 64 * RS_WAVES, 0, st>>>(a);
+        k_rsort_rowscan<<<1u << rb, 256, 0, st>>>(hist, a.totals, a.n_wave);
+        k_rsort_scatter<<<grid, 64 * RS_WAVES, 0, st>>>(a);
+    }
+    return check_launch("radix sort of the references");
+}
 
 struct CubSizes {
     size_t sort, rle, scan, total_cub;
@@ -46,10 +228,7 @@ struct CubSizes {
 static hipError_t cub_sizes(int64_t n, CubSizes* cs) {
     int32_t* p = nullptr;
     size_t a = 0, b = 0, c = 0;
-    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(nullptr, a, p, p, p, p, static_cast<size_t>(n), 0u, 32u,
-                                                          hipStream_t(0));
-    if (e != hipSuccess) return e;
-    e = hipcub::DeviceRunLengthEncode::Encode(nullptr, b, p, p, p, p, static_cast<int>(n), 0);
+    hipError_t e = hipcub::DeviceRunLengthEncode::Encode(nullptr, b, p, p, p, p, static_cast<int>(n), 0);
     if (e != hipSuccess) return e;
     e = hipcub::DeviceScan::ExclusiveSum(nullptr, c, p, p, static_cast<int>(n), 0);
     if (e != hipSuccess) return e;
@@ -197,10 +376,6 @@ __global__ __launch_bounds__(SMALL_T) void k_step_prologue(WordJobs J, IdLists i
         const int64_t off = i - J.first[j];
         J.dst[j][off] = J.src[j] ? J.src[j][off] : J.value[j];
     }
-}
-
-__global__ __launch_bounds__(256) void k_iota(int32_t* __restrict__ out, int64_t n) {
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) out[i] = static_cast<int32_t>(i);
 }
 
 // seg_offsets[n_seg] = n_refs (close the last segment); ExclusiveSum wrote only n entries
@@ -857,8 +1032,9 @@ extern "C" int bess_segment_index_workspace(int64_t n_refs, size_t* bytes) {
     CubSizes cs;
     hipError_t e = cub_sizes(n_refs > 0 ? n_refs : 1, &cs);
     if (e != hipSuccess) return fail(static_cast<int>(e), "hipcub size query: %s", hipGetErrorString(e));
-    // [sorted keys][iota][counts][cub temp]
-    *bytes = 3 * align_up(sizeof(int32_t) * static_cast<size_t>(n_refs)) + align_up(cs.total_cub) + 256;
+    // [sorted keys][sort scratch: keys][sort scratch: references][counts][digit histograms][cub temp]
+    *bytes = 4 * align_up(sizeof(int32_t) * static_cast<size_t>(n_refs)) + align_up(rsort_hist_bytes(n_refs > 0 ? n_refs : 1)) +
+             align_up(cs.total_cub) + 256;
     return BESS_OK;
 }
 
@@ -893,16 +1069,17 @@ extern "C" int bess_build_segment_index(const int32_t* idx, int64_t n_refs, int3
     char* ws = static_cast<char*>(workspace);
     const size_t blk = align_up(sizeof(int32_t) * static_cast<size_t>(n_refs));
     int32_t* keys_sorted = reinterpret_cast<int32_t*>(ws);
-    int32_t* iota = reinterpret_cast<int32_t*>(ws + blk);
-    int32_t* counts = reinterpret_cast<int32_t*>(ws + 2 * blk);
-    void* cub_tmp = ws + 3 * blk;
-    size_t cub_bytes = workspace_bytes - 3 * blk;
-    k_iota<<<static_cast<unsigned>(std::min<int64_t>(ceil_div(n_refs, 256), 2048)), 256, 0, st>>>(iota, n_refs);
-    // stable LSD radix sort on the significant bits only: equal rows keep reference order
-    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(cub_tmp, cub_bytes, idx, keys_sorted, iota, refs_sorted,
-                                                          static_cast<size_t>(n_refs), 0u,
-                                                          static_cast<unsigned>(row_bits), st);
-    if (e != hipSuccess) return fail(static_cast<int>(e), "radix sort: %s", hipGetErrorString(e));
+    int32_t* tmp_k = reinterpret_cast<int32_t*>(ws + blk);
+    int32_t* tmp_v = reinterpret_cast<int32_t*>(ws + 2 * blk);
+    int32_t* counts = reinterpret_cast<int32_t*>(ws + 3 * blk);
+    int32_t* hist = reinterpret_cast<int32_t*>(ws + 4 * blk);
+    const size_t hist_bytes = align_up(rsort_hist_bytes(n_refs));
+    void* cub_tmp = ws + 4 * blk + hist_bytes;
+    size_t cub_bytes = workspace_bytes - 4 * blk - hist_bytes;
+    // stable LSD radix sort on the significant bits only: equal rows keep reference order (own kernels: no memset
+    // node when the step is recorded into a hipGraph)
+    if (int rc = radix_sort_refs(idx, n_refs, row_bits, keys_sorted, refs_sorted, tmp_k, tmp_v, hist, st)) return rc;
+    hipError_t e;
     e = hipcub::DeviceRunLengthEncode::Encode(cub_tmp, cub_bytes, keys_sorted, seg_rows, counts, n_seg, n, st);
     if (e != hipSuccess) return fail(static_cast<int>(e), "run-length encode: %s", hipGetErrorString(e));
     // counts beyond n_seg are undefined but never read: offsets are consumed up to n_seg only

@@ -765,6 +765,21 @@ int bess_pack_exchange(bess_comm* comm, int32_t dtype, int32_t width, const void
                        const int32_t* idx, int64_t rows_per_peer, void* send, void* recv,
                        void* stream);
 
+/* K4 + K7 + K8 of a training step with shared negatives behind one call (scoring.py:194-197 / 251-252 +
+ * bess.py:182-245 + loss.py:28-251): out [n_query, ld_out] receives the (masked) scores as from
+ * bess_neg_score_shared_fwd_masked (kill may be NULL), then row_loss / loss / d_pos / d_neg as from
+ * bess_loss_fwd_bwd with pos = the positive scores.  TransE / RotatE with p = 1 on f16 tables and rows of up to
+ * 1024 scores (16-byte aligned, n_neg % 4 == 0): ONE launch - the workgroup that stores the last tile of a block
+ * of rows finishes the block's loss rows, the last block sums the terms in a fixed order (bitwise reproducible);
+ * every other case: the scoring launch followed by the loss launch(es).  counters: int32
+ * [ceil(n_query / 16) + 1] on the device, zero on entry, left zero (keep one array per stream). */
+int bess_neg_score_shared_fwd_loss(const bess_model_desc* desc, const float* query, int64_t n_query,
+                                   const void* neg_base, const int32_t* neg_idx, int64_t n_neg, float* out,
+                                   int64_t ld_out, const bess_kill_desc* kill, const bess_loss_desc* loss_desc,
+                                   const float* pos, const float* weight, int64_t weight_len, float* row_loss,
+                                   float* loss, float* d_pos, float* d_neg, int64_t ld_dneg, int32_t* counters,
+                                   void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- recorded steps -----------------------------------------------------------
  * A step of this library can be captured into a hipGraph as a whole (every call is asynchronous on the
  * caller's stream, every clear is a kernel).  bess_graph_node_counts tells what a captured graph holds:

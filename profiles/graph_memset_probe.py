@@ -91,6 +91,43 @@ for i in range(4):
 (counts,) = runner.graph_node_counts().values()
 print(json.dumps(dict(exp="B", build=mode, adam_m_max_per_step=m_max, nodes=counts,
                       verdict="stale" if max(m_max) > 1e3 else "clean")), flush=True)
+# ---- B2: the round-3 code path itself.  B no longer reaches a library clear (ComplEx rows that arrived through the
+# exchange are scored by the fused forward since round 3; the backward then gets d_query = NULL).  TransE p = 1
+# with 64 negatives per shard pair does: bess_neg_score_pertriple_bwd clears d_query (two work items per query add
+# to it with atomics) - through hipMemsetAsync in the probe build.
+from besskge.bess import EmbeddingMovingBessKGE as _EM  # noqa: E402
+from besskge.loss import LogSigmoidLoss as _LS  # noqa: E402
+from besskge.negative_sampler import RandomShardedNegativeSampler as _NS  # noqa: E402
+from besskge.scoring import TransE as _TransE  # noqa: E402
+
+torch.manual_seed(0)
+fn2 = _TransE(False, 1, sharding, 7, 32, device=dev)
+ns2 = _NS(64, sharding, 3, "h", local_sampling=False, flat_negative_format=False)
+model2 = _EM(ns2, fn2, _LS(margin=2.0, negative_adversarial_sampling=True))
+batches2 = [_batch(sharding, 2, 16, 64, s) for s in range(6)]
+runner2 = runtime.training_model(model2, runtime.Options(use_graphs=True, keep_graph=True), runtime.Adam(lr=0.01), device=dev)
+m2, t2 = [], []
+for i in range(6):
+    runner2(**batches2[i])
+    torch.cuda.synchronize()
+    st = model2._optimizer_state[model2._local_table(0).data_ptr()]
+    m2.append(float(st["s"][0].abs().max()))
+    t2.append(float(model2.score_fn.entity_embedding.detach().abs().max()))
+(counts2,) = runner2.graph_node_counts().values()
+# the same six steps without a graph, from the same start: the reference trajectory
+torch.manual_seed(0)
+fn3 = _TransE(False, 1, sharding, 7, 32, device=dev)
+model3 = _EM(_NS(64, sharding, 3, "h", local_sampling=False, flat_negative_format=False), fn3,
+             _LS(margin=2.0, negative_adversarial_sampling=True))
+runner3 = runtime.training_model(model3, runtime.Options(), runtime.Adam(lr=0.01), device=dev)
+for i in range(6):
+    runner3(**batches2[i])
+torch.cuda.synchronize()
+off = (model3.score_fn.entity_embedding.detach() - model2.score_fn.entity_embedding.detach()).abs()
+print(json.dumps(dict(exp="B2", build=mode, adam_m_max_per_step=m2, table_max_per_step=t2, nodes=counts2,
+                      replayed_vs_eager_max_diff=float(off.max()), rows_differing=int((off.max(-1).values > 1e-4).sum()),
+                      verdict="stale" if (max(m2) > 1e3 or float(off.max()) > 0.05) else "clean")), flush=True)
+
 # ---- C: the DOT dump names every memset node with its parameters
 (entry,) = runner._graphs.values()
 dot = out_dir / f"graph_memset_probe_{mode}.dot"

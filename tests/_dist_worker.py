@@ -102,14 +102,14 @@ def bess(out_dir: str) -> None:
             model = build_model(c, dev)
             lr = 0.125
             runner = runtime.training_model(model, options(device_iterations=1), runtime.SGD(lr=lr), group=g, device=dev)
+            recorded = os.environ.get("BESS_USE_GRAPHS", "0") == "1"
+            snap = runner._training_snapshot() if recorded else None  # tables, dense parameters, buffers
             res = runner(**{k: v[: n] for k, v in batch.items()})
-            if os.environ.get("BESS_USE_GRAPHS", "0") == "1":
-                # recorded steps: the first call recorded AND took the step; a replay on restored tables must take
-                # the same one (the collectives of the graph re-run with the peers' new data)
+            if recorded:
+                # recorded steps: the first call recorded AND took the step; a replay from the same start must take
+                # the same one (the collectives of the graph re-run with the peers' data)
                 first = model.score_fn.entity_embedding.detach().clone()
-                c2 = load_bess_case(case)
-                model.score_fn.entity_embedding.data.copy_(c2["table"][r: r + 1].to(dev))
-                model.score_fn.relation_embedding.data.copy_(c2["rel"].to(dev))
+                runner._restore_training_snapshot(snap)
                 res = runner(**{k: v[: n] for k, v in batch.items()})
                 torch.cuda.synchronize()
                 # (fp32 atomics of the plain-SGD scatter: equal up to the order of the additions)
