@@ -85,7 +85,7 @@ class OptDesc(ctypes.Structure):
 OPT_SGD, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
 FLAG_FP32_MATH = 1  # BESS_FLAG_FP32_MATH (ModelDesc.reserved[0] of the four native scorers)
 FLAG_PREZEROED = 2  # BESS_FLAG_PREZEROED: the targets of bess_neg_score_shared_bwd are zero on entry
-FLAG_DNEG_BY_ROW = 4  # BESS_FLAG_DNEG_BY_ROW: bess_neg_score_pertriple_bwd stores d_neg at row neg_idx[k] of a row-space matrix
+FLAG_DNEG_BY_ROW = 4  # BESS_FLAG_DNEG_BY_ROW: entity gradients land at their row ids in row-space matrices (include/besskge_hip.h)
 
 
 class KillDesc(ctypes.Structure):
@@ -198,6 +198,11 @@ SIGNATURES = {
     "bess_allreduce_sum_f32": [_vp, _vp, _vp, _i64, _vp],
     "bess_pack_exchange": [_vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp],
     "bess_graph_node_counts": [_vp, _c_i32p, _i32],
+    "bess_direct_update": [ctypes.POINTER(OptDesc), _i32, _i32, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_i64), _vp, _vp,
+                           _vp, _vp, _vp, _vp, _vp, _i64, _f32, _vp],
+    "bess_neg_score_shared_bwd_by_row": [_MD, _i64, _i64],
+    "bess_query_triple_fwd_jobs": [_MD, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, ctypes.POINTER(_vp),
+                                   ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(_i64), _vp],
     "bess_neg_score_shared_fwd_loss": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, ctypes.POINTER(KillDesc), _LD, _vp, _vp, _i64,
                                        _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp],
 }
@@ -470,12 +475,40 @@ def score_triple_bwd(d: ModelDesc, head: RowSource, tail: RowSource, rel_table: 
     return dh, dt
 
 
+def _job_arrays(jobs: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], int]], who: str):
+    """ctypes arrays (dst, src, value, words) of copy / fill jobs over 4-byte elements (`step_prologue`)."""
+    nj = len(jobs)
+    if nj > MAX_WORD_JOBS:
+        raise ValueError(f"{who}: too many jobs")
+    dst, src = (_vp * max(1, nj))(), (_vp * max(1, nj))()
+    val, words = (ctypes.c_uint32 * max(1, nj))(), (_i64 * max(1, nj))()
+    for i, (d_, s_, v_) in enumerate(jobs):
+        if d_.element_size() != 4 or not d_.is_contiguous():
+            raise ValueError(f"{who}: job targets must be contiguous tensors of 4-byte elements")
+        if s_ is not None and (s_.element_size() != 4 or not s_.is_contiguous() or s_.numel() != d_.numel()):
+            raise ValueError(f"{who}: a job's source must match its target")
+        dst[i], src[i], val[i], words[i] = d_.data_ptr(), (s_.data_ptr() if s_ is not None else None), int(v_), d_.numel()
+    return dst, src, val, words
+
+
 def query_triple_fwd(d: ModelDesc, side: int, head: RowSource, tail: RowSource, rel_table: torch.Tensor,
-                     rel_idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(query [n, W], positive score [n]) in one launch."""
+                     rel_idx: torch.Tensor, jobs: Optional[Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], int]]] = None
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(query [n, W], positive score [n]) in one launch.  `jobs`: copy / fill jobs as `step_prologue` takes them, run
+    by spare workgroups of the same launch (`bess_query_triple_fwd_jobs`)."""
     dev, n = _triple_operands(d, head, tail, rel_table, rel_idx)
     q = torch.empty((n, d.width), dtype=torch.float32, device=dev)
     out = torch.empty((n,), dtype=torch.float32, device=dev)
+    if jobs:
+        _same_device([("query rows", head.base)] + [("job dst", j[0]) for j in jobs] + [("job src", j[1]) for j in jobs])
+        dst, src, val, words = _job_arrays(jobs, "query_triple_fwd")
+        with _on(dev):
+            rc = load().bess_query_triple_fwd_jobs(
+                ctypes.byref(d), side, head.base.data_ptr(), _idx(head.idx, "head_idx"), tail.base.data_ptr(),
+                _idx(tail.idx, "tail_idx"), rel_table.data_ptr(), rel_idx.data_ptr(), n, q.data_ptr(), out.data_ptr(),
+                len(jobs), dst, src, val, words, _stream(dev))
+        _check(rc, "bess_query_triple_fwd_jobs")
+        return q, out
     with _on(dev):
         rc = load().bess_query_triple_fwd(
             ctypes.byref(d), side, head.base.data_ptr(), _idx(head.idx, "head_idx"), tail.base.data_ptr(),
@@ -486,10 +519,32 @@ def query_triple_fwd(d: ModelDesc, side: int, head: RowSource, tail: RowSource, 
 
 
 def query_triple_bwd(d: ModelDesc, side: int, head: RowSource, tail: RowSource, rel_table: torch.Tensor,
-                     rel_idx: torch.Tensor, d_out: torch.Tensor, d_query: torch.Tensor, d_rel_table: torch.Tensor
-                     ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(d_head [n, W], d_tail [n, W]) of positive score and query together; accumulates into d_rel_table."""
+                     rel_idx: torch.Tensor, d_out: torch.Tensor, d_query: torch.Tensor, d_rel_table: torch.Tensor,
+                     rows_acc: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+                     ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """(d_head [n, W], d_tail [n, W]) of positive score and query together; accumulates into d_rel_table.
+    `rows_acc` = (accumulator over head.base's rows, accumulator over tail.base's rows), f32 [rows, W]: the
+    gradient rows are ADDED there at the triples' row ids (BESS_FLAG_DNEG_BY_ROW), nothing is returned."""
     dev, n = _triple_operands(d, head, tail, rel_table, rel_idx)
+    if rows_acc is not None:
+        acc_h, acc_t = rows_acc
+        _same_device([("d_out", d_out), ("d_query", d_query), ("d_rel_table", d_rel_table), ("acc_h", acc_h), ("acc_t", acc_t)])
+        for t, nm in ((d_out, "d_out"), (d_query, "d_query"), (d_rel_table, "d_rel_table"), (acc_h, "acc_h"), (acc_t, "acc_t")):
+            _f32(t, nm)
+        if tuple(acc_h.shape) != (int(head.base.shape[0]), d.width) or tuple(acc_t.shape) != (int(tail.base.shape[0]), d.width) \
+                or head.idx is None or tail.idx is None:
+            raise ValueError("query_triple_bwd: `rows_acc` must cover the row spaces of head.base / tail.base (indexed rows)")
+        if d_out.numel() != n or tuple(d_query.shape) != (n, d.width) or tuple(d_rel_table.shape) != tuple(rel_table.shape):
+            raise ValueError("query_triple_bwd: gradient shapes do not match")
+        d = copy_desc(d)
+        d.reserved[0] |= FLAG_DNEG_BY_ROW
+        with _on(dev):
+            rc = load().bess_query_triple_bwd(
+                ctypes.byref(d), side, head.base.data_ptr(), _idx(head.idx, "head_idx"), tail.base.data_ptr(),
+                _idx(tail.idx, "tail_idx"), rel_table.data_ptr(), rel_idx.data_ptr(), n, d_out.data_ptr(),
+                d_query.data_ptr(), acc_h.data_ptr(), acc_t.data_ptr(), d_rel_table.data_ptr(), _stream(dev))
+        _check(rc, "bess_query_triple_bwd")
+        return None, None
     _same_device([("d_out", d_out), ("d_query", d_query), ("d_rel_table", d_rel_table), ("x", head.base)])
     for t, nm in ((d_out, "d_out"), (d_query, "d_query"), (d_rel_table, "d_rel_table")):
         _f32(t, nm)
@@ -895,12 +950,43 @@ def shared_bwd_buffer(d: ModelDesc, nq: int, n_neg: int, device: torch.device) -
     return torch.empty((nq + n_neg, d.width), dtype=torch.float32, device=device)
 
 
+def shared_bwd_by_row_ok(d: ModelDesc, nq: int, n_neg: int) -> bool:
+    """Does `neg_score_shared_bwd(..., rows_acc=...)` exist for this scorer and shape?"""
+    return bool(load().bess_neg_score_shared_bwd_by_row(ctypes.byref(d), int(nq), int(n_neg)))
+
+
 def neg_score_shared_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, out: torch.Tensor,
-                         d_out: torch.Tensor, prezeroed: Optional[torch.Tensor] = None
-                         ) -> Tuple[torch.Tensor, torch.Tensor]:
+                         d_out: torch.Tensor, prezeroed: Optional[torch.Tensor] = None,
+                         rows_acc: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """Returns (d_query [nq, W], d_neg [n_neg, W]).  `prezeroed`: a `shared_bwd_buffer` the caller has
-    already cleared on this stream - the call then writes into it and does not clear anything."""
+    already cleared on this stream - the call then writes into it and does not clear anything.
+    `rows_acc` (f32 [rows of neg.base, W], `shared_bwd_by_row_ok`): the candidates' gradient rows are ADDED there at
+    their row ids (BESS_FLAG_DNEG_BY_ROW) instead of being returned; `prezeroed` is then the cleared d_query [nq, W]."""
     nq, n_neg = int(query.shape[0]), len(neg)
+    if rows_acc is not None:
+        dev = _neg_operands(d, query, neg, n_neg)
+        _same_device([("d_out", d_out), ("out", out), ("query", query), ("rows_acc", rows_acc)])
+        _f32(d_out, "d_out")
+        _f32(rows_acc, "rows_acc")
+        if tuple(d_out.shape) != (nq, n_neg) or tuple(rows_acc.shape) != (int(neg.base.shape[0]), d.width) or neg.idx is None:
+            raise ValueError("neg_score_shared_bwd: `rows_acc` must be [rows of the candidates' table, W], candidates indexed")
+        d = copy_desc(d)
+        d.reserved[0] |= FLAG_DNEG_BY_ROW
+        if prezeroed is not None:
+            if tuple(prezeroed.shape) != (nq, d.width) or prezeroed.dtype != torch.float32:
+                raise ValueError("neg_score_shared_bwd: with `rows_acc`, `prezeroed` is the cleared d_query [nq, W]")
+            dq = prezeroed
+            d.reserved[0] |= FLAG_PREZEROED
+        else:
+            dq = torch.empty((nq, d.width), dtype=torch.float32, device=dev)
+        with _on(dev), _Timed("bess_neg_score_shared_bwd", dev):
+            rc = load().bess_neg_score_shared_bwd_ws(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
+                                                     _idx(neg.idx, "negative idx"), n_neg, out.data_ptr(), n_neg,
+                                                     d_out.data_ptr(), n_neg, dq.data_ptr(), rows_acc.data_ptr(),
+                                                     None, 0, _stream(dev))
+        _check(rc, "bess_neg_score_shared_bwd")
+        return dq, None
+
     dev = _neg_operands(d, query, neg, n_neg)
     _same_device([("d_out", d_out), ("out", out), ("query", query)])
     _f32(d_out, "d_out")
@@ -1400,6 +1486,66 @@ def coalesced_update(o: Optional[OptDesc], table: torch.Tensor, seg: SegmentInde
             x_table.data_ptr() if x_n else None, x_grad.data_ptr() if x_n else None, x_n, float(x_alpha), _stream(dev))
     _check(rc, "bess_coalesced_update")
     return out
+
+
+class DirectAccumulator:
+    """Scratch of `bess_direct_update` for one table: `acc` [M, W] f32 (zero between steps), `claim` [M] int32 (the
+    generation of the last step that updated each row), `generation` [1] int32 on the device (incremented once per
+    step, before the update: `increment_job()` is the copy job for `step_prologue` that does it)."""
+
+    __slots__ = ("acc", "claim", "generation")
+
+    def __init__(self, table: torch.Tensor) -> None:
+        dev = _dev(table, "table")
+        self.acc = torch.zeros(tuple(table.shape), dtype=torch.float32, device=dev)
+        self.claim = torch.zeros((int(table.shape[0]),), dtype=torch.int32, device=dev)
+        self.generation = torch.ones((1,), dtype=torch.int32, device=dev)
+
+    @staticmethod
+    def bytes_for(table: torch.Tensor) -> int:
+        return int(table.shape[0]) * (int(table.shape[1]) * 4 + 4)
+
+    def increment_job(self) -> Tuple[torch.Tensor, torch.Tensor, int]:
+        return (self.generation, self.generation, 1)
+
+
+def direct_update(o: OptDesc, table: torch.Tensor, id_lists: Sequence[torch.Tensor], scratch: DirectAccumulator,
+                  state1: Optional[torch.Tensor] = None, state2: Optional[torch.Tensor] = None,
+                  axpy: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None) -> None:
+    """K9 + K10 without an index (`bess_direct_update`): the gradients of the rows named by `id_lists` have been
+    added into `scratch.acc` at their row ids; every such row gets ONE optimiser update with its summed gradient,
+    its acc row goes back to zero.  `scratch.generation` must have been incremented for this step."""
+    dev = _same_device([("table", table), ("acc", scratch.acc), ("state1", state1), ("state2", state2)]
+                       + [(f"id_lists[{i}]", x) for i, x in enumerate(id_lists)])
+    W = int(table.shape[1])
+    _rows(table, "table", W)
+    if not 1 <= len(id_lists) <= MAX_ROW_LISTS:
+        raise ValueError(f"direct_update: {len(id_lists)} lists (1 .. {MAX_ROW_LISTS})")
+    if tuple(scratch.acc.shape) != tuple(table.shape):
+        raise ValueError("direct_update: the accumulator belongs to another table")
+    for i, x in enumerate(id_lists):
+        if x.dtype != torch.int32 or not x.is_contiguous():
+            raise ValueError(f"direct_update: id_lists[{i}] must be a contiguous int32 tensor")
+    _state_ok(state1, table, o, "state1")
+    _state_ok(state2, table, o, "state2")
+    ptrs = (_vp * len(id_lists))(*[x.data_ptr() for x in id_lists])
+    lens = (_i64 * len(id_lists))(*[int(x.numel()) for x in id_lists])
+    x_table = x_grad = None
+    x_n, x_alpha = 0, 0.0
+    if axpy is not None:
+        x_table, x_grad, x_alpha = axpy
+        _same_device([("table", table), ("axpy table", x_table), ("axpy grad", x_grad)])
+        _f32(x_grad, "axpy grad")
+        if x_table.dtype != table.dtype or not x_table.is_contiguous() or x_grad.numel() != x_table.numel():
+            raise ValueError("direct_update: the axpy table must be contiguous, of the table's dtype, and match its gradient")
+        x_n = int(x_table.numel())
+    with _on(dev), _Timed("bess_direct_update", dev):
+        rc = load().bess_direct_update(
+            ctypes.byref(o), _dtype_code(table), W, table.data_ptr(), len(id_lists), ptrs, lens, scratch.acc.data_ptr(),
+            scratch.claim.data_ptr(), scratch.generation.data_ptr(),
+            state1.data_ptr() if state1 is not None else None, state2.data_ptr() if state2 is not None else None,
+            x_table.data_ptr() if x_n else None, x_grad.data_ptr() if x_n else None, x_n, float(x_alpha), _stream(dev))
+    _check(rc, "bess_direct_update")
 
 
 def assign_state_rows(seg: Any, slot_map: torch.Tensor, counter: torch.Tensor, capacity: int,

@@ -132,6 +132,10 @@ class _ReplicaStep:
         # training, shared negatives: (loss, d_pos, d_neg) that came out of the scoring call (K4 + K7 + K8 behind
         # `bess_neg_score_shared_fwd_loss`: one launch where the scoring kernel finishes the loss rows itself)
         self.loss_pre: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
+        # training: the shard's update goes through `bess_direct_update` - the backward kernels add their gradient
+        # rows into `direct.acc` at the rows' ids, `direct_lists` names the rows (no index, no dense row gradients)
+        self.direct: Any = None
+        self.direct_lists: List[torch.Tensor] = []
 
 
 class _PendingUpdate:
@@ -623,7 +627,7 @@ class BessKGE(torch.nn.Module, ABC):
         forward kernels - instead of on the critical path after the backward."""
         out: Dict[int, Any] = {}
         for st in steps:
-            plan = self._small_plan(st, optimizer)
+            plan = None if st.direct is not None else self._small_plan(st, optimizer)
             if plan is None:
                 continue
             if sum(int(x.numel()) for x in plan) < 4096:
@@ -644,6 +648,38 @@ class BessKGE(torch.nn.Module, ABC):
     #: unique row (`bess_coalesced_update`) instead of added with fp32 atomics
     coalesce_sgd_from = 65536
 
+    #: shards whose fp32 image (+ 4 bytes per row) is at most this many bytes get a direct-addressed accumulator
+    #: (`bess_direct_update`): their small update lists need no index.  0 switches it off.
+    direct_update_max_bytes = 2 << 30
+
+    def _direct_scratch(self, table: torch.Tensor) -> Any:
+        held = self.__dict__.setdefault("_direct_acc", {})
+        key = (table.data_ptr(), tuple(table.shape))
+        if key not in held:
+            held[key] = nat.DirectAccumulator(table)
+        return held[key]
+
+    def _direct_ok(self, st: _ReplicaStep, optimizer: Any, desc: Any) -> bool:
+        """Does this step's shard update go through `bess_direct_update`?  One shard in the process, one group of
+        shared candidates of the own shard, query + positive score fused (so are their backwards), an update that
+        coalesces per row (f16 shard or a stateful optimiser - plain SGD on fp32 rows adds its atomics straight to
+        the table), full-size optimiser state, a backward that can add its candidate rows by row id, and a shard
+        whose fp32 image fits the scratch budget."""
+        if st.n != 1 or len(st.groups) != 1 or not st.fused_qt:
+            return False
+        g = st.groups[0]
+        if not g.shared or g.neg.base is not st.table or g.neg.idx is None or st.tail.base is not st.table:
+            return False
+        plain = not hasattr(optimizer, "kind") or optimizer.is_plain_sgd
+        if plain and st.table.dtype == torch.float32:
+            return False
+        rows = getattr(optimizer, "state_rows", None)
+        if rows is not None and int(rows) < st.table.shape[0]:
+            return False
+        if nat.DirectAccumulator.bytes_for(st.table) > self.direct_update_max_bytes:
+            return False
+        return nat.shared_bwd_by_row_ok(desc, len(g.ent), len(g.neg))
+
     def _launch_prologue(self, st: _ReplicaStep, optimizer: Any, d_rel: Optional[torch.Tensor]) -> Optional[Any]:
         """ONE launch in front of a training step's kernels (`bess_step_prologue`): the concatenated candidate
         list of an augmented step, the cleared relation gradient and backward targets, and - when the update
@@ -651,7 +687,15 @@ class BessKGE(torch.nn.Module, ABC):
         Returns what `_small_index_ahead` would have: (lists, their SegmentIndex), or None."""
         jobs = st.jobs or []
         desc = self.score_fn.kernel_desc()
+        if len(jobs) + 3 <= nat.MAX_WORD_JOBS and self._direct_ok(st, optimizer, desc):
+            st.direct = self._direct_scratch(st.table)
+            g = st.groups[0]
+            g.bwd_buf = torch.empty((len(g.ent), desc.width), dtype=torch.float32, device=st.table.device)  # d_query only
+            jobs.append((g.bwd_buf, None, 0))
+            jobs.append(st.direct.increment_job())  # this step's generation number
         for g in st.groups:
+            if st.direct is not None:
+                break
             if g.shared and len(jobs) < nat.MAX_WORD_JOBS - 1 and self.score_fn.supports_fused_query_triple:
                 g.bwd_buf = nat.shared_bwd_buffer(desc, len(g.ent), len(g.neg), st.table.device)
                 if g.bwd_buf is not None:
@@ -668,7 +712,12 @@ class BessKGE(torch.nn.Module, ABC):
                 st.d_recv.view(st.n, -1, st.d_recv.shape[1])[:, : st.ppp].zero_()
             else:
                 jobs.append((st.d_recv, None, 0))
-        plan = self._small_plan(st, optimizer)
+        if st.direct is not None and st.fused_qt:
+            # nothing to index: the jobs ride in the query / positive-score launch (`fn.query_triple_fwd(jobs=...)`),
+            # none of whose inputs they write
+            st.jobs = jobs
+            return None
+        plan = None if st.direct is not None else self._small_plan(st, optimizer)
         # one workgroup indexes up to 4096 ids in ~12-15 us (notebook-size steps: cheaper than any fork / join);
         # longer lists are indexed by the device-wide pipeline on the side stream, under the forward kernels
         # (`_small_index_ahead`) - 12.5 k ids in the prologue's one workgroup were 58 us on the critical path
@@ -859,6 +908,14 @@ class BessKGE(torch.nn.Module, ABC):
             native = desc.scorer <= nat.COMPLEX
             for st, upd in zip(steps, local_updates):
                 mine = [item for item in deferred if item[0] is st.table]
+                if st.direct is not None:
+                    assert not upd and not mine, "a direct-update step hands over no row gradients"
+                    o, s1, s2 = self._opt_desc(optimizer, st.table)
+                    last = st is steps[-1]
+                    nat.direct_update(o, st.table, [x.contiguous() for x in st.direct_lists], st.direct, s1, s2,
+                                      axpy=rel_axpy if last else None)
+                    rel_done = rel_done or (last and rel_axpy is not None)
+                    continue
                 if native and len(mine) == 1:
                     table, g, go = mine[0]
                     self._apply_optimizer_fused(optimizer, desc, table, g, go, seg_index[id(g)], list(upd),
@@ -1040,7 +1097,9 @@ class EmbeddingMovingBessKGE(BessKGE):
             if st.fused_qt:
                 # K2 + K3 + K6: the query of the one negative-scoring problem and the positive scores, one launch
                 g0.query, st.positive_score = fn.query_triple_fwd(g0.side, RowSource(st.table, st.head_idx), st.tail,
-                                                                  st.rel_idx)
+                                                                  st.rel_idx, jobs=st.jobs if st.direct is not None else None)
+                if st.direct is not None:
+                    st.jobs = None
             else:
                 st.positive_score, st.triple_ctx = fn.triple_fwd(
                     RowSource(st.table, st.head_idx), st.tail, st.rel_idx)
@@ -1299,7 +1358,12 @@ class EmbeddingMovingBessKGE(BessKGE):
                 d_outs = [dn3[:, :cut].reshape(-1, dn3.shape[-1]).contiguous(),
                           dn3[:, cut:].reshape(-1, dn3.shape[-1]).contiguous()]
             for g, go in zip(st.groups, d_outs):
-                if g.shared:
+                if g.shared and st.direct is not None:
+                    # the candidates' gradient rows go straight into the shard's accumulator, at their row ids
+                    dq, _ = nat.neg_score_shared_bwd(desc, g.query, g.neg, g.out, go, prezeroed=g.bwd_buf,
+                                                     rows_acc=st.direct.acc)
+                    st.direct_lists.append(g.neg.idx.reshape(-1))
+                elif g.shared:
                     dq, dn = nat.neg_score_shared_bwd(desc, g.query, g.neg, g.out, go, prezeroed=g.bwd_buf)
                     sink(g.neg, dn)
                 elif g.neg.base is st.table and fn.supports_fused_segments:
@@ -1325,7 +1389,11 @@ class EmbeddingMovingBessKGE(BessKGE):
                         dq = g.dq
                     if not in_place:
                         sink(g.neg, dn)
-                if st.fused_qt:
+                if st.fused_qt and st.direct is not None:
+                    fn.query_triple_bwd(g.side, RowSource(st.table, st.head_idx), st.tail, st.rel_idx, d_pos, dq, d_rel,
+                                        rows_acc=(st.direct.acc, st.direct.acc))
+                    st.direct_lists += [st.head_idx.reshape(-1), st.tail.idx.reshape(-1)]
+                elif st.fused_qt:
                     dh, dt = fn.query_triple_bwd(g.side, RowSource(st.table, st.head_idx), st.tail, st.rel_idx, d_pos,
                                                  dq, d_rel)
                     sink(RowSource(st.table, st.head_idx), dh)

@@ -133,17 +133,21 @@ class BaseScoreFunction(torch.nn.Module, ABC):
     #: (`bess_query_triple_fwd / _bwd`: TransE / RotatE / DistMult / ComplEx)
     supports_fused_query_triple = True
 
-    def query_triple_fwd(self, side: int, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor
-                         ) -> Tuple[torch.Tensor, torch.Tensor]:
-        """(query matrix of the side's negative-scoring problem, positive scores) of the same triples."""
-        return nat.query_triple_fwd(self.kernel_desc(), side, head, tail, self.relation_embedding.data, rel_idx)
+    def query_triple_fwd(self, side: int, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor,
+                         jobs: Any = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(query matrix of the side's negative-scoring problem, positive scores) of the same triples.  `jobs`: copy /
+        fill jobs of the step's prologue that ride in the same launch (`nat.query_triple_fwd`)."""
+        return nat.query_triple_fwd(self.kernel_desc(), side, head, tail, self.relation_embedding.data, rel_idx,
+                                    jobs=jobs)
 
     def query_triple_bwd(self, side: int, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor,
-                         d_pos: torch.Tensor, dq: torch.Tensor, d_rel: torch.Tensor
-                         ) -> Tuple[torch.Tensor, torch.Tensor]:
-        """(d_head rows, d_tail rows) of positive score + query together; relation gradient added to `d_rel`."""
+                         d_pos: torch.Tensor, dq: torch.Tensor, d_rel: torch.Tensor,
+                         rows_acc: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+                         ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+        """(d_head rows, d_tail rows) of positive score + query together; relation gradient added to `d_rel`.
+        `rows_acc`: the rows are added into accumulators over the tables' row spaces instead (`nat.query_triple_bwd`)."""
         return nat.query_triple_bwd(self.kernel_desc(), side, head, tail, self.relation_embedding.data, rel_idx,
-                                    d_pos, dq, d_rel)
+                                    d_pos, dq, d_rel, rows_acc=rows_acc)
 
     def dense_parameters(self) -> List[torch.nn.Parameter]:
         """Parameters besides the two embedding tables (ConvE's network); replicated like the

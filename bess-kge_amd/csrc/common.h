@@ -197,6 +197,34 @@ __device__ __forceinline__ float sgn_prescaled(float d_scaled) {
     return __builtin_amdgcn_fmed3f(d_scaled, -1.f, 1.f);
 }
 
+// Copy / fill jobs over 32-bit words that ride in the spare workgroups of a step's early launches
+// (bess_step_prologue, bess_query_triple_fwd_jobs): the concatenated candidate list of an augmented step, cleared
+// gradient targets, the generation counter of bess_direct_update ...
+struct WordJobs {
+    uint32_t* dst[BESS_MAX_WORD_JOBS];
+    const uint32_t* src[BESS_MAX_WORD_JOBS];  // NULL: fill with value
+    uint32_t value[BESS_MAX_WORD_JOBS];
+    int64_t first[BESS_MAX_WORD_JOBS + 1];    // prefix sums of the jobs' word counts
+    int n;
+};
+// workgroup `block` of `n_blocks` (of `threads` threads each) takes its share of the jobs' words
+__device__ __forceinline__ void run_word_jobs(const WordJobs& J, int block, int n_blocks, int threads) {
+    const int64_t total = J.first[J.n];
+    const int64_t stride = static_cast<int64_t>(n_blocks) * threads;
+    for (int64_t i = static_cast<int64_t>(block) * threads + threadIdx.x; i < total; i += stride) {
+        int j = 0;
+#pragma unroll
+        for (int k = 1; k < BESS_MAX_WORD_JOBS; ++k) j += (k < J.n && i >= J.first[k]) ? 1 : 0;
+        const int64_t off = i - J.first[j];
+        // (copy jobs add their value to what they copy: 0 for a plain copy; src == dst with value 1 is the
+        // increment of a device-side counter - the generation of bess_direct_update)
+        J.dst[j][off] = J.src[j] ? J.src[j][off] + J.value[j] : J.value[j];
+    }
+}
+// host side: checked jobs from the C ABI's arrays; *words = their total
+int make_word_jobs(int32_t n_jobs, void* const* job_dst, const void* const* job_src, const uint32_t* job_value,
+                   const int64_t* job_words, WordJobs* J, int64_t* words, const char* who);
+
 // Fill `n` 32-bit words with `v` on `st` - a kernel, not hipMemsetAsync: memset nodes recorded into a hipGraph
 // (torch.cuda.graph capture of a training step) did not reliably re-run in order on replay - a buffer zeroed
 // this way kept what an earlier replay had left in its (pool-recycled) memory.  A kernel node does.

@@ -371,7 +371,8 @@ constexpr int FB_TW = 64, FB_IS = 8;  // (FB_NW waves = groups of 32 candidates 
 template <typename TE, bool ROUND16, int FB_NW>
 __global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, RowSrc<TE> E, int W, float sign,
                                                         const float* __restrict__ d_out, int64_t ld,
-                                                        float* __restrict__ dq, float* __restrict__ de, int i_chunk) {
+                                                        float* __restrict__ dq, float* __restrict__ de, int i_chunk,
+                                                        int de_by_row) {
     // A wave = 64 columns x ONE group of 32 candidates: the coefficient of (query, candidate) is the same for all
     // its lanes - a wave-uniform address, i.e. scalar loads (s_load_dwordx8 into SGPRs that the v_fma reads
     // directly): no LDS staging of the coefficients, no barrier for them.  Eight waves = 256 candidates; their
@@ -478,7 +479,12 @@ __global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, 
 #pragma unroll
         for (int jj = 0; jj < 32; ++jj) {
             const int64_t j = jbase + jj;
-            if (j < E.n && acc[jj] != 0.f) unsafeAtomicAdd(de + j * W + w0 + w, -sign * acc[jj]);
+            // (de_by_row - BESS_FLAG_DNEG_BY_ROW: `de` is a matrix over the ROW SPACE of the candidates' table, the
+            // sums of candidate j are added at its row id: bess_direct_update picks them up there)
+            if (j < E.n && acc[jj] != 0.f) {
+                const int64_t r = (de_by_row && E.idx) ? static_cast<int64_t>(E.idx[j]) : j;
+                unsafeAtomicAdd(de + r * W + w0 + w, -sign * acc[jj]);
+            }
         }
     }
 }
@@ -519,8 +525,9 @@ static int run_l1_bwd_both(const bess_model_desc* d, RowSrc<float> Q, RowSrc<TE>
     const dim3 grid(static_cast<unsigned>(jt), static_cast<unsigned>(wt), static_cast<unsigned>(slices));
     const float sign = is_distance(d->scorer) ? -1.f : 1.f;
     const int ic = static_cast<int>(i_chunk);
+    const int by_row = (d->reserved[0] & BESS_FLAG_DNEG_BY_ROW) ? 1 : 0;
 #define BESS_FB(R16, NW) \
-    k_l1_bwd_both<TE, R16, NW><<<grid, 64 * NW, 0, st>>>(Q, E, W, sign, d_out, ld_dout, d_query, d_neg, ic)
+    k_l1_bwd_both<TE, R16, NW><<<grid, 64 * NW, 0, st>>>(Q, E, W, sign, d_out, ld_dout, d_query, d_neg, ic, by_row)
     if (nw == 8) {
         if (round16) BESS_FB(true, 8);
         else BESS_FB(false, 8);
@@ -592,10 +599,12 @@ template <typename TE>
 static int run_bwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<TE> E, const float* d_out, int64_t ld_dout,
                    const float* out, int64_t ld_out, float* d_query, float* d_neg, hipStream_t st, bool round16) {
     const int W = d->width;
+    const bool by_row = d->reserved[0] & BESS_FLAG_DNEG_BY_ROW;
     if (use_l1_bwd_both(d, Q.n, E.n) && Q.idx == nullptr) {  // (the kernel reads the dense f32 query matrix)
         if (!(d->reserved[0] & BESS_FLAG_PREZEROED)) {  // its outputs are sums of atomics
             hipError_t e = hipSuccess;
-            if (d_neg == d_query + Q.n * W) e = fill_words_async(d_query, 0u, (Q.n + E.n) * W, st);
+            if (by_row) e = fill_words_async(d_query, 0u, Q.n * W, st);  // (d_neg: the caller's accumulator, added to)
+            else if (d_neg == d_query + Q.n * W) e = fill_words_async(d_query, 0u, (Q.n + E.n) * W, st);
             else {
                 e = fill_words_async(d_query, 0u, Q.n * W, st);
                 if (e == hipSuccess) e = fill_words_async(d_neg, 0u, E.n * W, st);
@@ -604,6 +613,9 @@ static int run_bwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<TE> E, cons
         }
         return run_l1_bwd_both<TE>(d, Q, E, d_out, ld_dout, d_query, d_neg, st, round16);
     }
+    if (by_row)
+        return fail(BESS_EUNSUPPORTED, "neg_score_shared_bwd: BESS_FLAG_DNEG_BY_ROW for this scorer / shape "
+                                       "(bess_neg_score_shared_bwd_by_row says which take it)");
     BwdSide<float, TE> A{Q, E, ld_dout, 1, ld_out, 1, d_query, 0, 0, 0, 0};
     BwdSide<TE, float> B{E, Q, 1, ld_dout, 1, ld_out, d_neg, 0, 0, 0, 0};
     const bool small_a = plan_bwd_side(W, A), small_b = plan_bwd_side(W, B);
@@ -987,6 +999,11 @@ extern "C" int64_t bess_neg_score_shared_bwd_workspace(const bess_model_desc* d,
     return gemm_split_bwd_workspace(n_query, n_neg, d->width);
 }
 
+extern "C" int bess_neg_score_shared_bwd_by_row(const bess_model_desc* d, int64_t n_query, int64_t n_neg) {
+    if (!d || check_desc(d) || d->scorer > BESS_COMPLEX) return 0;
+    return use_l1_bwd_both(d, n_query, n_neg) ? 1 : 0;
+}
+
 extern "C" int bess_neg_score_shared_bwd(const bess_model_desc* d, const float* query,
                                          int64_t n_query, const void* neg_base,
                                          const int32_t* neg_idx, int64_t n_neg, const float* out,
@@ -1009,6 +1026,10 @@ extern "C" int bess_neg_score_shared_bwd_ws(const bess_model_desc* d, const floa
     BESS_REQUIRE(reduce_of(d) != RED_L2 || out, "neg_score_shared_bwd: p=2 needs the forward scores");
     BESS_REQUIRE(ld_dout >= n_neg && (!out || ld_out >= n_neg), "neg_score_shared_bwd: leading dimension < n_neg");
     hipStream_t st = as_stream(stream);
+    if (d->scorer <= BESS_COMPLEX && (d->reserved[0] & BESS_FLAG_DNEG_BY_ROW) &&
+        !bess_neg_score_shared_bwd_by_row(d, n_query, n_neg))
+        return fail(BESS_EUNSUPPORTED, "neg_score_shared_bwd: BESS_FLAG_DNEG_BY_ROW for this scorer / shape "
+                                       "(bess_neg_score_shared_bwd_by_row says which take it)");
     if (d->scorer == BESS_BOXE)
         return boxe_negatives(d, false, true, query, n_query, neg_base, neg_idx, n_neg, nullptr, d_out, ld_dout,
                               d_query, d_neg, st);

@@ -145,14 +145,50 @@ __global__ __launch_bounds__(256) void k_query_triple_fwd(TripleArgs a, QueryArg
     triple_fwd_body<T, SCORER>(a, s, lane, out);
 }
 
+// the same launch with copy / fill jobs in spare workgroups behind the triples' (a training step's prologue - the
+// concatenated candidate list, cleared gradient targets, the update's generation counter - without a launch of
+// its own: nothing of this launch reads what the jobs write)
+template <typename T, int SCORER>
+__global__ __launch_bounds__(256) void k_query_triple_fwd_jobs(TripleArgs a, QueryArgs qa, float* __restrict__ query,
+                                                               float* __restrict__ out, WordJobs J, int triple_blocks) {
+    if (static_cast<int>(blockIdx.x) >= triple_blocks) {
+        run_word_jobs(J, static_cast<int>(blockIdx.x) - triple_blocks, static_cast<int>(gridDim.x) - triple_blocks, 256);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (s >= a.n) return;
+    query_fwd_body<T, SCORER>(qa, s, lane, query);
+    triple_fwd_body<T, SCORER>(a, s, lane, out);
+}
+
 // ----------------------------------------------------------------- backward
 template <bool ACCUM>
 __device__ __forceinline__ void put(float* p, float v) {
     if (ACCUM) *p += v;
     else *p = v;
 }
+// BYROW (BESS_FLAG_DNEG_BY_ROW): the entity gradients are ADDED (fp32 atomics) into matrices over the row space of
+// the entities' tables, at the row ids the triple names - where bess_direct_update picks them up - instead of being
+// stored as row s of dense [n_triple, W] arrays
+template <bool BYROW>
+__device__ __forceinline__ void emit(float* p, float v) {
+    if (BYROW) {
+        if (v != 0.f) unsafeAtomicAdd(p, v);
+    } else {
+        *p = v;
+    }
+}
+template <bool BYROW, bool ACCUM>
+__device__ __forceinline__ void emit2(float* p, float v) {
+    if (BYROW) {
+        if (v != 0.f) unsafeAtomicAdd(p, v);
+    } else {
+        put<ACCUM>(p, v);
+    }
+}
 
-template <typename T, int SCORER>
+template <typename T, int SCORER, bool BYROW = false>
 __device__ __forceinline__ void triple_bwd_body(const TripleArgs& a, int64_t s, int lane,
                                                 const float* __restrict__ d_out, float* __restrict__ d_head,
                                                 float* __restrict__ d_tail, float* __restrict__ d_rel) {
@@ -160,8 +196,8 @@ __device__ __forceinline__ void triple_bwd_body(const TripleArgs& a, int64_t s, 
     const T* t = row_ptr(static_cast<const T*>(a.tail_base), a.tail_idx, s, a.W);
     const int64_t rid = a.rel_idx[s];
     const T* r = static_cast<const T*>(a.rel_table) + rid * a.Wr;
-    float* dh = d_head + s * a.W;
-    float* dt = d_tail + s * a.W;
+    float* dh = d_head + (BYROW ? (a.head_idx ? static_cast<int64_t>(a.head_idx[s]) : s) : s) * a.W;
+    float* dt = d_tail + (BYROW ? (a.tail_idx ? static_cast<int64_t>(a.tail_idx[s]) : s) : s) * a.W;
     float* dr = d_rel + rid * a.Wr;
     const float g = d_out[s];
 
@@ -180,15 +216,15 @@ __device__ __forceinline__ void triple_bwd_body(const TripleArgs& a, int64_t s, 
         for (int e = lane; e < a.W; e += 64) {
             const float x = to_f32(h[e]) + to_f32(r[e]) - to_f32(t[e]);
             const float dx = -g * ((a.norm_p == 1) ? sgnf(x) : lp_dterm(x, pf) * inv);
-            dh[e] = dx;
-            dt[e] = -dx;
+            emit<BYROW>(dh + e, dx);
+            emit<BYROW>(dt + e, -dx);
             if (dx != 0.f) unsafeAtomicAdd(dr + e, dx);
         }
     } else if (SCORER == BESS_DISTMULT) {
         for (int e = lane; e < a.W; e += 64) {
             const float hv = to_f32(h[e]), rv = to_f32(r[e]), tv = to_f32(t[e]);
-            dh[e] = g * rv * tv;
-            dt[e] = g * hv * rv;
+            emit<BYROW>(dh + e, g * rv * tv);
+            emit<BYROW>(dt + e, g * hv * rv);
             unsafeAtomicAdd(dr + e, g * hv * tv);
         }
     } else {
@@ -218,18 +254,18 @@ __device__ __forceinline__ void triple_bwd_body(const TripleArgs& a, int64_t s, 
                 const float xi = hr * sn + hi * c - ti;
                 const float dxr = -g * ((a.norm_p == 1) ? sgnf(xr) : lp_dterm(xr, pf) * inv);
                 const float dxi = -g * ((a.norm_p == 1) ? sgnf(xi) : lp_dterm(xi, pf) * inv);
-                dh[e] = dxr * c + dxi * sn;
-                dh[d + e] = -dxr * sn + dxi * c;
-                dt[e] = -dxr;
-                dt[d + e] = -dxi;
+                emit<BYROW>(dh + e, dxr * c + dxi * sn);
+                emit<BYROW>(dh + d + e, -dxr * sn + dxi * c);
+                emit<BYROW>(dt + e, -dxr);
+                emit<BYROW>(dt + d + e, -dxi);
                 const float dph = dxr * (-hr * sn - hi * c) + dxi * (hr * c - hi * sn);
                 if (dph != 0.f) unsafeAtomicAdd(dr + e, dph);
             } else {
                 const float rr = to_f32(r[e]), ri = to_f32(r[d + e]);
-                dh[e] = g * (rr * tr + ri * ti);
-                dh[d + e] = g * (-ri * tr + rr * ti);
-                dt[e] = g * (hr * rr - hi * ri);
-                dt[d + e] = g * (hr * ri + hi * rr);
+                emit<BYROW>(dh + e, g * (rr * tr + ri * ti));
+                emit<BYROW>(dh + d + e, g * (-ri * tr + rr * ti));
+                emit<BYROW>(dt + e, g * (hr * rr - hi * ri));
+                emit<BYROW>(dt + d + e, g * (hr * ri + hi * rr));
                 unsafeAtomicAdd(dr + e, g * (hr * tr + hi * ti));
                 unsafeAtomicAdd(dr + d + e, g * (-hi * tr + hr * ti));
             }
@@ -251,7 +287,7 @@ __global__ __launch_bounds__(256) void k_score_triple_bwd(TripleArgs a,
 
 // ACCUM: d_ent already holds this lane's contribution of the positive score (written by the same lane
 // just before: same element -> lane mapping in both bodies); add instead of overwrite
-template <typename T, int SCORER, bool ACCUM>
+template <typename T, int SCORER, bool ACCUM, bool BYROW = false>
 __device__ __forceinline__ void query_bwd_body(const QueryArgs& a, int64_t q, int lane,
                                                const float* __restrict__ d_query, float* __restrict__ d_ent,
                                                float* __restrict__ d_rel) {
@@ -259,19 +295,19 @@ __device__ __forceinline__ void query_bwd_body(const QueryArgs& a, int64_t q, in
     const int64_t rid = a.rel_idx[q];
     const T* r = static_cast<const T*>(a.rel_table) + rid * a.Wr;
     const float* dq = d_query + q * a.W;
-    float* dx = d_ent + q * a.W;
+    float* dx = d_ent + (BYROW ? (a.ent_idx ? static_cast<int64_t>(a.ent_idx[q]) : q) : q) * a.W;
     float* dr = d_rel + rid * a.Wr;
     const bool tail = a.side == BESS_CORRUPT_TAIL;
     if (SCORER == BESS_TRANSE) {
         for (int e = lane; e < a.W; e += 64) {
             const float g = dq[e];
-            put<ACCUM>(dx + e, g);
+            emit2<BYROW, ACCUM>(dx + e, g);
             if (g != 0.f) unsafeAtomicAdd(dr + e, tail ? g : -g);
         }
     } else if (SCORER == BESS_DISTMULT) {
         for (int e = lane; e < a.W; e += 64) {
             const float g = dq[e];
-            put<ACCUM>(dx + e, g * to_f32(r[e]));
+            emit2<BYROW, ACCUM>(dx + e, g * to_f32(r[e]));
             unsafeAtomicAdd(dr + e, g * to_f32(x[e]));
         }
     } else {
@@ -283,15 +319,15 @@ __device__ __forceinline__ void query_bwd_body(const QueryArgs& a, int64_t q, in
                 const float sg = tail ? 1.f : -1.f;
                 const float ph = sg * to_f32(r[e]);
                 const float c = cosf(ph), sn = sinf(ph);
-                put<ACCUM>(dx + e, gr * c + gi * sn);
-                put<ACCUM>(dx + d + e, -gr * sn + gi * c);
+                emit2<BYROW, ACCUM>(dx + e, gr * c + gi * sn);
+                emit2<BYROW, ACCUM>(dx + d + e, -gr * sn + gi * c);
                 const float dph = gr * (-xr * sn - xi * c) + gi * (xr * c - xi * sn);
                 unsafeAtomicAdd(dr + e, sg * dph);
             } else {
                 const float sg = tail ? 1.f : -1.f;  // conj r for heads
                 const float rr = to_f32(r[e]), ri = sg * to_f32(r[d + e]);
-                put<ACCUM>(dx + e, gr * rr + gi * ri);
-                put<ACCUM>(dx + d + e, -gr * ri + gi * rr);
+                emit2<BYROW, ACCUM>(dx + e, gr * rr + gi * ri);
+                emit2<BYROW, ACCUM>(dx + d + e, -gr * ri + gi * rr);
                 unsafeAtomicAdd(dr + e, gr * xr + gi * xi);
                 unsafeAtomicAdd(dr + d + e, sg * (-gr * xi + gi * xr));
             }
@@ -312,7 +348,7 @@ __global__ __launch_bounds__(256) void k_query_bwd(QueryArgs a, const float* __r
 // K3' + K6' in one launch: gradients of the positive score w.r.t. head / tail rows and of the query w.r.t. the
 // entity it was built from, summed where both hit the same row (the query of a tail-corruption step is built
 // from the head: d_head = d pos / d h + d query / d h), relation gradients accumulated once
-template <typename T, int SCORER>
+template <typename T, int SCORER, bool BYROW>
 __global__ __launch_bounds__(256) void k_query_triple_bwd(TripleArgs a, QueryArgs qa, const float* __restrict__ d_out,
                                                           const float* __restrict__ d_query,
                                                           float* __restrict__ d_head, float* __restrict__ d_tail,
@@ -320,8 +356,8 @@ __global__ __launch_bounds__(256) void k_query_triple_bwd(TripleArgs a, QueryArg
     const int lane = threadIdx.x & 63;
     const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
     if (s >= a.n) return;
-    triple_bwd_body<T, SCORER>(a, s, lane, d_out, d_head, d_tail, d_rel);
-    query_bwd_body<T, SCORER, true>(qa, s, lane, d_query, qa.side == BESS_CORRUPT_TAIL ? d_head : d_tail, d_rel);
+    triple_bwd_body<T, SCORER, BYROW>(a, s, lane, d_out, d_head, d_tail, d_rel);
+    query_bwd_body<T, SCORER, true, BYROW>(qa, s, lane, d_query, qa.side == BESS_CORRUPT_TAIL ? d_head : d_tail, d_rel);
 }
 
 template <template <typename, int> class Launcher, typename... Args>
@@ -373,10 +409,18 @@ struct LQueryTripleFwd {
     }
 };
 template <typename T, int SC>
+struct LQueryTripleFwdJobs {
+    static void run(TripleArgs a, QueryArgs qa, float* q, float* out, WordJobs J, int job_blocks, hipStream_t st) {
+        const int tb = static_cast<int>(ceil_div(a.n, 4));
+        k_query_triple_fwd_jobs<T, SC><<<tb + job_blocks, 256, 0, st>>>(a, qa, q, out, J, tb);
+    }
+};
+template <typename T, int SC>
 struct LQueryTripleBwd {
     static void run(TripleArgs a, QueryArgs qa, const float* d_out, const float* dq, float* dh, float* dt, float* dr,
-                    hipStream_t st) {
-        k_query_triple_bwd<T, SC><<<ceil_div(a.n, 4), 256, 0, st>>>(a, qa, d_out, dq, dh, dt, dr);
+                    bool by_row, hipStream_t st) {
+        if (by_row) k_query_triple_bwd<T, SC, true><<<ceil_div(a.n, 4), 256, 0, st>>>(a, qa, d_out, dq, dh, dt, dr);
+        else k_query_triple_bwd<T, SC, false><<<ceil_div(a.n, 4), 256, 0, st>>>(a, qa, d_out, dq, dh, dt, dr);
     }
 };
 
@@ -484,6 +528,31 @@ extern "C" int bess_query_triple_fwd(const bess_model_desc* d, int32_t side, con
     return check_launch("query_triple_fwd");
 }
 
+extern "C" int bess_query_triple_fwd_jobs(const bess_model_desc* d, int32_t side, const void* head_base,
+                                          const int32_t* head_idx, const void* tail_base, const int32_t* tail_idx,
+                                          const void* rel_table, const int32_t* rel_idx, int64_t n_triple, float* query,
+                                          float* out, int32_t n_jobs, void* const* job_dst, const void* const* job_src,
+                                          const uint32_t* job_value, const int64_t* job_words, void* stream) {
+    TripleArgs a;
+    if (int e = triple_args(d, head_base, head_idx, tail_base, tail_idx, rel_table, rel_idx, n_triple, &a))
+        return e;
+    BESS_REQUIRE(d->scorer <= BESS_COMPLEX, "query_triple_fwd_jobs: TransE / RotatE / DistMult / ComplEx only");
+    QueryArgs qa;
+    const bool tail = side == BESS_CORRUPT_TAIL;
+    if (int e = query_args(d, side, tail ? head_base : tail_base, tail ? head_idx : tail_idx, rel_table, rel_idx,
+                           n_triple, &qa))
+        return e;
+    WordJobs J{};
+    int64_t words = 0;
+    if (int e = make_word_jobs(n_jobs, job_dst, job_src, job_value, job_words, &J, &words, "query_triple_fwd_jobs")) return e;
+    if (n_triple == 0 && words == 0) return BESS_OK;
+    BESS_REQUIRE(n_triple == 0 || (query && out), "query_triple_fwd_jobs: NULL out");
+    // ~8 words per thread of the job workgroups, at most one workgroup per CU
+    const int job_blocks = static_cast<int>(std::min<int64_t>(ceil_div(words, 8 * 256), 256));
+    dispatch<LQueryTripleFwdJobs>(d, a, qa, query, out, J, job_blocks, as_stream(stream));
+    return check_launch("query_triple_fwd_jobs");
+}
+
 extern "C" int bess_query_triple_bwd(const bess_model_desc* d, int32_t side, const void* head_base,
                                      const int32_t* head_idx, const void* tail_base, const int32_t* tail_idx,
                                      const void* rel_table, const int32_t* rel_idx, int64_t n_triple,
@@ -500,6 +569,8 @@ extern "C" int bess_query_triple_bwd(const bess_model_desc* d, int32_t side, con
         return e;
     if (n_triple == 0) return BESS_OK;
     BESS_REQUIRE(d_out && d_query && d_head && d_tail && d_rel_table, "query_triple_bwd: NULL pointer");
-    dispatch<LQueryTripleBwd>(d, a, qa, d_out, d_query, d_head, d_tail, d_rel_table, as_stream(stream));
+    // (BESS_FLAG_DNEG_BY_ROW: d_head / d_tail are accumulators over the row spaces of head_base / tail_base)
+    const bool by_row = d->reserved[0] & BESS_FLAG_DNEG_BY_ROW;
+    dispatch<LQueryTripleBwd>(d, a, qa, d_out, d_query, d_head, d_tail, d_rel_table, by_row, as_stream(stream));
     return check_launch("query_triple_bwd");
 }

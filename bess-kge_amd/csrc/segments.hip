@@ -345,13 +345,8 @@ __global__ __launch_bounds__(SMALL_T) void k_small_segment_index(IdLists ids, in
 // (their row ids are inputs of the step), the other workgroups run copy / fill jobs on 32-bit words - the
 // concatenated candidate list of an augmented step, the zeroed relation gradient, the zeroed targets of the
 // backward's atomics, ...
-struct WordJobs {
-    uint32_t* dst[BESS_MAX_WORD_JOBS];
-    const uint32_t* src[BESS_MAX_WORD_JOBS];  // NULL: fill with value
-    uint32_t value[BESS_MAX_WORD_JOBS];
-    int64_t first[BESS_MAX_WORD_JOBS + 1];    // prefix sums of the jobs' word counts
-    int n;
-};
+// (struct WordJobs, run_word_jobs, make_word_jobs: common.h - bess_query_triple_fwd_jobs runs the same jobs in the
+// spare workgroups of the query / positive-score launch)
 
 template <int SMALL_I>
 __global__ __launch_bounds__(SMALL_T) void k_step_prologue(WordJobs J, IdLists ids, int n_ids, int row_bits,
@@ -367,15 +362,7 @@ __global__ __launch_bounds__(SMALL_T) void k_step_prologue(WordJobs J, IdLists i
                                      long_cap);
         return;
     }
-    const int64_t total = J.first[J.n];
-    const int64_t stride = static_cast<int64_t>(gridDim.x - index_blocks) * SMALL_T;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x - index_blocks) * SMALL_T + threadIdx.x; i < total; i += stride) {
-        int j = 0;
-#pragma unroll
-        for (int k = 1; k < BESS_MAX_WORD_JOBS; ++k) j += (k < J.n && i >= J.first[k]) ? 1 : 0;
-        const int64_t off = i - J.first[j];
-        J.dst[j][off] = J.src[j] ? J.src[j][off] : J.value[j];
-    }
+    run_word_jobs(J, static_cast<int>(blockIdx.x) - index_blocks, static_cast<int>(gridDim.x) - index_blocks, SMALL_T);
 }
 
 // seg_offsets[n_seg] = n_refs (close the last segment); ExclusiveSum wrote only n entries
@@ -1022,6 +1009,95 @@ static int seg_by_it(int it, int red, const SegArgs& a, float* grad_seg, void* r
     return BESS_OK;
 }
 
+// ---- K9 + K10 without an index: direct-addressed accumulation --------------------------------------------------
+// For shards whose fp32 image fits a scratch budget, the backward kernels ADD their gradient rows straight into
+// acc[row id] (an [M, W] fp32 matrix that is zero between steps; fp32 atomics), so nothing has to be sorted to
+// find the rows of a step: one wave per REFERENCE of the step's row-id lists claims its row (atomic exchange of
+// the step's generation number into claim[row]: the first reference of a row wins, the others see the generation
+// already there and leave), reads the summed gradient, applies the optimiser - one read-modify-write and ONE
+// rounding of the row per step, whatever the optimiser - and leaves the acc row zero again.  What the notebook-size
+// steps paid for the sorted index (12 of 75 us, profiles/r03/step_r03_c4g.txt) is gone, and so are the dense
+// [n, W] gradient arrays of heads / tails / shared negatives and their clears.
+template <typename T>
+__global__ __launch_bounds__(256) void k_direct_update(OptArgs o, IdLists ids, int n_ids, T* __restrict__ table, int W,
+                                                       float* __restrict__ acc, int32_t* __restrict__ claim,
+                                                       const int32_t* __restrict__ generation,
+                                                       float* __restrict__ state1, float* __restrict__ state2,
+                                                       AxpyJob x) {
+    const int main_blocks = static_cast<int>(gridDim.x) - x.blocks;
+    if (static_cast<int>(blockIdx.x) >= main_blocks) {
+        T* t2 = static_cast<T*>(x.table);
+        for (int64_t t = (blockIdx.x - main_blocks) * 256ll + threadIdx.x; t < x.n; t += 256ll * x.blocks)
+            t2[t] = static_cast<T>(static_cast<float>(t2[t]) + x.alpha * x.grad[t]);
+        return;
+    }
+    o = opt_resolve(o);
+    const int lane = threadIdx.x & 63;
+    const int gen = *generation;
+    const int64_t wave0 = (blockIdx.x * 256ll + threadIdx.x) >> 6;
+    const int64_t n_wave = (main_blocks * 256ll) >> 6;
+    for (int64_t ref = wave0; ref < n_ids; ref += n_wave) {
+        const int64_t row = id_at(ids, static_cast<int>(ref));
+        int seen = 0;
+        if (lane == 0) seen = atomicExch(claim + row, gen);
+        seen = __shfl(seen, 0, 64);
+        if (seen == gen) continue;  // an earlier reference of this row has taken it
+        float* a = acc + row * W;
+        T* p = table + row * W;
+        float* s1 = state1 ? state1 + row * W : nullptr;
+        float* s2 = state2 ? state2 + row * W : nullptr;
+        if ((W & 3) == 0) {
+            for (int c = lane * 4; c < W; c += 256) {
+                const float4 g4 = *reinterpret_cast<const float4*>(a + c);
+                *reinterpret_cast<float4*>(a + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = static_cast<float>(p[c + j]);
+                    float m1 = s1 ? s1[c + j] : 0.f, m2 = s2 ? s2[c + j] : 0.f;
+                    opt_step(o, v, g[j], m1, m2);
+                    if (s1) s1[c + j] = m1;
+                    if (s2) s2[c + j] = m2;
+                    p[c + j] = static_cast<T>(v);
+                }
+            }
+        } else {
+            for (int c = lane; c < W; c += 64) {
+                const float g = a[c];
+                a[c] = 0.f;
+                float v = static_cast<float>(p[c]);
+                float m1 = s1 ? s1[c] : 0.f, m2 = s2 ? s2[c] : 0.f;
+                opt_step(o, v, g, m1, m2);
+                if (s1) s1[c] = m1;
+                if (s2) s2[c] = m2;
+                p[c] = static_cast<T>(v);
+            }
+        }
+    }
+}
+
+int make_word_jobs(int32_t n_jobs, void* const* job_dst, const void* const* job_src, const uint32_t* job_value,
+                   const int64_t* job_words, WordJobs* J, int64_t* words, const char* who) {
+    BESS_REQUIRE(n_jobs >= 0 && n_jobs <= BESS_MAX_WORD_JOBS, "%s: %d jobs (0 .. %d)", who, n_jobs, BESS_MAX_WORD_JOBS);
+    BESS_REQUIRE(n_jobs == 0 || (job_dst && job_src && job_value && job_words), "%s: NULL job arrays", who);
+    *J = WordJobs{};
+    J->n = n_jobs;
+    int64_t w = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        BESS_REQUIRE(job_words[j] >= 0 && (job_words[j] == 0 || job_dst[j]), "%s: job %d", who, j);
+        BESS_REQUIRE(reinterpret_cast<uintptr_t>(job_dst[j]) % 4 == 0 && reinterpret_cast<uintptr_t>(job_src[j]) % 4 == 0,
+                     "%s: job %d is not 4-byte aligned", who, j);
+        J->dst[j] = static_cast<uint32_t*>(job_dst[j]);
+        J->src[j] = static_cast<const uint32_t*>(job_src[j]);
+        J->value[j] = job_value[j];
+        J->first[j] = w;
+        w += job_words[j];
+    }
+    for (int j = n_jobs; j <= BESS_MAX_WORD_JOBS; ++j) J->first[j] = w;
+    *words = w;
+    return BESS_OK;
+}
+
 }  // namespace bess
 
 using namespace bess;
@@ -1124,24 +1200,11 @@ extern "C" int bess_step_prologue(int32_t n_jobs, void* const* job_dst, const vo
                                   const int32_t* const* id_lists, const int64_t* id_lens, int32_t row_bits,
                                   int32_t* refs_sorted, int32_t* seg_rows, int32_t* seg_offsets, int32_t* n_seg,
                                   int32_t* long_segs, int64_t long_cap, void* stream) {
-    BESS_REQUIRE(n_jobs >= 0 && n_jobs <= BESS_MAX_WORD_JOBS, "step_prologue: %d jobs (0 .. %d)", n_jobs, BESS_MAX_WORD_JOBS);
     BESS_REQUIRE(n_lists >= 0 && n_lists <= BESS_MAX_ROW_LISTS, "step_prologue: %d id lists (0 .. %d)", n_lists,
                  BESS_MAX_ROW_LISTS);
-    BESS_REQUIRE(n_jobs == 0 || (job_dst && job_src && job_value && job_words), "step_prologue: NULL job arrays");
     WordJobs J{};
-    J.n = n_jobs;
     int64_t words = 0;
-    for (int j = 0; j < n_jobs; ++j) {
-        BESS_REQUIRE(job_words[j] >= 0 && (job_words[j] == 0 || job_dst[j]), "step_prologue: job %d", j);
-        BESS_REQUIRE(reinterpret_cast<uintptr_t>(job_dst[j]) % 4 == 0 && reinterpret_cast<uintptr_t>(job_src[j]) % 4 == 0,
-                     "step_prologue: job %d is not 4-byte aligned", j);
-        J.dst[j] = static_cast<uint32_t*>(job_dst[j]);
-        J.src[j] = static_cast<const uint32_t*>(job_src[j]);
-        J.value[j] = job_value[j];
-        J.first[j] = words;
-        words += job_words[j];
-    }
-    for (int j = n_jobs; j <= BESS_MAX_WORD_JOBS; ++j) J.first[j] = words;
+    if (int e = make_word_jobs(n_jobs, job_dst, job_src, job_value, job_words, &J, &words, "step_prologue")) return e;
     IdLists ids{};
     ids.n = n_lists;
     int64_t n_ids = 0;
@@ -1403,6 +1466,45 @@ extern "C" int bess_apply_segments_opt(const bess_opt_desc* o, int32_t dtype, in
         k_apply_segments_opt<half_t><<<grid, 256, 0, as_stream(stream)>>>(a, static_cast<half_t*>(table), width,
                                                                           seg_rows, n_seg, grad_seg, s1, s2, keep);
     return check_launch("apply_segments_opt");
+}
+
+extern "C" int bess_direct_update(const bess_opt_desc* o, int32_t dtype, int32_t width, void* table, int32_t n_lists,
+                                  const int32_t* const* id_lists, const int64_t* id_lens, float* acc, int32_t* claim,
+                                  const int32_t* generation, float* state1, float* state2, void* axpy_table,
+                                  const float* axpy_grad, int64_t axpy_n, float axpy_alpha, void* stream) {
+    if (int e = check_opt(o, state1, state2, "direct_update")) return e;
+    BESS_REQUIRE(!o->slot_map, "direct_update: paged optimiser state goes through the indexed update");
+    BESS_REQUIRE(dtype == BESS_F32 || dtype == BESS_F16, "direct_update: unknown dtype %d", dtype);
+    BESS_REQUIRE(width > 0 && table && acc && claim && generation, "direct_update: NULL pointer / bad width");
+    BESS_REQUIRE(n_lists >= 1 && n_lists <= BESS_MAX_ROW_LISTS && id_lists && id_lens, "direct_update: %d lists (1 .. %d)",
+                 n_lists, BESS_MAX_ROW_LISTS);
+    BESS_REQUIRE(axpy_n >= 0 && (axpy_n == 0 || (axpy_table && axpy_grad)), "direct_update: axpy operands");
+    IdLists ids{};
+    ids.n = n_lists;
+    int64_t total = 0;
+    for (int l = 0; l < n_lists; ++l) {
+        BESS_REQUIRE(id_lens[l] >= 0 && (id_lens[l] == 0 || id_lists[l]), "direct_update: list %d", l);
+        ids.p[l] = id_lists[l];
+        ids.first[l] = static_cast<int32_t>(total);
+        total += id_lens[l];
+    }
+    BESS_REQUIRE(total > 0 && total < (1ll << 31), "direct_update: %lld references", static_cast<long long>(total));
+    for (int l = n_lists; l <= BESS_MAX_ROW_LISTS; ++l) ids.first[l] = static_cast<int32_t>(total);
+    const OptArgs a = opt_args(o);
+    float* s1 = o->kind == BESS_OPT_SGD && o->momentum == 0.f ? nullptr : state1;
+    float* s2 = o->kind == BESS_OPT_ADAM ? state2 : nullptr;
+    AxpyJob x{axpy_table, axpy_grad, axpy_n, axpy_alpha,
+              static_cast<int>(std::min<int64_t>(ceil_div(axpy_n, 256 * 4), 256))};
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(total, 4), 256 * 16)) + x.blocks;
+    if (dtype == BESS_F32)
+        k_direct_update<float><<<grid, 256, 0, as_stream(stream)>>>(a, ids, static_cast<int>(total),
+                                                                    static_cast<float*>(table), width, acc, claim,
+                                                                    generation, s1, s2, x);
+    else
+        k_direct_update<half_t><<<grid, 256, 0, as_stream(stream)>>>(a, ids, static_cast<int>(total),
+                                                                     static_cast<half_t*>(table), width, acc, claim,
+                                                                     generation, s1, s2, x);
+    return check_launch("direct_update");
 }
 
 extern "C" int bess_coalesced_update(const bess_opt_desc* o, int32_t dtype, int32_t width, void* table,

@@ -93,7 +93,12 @@ extern "C" {
 /* bess_model_desc.reserved[0] of TransE / RotatE / DistMult / ComplEx: flags */
 #define BESS_FLAG_PREZEROED 2 /* bess_neg_score_shared_bwd(_ws): d_query and d_neg are zero on entry (e.g. cleared by
                                * bess_step_prologue): the call does not clear them itself */
-#define BESS_FLAG_DNEG_BY_ROW 4 /* bess_neg_score_pertriple_bwd: d_neg is a matrix over the ROW SPACE of neg_base and the
+#define BESS_FLAG_DNEG_BY_ROW 4 /* (1) bess_neg_score_shared_bwd(_ws), where bess_neg_score_shared_bwd_by_row says so, and
+                                  * bess_query_triple_bwd: the entity gradients (d_neg; d_head, d_tail) are matrices over
+                                  * the ROW SPACE of the tables the rows came from - [rows of the base, W] f32 accumulators
+                                  * such as bess_direct_update's - and every gradient row is ADDED (fp32 atomics) at the
+                                  * row id its reference names: no dense [n, W] gradient arrays, nothing to index;
+                                  * (2) bess_neg_score_pertriple_bwd: d_neg is a matrix over the ROW SPACE of neg_base and the
                                   * gradient of reference k is stored at row neg_idx[k] (plain stores) - for lists that
                                   * name every row at most once (negatives that arrived through the all-to-all: the
                                   * receive-buffer gradient is written in place, no [n_query * n_neg, W] copy) */
@@ -487,8 +492,10 @@ int bess_pad_segments(int32_t* seg_rows, const int32_t* n_seg, int64_t max_seg, 
 /* Prologue of a notebook-size step in ONE launch (the step is launch-bound there: reference micro-batch
  * S = 512, K = 32 of notebooks/3_wikikg2_fp16.ipynb:251-256):
  *   - up to BESS_MAX_WORD_JOBS copy / fill jobs over 32-bit words: job j writes job_words[j] words at
- *     job_dst[j], copied from job_src[j] or, when that is NULL, set to job_value[j] (the concatenated
- *     candidate list of an augmented step = the `torch.concat` of bess.py:369-393; zeroed gradient buffers);
+ *     job_dst[j], copied from job_src[j] PLUS job_value[j] (0 for a plain copy; source == destination with
+ *     value 1 increments a device-side counter: the generation of bess_direct_update) or, when job_src[j] is
+ *     NULL, set to job_value[j] (the concatenated candidate list of an augmented step = the `torch.concat` of
+ *     bess.py:369-393; zeroed gradient buffers);
  *   - the segment index (as bess_build_segment_index builds it) of the concatenation of up to
  *     BESS_MAX_ROW_LISTS row-id lists, read where they are (1 .. BESS_SMALL_INDEX_MAX ids in all; n_lists = 0:
  *     no index).  refs_sorted / seg_rows: int32 [n_ids], seg_offsets: [n_ids + 1], n_seg: [1],
@@ -779,6 +786,34 @@ int bess_neg_score_shared_fwd_loss(const bess_model_desc* desc, const float* que
                                    const float* pos, const float* weight, int64_t weight_len, float* row_loss,
                                    float* loss, float* d_pos, float* d_neg, int64_t ld_dneg, int32_t* counters,
                                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* bess_query_triple_fwd with the copy / fill jobs of bess_step_prologue (same arrays, same meaning) run by spare
+ * workgroups of the SAME launch: the prologue of a training step whose update needs no index costs no launch of
+ * its own.  Nothing this launch reads may be written by a job. */
+int bess_query_triple_fwd_jobs(const bess_model_desc* desc, int32_t side, const void* head_base,
+                               const int32_t* head_idx, const void* tail_base, const int32_t* tail_idx,
+                               const void* rel_table, const int32_t* rel_idx, int64_t n_triple, float* query,
+                               float* out, int32_t n_jobs, void* const* job_dst, const void* const* job_src,
+                               const uint32_t* job_value, const int64_t* job_words, void* stream);
+
+/* K9 + K10 without an index (direct-addressed accumulation): for a table whose fp32 image the caller can afford
+ * as scratch.  acc [rows of table, width] f32 is ZERO between steps; the step's backward kernels add their
+ * gradient rows into it at the rows' ids (BESS_FLAG_DNEG_BY_ROW; bess_scatter_add_rows / bess_sparse_sgd_lists with
+ * lr = -1 for gradients that exist as dense lists).  bess_direct_update then visits the step's row-id lists
+ * (n_lists <= BESS_MAX_ROW_LISTS, read where they are): one wave per reference claims its row - claim
+ * [rows of table] int32 holds the generation number of the last step that updated the row, *generation is this
+ * step's (the caller increments it once per step before the call, e.g. with a copy job of bess_step_prologue
+ * whose source is its destination and whose value is 1) - the first reference of a row applies the optimiser
+ * to table[row] with acc[row] as the summed gradient (one read-modify-write, one rounding per row and step; state1
+ * / state2 as for bess_coalesced_update, full-size state only) and zeroes acc[row]; the others leave.  Replaces
+ * bess_build_segment_index + bess_coalesced_update for the small lists of a step (reference: autograd's
+ * index_put_(accumulate) + the optimiser step).  axpy_*: as bess_coalesced_update_axpy. */
+int bess_direct_update(const bess_opt_desc* opt, int32_t dtype, int32_t width, void* table, int32_t n_lists,
+                       const int32_t* const* id_lists, const int64_t* id_lens, float* acc, int32_t* claim,
+                       const int32_t* generation, float* state1, float* state2, void* axpy_table,
+                       const float* axpy_grad, int64_t axpy_n, float axpy_alpha, void* stream);
+/* 1 if bess_neg_score_shared_bwd(_ws) takes BESS_FLAG_DNEG_BY_ROW for this scorer and shape, else 0 */
+int bess_neg_score_shared_bwd_by_row(const bess_model_desc* desc, int64_t n_query, int64_t n_neg);
 
 /* ---- recorded steps -----------------------------------------------------------
  * A step of this library can be captured into a hipGraph as a whole (every call is asynchronous on the
