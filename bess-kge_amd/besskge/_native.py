@@ -85,7 +85,7 @@ class OptDesc(ctypes.Structure):
 OPT_SGD, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
 FLAG_FP32_MATH = 1  # BESS_FLAG_FP32_MATH (ModelDesc.reserved[0] of the four native scorers)
 FLAG_PREZEROED = 2  # BESS_FLAG_PREZEROED: the targets of bess_neg_score_shared_bwd are zero on entry
-FLAG_DNEG_BY_ROW = 4  # BESS_FLAG_DNEG_BY_ROW: entity gradients land at their row ids in row-space matrices (include/besskge_hip.h)
+FLAG_DNEG_BY_ROW = 4  # BESS_FLAG_DNEG_BY_ROW: bess_neg_score_pertriple_bwd stores d_neg at row neg_idx[k] of a row-space matrix
 
 
 class KillDesc(ctypes.Structure):
@@ -200,7 +200,10 @@ SIGNATURES = {
     "bess_graph_node_counts": [_vp, _c_i32p, _i32],
     "bess_direct_update": [ctypes.POINTER(OptDesc), _i32, _i32, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_i64), _vp, _vp,
                            _vp, _vp, _vp, _vp, _vp, _i64, _f32, _vp],
-    "bess_neg_score_shared_bwd_by_row": [_MD, _i64, _i64],
+    "bess_neg_score_shared_bwd_parts_plan": [_MD, _i64, _i64, _c_i32p, _c_i32p],
+    "bess_neg_score_shared_bwd_parts": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
+    "bess_query_triple_bwd_parts": [_MD, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _i64, _vp,
+                                    _vp, _vp, _vp, _vp, _vp],
     "bess_query_triple_fwd_jobs": [_MD, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, ctypes.POINTER(_vp),
                                    ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(_i64), _vp],
     "bess_neg_score_shared_fwd_loss": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, ctypes.POINTER(KillDesc), _LD, _vp, _vp, _i64,
@@ -519,32 +522,10 @@ def query_triple_fwd(d: ModelDesc, side: int, head: RowSource, tail: RowSource, 
 
 
 def query_triple_bwd(d: ModelDesc, side: int, head: RowSource, tail: RowSource, rel_table: torch.Tensor,
-                     rel_idx: torch.Tensor, d_out: torch.Tensor, d_query: torch.Tensor, d_rel_table: torch.Tensor,
-                     rows_acc: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
-                     ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
-    """(d_head [n, W], d_tail [n, W]) of positive score and query together; accumulates into d_rel_table.
-    `rows_acc` = (accumulator over head.base's rows, accumulator over tail.base's rows), f32 [rows, W]: the
-    gradient rows are ADDED there at the triples' row ids (BESS_FLAG_DNEG_BY_ROW), nothing is returned."""
+                     rel_idx: torch.Tensor, d_out: torch.Tensor, d_query: torch.Tensor, d_rel_table: torch.Tensor
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(d_head [n, W], d_tail [n, W]) of positive score and query together; accumulates into d_rel_table."""
     dev, n = _triple_operands(d, head, tail, rel_table, rel_idx)
-    if rows_acc is not None:
-        acc_h, acc_t = rows_acc
-        _same_device([("d_out", d_out), ("d_query", d_query), ("d_rel_table", d_rel_table), ("acc_h", acc_h), ("acc_t", acc_t)])
-        for t, nm in ((d_out, "d_out"), (d_query, "d_query"), (d_rel_table, "d_rel_table"), (acc_h, "acc_h"), (acc_t, "acc_t")):
-            _f32(t, nm)
-        if tuple(acc_h.shape) != (int(head.base.shape[0]), d.width) or tuple(acc_t.shape) != (int(tail.base.shape[0]), d.width) \
-                or head.idx is None or tail.idx is None:
-            raise ValueError("query_triple_bwd: `rows_acc` must cover the row spaces of head.base / tail.base (indexed rows)")
-        if d_out.numel() != n or tuple(d_query.shape) != (n, d.width) or tuple(d_rel_table.shape) != tuple(rel_table.shape):
-            raise ValueError("query_triple_bwd: gradient shapes do not match")
-        d = copy_desc(d)
-        d.reserved[0] |= FLAG_DNEG_BY_ROW
-        with _on(dev):
-            rc = load().bess_query_triple_bwd(
-                ctypes.byref(d), side, head.base.data_ptr(), _idx(head.idx, "head_idx"), tail.base.data_ptr(),
-                _idx(tail.idx, "tail_idx"), rel_table.data_ptr(), rel_idx.data_ptr(), n, d_out.data_ptr(),
-                d_query.data_ptr(), acc_h.data_ptr(), acc_t.data_ptr(), d_rel_table.data_ptr(), _stream(dev))
-        _check(rc, "bess_query_triple_bwd")
-        return None, None
     _same_device([("d_out", d_out), ("d_query", d_query), ("d_rel_table", d_rel_table), ("x", head.base)])
     for t, nm in ((d_out, "d_out"), (d_query, "d_query"), (d_rel_table, "d_rel_table")):
         _f32(t, nm)
@@ -950,43 +931,79 @@ def shared_bwd_buffer(d: ModelDesc, nq: int, n_neg: int, device: torch.device) -
     return torch.empty((nq + n_neg, d.width), dtype=torch.float32, device=device)
 
 
-def shared_bwd_by_row_ok(d: ModelDesc, nq: int, n_neg: int) -> bool:
-    """Does `neg_score_shared_bwd(..., rows_acc=...)` exist for this scorer and shape?"""
-    return bool(load().bess_neg_score_shared_bwd_by_row(ctypes.byref(d), int(nq), int(n_neg)))
+def shared_bwd_parts_plan(d: ModelDesc, nq: int, n_neg: int) -> Tuple[int, int]:
+    """(n_dq_parts, n_dneg_parts) of `neg_score_shared_bwd_parts` for this scorer and shape; (0, 0): no such form."""
+    a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+    _check(load().bess_neg_score_shared_bwd_parts_plan(ctypes.byref(d), int(nq), int(n_neg), ctypes.byref(a), ctypes.byref(b)),
+           "bess_neg_score_shared_bwd_parts_plan")
+    return a.value, b.value
+
+
+def neg_score_shared_bwd_parts(d: ModelDesc, query: torch.Tensor, neg: RowSource, d_out: torch.Tensor
+                               ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(dq_parts [n_dq, nq, W], dneg_parts [n_de, n_neg, W]): the two products of the shared-negative backward as
+    partial sums, written with plain stores - no atomics, nothing to clear (`bess_neg_score_shared_bwd_parts`);
+    `query_triple_bwd_parts` adds them up where it consumes them."""
+    nq, n_neg = int(query.shape[0]), len(neg)
+    dev = _neg_operands(d, query, neg, n_neg)
+    _same_device([("d_out", d_out), ("query", query)])
+    _f32(d_out, "d_out")
+    if tuple(d_out.shape) != (nq, n_neg):
+        raise ValueError("neg_score_shared_bwd_parts: bad score-gradient shape")
+    n_dq, n_de = shared_bwd_parts_plan(d, nq, n_neg)
+    if n_dq == 0:
+        raise RuntimeError("neg_score_shared_bwd_parts: this scorer / shape has no partial-sum form")
+    W = int(d.width)
+    buf = torch.empty((n_dq * nq + n_de * n_neg, W), dtype=torch.float32, device=dev)
+    dqp, dep = buf[: n_dq * nq].view(n_dq, nq, W), buf[n_dq * nq:].view(n_de, n_neg, W)
+    with _on(dev), _Timed("bess_neg_score_shared_bwd", dev):
+        rc = load().bess_neg_score_shared_bwd_parts(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
+                                                    _idx(neg.idx, "negative idx"), n_neg, d_out.data_ptr(), n_neg,
+                                                    dqp.data_ptr(), dep.data_ptr(), _stream(dev))
+    _check(rc, "bess_neg_score_shared_bwd_parts")
+    return dqp, dep
+
+
+def query_triple_bwd_parts(d: ModelDesc, side: int, head: RowSource, tail: RowSource, rel_table: torch.Tensor,
+                           rel_idx: torch.Tensor, d_out: torch.Tensor, dq_parts: torch.Tensor, dneg_parts: torch.Tensor,
+                           neg_idx: torch.Tensor, rows_acc: Tuple[torch.Tensor, torch.Tensor, torch.Tensor],
+                           d_rel_table: torch.Tensor) -> None:
+    """`query_triple_bwd` by row, fed by the partial sums of `neg_score_shared_bwd_parts`: the heads' and tails' gradient
+    rows are added into `rows_acc[0]` / `rows_acc[1]` at the triples' row ids, the candidates' summed rows into
+    `rows_acc[2]` at theirs.  rows_acc = accumulators over the row
+    spaces of (head.base, tail.base, the candidates' table)."""
+    dev, n = _triple_operands(d, head, tail, rel_table, rel_idx)
+    acc_h, acc_t, acc_n = rows_acc
+    _same_device([("d_out", d_out), ("dq_parts", dq_parts), ("dneg_parts", dneg_parts), ("neg_idx", neg_idx),
+                  ("d_rel_table", d_rel_table), ("acc_h", acc_h), ("acc_t", acc_t), ("acc_n", acc_n)])
+    for t, nm in ((d_out, "d_out"), (dq_parts, "dq_parts"), (dneg_parts, "dneg_parts"), (d_rel_table, "d_rel_table"),
+                  (acc_h, "acc_h"), (acc_t, "acc_t"), (acc_n, "acc_n")):
+        _f32(t, nm)
+    W = int(d.width)
+    n_neg = int(neg_idx.numel())
+    if dq_parts.dim() != 3 or tuple(dq_parts.shape[1:]) != (n, W) or dneg_parts.dim() != 3 \
+            or tuple(dneg_parts.shape[1:]) != (n_neg, W) or d_out.numel() != n or head.idx is None or tail.idx is None \
+            or tuple(d_rel_table.shape) != tuple(rel_table.shape):
+        raise ValueError("query_triple_bwd_parts: shapes do not match")
+    if tuple(acc_h.shape) != (int(head.base.shape[0]), W) or tuple(acc_t.shape) != (int(tail.base.shape[0]), W) \
+            or acc_n.dim() != 2 or acc_n.shape[1] != W:
+        raise ValueError("query_triple_bwd_parts: accumulators must cover the row spaces of the tables")
+    with _on(dev):
+        rc = load().bess_query_triple_bwd_parts(
+            ctypes.byref(d), side, head.base.data_ptr(), _idx(head.idx, "head_idx"), tail.base.data_ptr(),
+            _idx(tail.idx, "tail_idx"), rel_table.data_ptr(), rel_idx.data_ptr(), n, d_out.data_ptr(),
+            dq_parts.data_ptr(), int(dq_parts.shape[0]), dneg_parts.data_ptr(), int(dneg_parts.shape[0]), n_neg,
+            _idx(neg_idx, "neg_idx", n_neg), acc_h.data_ptr(), acc_t.data_ptr(), acc_n.data_ptr(), d_rel_table.data_ptr(),
+            _stream(dev))
+    _check(rc, "bess_query_triple_bwd_parts")
 
 
 def neg_score_shared_bwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, out: torch.Tensor,
-                         d_out: torch.Tensor, prezeroed: Optional[torch.Tensor] = None,
-                         rows_acc: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                         d_out: torch.Tensor, prezeroed: Optional[torch.Tensor] = None
+                         ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Returns (d_query [nq, W], d_neg [n_neg, W]).  `prezeroed`: a `shared_bwd_buffer` the caller has
-    already cleared on this stream - the call then writes into it and does not clear anything.
-    `rows_acc` (f32 [rows of neg.base, W], `shared_bwd_by_row_ok`): the candidates' gradient rows are ADDED there at
-    their row ids (BESS_FLAG_DNEG_BY_ROW) instead of being returned; `prezeroed` is then the cleared d_query [nq, W]."""
+    already cleared on this stream - the call then writes into it and does not clear anything."""
     nq, n_neg = int(query.shape[0]), len(neg)
-    if rows_acc is not None:
-        dev = _neg_operands(d, query, neg, n_neg)
-        _same_device([("d_out", d_out), ("out", out), ("query", query), ("rows_acc", rows_acc)])
-        _f32(d_out, "d_out")
-        _f32(rows_acc, "rows_acc")
-        if tuple(d_out.shape) != (nq, n_neg) or tuple(rows_acc.shape) != (int(neg.base.shape[0]), d.width) or neg.idx is None:
-            raise ValueError("neg_score_shared_bwd: `rows_acc` must be [rows of the candidates' table, W], candidates indexed")
-        d = copy_desc(d)
-        d.reserved[0] |= FLAG_DNEG_BY_ROW
-        if prezeroed is not None:
-            if tuple(prezeroed.shape) != (nq, d.width) or prezeroed.dtype != torch.float32:
-                raise ValueError("neg_score_shared_bwd: with `rows_acc`, `prezeroed` is the cleared d_query [nq, W]")
-            dq = prezeroed
-            d.reserved[0] |= FLAG_PREZEROED
-        else:
-            dq = torch.empty((nq, d.width), dtype=torch.float32, device=dev)
-        with _on(dev), _Timed("bess_neg_score_shared_bwd", dev):
-            rc = load().bess_neg_score_shared_bwd_ws(ctypes.byref(d), query.data_ptr(), nq, neg.base.data_ptr(),
-                                                     _idx(neg.idx, "negative idx"), n_neg, out.data_ptr(), n_neg,
-                                                     d_out.data_ptr(), n_neg, dq.data_ptr(), rows_acc.data_ptr(),
-                                                     None, 0, _stream(dev))
-        _check(rc, "bess_neg_score_shared_bwd")
-        return dq, None
-
     dev = _neg_operands(d, query, neg, n_neg)
     _same_device([("d_out", d_out), ("out", out), ("query", query)])
     _f32(d_out, "d_out")

@@ -678,7 +678,7 @@ class BessKGE(torch.nn.Module, ABC):
             return False
         if nat.DirectAccumulator.bytes_for(st.table) > self.direct_update_max_bytes:
             return False
-        return nat.shared_bwd_by_row_ok(desc, len(g.ent), len(g.neg))
+        return nat.shared_bwd_parts_plan(desc, len(g.ent), len(g.neg))[0] > 0
 
     def _launch_prologue(self, st: _ReplicaStep, optimizer: Any, d_rel: Optional[torch.Tensor]) -> Optional[Any]:
         """ONE launch in front of a training step's kernels (`bess_step_prologue`): the concatenated candidate
@@ -687,11 +687,9 @@ class BessKGE(torch.nn.Module, ABC):
         Returns what `_small_index_ahead` would have: (lists, their SegmentIndex), or None."""
         jobs = st.jobs or []
         desc = self.score_fn.kernel_desc()
-        if len(jobs) + 3 <= nat.MAX_WORD_JOBS and self._direct_ok(st, optimizer, desc):
+        if len(jobs) + 2 <= nat.MAX_WORD_JOBS and self._direct_ok(st, optimizer, desc):
+            # (the backward's sums leave as partial results with plain stores: nothing of it to clear)
             st.direct = self._direct_scratch(st.table)
-            g = st.groups[0]
-            g.bwd_buf = torch.empty((len(g.ent), desc.width), dtype=torch.float32, device=st.table.device)  # d_query only
-            jobs.append((g.bwd_buf, None, 0))
             jobs.append(st.direct.increment_job())  # this step's generation number
         for g in st.groups:
             if st.direct is not None:
@@ -1359,10 +1357,14 @@ class EmbeddingMovingBessKGE(BessKGE):
                           dn3[:, cut:].reshape(-1, dn3.shape[-1]).contiguous()]
             for g, go in zip(st.groups, d_outs):
                 if g.shared and st.direct is not None:
-                    # the candidates' gradient rows go straight into the shard's accumulator, at their row ids
-                    dq, _ = nat.neg_score_shared_bwd(desc, g.query, g.neg, g.out, go, prezeroed=g.bwd_buf,
-                                                     rows_acc=st.direct.acc)
-                    st.direct_lists.append(g.neg.idx.reshape(-1))
+                    # both products as partial sums (plain stores, no atomics); the query / triple backward adds them
+                    # up where it reads them and puts every gradient row into the shard's accumulator at its row id
+                    dq_parts, dneg_parts = nat.neg_score_shared_bwd_parts(desc, g.query, g.neg, go)
+                    acc = st.direct.acc
+                    fn.query_triple_bwd_parts(g.side, RowSource(st.table, st.head_idx), st.tail, st.rel_idx, d_pos,
+                                              dq_parts, dneg_parts, g.neg.idx.reshape(-1), (acc, acc, acc), d_rel)
+                    st.direct_lists += [g.neg.idx.reshape(-1), st.head_idx.reshape(-1), st.tail.idx.reshape(-1)]
+                    continue
                 elif g.shared:
                     dq, dn = nat.neg_score_shared_bwd(desc, g.query, g.neg, g.out, go, prezeroed=g.bwd_buf)
                     sink(g.neg, dn)
@@ -1389,11 +1391,7 @@ class EmbeddingMovingBessKGE(BessKGE):
                         dq = g.dq
                     if not in_place:
                         sink(g.neg, dn)
-                if st.fused_qt and st.direct is not None:
-                    fn.query_triple_bwd(g.side, RowSource(st.table, st.head_idx), st.tail, st.rel_idx, d_pos, dq, d_rel,
-                                        rows_acc=(st.direct.acc, st.direct.acc))
-                    st.direct_lists += [st.head_idx.reshape(-1), st.tail.idx.reshape(-1)]
-                elif st.fused_qt:
+                if st.fused_qt:
                     dh, dt = fn.query_triple_bwd(g.side, RowSource(st.table, st.head_idx), st.tail, st.rel_idx, d_pos,
                                                  dq, d_rel)
                     sink(RowSource(st.table, st.head_idx), dh)

@@ -141,13 +141,19 @@ class BaseScoreFunction(torch.nn.Module, ABC):
                                     jobs=jobs)
 
     def query_triple_bwd(self, side: int, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor,
-                         d_pos: torch.Tensor, dq: torch.Tensor, d_rel: torch.Tensor,
-                         rows_acc: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
-                         ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
-        """(d_head rows, d_tail rows) of positive score + query together; relation gradient added to `d_rel`.
-        `rows_acc`: the rows are added into accumulators over the tables' row spaces instead (`nat.query_triple_bwd`)."""
+                         d_pos: torch.Tensor, dq: torch.Tensor, d_rel: torch.Tensor
+                         ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(d_head rows, d_tail rows) of positive score + query together; relation gradient added to `d_rel`."""
         return nat.query_triple_bwd(self.kernel_desc(), side, head, tail, self.relation_embedding.data, rel_idx,
-                                    d_pos, dq, d_rel, rows_acc=rows_acc)
+                                    d_pos, dq, d_rel)
+
+    def query_triple_bwd_parts(self, side: int, head: nat.RowSource, tail: nat.RowSource, rel_idx: torch.Tensor,
+                               d_pos: torch.Tensor, dq_parts: torch.Tensor, dneg_parts: torch.Tensor, neg_idx: torch.Tensor,
+                               rows_acc: Tuple[torch.Tensor, torch.Tensor, torch.Tensor], d_rel: torch.Tensor) -> None:
+        """`query_triple_bwd` with every gradient row ADDED into accumulators over the tables' row spaces (`rows_acc` =
+        heads', tails', candidates'), fed by the partial sums of `nat.neg_score_shared_bwd_parts`."""
+        nat.query_triple_bwd_parts(self.kernel_desc(), side, head, tail, self.relation_embedding.data, rel_idx, d_pos,
+                                   dq_parts, dneg_parts, neg_idx, rows_acc, d_rel)
 
     def dense_parameters(self) -> List[torch.nn.Parameter]:
         """Parameters besides the two embedding tables (ConvE's network); replicated like the

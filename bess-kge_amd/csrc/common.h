@@ -78,11 +78,6 @@ int l1_pk_fwd(const bess_model_desc* d, const float* query, int64_t n_query, con
               const int32_t* neg_idx, int64_t n_neg, float* out, int64_t ld_out, const bess_kill_desc* kill,
               hipStream_t st, const float* thr = nullptr, uint8_t* flags = nullptr, int64_t ld_flags = 0,
               const CountArgs* count = nullptr, bool diag = false);  // diag: out [n, 64] = the diagonal 64 x 64 tiles
-bool l1_pk_loss_in_launch(int64_t n_neg, const float* out, int64_t ld_out, const float* d_neg, int64_t ld_dneg);
-int l1_pk_fwd_loss(const bess_model_desc* d, const float* query, int64_t n_query, const void* neg_base,
-                   const int32_t* neg_idx, int64_t n_neg, float* out, int64_t ld_out, const bess_kill_desc* kill,
-                   const bess_loss_desc* l, const float* pos, const float* weight, int64_t weight_len, float* row_loss,
-                   float* loss, float* d_pos, float* d_neg, int64_t ld_dneg, int32_t* counters, hipStream_t st);
 
 // affine-in-the-candidate distance scorers (affine.hip)
 int affine_pertriple(const bess_model_desc* d, bool fwd, const float* query, int64_t n_query, const void* neg_base,

@@ -30,7 +30,6 @@
 // as packed dwords ([pair][row] images, one ds_read_b128 per operand and pair step), rows
 // gathered by index straight into the image, next stage prefetched into registers.
 #include "common.h"
-#include "loss_rows.h"
 
 namespace bess {
 
@@ -87,31 +86,13 @@ struct PruneArgs {
     int diag;          // only the diagonal 64 x 64 tiles (nq == ne), stored side by side: out is [nq, 64]
 };
 
-// K8 in the scoring launch (TAIL): the workgroup that stores the LAST 64-column tile of a block of rows turns the
-// block's finished score rows into loss terms and score gradients (one wave per row, rows of up to 1024 scores in
-// registers), and the workgroup that finishes the last block sums the terms in a fixed order - the loss launch
-// of a notebook-size step (9.4 of its 75 us, profiles/r03/step_r03_c4g.txt) and its 128 same-address atomics are
-// gone: one atomic per tile on the block's own counter, one per block on the last one.
-struct LossTail {
-    bess_loss_desc l;
-    const float* pos;
-    const float* weight;
-    int64_t weight_len;
-    float* row_loss;
-    float* loss;
-    float* d_pos;
-    float* d_neg;
-    int64_t ld_dneg;
-    int32_t* counters;  // [row blocks + 1] zero on entry, left zero
-};
-
 // out[q, j] = -sum_w |fp16(Q[q, w]) - E[idx[j], w]|        W % 32 == 0
 // MI: query rows per thread (4: 64 x 64 tile; 2: 32 x 64 tile for launches whose 64-row grid leaves CUs idle)
-template <int MI, bool TAIL>
+template <int MI>
 __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, int64_t nq,
                                                    const half_t* __restrict__ E, const int32_t* __restrict__ eidx,
                                                    int64_t ne, int W, float* __restrict__ out, int64_t ld,
-                                                   KillArgs kill, PruneArgs prune, LossTail tail) {
+                                                   KillArgs kill, PruneArgs prune) {
     __shared__ __attribute__((aligned(16))) uint32_t Qs[FKH / 2][PLD];
     __shared__ __attribute__((aligned(16))) uint32_t Es[FKH / 2][PLD];
     __shared__ float rsq[PT], rse[PT];
@@ -244,42 +225,6 @@ __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, 
                 if (jj0 + j < ne) o[oc + j] = v4[j];
         }
     }
-    if constexpr (TAIL) {
-        __shared__ int last_s;
-        __shared__ float part[256];
-        __syncthreads();  // this workgroup's scores are on their way
-        if (t == 0) {
-            __threadfence();
-            last_s = atomicAdd(tail.counters + blockIdx.y, 1) == static_cast<int>(gridDim.x) - 1;
-        }
-        __syncthreads();
-        if (!last_s) return;
-        __threadfence();  // (acquire: the other tiles' scores of these rows are visible)
-        for (int r = t >> 6; r < QT; r += 4) {
-            const int64_t q = q0 + r;
-            if (q < nq)
-                loss_row_dyn<true, 4>(tail.l, tail.pos, out, q, ne, ld, tail.weight, tail.weight_len, tail.row_loss,
-                                      tail.d_pos, tail.d_neg, tail.ld_dneg);
-        }
-        __syncthreads();
-        if (t == 0) {
-            __threadfence();
-            last_s = atomicAdd(tail.counters + gridDim.y, 1) == static_cast<int>(gridDim.y) - 1;
-        }
-        __syncthreads();
-        if (!last_s) return;
-        __threadfence();
-        float acc = 0.f;  // fixed order: bitwise reproducible whatever the order the blocks finished in
-        for (int64_t i = t; i < nq; i += 256) acc += __builtin_nontemporal_load(tail.row_loss + i);
-        part[t] = acc;
-        __syncthreads();
-        for (int h = 128; h > 0; h >>= 1) {
-            if (t < h) part[t] += part[t + h];
-            __syncthreads();
-        }
-        if (t == 0) tail.loss[0] = part[0];
-        for (int i = t; i <= static_cast<int>(gridDim.y); i += 256) tail.counters[i] = 0;
-    }
 }
 
 bool l1_pk_eligible(const bess_model_desc* d) {
@@ -293,9 +238,8 @@ int l1_pk_fwd(const bess_model_desc* d, const float* query, int64_t n_query, con
     const PruneArgs pr{thr, flags, ld_flags, count ? *count : CountArgs{nullptr, nullptr, 0, 0}, diag ? 1 : 0};
     if (diag) {  // pair scores: 64 x 64 tiles on the diagonal, out [n, 64]
         BESS_REQUIRE(n_query == n_neg && ld_out == PT && !thr && !count && !k, "l1_pk_fwd: bad diagonal problem");
-        k_l1_fwd_pk<4, false><<<dim3(static_cast<unsigned>(ceil_div(n_neg, PT)), 1), 256, 0, st>>>(
-            query, n_query, static_cast<const half_t*>(neg_base), neg_idx, n_neg, d->width, out, ld_out, KillArgs{}, pr,
-            LossTail{});
+        k_l1_fwd_pk<4><<<dim3(static_cast<unsigned>(ceil_div(n_neg, PT)), 1), 256, 0, st>>>(
+            query, n_query, static_cast<const half_t*>(neg_base), neg_idx, n_neg, d->width, out, ld_out, KillArgs{}, pr);
         return check_launch("neg_score_shared_fwd (packed f16 L1, diagonal tiles)");
     }
     KillArgs ka{};
@@ -304,39 +248,12 @@ int l1_pk_fwd(const bess_model_desc* d, const float* query, int64_t n_query, con
     const bool small = ceil_div(n_neg, PT) * ceil_div(n_query, PT) < 192;
     const dim3 grid(static_cast<unsigned>(ceil_div(n_neg, PT)), static_cast<unsigned>(ceil_div(n_query, small ? PT / 2 : PT)));
     if (small)
-        k_l1_fwd_pk<2, false><<<grid, 256, 0, st>>>(query, n_query, static_cast<const half_t*>(neg_base), neg_idx, n_neg,
-                                                    d->width, out, ld_out, ka, pr, LossTail{});
+        k_l1_fwd_pk<2><<<grid, 256, 0, st>>>(query, n_query, static_cast<const half_t*>(neg_base), neg_idx, n_neg,
+                                                    d->width, out, ld_out, ka, pr);
     else
-        k_l1_fwd_pk<4, false><<<grid, 256, 0, st>>>(query, n_query, static_cast<const half_t*>(neg_base), neg_idx, n_neg,
-                                                    d->width, out, ld_out, ka, pr, LossTail{});
+        k_l1_fwd_pk<4><<<grid, 256, 0, st>>>(query, n_query, static_cast<const half_t*>(neg_base), neg_idx, n_neg,
+                                                    d->width, out, ld_out, ka, pr);
     return check_launch("neg_score_shared_fwd (packed f16 L1)");
-}
-
-// Can l1_pk_fwd_loss finish the loss inside the scoring launch?  Rows of up to 1024 scores with 16-byte accesses
-// (the wave that finishes a row keeps it in registers), score matrix and gradient 16-byte aligned.
-bool l1_pk_loss_in_launch(int64_t n_neg, const float* out, int64_t ld_out, const float* d_neg, int64_t ld_dneg) {
-    return n_neg <= 1024 && n_neg % 4 == 0 && ld_out % 4 == 0 && ld_dneg % 4 == 0 &&
-           reinterpret_cast<uintptr_t>(out) % 16 == 0 && reinterpret_cast<uintptr_t>(d_neg) % 16 == 0;
-}
-
-// scores (+ K7) + K8 in ONE launch; counters: int32 [ceil(n_query / 16) + 1], zero on entry, left zero
-int l1_pk_fwd_loss(const bess_model_desc* d, const float* query, int64_t n_query, const void* neg_base,
-                   const int32_t* neg_idx, int64_t n_neg, float* out, int64_t ld_out, const bess_kill_desc* k,
-                   const bess_loss_desc* l, const float* pos, const float* weight, int64_t weight_len, float* row_loss,
-                   float* loss, float* d_pos, float* d_neg, int64_t ld_dneg, int32_t* counters, hipStream_t st) {
-    KillArgs ka{};
-    if (k) ka = KillArgs{k->diag_step, k->ht, k->ppp, k->mask, k->mask_rows, k->mask ? k->mask_cols : 0, n_neg};
-    const PruneArgs pr{nullptr, nullptr, 0, CountArgs{nullptr, nullptr, 0, 0}, 0};
-    const LossTail lt{*l, pos, weight, weight_len, row_loss, loss, d_pos, d_neg, ld_dneg, counters};
-    const bool small = ceil_div(n_neg, PT) * ceil_div(n_query, PT) < 192;
-    const dim3 grid(static_cast<unsigned>(ceil_div(n_neg, PT)), static_cast<unsigned>(ceil_div(n_query, small ? PT / 2 : PT)));
-    if (small)
-        k_l1_fwd_pk<2, true><<<grid, 256, 0, st>>>(query, n_query, static_cast<const half_t*>(neg_base), neg_idx, n_neg,
-                                                   d->width, out, ld_out, ka, pr, lt);
-    else
-        k_l1_fwd_pk<4, true><<<grid, 256, 0, st>>>(query, n_query, static_cast<const half_t*>(neg_base), neg_idx, n_neg,
-                                                   d->width, out, ld_out, ka, pr, lt);
-    return check_launch("neg_score_shared_fwd_loss (packed f16 L1 + loss rows)");
 }
 
 }  // namespace bess

@@ -1,6 +1,4 @@
-// K8 row by row: the loss term of one triple and the gradient of its scores, by one wave.  Shared by the loss
-// kernels (loss.hip) and by scoring kernels that finish a micro-batch's rows themselves (l1_f16.hip: the packed L1
-// forward whose last workgroup of a row block turns the block's scores into loss terms and score gradients).
+// K8 row by row: the loss term of one triple and the gradient of its scores, by one wave (loss.hip).
 //   reference loss.py:28-51 (self-adversarial weights = detached softmax), 115-134 (log-sigmoid), 179-195 (margin
 //   ranking), 224-251 (sampled-softmax cross entropy); fp32, summed over the micro-batch (bess.py:254-260).
 #pragma once
@@ -156,21 +154,5 @@ __device__ __forceinline__ void loss_row(const bess_loss_desc& l, const float* _
                                        row_norm);
 }
 
-
-// the same with kind / adversarial switch taken at run time (callers that cannot be templates over the loss)
-template <bool GRAD, int CH>
-__device__ __forceinline__ void loss_row_dyn(const bess_loss_desc& l, const float* __restrict__ pos,
-                                             const float* __restrict__ neg, int64_t s, int64_t n_neg, int64_t ld_neg,
-                                             const float* __restrict__ weight, int64_t weight_len,
-                                             float* __restrict__ row_loss, float* __restrict__ d_pos,
-                                             float* __restrict__ d_neg, int64_t ld_dneg) {
-    const bool adv = l.adversarial != 0;
-#define BESS_ROW(KIND, ADV) \
-    loss_row_impl<KIND, ADV, GRAD, CH>(l, pos, neg, s, n_neg, ld_neg, weight, weight_len, row_loss, d_pos, d_neg, ld_dneg, nullptr)
-    if (l.kind == BESS_LOSS_SSCE) BESS_ROW(BESS_LOSS_SSCE, false);
-    else if (l.kind == BESS_LOSS_LOGSIGMOID) { if (adv) BESS_ROW(BESS_LOSS_LOGSIGMOID, true); else BESS_ROW(BESS_LOSS_LOGSIGMOID, false); }
-    else { if (adv) BESS_ROW(BESS_LOSS_MARGIN, true); else BESS_ROW(BESS_LOSS_MARGIN, false); }
-#undef BESS_ROW
-}
 
 }  // namespace bess

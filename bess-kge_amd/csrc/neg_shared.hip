@@ -371,8 +371,7 @@ constexpr int FB_TW = 64, FB_IS = 8;  // (FB_NW waves = groups of 32 candidates 
 template <typename TE, bool ROUND16, int FB_NW>
 __global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, RowSrc<TE> E, int W, float sign,
                                                         const float* __restrict__ d_out, int64_t ld,
-                                                        float* __restrict__ dq, float* __restrict__ de, int i_chunk,
-                                                        int de_by_row) {
+                                                        float* __restrict__ dq, float* __restrict__ de, int i_chunk) {
     // A wave = 64 columns x ONE group of 32 candidates: the coefficient of (query, candidate) is the same for all
     // its lanes - a wave-uniform address, i.e. scalar loads (s_load_dwordx8 into SGPRs that the v_fma reads
     // directly): no LDS staging of the coefficients, no barrier for them.  Eight waves = 256 candidates; their
@@ -479,13 +478,101 @@ __global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, 
 #pragma unroll
         for (int jj = 0; jj < 32; ++jj) {
             const int64_t j = jbase + jj;
-            // (de_by_row - BESS_FLAG_DNEG_BY_ROW: `de` is a matrix over the ROW SPACE of the candidates' table, the
-            // sums of candidate j are added at its row id: bess_direct_update picks them up there)
-            if (j < E.n && acc[jj] != 0.f) {
-                const int64_t r = (de_by_row && E.idx) ? static_cast<int64_t>(E.idx[j]) : j;
-                unsafeAtomicAdd(de + r * W + w0 + w, -sign * acc[jj]);
-            }
+            if (j < E.n && acc[jj] != 0.f) unsafeAtomicAdd(de + j * W + w0 + w, -sign * acc[jj]);
         }
+    }
+}
+
+// ---- the same two products as PARTIAL SUMS: no atomics, no LDS, no barrier ---------------------------------------
+// A wave = 64 columns x one group of 32 candidates x one slice of the queries, exactly as above - but it shares
+// nothing with other waves: the query's partial sum over the wave's 32 candidates is STORED, as row i of slab
+// `candidate group` of dq_parts [groups, S, W], the candidates' sums over the slice as rows of slab `slice` of
+// de_parts [slices, N, W].  Their consumer (k_query_triple_bwd_parts) adds the slabs up where it reads them.
+// At the notebook micro-batch (S = 512, N = 544) the 3.7 M fp32 atomics of the sums - 15 MB at the ~1.3 TB/s
+// memory-side atomics run at - the barriers of the LDS meeting every 8 queries and the idle waves of the last
+// candidate tile (3 of 20) were most of the kernel's 24 us.  Workgroups are four independent waves.
+template <typename TE, bool ROUND16>
+__global__ __launch_bounds__(256, 2) void k_l1_bwd_parts(RowSrc<float> Q, RowSrc<TE> E, int W, float sign,
+                                                     const float* __restrict__ d_out, int64_t ld,
+                                                     float* __restrict__ dq_parts, float* __restrict__ de_parts,
+                                                     int i_chunk, int n_group, int n_task) {
+    const int w = threadIdx.x & 63;
+    // task = (slice, candidate group): consecutive waves take consecutive groups of the same slice
+    const int task = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * 4 + (threadIdx.x >> 6));
+    if (task >= n_task) return;
+    const int jg = task % n_group, sl = task / n_group;
+    const int w0 = blockIdx.y * FB_TW;
+    const int i_lo = sl * i_chunk;
+    const int n_i = min(i_chunk, static_cast<int>(Q.n) - i_lo);  // even: S % 8 == 0, slices of multiples of 8
+    const int wc = min(w0 + w, W - 1);  // (columns past the end: clamped, dropped at the stores)
+    const bool w_ok = w0 + w < W;
+    const int64_t jbase = static_cast<int64_t>(jg) * 32;  // (n_neg % 32 == 0: all 32 candidates exist)
+    float e[32], acc[32];
+    {
+        int32_t rows[32];
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) rows[jj] = static_cast<int32_t>(jbase + jj);
+        if (E.idx) {
+#pragma unroll
+            for (int jj = 0; jj < 32; ++jj) rows[jj] = E.idx[rows[jj]];
+        }
+        const TE* col = E.base + wc;
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) {
+            e[jj] = to_f32(col[static_cast<int64_t>(rows[jj]) * W]) * SGN_PRESCALE;
+            acc[jj] = 0.f;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) asm volatile("" : "+v"(e[jj]));  // (see k_l1_bwd_both)
+    }
+    // running pointers (one add per query instead of 64-bit index products: the kernel lives at the SGPR limit -
+    // two sets of 32 coefficient registers)
+    const float* qptr = Q.base + static_cast<int64_t>(i_lo) * W + wc;        // the query value one query ahead
+    const float* __restrict__ cptr = d_out + static_cast<int64_t>(i_lo) * ld + jbase;  // wave-uniform: scalar loads
+    float* __restrict__ dq_out = dq_parts + (static_cast<int64_t>(jg) * Q.n + i_lo) * W + w0 + w;
+    float qnext = *qptr;
+    float cA[32], cB[32];
+#pragma unroll
+    for (int jj = 0; jj < 32; ++jj) cA[jj] = cptr[jj];
+    auto one_query = [&](const float (&cur)[32], float (&nxt)[32], bool more) {
+        float qv = qnext;
+        if (more) {  // (wave-uniform)
+            qptr += W;
+            cptr += ld;
+        }
+        qnext = *qptr;
+        if (ROUND16) qv = static_cast<float>(static_cast<_Float16>(qv));
+        qv *= SGN_PRESCALE;
+        asm volatile("" : "+v"(qv));
+        float pq4[4] = {0.f, 0.f, 0.f, 0.f};
+        {
+            const float sg = sgn_prescaled(qv - e[0]);
+            pq4[0] = fmaf(cur[0], sg, pq4[0]);
+            acc[0] = fmaf(cur[0], sg, acc[0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) nxt[jj] = cptr[jj];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 1; jj < 32; ++jj) {
+            const float c = cur[jj];
+            const float sg = sgn_prescaled(qv - e[jj]);
+            pq4[jj & 3] = fmaf(c, sg, pq4[jj & 3]);
+            acc[jj] = fmaf(c, sg, acc[jj]);
+        }
+        if (w_ok) *dq_out = sign * ((pq4[0] + pq4[1]) + (pq4[2] + pq4[3]));
+        dq_out += W;
+    };
+#pragma unroll 1
+    for (int i = 0; i < n_i; i += 2) {
+        one_query(cA, cB, true);            // (n_i is even: query i + 1 exists)
+        one_query(cB, cA, i + 2 < n_i);
+    }
+    if (w_ok) {
+        float* __restrict__ de_out = de_parts + (static_cast<int64_t>(sl) * E.n + jbase) * W + w0 + w;
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) de_out[static_cast<int64_t>(jj) * W] = -sign * acc[jj];
     }
 }
 
@@ -498,36 +585,105 @@ static bool use_l1_bwd_both(const bess_model_desc* d, int64_t S, int64_t N) {
            d->width >= FB_TW;
 }
 
-template <typename TE>
-static int run_l1_bwd_both(const bess_model_desc* d, RowSrc<float> Q, RowSrc<TE> E, const float* d_out,
-                           int64_t ld_dout, float* d_query, float* d_neg, hipStream_t st, bool round16) {
-    const int W = d->width;
+// The partial-sum form pays for having no atomics with the slabs of d_query it stores - one per group of 32
+// candidates, S x W each: up to notebook sizes (512 x 544: 8.9 MB, 21.6 -> ~19 us against 24.1 with atomics;
+// 256 x 288: 9.8 against 14.8) a gain, from 1024 x 1088 on (36 MB: 50.4 against 48.5, then 2x slower) a loss.
+static bool use_l1_bwd_parts(const bess_model_desc* d, int64_t S, int64_t N) {
+    return use_l1_bwd_both(d, S, N) && S * (N / 32) * d->width * 4 <= (24ll << 20);
+}
+
+// launch plan of k_l1_bwd_both: waves per workgroup, queries per slice, slices, candidate tiles
+struct L1BothPlan {
+    int nw;
+    int64_t i_chunk, slices, jt, wt;
+};
+static L1BothPlan plan_l1_bwd_both(int64_t S, int64_t N, int W, bool /*unused*/) {
+    L1BothPlan p;
     // eight waves (256 candidates) per workgroup; four where the candidates are few (finer tiles: 544 candidates
     // are 4.25 tiles of 128 but 2.1 of 256).  Measured (profiles/sweep_l1_bwd.py, us, 4 / 8 waves): 512 x 544
     // 25.2 / 29.5, 1024 x 1088 49.3 / 52.8, 2048 x 2176 123.7 / 123.4, 4096 x 4352 451 / 409
-    const int nw = E.n < 2048 ? 4 : 8;
-    const int64_t jt = ceil_div(E.n, 32 * nw), wt = ceil_div(W, FB_TW);
+    p.nw = N < 2048 ? 4 : 8;
+    p.jt = ceil_div(N, 32 * p.nw);
+    p.wt = ceil_div(W, FB_TW);
     // Query slices.  16 waves per CU are resident (103 VGPRs: 4 per SIMD): the grid should fill them in whole
     // rounds - 1564 eight-wave workgroups are 4 rounds of 512 of which the last is almost empty, 1496 are 3.  Cost of
     // a plan = rounds x (queries per slice + ~24 queries' worth of loading the candidates' registers and storing
     // their sums) + 1 per slice (every slice adds one atomic per element of d_neg: at 512 x 544, 22 slices of 24
     // queries take 23.8 us, 32 of 16 take 27.5).
-    const int64_t resident = 256 * 16 / nw, tiles = jt * wt;
-    int64_t i_chunk = Q.n, slices = 1;
+    const int64_t resident = 256 * 16 / p.nw, tiles = p.jt * p.wt;
+    p.i_chunk = S;
+    p.slices = 1;
     double best = 1e300;
-    for (int64_t sl = 1; sl <= ceil_div(Q.n, 16); ++sl) {
-        const int64_t ch = ceil_div(ceil_div(Q.n, sl), FB_IS) * FB_IS;
-        const int64_t actual = ceil_div(Q.n, ch);
-        const double cost = static_cast<double>(ceil_div(tiles * actual, resident)) * (ch + 24) + actual;
-        if (cost < best) best = cost, i_chunk = ch, slices = actual;
+    const double per_slice = 1.0;
+    for (int64_t sl = 1; sl <= ceil_div(S, 16); ++sl) {
+        const int64_t ch = ceil_div(ceil_div(S, sl), FB_IS) * FB_IS;
+        const int64_t actual = ceil_div(S, ch);
+        const double cost = static_cast<double>(ceil_div(tiles * actual, resident)) * (ch + 24) + actual * per_slice;
+        if (cost < best) best = cost, p.i_chunk = ch, p.slices = actual;
     }
+    return p;
+}
+
+// plan of k_l1_bwd_parts: candidate groups (= slabs of dq_parts), query slices (= slabs of de_parts).  The waves are
+// independent: (groups x column tiles x slices) of them should fill the chip's 1024 SIMDs a whole number of times,
+// 2 - 4 waves each, without making a slice shorter than 8 queries (every wave pays ~24 queries' worth of loading its
+// candidates and storing their sums).
+struct L1PartsPlan {
+    int64_t groups, slices, i_chunk;
+};
+static L1PartsPlan plan_l1_bwd_parts(int64_t S, int64_t N, int W) {
+    L1PartsPlan p;
+    p.groups = N / 32;
+    const int64_t per_slice = p.groups * ceil_div(W, FB_TW);  // waves per slice
+    p.i_chunk = S;
+    p.slices = 1;
+    double best = 1e300;
+    for (int64_t sl = 1; sl <= S / FB_IS; ++sl) {
+        const int64_t ch = ceil_div(ceil_div(S, sl), FB_IS) * FB_IS;
+        const int64_t actual = ceil_div(S, ch);
+        const int64_t waves = per_slice * actual;
+        // rounds over the 4096 wave slots of the chip at 4 per SIMD; a SIMD's waves share its issue slots
+        const double per_simd = static_cast<double>(ceil_div(waves, 1024));
+        // (measured, profiles/sweep_l1_bwd.py: 512 x 768 in 32 slices of 16 queries 20.7 us, 512 x 544 in 22 of 24 21.6)
+        const double cost = per_simd * (ch + 12.0) / std::min(per_simd, 2.5) + 0.1 * actual;
+        if (cost < best) best = cost, p.i_chunk = ch, p.slices = actual;
+    }
+    return p;
+}
+
+template <typename TE>
+static int run_l1_bwd_parts(const bess_model_desc* d, RowSrc<float> Q, RowSrc<TE> E, const float* d_out,
+                            int64_t ld_dout, float* dq_parts, float* de_parts, hipStream_t st, bool round16) {
+    const int W = d->width;
+    const L1PartsPlan p = plan_l1_bwd_parts(Q.n, E.n, W);
+    const int64_t tasks = p.groups * p.slices;
+    BESS_REQUIRE(tasks < (1ll << 31) && ceil_div(W, FB_TW) < 65536, "neg_score_shared_bwd_parts: problem too large");
+    const dim3 grid(static_cast<unsigned>(ceil_div(tasks, 4)), static_cast<unsigned>(ceil_div(W, FB_TW)));
+    const float sign = is_distance(d->scorer) ? -1.f : 1.f;
+    if (round16)
+        k_l1_bwd_parts<TE, true><<<grid, 256, 0, st>>>(Q, E, W, sign, d_out, ld_dout, dq_parts, de_parts,
+                                                       static_cast<int>(p.i_chunk), static_cast<int>(p.groups),
+                                                       static_cast<int>(tasks));
+    else
+        k_l1_bwd_parts<TE, false><<<grid, 256, 0, st>>>(Q, E, W, sign, d_out, ld_dout, dq_parts, de_parts,
+                                                        static_cast<int>(p.i_chunk), static_cast<int>(p.groups),
+                                                        static_cast<int>(tasks));
+    return check_launch("neg_score_shared_bwd_parts");
+}
+
+template <typename TE>
+static int run_l1_bwd_both(const bess_model_desc* d, RowSrc<float> Q, RowSrc<TE> E, const float* d_out,
+                           int64_t ld_dout, float* d_query, float* d_neg, hipStream_t st, bool round16) {
+    const int W = d->width;
+    const L1BothPlan p = plan_l1_bwd_both(Q.n, E.n, W, false);
+    const int nw = p.nw;
+    const int64_t jt = p.jt, wt = p.wt, slices = p.slices;
     BESS_REQUIRE(jt < (1ll << 31) && wt < 65536 && slices < 65536, "neg_score_shared_bwd: problem too large for one launch");
     const dim3 grid(static_cast<unsigned>(jt), static_cast<unsigned>(wt), static_cast<unsigned>(slices));
     const float sign = is_distance(d->scorer) ? -1.f : 1.f;
-    const int ic = static_cast<int>(i_chunk);
-    const int by_row = (d->reserved[0] & BESS_FLAG_DNEG_BY_ROW) ? 1 : 0;
+    const int ic = static_cast<int>(p.i_chunk);
 #define BESS_FB(R16, NW) \
-    k_l1_bwd_both<TE, R16, NW><<<grid, 64 * NW, 0, st>>>(Q, E, W, sign, d_out, ld_dout, d_query, d_neg, ic, by_row)
+    k_l1_bwd_both<TE, R16, NW><<<grid, 64 * NW, 0, st>>>(Q, E, W, sign, d_out, ld_dout, d_query, d_neg, ic)
     if (nw == 8) {
         if (round16) BESS_FB(true, 8);
         else BESS_FB(false, 8);
@@ -599,12 +755,10 @@ template <typename TE>
 static int run_bwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<TE> E, const float* d_out, int64_t ld_dout,
                    const float* out, int64_t ld_out, float* d_query, float* d_neg, hipStream_t st, bool round16) {
     const int W = d->width;
-    const bool by_row = d->reserved[0] & BESS_FLAG_DNEG_BY_ROW;
     if (use_l1_bwd_both(d, Q.n, E.n) && Q.idx == nullptr) {  // (the kernel reads the dense f32 query matrix)
         if (!(d->reserved[0] & BESS_FLAG_PREZEROED)) {  // its outputs are sums of atomics
             hipError_t e = hipSuccess;
-            if (by_row) e = fill_words_async(d_query, 0u, Q.n * W, st);  // (d_neg: the caller's accumulator, added to)
-            else if (d_neg == d_query + Q.n * W) e = fill_words_async(d_query, 0u, (Q.n + E.n) * W, st);
+            if (d_neg == d_query + Q.n * W) e = fill_words_async(d_query, 0u, (Q.n + E.n) * W, st);
             else {
                 e = fill_words_async(d_query, 0u, Q.n * W, st);
                 if (e == hipSuccess) e = fill_words_async(d_neg, 0u, E.n * W, st);
@@ -613,9 +767,6 @@ static int run_bwd(const bess_model_desc* d, RowSrc<float> Q, RowSrc<TE> E, cons
         }
         return run_l1_bwd_both<TE>(d, Q, E, d_out, ld_dout, d_query, d_neg, st, round16);
     }
-    if (by_row)
-        return fail(BESS_EUNSUPPORTED, "neg_score_shared_bwd: BESS_FLAG_DNEG_BY_ROW for this scorer / shape "
-                                       "(bess_neg_score_shared_bwd_by_row says which take it)");
     BwdSide<float, TE> A{Q, E, ld_dout, 1, ld_out, 1, d_query, 0, 0, 0, 0};
     BwdSide<TE, float> B{E, Q, 1, ld_dout, 1, ld_out, d_neg, 0, 0, 0, 0};
     const bool small_a = plan_bwd_side(W, A), small_b = plan_bwd_side(W, B);
@@ -709,22 +860,7 @@ extern "C" int bess_neg_score_shared_fwd_loss(const bess_model_desc* d, const fl
                  "neg_score_shared_fwd_loss: bad sizes / NULL pointer");
     BESS_REQUIRE(l->kind >= BESS_LOSS_LOGSIGMOID && l->kind <= BESS_LOSS_SSCE, "neg_score_shared_fwd_loss: unknown loss %d", l->kind);
     BESS_REQUIRE(weight_len == 1 || weight_len == n_query, "neg_score_shared_fwd_loss: weight_len must be 1 or n_query");
-    if (d->scorer <= BESS_COMPLEX && use_l1_pk(d, query, neg_base) && l1_pk_loss_in_launch(n_neg, out, ld_out, d_neg, ld_dneg)) {
-        if (kill) {
-            BESS_REQUIRE(kill->diag_step >= 0, "neg_score_shared_fwd_loss: negative diag_step");
-            if (kill->mask) {
-                BESS_REQUIRE(kill->mask_cols > 0 && kill->mask_cols <= n_neg, "neg_score_shared_fwd_loss: mask_cols");
-                BESS_REQUIRE(kill->mask_rows == 1 || kill->mask_rows == 2 || kill->mask_rows == n_query,
-                             "neg_score_shared_fwd_loss: mask_rows %lld not 1, 2 or n_query", (long long)kill->mask_rows);
-            }
-            if (kill->ht || (kill->mask && kill->mask_rows == 2))
-                BESS_REQUIRE(kill->ppp >= 2 && (kill->ppp % 2) == 0 && (n_query % kill->ppp) == 0,
-                             "neg_score_shared_fwd_loss: 'ht' needs an even block size dividing n_query");
-        }
-        return l1_pk_fwd_loss(d, query, n_query, neg_base, neg_idx, n_neg, out, ld_out, kill, l, pos, weight, weight_len,
-                              row_loss, loss, d_pos, d_neg, ld_dneg, counters, as_stream(stream));
-    }
-    // the other kernel families: the scoring launch (+ K7), then the loss launch(es)
+    // the scoring launch (K7 in its epilogue where the kernel has one), then the loss launch(es)
     if (int e = bess_neg_score_shared_fwd_masked(d, query, n_query, neg_base, neg_idx, n_neg, out, ld_out, kill, workspace,
                                                  workspace_bytes, stream))
         return e;
@@ -999,9 +1135,35 @@ extern "C" int64_t bess_neg_score_shared_bwd_workspace(const bess_model_desc* d,
     return gemm_split_bwd_workspace(n_query, n_neg, d->width);
 }
 
-extern "C" int bess_neg_score_shared_bwd_by_row(const bess_model_desc* d, int64_t n_query, int64_t n_neg) {
-    if (!d || check_desc(d) || d->scorer > BESS_COMPLEX) return 0;
-    return use_l1_bwd_both(d, n_query, n_neg) ? 1 : 0;
+extern "C" int bess_neg_score_shared_bwd_parts_plan(const bess_model_desc* d, int64_t n_query, int64_t n_neg,
+                                                    int32_t* n_dq_parts, int32_t* n_dneg_parts) {
+    BESS_REQUIRE(n_dq_parts && n_dneg_parts, "neg_score_shared_bwd_parts_plan: NULL out");
+    *n_dq_parts = *n_dneg_parts = 0;
+    if (!d || check_desc(d) || d->scorer > BESS_COMPLEX || !use_l1_bwd_parts(d, n_query, n_neg)) return BESS_OK;
+    const L1PartsPlan p = plan_l1_bwd_parts(n_query, n_neg, d->width);
+    *n_dq_parts = static_cast<int32_t>(p.groups);
+    *n_dneg_parts = static_cast<int32_t>(p.slices);
+    return BESS_OK;
+}
+
+extern "C" int bess_neg_score_shared_bwd_parts(const bess_model_desc* d, const float* query, int64_t n_query,
+                                               const void* neg_base, const int32_t* neg_idx, int64_t n_neg,
+                                               const float* d_out, int64_t ld_dout, float* dq_parts,
+                                               float* dneg_parts, void* stream) {
+    if (int e = check_desc(d)) return e;
+    BESS_REQUIRE(n_query > 0 && n_neg > 0 && query && neg_base && d_out && dq_parts && dneg_parts && ld_dout >= n_neg,
+                 "neg_score_shared_bwd_parts: NULL pointer / bad sizes");
+    if (d->scorer > BESS_COMPLEX || !use_l1_bwd_parts(d, n_query, n_neg))
+        return fail(BESS_EUNSUPPORTED, "neg_score_shared_bwd_parts: this scorer / shape has no partial-sum form "
+                                       "(bess_neg_score_shared_bwd_parts_plan says 0 parts)");
+    const bool r16 = use_l1_pk(d, query, neg_base);
+    RowSrc<float> Q{query, nullptr, n_query};
+    hipStream_t st = as_stream(stream);
+    if (d->dtype == BESS_F32)
+        return run_l1_bwd_parts<float>(d, Q, RowSrc<float>{static_cast<const float*>(neg_base), neg_idx, n_neg}, d_out,
+                                       ld_dout, dq_parts, dneg_parts, st, false);
+    return run_l1_bwd_parts<half_t>(d, Q, RowSrc<half_t>{static_cast<const half_t*>(neg_base), neg_idx, n_neg}, d_out,
+                                    ld_dout, dq_parts, dneg_parts, st, r16);
 }
 
 extern "C" int bess_neg_score_shared_bwd(const bess_model_desc* d, const float* query,
@@ -1026,10 +1188,6 @@ extern "C" int bess_neg_score_shared_bwd_ws(const bess_model_desc* d, const floa
     BESS_REQUIRE(reduce_of(d) != RED_L2 || out, "neg_score_shared_bwd: p=2 needs the forward scores");
     BESS_REQUIRE(ld_dout >= n_neg && (!out || ld_out >= n_neg), "neg_score_shared_bwd: leading dimension < n_neg");
     hipStream_t st = as_stream(stream);
-    if (d->scorer <= BESS_COMPLEX && (d->reserved[0] & BESS_FLAG_DNEG_BY_ROW) &&
-        !bess_neg_score_shared_bwd_by_row(d, n_query, n_neg))
-        return fail(BESS_EUNSUPPORTED, "neg_score_shared_bwd: BESS_FLAG_DNEG_BY_ROW for this scorer / shape "
-                                       "(bess_neg_score_shared_bwd_by_row says which take it)");
     if (d->scorer == BESS_BOXE)
         return boxe_negatives(d, false, true, query, n_query, neg_base, neg_idx, n_neg, nullptr, d_out, ld_dout,
                               d_query, d_neg, st);

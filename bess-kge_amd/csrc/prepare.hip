@@ -168,7 +168,7 @@ __device__ __forceinline__ void put(float* p, float v) {
     if (ACCUM) *p += v;
     else *p = v;
 }
-// BYROW (BESS_FLAG_DNEG_BY_ROW): the entity gradients are ADDED (fp32 atomics) into matrices over the row space of
+// BYROW (k_query_triple_bwd_parts): the entity gradients are ADDED (fp32 atomics) into matrices over the row space of
 // the entities' tables, at the row ids the triple names - where bess_direct_update picks them up - instead of being
 // stored as row s of dense [n_triple, W] arrays
 template <bool BYROW>
@@ -289,12 +289,12 @@ __global__ __launch_bounds__(256) void k_score_triple_bwd(TripleArgs a,
 // just before: same element -> lane mapping in both bodies); add instead of overwrite
 template <typename T, int SCORER, bool ACCUM, bool BYROW = false>
 __device__ __forceinline__ void query_bwd_body(const QueryArgs& a, int64_t q, int lane,
-                                               const float* __restrict__ d_query, float* __restrict__ d_ent,
+                                               const float* dq_row, float* __restrict__ d_ent,
                                                float* __restrict__ d_rel) {
     const T* x = row_ptr(static_cast<const T*>(a.ent_base), a.ent_idx, q, a.W);
     const int64_t rid = a.rel_idx[q];
     const T* r = static_cast<const T*>(a.rel_table) + rid * a.Wr;
-    const float* dq = d_query + q * a.W;
+    const float* dq = dq_row;
     float* dx = d_ent + (BYROW ? (a.ent_idx ? static_cast<int64_t>(a.ent_idx[q]) : q) : q) * a.W;
     float* dr = d_rel + rid * a.Wr;
     const bool tail = a.side == BESS_CORRUPT_TAIL;
@@ -342,13 +342,13 @@ __global__ __launch_bounds__(256) void k_query_bwd(QueryArgs a, const float* __r
     const int lane = threadIdx.x & 63;
     const int64_t q = blockIdx.x * 4ll + (threadIdx.x >> 6);
     if (q >= a.n) return;
-    query_bwd_body<T, SCORER, false>(a, q, lane, d_query, d_ent, d_rel);
+    query_bwd_body<T, SCORER, false>(a, q, lane, d_query + q * a.W, d_ent, d_rel);
 }
 
 // K3' + K6' in one launch: gradients of the positive score w.r.t. head / tail rows and of the query w.r.t. the
 // entity it was built from, summed where both hit the same row (the query of a tail-corruption step is built
 // from the head: d_head = d pos / d h + d query / d h), relation gradients accumulated once
-template <typename T, int SCORER, bool BYROW>
+template <typename T, int SCORER>
 __global__ __launch_bounds__(256) void k_query_triple_bwd(TripleArgs a, QueryArgs qa, const float* __restrict__ d_out,
                                                           const float* __restrict__ d_query,
                                                           float* __restrict__ d_head, float* __restrict__ d_tail,
@@ -356,8 +356,78 @@ __global__ __launch_bounds__(256) void k_query_triple_bwd(TripleArgs a, QueryArg
     const int lane = threadIdx.x & 63;
     const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
     if (s >= a.n) return;
-    triple_bwd_body<T, SCORER, BYROW>(a, s, lane, d_out, d_head, d_tail, d_rel);
-    query_bwd_body<T, SCORER, true, BYROW>(qa, s, lane, d_query, qa.side == BESS_CORRUPT_TAIL ? d_head : d_tail, d_rel);
+    triple_bwd_body<T, SCORER>(a, s, lane, d_out, d_head, d_tail, d_rel);
+    query_bwd_body<T, SCORER, true>(qa, s, lane, d_query + s * qa.W, qa.side == BESS_CORRUPT_TAIL ? d_head : d_tail, d_rel);
+}
+
+// The same behind bess_neg_score_shared_bwd_parts, by row: d_query arrives as
+// n_dq slabs [n_triple, W] that are summed as the triple's wave reads them (into LDS: the body then reads the row
+// from there), and spare workgroups behind the triples' add the candidates' gradient rows - the sum of n_de slabs
+// [n_neg, W] - into the accumulator at the candidates' row ids: one atomic per (candidate, column) instead of one
+// per query slice.  LDS: 4 waves x W floats (dynamic).
+template <typename T, int SCORER>
+__global__ __launch_bounds__(256) void k_query_triple_bwd_parts(TripleArgs a, QueryArgs qa, const float* __restrict__ d_out,
+                                                                const float* __restrict__ dq_parts, int n_dq,
+                                                                const float* __restrict__ de_parts, int n_de, int64_t n_neg,
+                                                                const int32_t* __restrict__ neg_idx,
+                                                                float* __restrict__ acc_head, float* __restrict__ acc_tail,
+                                                                float* __restrict__ acc_neg, float* __restrict__ d_rel,
+                                                                int triple_blocks) {
+    extern __shared__ float dq_rows[];  // [4][W]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (static_cast<int>(blockIdx.x) >= triple_blocks) {
+        const int64_t n_wave = (static_cast<int64_t>(gridDim.x) - triple_blocks) * 4;
+        for (int64_t j = (static_cast<int64_t>(blockIdx.x) - triple_blocks) * 4 + wv; j < n_neg; j += n_wave) {
+            float* dst = acc_neg + static_cast<int64_t>(neg_idx[j]) * a.W;
+            if ((a.W & 3) == 0) {  // 16 bytes per lane, the slabs' loads in flight together
+                for (int e = lane * 4; e < a.W; e += 256) {
+                    const float* src = de_parts + j * a.W + e;
+                    const int64_t slab = n_neg * a.W;
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+                    for (int p = 0; p < n_de; ++p) {
+                        const float4 v = *reinterpret_cast<const float4*>(src + p * slab);
+                        s0 += v.x, s1 += v.y, s2 += v.z, s3 += v.w;
+                    }
+                    if (s0 != 0.f) unsafeAtomicAdd(dst + e, s0);
+                    if (s1 != 0.f) unsafeAtomicAdd(dst + e + 1, s1);
+                    if (s2 != 0.f) unsafeAtomicAdd(dst + e + 2, s2);
+                    if (s3 != 0.f) unsafeAtomicAdd(dst + e + 3, s3);
+                }
+                continue;
+            }
+            for (int e = lane; e < a.W; e += 64) {
+                float sum = 0.f;
+                for (int p = 0; p < n_de; ++p) sum += de_parts[(static_cast<int64_t>(p) * n_neg + j) * a.W + e];
+                if (sum != 0.f) unsafeAtomicAdd(dst + e, sum);
+            }
+        }
+        return;
+    }
+    const int64_t s = blockIdx.x * 4ll + wv;
+    if (s >= a.n) return;  // (whole waves; no barrier in this kernel)
+    float* row = dq_rows + wv * a.W;  // (read back below by the lanes of this wave, whose LDS accesses execute in order)
+    if ((a.W & 3) == 0) {
+        const int64_t slab = a.n * a.W;
+        for (int e = lane * 4; e < a.W; e += 256) {
+            const float* src = dq_parts + s * a.W + e;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+            for (int p = 0; p < n_dq; ++p) {
+                const float4 v = *reinterpret_cast<const float4*>(src + p * slab);
+                s0 += v.x, s1 += v.y, s2 += v.z, s3 += v.w;
+            }
+            *reinterpret_cast<float4*>(row + e) = make_float4(s0, s1, s2, s3);
+        }
+    } else {
+        for (int e = lane; e < a.W; e += 64) {
+            float sum = 0.f;
+            for (int p = 0; p < n_dq; ++p) sum += dq_parts[(static_cast<int64_t>(p) * a.n + s) * a.W + e];
+            row[e] = sum;
+        }
+    }
+    triple_bwd_body<T, SCORER, true>(a, s, lane, d_out, acc_head, acc_tail, d_rel);
+    query_bwd_body<T, SCORER, true, true>(qa, s, lane, row, qa.side == BESS_CORRUPT_TAIL ? acc_head : acc_tail, d_rel);
 }
 
 template <template <typename, int> class Launcher, typename... Args>
@@ -416,11 +486,20 @@ struct LQueryTripleFwdJobs {
     }
 };
 template <typename T, int SC>
+struct LQueryTripleBwdParts {
+    static void run(TripleArgs a, QueryArgs qa, const float* d_out, const float* dqp, int n_dq, const float* dep, int n_de,
+                    int64_t n_neg, const int32_t* neg_idx, float* ah, float* at, float* an, float* dr, hipStream_t st) {
+        const int tb = static_cast<int>(ceil_div(a.n, 4));
+        const int nb = static_cast<int>(std::min<int64_t>(ceil_div(n_neg, 4), 1024));
+        k_query_triple_bwd_parts<T, SC><<<tb + nb, 256, 4 * a.W * sizeof(float), st>>>(a, qa, d_out, dqp, n_dq, dep, n_de,
+                                                                                      n_neg, neg_idx, ah, at, an, dr, tb);
+    }
+};
+template <typename T, int SC>
 struct LQueryTripleBwd {
     static void run(TripleArgs a, QueryArgs qa, const float* d_out, const float* dq, float* dh, float* dt, float* dr,
-                    bool by_row, hipStream_t st) {
-        if (by_row) k_query_triple_bwd<T, SC, true><<<ceil_div(a.n, 4), 256, 0, st>>>(a, qa, d_out, dq, dh, dt, dr);
-        else k_query_triple_bwd<T, SC, false><<<ceil_div(a.n, 4), 256, 0, st>>>(a, qa, d_out, dq, dh, dt, dr);
+                    hipStream_t st) {
+        k_query_triple_bwd<T, SC><<<ceil_div(a.n, 4), 256, 0, st>>>(a, qa, d_out, dq, dh, dt, dr);
     }
 };
 
@@ -553,6 +632,31 @@ extern "C" int bess_query_triple_fwd_jobs(const bess_model_desc* d, int32_t side
     return check_launch("query_triple_fwd_jobs");
 }
 
+extern "C" int bess_query_triple_bwd_parts(const bess_model_desc* d, int32_t side, const void* head_base,
+                                           const int32_t* head_idx, const void* tail_base, const int32_t* tail_idx,
+                                           const void* rel_table, const int32_t* rel_idx, int64_t n_triple,
+                                           const float* d_out, const float* dq_parts, int32_t n_dq_parts,
+                                           const float* dneg_parts, int32_t n_dneg_parts, int64_t n_neg,
+                                           const int32_t* neg_idx, float* acc_head, float* acc_tail, float* acc_neg,
+                                           float* d_rel_table, void* stream) {
+    TripleArgs a;
+    if (int e = triple_args(d, head_base, head_idx, tail_base, tail_idx, rel_table, rel_idx, n_triple, &a))
+        return e;
+    BESS_REQUIRE(d->scorer <= BESS_COMPLEX, "query_triple_bwd_parts: TransE / RotatE / DistMult / ComplEx only");
+    QueryArgs qa;
+    const bool tail = side == BESS_CORRUPT_TAIL;
+    if (int e = query_args(d, side, tail ? head_base : tail_base, tail ? head_idx : tail_idx, rel_table, rel_idx,
+                           n_triple, &qa))
+        return e;
+    BESS_REQUIRE(n_triple > 0 && n_neg > 0 && n_dq_parts >= 1 && n_dneg_parts >= 1, "query_triple_bwd_parts: bad sizes");
+    BESS_REQUIRE(d_out && dq_parts && dneg_parts && neg_idx && head_idx && tail_idx && acc_head && acc_tail && acc_neg &&
+                     d_rel_table, "query_triple_bwd_parts: NULL pointer (rows are named by index: by-row accumulators)");
+    BESS_REQUIRE(d->width <= 4096, "query_triple_bwd_parts: rows of %d scalars (at most 4096)", d->width);
+    dispatch<LQueryTripleBwdParts>(d, a, qa, d_out, dq_parts, n_dq_parts, dneg_parts, n_dneg_parts, n_neg, neg_idx, acc_head,
+                                   acc_tail, acc_neg, d_rel_table, as_stream(stream));
+    return check_launch("query_triple_bwd_parts");
+}
+
 extern "C" int bess_query_triple_bwd(const bess_model_desc* d, int32_t side, const void* head_base,
                                      const int32_t* head_idx, const void* tail_base, const int32_t* tail_idx,
                                      const void* rel_table, const int32_t* rel_idx, int64_t n_triple,
@@ -569,8 +673,6 @@ extern "C" int bess_query_triple_bwd(const bess_model_desc* d, int32_t side, con
         return e;
     if (n_triple == 0) return BESS_OK;
     BESS_REQUIRE(d_out && d_query && d_head && d_tail && d_rel_table, "query_triple_bwd: NULL pointer");
-    // (BESS_FLAG_DNEG_BY_ROW: d_head / d_tail are accumulators over the row spaces of head_base / tail_base)
-    const bool by_row = d->reserved[0] & BESS_FLAG_DNEG_BY_ROW;
-    dispatch<LQueryTripleBwd>(d, a, qa, d_out, d_query, d_head, d_tail, d_rel_table, by_row, as_stream(stream));
+    dispatch<LQueryTripleBwd>(d, a, qa, d_out, d_query, d_head, d_tail, d_rel_table, as_stream(stream));
     return check_launch("query_triple_bwd");
 }

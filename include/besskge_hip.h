@@ -93,12 +93,7 @@ extern "C" {
 /* bess_model_desc.reserved[0] of TransE / RotatE / DistMult / ComplEx: flags */
 #define BESS_FLAG_PREZEROED 2 /* bess_neg_score_shared_bwd(_ws): d_query and d_neg are zero on entry (e.g. cleared by
                                * bess_step_prologue): the call does not clear them itself */
-#define BESS_FLAG_DNEG_BY_ROW 4 /* (1) bess_neg_score_shared_bwd(_ws), where bess_neg_score_shared_bwd_by_row says so, and
-                                  * bess_query_triple_bwd: the entity gradients (d_neg; d_head, d_tail) are matrices over
-                                  * the ROW SPACE of the tables the rows came from - [rows of the base, W] f32 accumulators
-                                  * such as bess_direct_update's - and every gradient row is ADDED (fp32 atomics) at the
-                                  * row id its reference names: no dense [n, W] gradient arrays, nothing to index;
-                                  * (2) bess_neg_score_pertriple_bwd: d_neg is a matrix over the ROW SPACE of neg_base and the
+#define BESS_FLAG_DNEG_BY_ROW 4 /* bess_neg_score_pertriple_bwd: d_neg is a matrix over the ROW SPACE of neg_base and the
                                   * gradient of reference k is stored at row neg_idx[k] (plain stores) - for lists that
                                   * name every row at most once (negatives that arrived through the all-to-all: the
                                   * receive-buffer gradient is written in place, no [n_query * n_neg, W] copy) */
@@ -775,11 +770,12 @@ int bess_pack_exchange(bess_comm* comm, int32_t dtype, int32_t width, const void
 /* K4 + K7 + K8 of a training step with shared negatives behind one call (scoring.py:194-197 / 251-252 +
  * bess.py:182-245 + loss.py:28-251): out [n_query, ld_out] receives the (masked) scores as from
  * bess_neg_score_shared_fwd_masked (kill may be NULL), then row_loss / loss / d_pos / d_neg as from
- * bess_loss_fwd_bwd with pos = the positive scores.  TransE / RotatE with p = 1 on f16 tables and rows of up to
- * 1024 scores (16-byte aligned, n_neg % 4 == 0): ONE launch - the workgroup that stores the last tile of a block
- * of rows finishes the block's loss rows, the last block sums the terms in a fixed order (bitwise reproducible);
- * every other case: the scoring launch followed by the loss launch(es).  counters: int32
- * [ceil(n_query / 16) + 1] on the device, zero on entry, left zero (keep one array per stream). */
+ * bess_loss_fwd_bwd_one_launch with pos = the positive scores: the scoring launch followed by the loss launch(es),
+ * issued by one call (a step driven from C or from a recorded plan makes one call less; a variant that finished
+ * the loss rows inside the packed L1 kernel - its last workgroup per block of rows - was built and measured in
+ * round 4: 49 us against 12.7 + 9.4 at the notebook micro-batch, the rows of a block then run one after the other
+ * on four waves).  counters: int32 [ceil(n_query / 16) + 1] on the device, zero on entry,
+ * left zero (keep one array per stream). */
 int bess_neg_score_shared_fwd_loss(const bess_model_desc* desc, const float* query, int64_t n_query,
                                    const void* neg_base, const int32_t* neg_idx, int64_t n_neg, float* out,
                                    int64_t ld_out, const bess_kill_desc* kill, const bess_loss_desc* loss_desc,
@@ -796,10 +792,34 @@ int bess_query_triple_fwd_jobs(const bess_model_desc* desc, int32_t side, const 
                                float* out, int32_t n_jobs, void* const* job_dst, const void* const* job_src,
                                const uint32_t* job_value, const int64_t* job_words, void* stream);
 
+/* The two products of the shared-negative backward WITHOUT atomics, and their consumer (TransE / RotatE with p = 1:
+ * the kernel that forms both products from one evaluation of sgn(q - e); bess_neg_score_shared_bwd_parts_plan
+ * returns 0 parts for everything else).  bess_neg_score_shared_bwd_parts writes
+ *     dq_parts   f32 [n_dq_parts,   n_query, W]   d_query   = their sum over the first axis
+ *     dneg_parts f32 [n_dneg_parts, n_neg,   W]   d_neg     = likewise
+ * (every element written, nothing to clear; part counts from the _plan call for the same desc and sizes) with plain
+ * stores.  bess_query_triple_bwd_parts is bess_query_triple_bwd BY ROW, fed by them: gradient rows are ADDED (fp32
+ * atomics) into accumulators over the row spaces of the tables, at the row ids the references name;
+ * the triple's wave sums its d_query row from the parts as it reads it; spare workgroups add every candidate's
+ * summed gradient row into acc_neg at row neg_idx[j] (one atomic per candidate and column, not one per query
+ * slice).  acc_head / acc_tail / acc_neg: accumulators over the row spaces of head_base / tail_base / the candidates'
+ * table (bess_direct_update).  Reference: autograd of pea.distance_matrix + index_put_ (scoring.py:194-197). */
+int bess_neg_score_shared_bwd_parts_plan(const bess_model_desc* desc, int64_t n_query, int64_t n_neg,
+                                         int32_t* n_dq_parts, int32_t* n_dneg_parts);
+int bess_neg_score_shared_bwd_parts(const bess_model_desc* desc, const float* query, int64_t n_query,
+                                    const void* neg_base, const int32_t* neg_idx, int64_t n_neg, const float* d_out,
+                                    int64_t ld_dout, float* dq_parts, float* dneg_parts, void* stream);
+int bess_query_triple_bwd_parts(const bess_model_desc* desc, int32_t side, const void* head_base,
+                                const int32_t* head_idx, const void* tail_base, const int32_t* tail_idx,
+                                const void* rel_table, const int32_t* rel_idx, int64_t n_triple, const float* d_out,
+                                const float* dq_parts, int32_t n_dq_parts, const float* dneg_parts,
+                                int32_t n_dneg_parts, int64_t n_neg, const int32_t* neg_idx, float* acc_head,
+                                float* acc_tail, float* acc_neg, float* d_rel_table, void* stream);
+
 /* K9 + K10 without an index (direct-addressed accumulation): for a table whose fp32 image the caller can afford
  * as scratch.  acc [rows of table, width] f32 is ZERO between steps; the step's backward kernels add their
- * gradient rows into it at the rows' ids (BESS_FLAG_DNEG_BY_ROW; bess_scatter_add_rows / bess_sparse_sgd_lists with
- * lr = -1 for gradients that exist as dense lists).  bess_direct_update then visits the step's row-id lists
+ * gradient rows into it at the rows' ids (bess_query_triple_bwd_parts; bess_scatter_add_rows / bess_sparse_sgd_lists
+ * with lr = -1 for gradients that exist as dense lists).  bess_direct_update then visits the step's row-id lists
  * (n_lists <= BESS_MAX_ROW_LISTS, read where they are): one wave per reference claims its row - claim
  * [rows of table] int32 holds the generation number of the last step that updated the row, *generation is this
  * step's (the caller increments it once per step before the call, e.g. with a copy job of bess_step_prologue
@@ -812,9 +832,6 @@ int bess_direct_update(const bess_opt_desc* opt, int32_t dtype, int32_t width, v
                        const int32_t* const* id_lists, const int64_t* id_lens, float* acc, int32_t* claim,
                        const int32_t* generation, float* state1, float* state2, void* axpy_table,
                        const float* axpy_grad, int64_t axpy_n, float axpy_alpha, void* stream);
-/* 1 if bess_neg_score_shared_bwd(_ws) takes BESS_FLAG_DNEG_BY_ROW for this scorer and shape, else 0 */
-int bess_neg_score_shared_bwd_by_row(const bess_model_desc* desc, int64_t n_query, int64_t n_neg);
-
 /* ---- recorded steps -----------------------------------------------------------
  * A step of this library can be captured into a hipGraph as a whole (every call is asynchronous on the
  * caller's stream, every clear is a kernel).  bess_graph_node_counts tells what a captured graph holds:

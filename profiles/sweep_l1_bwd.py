@@ -31,5 +31,26 @@ def time_graph(S, N, reps=20):
         best = min(best, a.elapsed_time(b) / reps * 1e3)
     return best
 
+def time_parts(S, N, reps=20):
+    """The same two products as partial sums (bess_neg_score_shared_bwd_parts: independent waves, plain stores)."""
+    q = torch.randn(S, W, device=dev)
+    neg = RowSource(table, torch.randint(100_000, (N,), dtype=torch.int32, device=dev))
+    go = torch.randn(S, N, device=dev)
+    nat.neg_score_shared_bwd_parts(dsc, q, neg, go)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            nat.neg_score_shared_bwd_parts(dsc, q, neg, go)
+    g.replay(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(5):
+        a.record(); g.replay(); b.record(); torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b) / reps * 1e3)
+    return best
+
 for S, N in ((256, 288), (512, 544), (512, 768), (1024, 1088), (2048, 2176), (4096, 4352), (8192, 8448)):
-    print(f"S={S:5d} N={N:5d}: {time_graph(S, N, reps=5 if S > 1024 else 20):8.1f} us", flush=True)
+    r = 5 if S > 1024 else 20
+    print(f"S={S:5d} N={N:5d}: atomic sums {time_graph(S, N, reps=r):8.1f} us   partial sums {time_parts(S, N, reps=r):8.1f} us "
+          f"(parts {nat.shared_bwd_parts_plan(dsc, S, N)})", flush=True)

@@ -142,12 +142,12 @@ def test_training_step_dispatch_count_c4_notebook_shape(dev):
         runner(**batch)
         torch.cuda.synchronize()
     kernels = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
-    # round 4: prologue (copy / fill jobs, generation), query + positive score, packed L1 scores + loss rows, both
-    # backward products (candidate rows added at their row ids), query / triple backward (likewise), direct update
-    # (+ relation step) - and torch's copy of the loss
+    # round 4: query + positive score (+ the step's copy / fill jobs and the update's generation in spare workgroups),
+    # packed L1 scores, loss rows, both backward products as partial sums (no atomics), query / triple backward (adds
+    # the parts up; every gradient row lands in the shard's accumulator at its row id), direct update (+ relation step)
     assert 0 < len(kernels) <= 7, kernels
-    assert not any("k_loss_rows" in k or "k_coalesced_update" in k for k in kernels), kernels
-    assert any("k_direct_update" in k for k in kernels), kernels
+    assert not any("k_step_prologue" in k or "k_coalesced_update" in k for k in kernels), kernels
+    assert any("k_direct_update" in k for k in kernels) and any("k_l1_bwd_parts" in k for k in kernels), kernels
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
@@ -257,3 +257,56 @@ def test_training_step_through_the_direct_update_equals_the_indexed_path(dev, dt
         torch.testing.assert_close(out[0][0], out[1][0], **tol)
         torch.testing.assert_close(out[0][1], out[1][1], **tol)
     np.testing.assert_allclose(out[0][2], out[1][2], rtol=2e-3)
+
+
+
+@pytest.mark.parametrize("scorer,dtype,S,N,W", [("TransE", torch.float16, 512, 544, 256), ("TransE", torch.float32, 256, 288, 64),
+                                                 ("RotatE", torch.float16, 1024, 1088, 128), ("TransE", torch.float16, 768, 800, 256)])
+def test_backward_as_partial_sums_equals_the_atomic_form(dev, scorer, dtype, S, N, W):
+    """bess_neg_score_shared_bwd_parts + bess_query_triple_bwd_parts (no atomics in the products: partial sums with plain
+    stores, added up by their consumer, every gradient row landing in a row-space accumulator) against
+    bess_neg_score_shared_bwd + bess_query_triple_bwd + a scatter of their dense rows."""
+    from besskge import _native as nat
+
+    gen = torch.Generator().manual_seed(S + W)
+    M, n_rel = 6000, 11
+    code = nat.TRANSE if scorer == "TransE" else nat.ROTATE
+    Wr = W if scorer == "TransE" else W // 2
+    table = (torch.randn(M, W, generator=gen) * 0.3).to(dtype).to(dev)
+    rel = (torch.randn(n_rel, Wr, generator=gen) * 0.3).to(dtype).to(dev)
+    d = nat.make_desc(code, 1, table, Wr)
+    head = nat.RowSource(table, torch.randint(M, (S,), generator=gen, dtype=torch.int32).to(dev))
+    tail = nat.RowSource(table, torch.randint(M, (S,), generator=gen, dtype=torch.int32).to(dev))
+    ridx = torch.randint(n_rel, (S,), generator=gen, dtype=torch.int32).to(dev)
+    nidx = torch.randint(M, (N,), generator=gen, dtype=torch.int32)
+    nidx[:40] = nidx[40:80]  # the same entity at several candidate positions
+    nidx[100:110] = head.idx[:10].cpu()  # ... and as a head
+    neg = nat.RowSource(table, nidx.to(dev))
+    q, pos = nat.query_triple_fwd(d, nat.CORRUPT_TAIL, head, tail, rel, ridx)
+    out = nat.neg_score_shared_fwd(d, q, neg)
+    go = (torch.randn(S, N, generator=gen) * 0.1).to(dev)
+    d_pos = torch.randn(S, generator=gen).to(dev)
+    n_dq, n_de = nat.shared_bwd_parts_plan(d, S, N)
+    assert n_dq >= 1 and n_de >= 1
+    # reference: atomic form + dense rows scattered into an accumulator
+    dq, dn = nat.neg_score_shared_bwd(d, q, neg, out, go)
+    d_rel0 = torch.zeros(n_rel, Wr, device=dev)
+    dh, dt = nat.query_triple_bwd(d, nat.CORRUPT_TAIL, head, tail, rel, ridx, d_pos, dq, d_rel0)
+    want = torch.zeros(M, W, device=dev)
+    nat.sparse_sgd_lists(want, [(neg.idx, dn), (head.idx, dh), (tail.idx, dt)], -1.0)
+    # partial sums
+    dqp, dep = nat.neg_score_shared_bwd_parts(d, q, neg, go)
+    assert tuple(dqp.shape) == (n_dq, S, W) and tuple(dep.shape) == (n_de, N, W)
+    torch.testing.assert_close(dqp.sum(0), dq, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dep.sum(0), dn, rtol=1e-4, atol=1e-4)
+    acc = torch.zeros(M, W, device=dev)
+    d_rel1 = torch.zeros(n_rel, Wr, device=dev)
+    nat.query_triple_bwd_parts(d, nat.CORRUPT_TAIL, head, tail, rel, ridx, d_pos, dqp, dep, neg.idx, (acc, acc, acc), d_rel1)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(acc, want, rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(d_rel1, d_rel0, rtol=1e-4, atol=2e-4)
+    # shapes without a partial-sum form say so
+    small = nat.make_desc(nat.DISTMULT, 0, table, W)
+    assert nat.shared_bwd_parts_plan(small, S, N) == (0, 0)
+    assert nat.shared_bwd_parts_plan(d, 8, 16) == (0, 0)
+    assert nat.shared_bwd_parts_plan(d, 4096, 4352) == (0, 0)  # (the slabs of d_query would be 570 MB: atomic form)
