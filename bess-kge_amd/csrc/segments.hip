@@ -36,27 +36,31 @@ static inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 // this library puts a memset node into a graph any more: every clear is a kernel (common.h: fill_words_async) and
 // the sort below is our own.  tests/test_graph_nodes.py pins "no memset node in any recorded step".
 //
-// One pass per RB-bit place (RB = ceil(row_bits / passes) <= 9: two passes for the 17-19 bits of BASELINE's
-// shards).  A WAVE owns a contiguous tile of the input and walks it 64 keys at a time; the lanes that share a
-// digit find each other with RB ballots (wave multisplit), so ranks inside a wave's 64 keys cost no atomics and
-// keep input order - the sort is stable, equal rows keep reference order, sums stay bitwise reproducible.
+// One pass per RB-bit place (RB = ceil(row_bits / passes) <= 6: three passes for the 17 bits of BASELINE configs[1]'s
+// shard, four for the 19 of configs[3]'s).  A WAVE owns a contiguous tile of up to 2048 keys.  The lanes that share
+// a digit find each other with RB ballots (wave multisplit), so ranks inside a wave's 64 keys cost no atomics and
+// keep input order - the sort is stable, equal rows keep reference order, sums stay bitwise reproducible.  The
+// wave first sorts its tile by digit INTO LDS and then writes it out in that order: keys of one digit leave as
+// runs of ~32 consecutive words (64 bins over 2048 keys).  A first version scattered every key straight to its
+// place with 9-bit digits - 4 M isolated 4-byte stores per index of C2's million references, ~270 MB of write
+// traffic that the HBM-bound forward kernel running beside the index build paid for with 30 us.
 //   k_rsort_hist     per-wave digit histograms                                  H[digit][wave]
-//   k_rsort_rowscan  one workgroup per digit: exclusive scan over the waves, the digit's total
-//   k_rsort_scatter  base of every digit (scan of the totals, per workgroup in LDS) + the wave's running
-//                    offsets in LDS; keys / references written to their places
-constexpr int RS_WAVES = 4;  // waves per workgroup (each with its own 2 KiB of counters)
-constexpr int RS_MAX_BITS = 9;
-constexpr int RS_MAX_WAVES = 2048;
+//   k_rsort_rowscan  one workgroup per digit: exclusive scan over the waves (kept next to the counts), the total
+//   k_rsort_scatter  tile sorted by digit in LDS, written out run by run
+constexpr int RS_WAVES = 4;   // waves per workgroup (each works alone)
+constexpr int RS_MAX_BITS = 6;
+constexpr int RS_TILE = 2048;  // keys per wave at most (2 x 8 KiB of LDS per wave)
 
 struct RSortArgs {
     const int32_t* keys_in;
     const int32_t* vals_in;  // NULL: the value is the position (first pass)
     int32_t* keys_out;
     int32_t* vals_out;
-    int32_t* hist;    // [1 << rb][n_wave]
-    int32_t* totals;  // [1 << rb]
+    int32_t* hist;     // [1 << rb][n_wave] counts
+    int32_t* scanned;  // [1 << rb][n_wave] their exclusive scan over the waves
+    int32_t* totals;   // [1 << rb]
     int64_t n;
-    int64_t tile;  // keys per wave (multiple of 64)
+    int64_t tile;  // keys per wave (multiple of 64, <= RS_TILE)
     int n_wave;
     int shift, rb;
 };
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_rsort_hist(RSortArgs a) {
     const int w = blockIdx.x * RS_WAVES + wv;
     const int nd = 1 << a.rb;
     if (w >= a.n_wave) return;  // (whole waves, no barrier in this kernel)
-    for (int d = lane; d < nd; d += 64) cnt[wv][d] = 0;
+    cnt[wv][lane] = 0;
     const int64_t lo = w * a.tile, hi = min(lo + a.tile, a.n);
     const uint64_t below = (1ull << lane) - 1ull;
     int32_t knext = lo + lane < hi ? a.keys_in[lo + lane] : 0;  // one chunk of keys ahead
@@ -89,14 +93,16 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_rsort_hist(RSortArgs a) {
         const uint64_t peers = rsort_peers(digit, a.rb, valid);
         if (valid && (peers & below) == 0) cnt[wv][digit] += __popcll(peers);  // the lowest lane of each digit
     }
-    for (int d = lane; d < nd; d += 64) a.hist[static_cast<int64_t>(d) * a.n_wave + w] = cnt[wv][d];
+    if (lane < nd) a.hist[static_cast<int64_t>(lane) * a.n_wave + w] = cnt[wv][lane];
 }
 
-// workgroup d: H[d][0 .. n_wave) becomes its exclusive scan, totals[d] its sum
-__global__ __launch_bounds__(256) void k_rsort_rowscan(int32_t* __restrict__ hist, int32_t* __restrict__ totals, int n_wave) {
+// workgroup d: scanned[d][0 .. n_wave) = exclusive scan of hist[d][.], totals[d] its sum
+__global__ __launch_bounds__(256) void k_rsort_rowscan(const int32_t* __restrict__ hist, int32_t* __restrict__ scanned,
+                                                       int32_t* __restrict__ totals, int n_wave) {
     __shared__ int32_t wsum[4];
     __shared__ int32_t carry_s;
-    int32_t* row = hist + static_cast<int64_t>(blockIdx.x) * n_wave;
+    const int32_t* row = hist + static_cast<int64_t>(blockIdx.x) * n_wave;
+    int32_t* out = scanned + static_cast<int64_t>(blockIdx.x) * n_wave;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     if (t == 0) carry_s = 0;
     __syncthreads();
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256) void k_rsort_rowscan(int32_t* __restrict__ his
         __syncthreads();
         int32_t before = carry_s;
         for (int k = 0; k < wv; ++k) before += wsum[k];
-        if (i < n_wave) row[i] = before + inc - v;
+        if (i < n_wave) out[i] = before + inc - v;
         __syncthreads();
         if (t == 255) carry_s = before + inc;
         __syncthreads();
@@ -122,37 +128,30 @@ __global__ __launch_bounds__(256) void k_rsort_rowscan(int32_t* __restrict__ his
 }
 
 __global__ __launch_bounds__(64 * RS_WAVES) void k_rsort_scatter(RSortArgs a) {
-    __shared__ int32_t off[RS_WAVES][1 << RS_MAX_BITS];
-    __shared__ int32_t base[1 << RS_MAX_BITS];
+    __shared__ int32_t lk[RS_WAVES][RS_TILE], lv[RS_WAVES][RS_TILE];
+    __shared__ int32_t off[RS_WAVES][1 << RS_MAX_BITS];     // running place of every digit inside the tile
+    __shared__ int32_t delta[RS_WAVES][1 << RS_MAX_BITS];   // global place of a digit's first key - its place in the tile
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int w = blockIdx.x * RS_WAVES + wv;
     const int nd = 1 << a.rb;
-    if (wv == 0) {  // first place of every digit: exclusive scan of the digits' totals (nd <= 512: 8 per lane)
-        int32_t v[8], sum = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int d = lane * 8 + k;
-            v[k] = d < nd ? a.totals[d] : 0;
-            sum += v[k];
-        }
-        int32_t inc = sum;
+    if (w >= a.n_wave) return;  // (whole waves: no barrier in this kernel; a wave's LDS accesses execute in order)
+    {
+        // lane d: digit d.  Place of the digit's run inside the tile (exclusive scan of the wave's counts over the
+        // digits) and in the output (scan of the totals over the digits + scan of the counts over the waves)
+        const int32_t c = lane < nd ? a.hist[static_cast<int64_t>(lane) * a.n_wave + w] : 0;
+        const int32_t tot = lane < nd ? a.totals[lane] : 0;
+        int32_t ci = c, ti = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const int32_t u = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += u;
+            const int32_t u = __shfl_up(ci, o, 64), v = __shfl_up(ti, o, 64);
+            if (lane >= o) ci += u, ti += v;
         }
-        int32_t run = inc - sum;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int d = lane * 8 + k;
-            if (d < nd) base[d] = run;
-            run += v[k];
-        }
+        const int32_t local = ci - c, base = ti - tot;
+        off[wv][lane] = local;
+        delta[wv][lane] = lane < nd ? base + a.scanned[static_cast<int64_t>(lane) * a.n_wave + w] - local : 0;
     }
-    __syncthreads();
-    if (w >= a.n_wave) return;
-    for (int d = lane; d < nd; d += 64) off[wv][d] = base[d] + a.hist[static_cast<int64_t>(d) * a.n_wave + w];
     const int64_t lo = w * a.tile, hi = min(lo + a.tile, a.n);
+    const int n_tile = static_cast<int>(hi - lo);
     const uint64_t below = (1ull << lane) - 1ull;
     int32_t knext = lo + lane < hi ? a.keys_in[lo + lane] : 0;
     int32_t vnext = (a.vals_in && lo + lane < hi) ? a.vals_in[lo + lane] : 0;
@@ -166,31 +165,37 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_rsort_scatter(RSortArgs a) {
         }
         const int digit = (static_cast<uint32_t>(key) >> a.shift) & (nd - 1);
         const uint64_t peers = rsort_peers(digit, a.rb, valid);
-        // (a wave's LDS accesses execute in program order: every lane of a digit reads the running offset before
-        // the digit's lowest lane advances it)
-        const int32_t at = valid ? off[wv][digit] : 0;
+        const int32_t at = valid ? off[wv][digit] : 0;  // (read by every lane of the digit before its lowest lane advances it)
         const int rank = __popcll(peers & below);
         if (valid) {
-            a.keys_out[at + rank] = key;
-            a.vals_out[at + rank] = val;
+            lk[wv][at + rank] = key;
+            lv[wv][at + rank] = val;
             if (rank == 0) off[wv][digit] = at + __popcll(peers);
         }
     }
+    for (int i = lane; i < n_tile; i += 64) {  // the tile in digit order: runs of one digit go to consecutive places
+        const int32_t key = lk[wv][i];
+        const int digit = (static_cast<uint32_t>(key) >> a.shift) & (nd - 1);
+        const int64_t at = static_cast<int64_t>(delta[wv][digit]) + i;
+        a.keys_out[at] = key;
+        a.vals_out[at] = lv[wv][i];
+    }
 }
 
-// waves (= tiles) of a sort of n keys: tiles of at least 512 keys, at most RS_MAX_WAVES waves
+// waves (= tiles) of a sort of n keys: tiles of RS_TILE keys (runs of ~32 keys per digit at the write-out), shorter
+// ones (>= 512) for short lists
 static void rsort_plan(int64_t n, int* n_wave, int64_t* tile) {
-    int64_t t = std::max<int64_t>(512, (n + RS_MAX_WAVES - 1) / RS_MAX_WAVES);
+    int64_t t = std::min<int64_t>(RS_TILE, std::max<int64_t>(512, (n + 511) / 512));
     t = (t + 63) / 64 * 64;
     *tile = t;
     *n_wave = static_cast<int>((n + t - 1) / t);
 }
 static int rsort_passes(int bits) { return (bits + RS_MAX_BITS - 1) / RS_MAX_BITS; }
-static size_t rsort_hist_bytes(int64_t n) {  // histograms + totals
+static size_t rsort_hist_bytes(int64_t n) {  // counts + scanned counts + totals
     int nw;
     int64_t tile;
     rsort_plan(n, &nw, &tile);
-    return sizeof(int32_t) * (size_t(1) << RS_MAX_BITS) * (static_cast<size_t>(nw) + 1);
+    return sizeof(int32_t) * (size_t(1) << RS_MAX_BITS) * (2 * static_cast<size_t>(nw) + 1);
 }
 
 // keys[n] (row ids < 2^bits) -> keys_sorted, refs_sorted (positions 0 .. n-1 in sorted order, stable).
@@ -204,7 +209,8 @@ static int radix_sort_refs(const int32_t* keys, int64_t n, int bits, int32_t* ke
     a.hist = hist;
     a.rb = rb;
     rsort_plan(n, &a.n_wave, &a.tile);
-    a.totals = hist + (size_t(1) << RS_MAX_BITS) * static_cast<size_t>(a.n_wave);
+    a.scanned = hist + (size_t(1) << RS_MAX_BITS) * static_cast<size_t>(a.n_wave);
+    a.totals = a.scanned + (size_t(1) << RS_MAX_BITS) * static_cast<size_t>(a.n_wave);
     const unsigned grid = static_cast<unsigned>((a.n_wave + RS_WAVES - 1) / RS_WAVES);
     // the last pass writes (keys_sorted, refs_sorted); the passes before alternate so that it does
     for (int p = 0; p < passes; ++p) {
@@ -215,7 +221,7 @@ static int radix_sort_refs(const int32_t* keys, int64_t n, int bits, int32_t* ke
         a.vals_out = to_final ? refs_sorted : tmp_v;
         a.shift = p * rb;
         k_rsort_hist<<<grid, 64 * RS_WAVES, 0, st>>>(a);
-        k_rsort_rowscan<<<1u << rb, 256, 0, st>>>(hist, a.totals, a.n_wave);
+        k_rsort_rowscan<<<1u << rb, 256, 0, st>>>(hist, a.scanned, a.totals, a.n_wave);
         k_rsort_scatter<<<grid, 64 * RS_WAVES, 0, st>>>(a);
     }
     return check_launch("radix sort of the references");
