@@ -198,6 +198,13 @@ SIGNATURES = {
     "bess_allreduce_sum_f32": [_vp, _vp, _vp, _i64, _vp],
     "bess_pack_exchange": [_vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp],
     "bess_graph_node_counts": [_vp, _c_i32p, _i32],
+    "bess_plan_create": [ctypes.POINTER(_vp)],
+    "bess_plan_destroy": [_vp],
+    "bess_plan_knows": [ctypes.c_char_p],
+    "bess_plan_length": [_vp],
+    "bess_plan_add_call": [_vp, ctypes.c_char_p, _i32, _c_u8p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(_vp),
+                           ctypes.POINTER(_i64)],
+    "bess_plan_run": [_vp, _vp],
     "bess_direct_update": [ctypes.POINTER(OptDesc), _i32, _i32, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_i64), _vp, _vp,
                            _vp, _vp, _vp, _vp, _vp, _i64, _f32, _vp],
     "bess_neg_score_shared_bwd_parts_plan": [_MD, _i64, _i64, _c_i32p, _c_i32p],
@@ -1993,3 +2000,128 @@ def graph_node_counts(graph: Any) -> dict:
     _check(load().bess_graph_node_counts(ctypes.c_void_p(raw), counts, len(GRAPH_NODE_KINDS)),
            "bess_graph_node_counts")
     return {k: int(c) for k, c in zip(GRAPH_NODE_KINDS, counts) if c}
+
+
+# --------------------------------------------------------------------------- #
+# step plans (csrc/plan.hip): a step as a recorded list of the library's own calls, replayed from C
+PLAN_ARG_INT, PLAN_ARG_FLOAT, PLAN_ARG_PTR, PLAN_ARG_BLOB, PLAN_ARG_STREAM = 0, 1, 2, 3, 4
+_INT_TYPES = (ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int)
+
+
+class Plan:
+    """`bess_plan*`: the calls of one recorded step (`record_plan`); `run()` issues them again on PyTorch's current
+    stream of `device` - no Python between the calls, and none of the GIL while they are issued (ctypes releases it
+    for the duration of a foreign call), so a process that drives several GPUs runs one plan per device from one
+    host thread each.  The plan names device buffers by address: the recorder's caller keeps them alive and in place
+    (`Runner`: a private memory pool + static input buffers)."""
+
+    def __init__(self, device: torch.device) -> None:
+        self.device = device
+        self._h = _vp()
+        _check(load().bess_plan_create(ctypes.byref(self._h)), "bess_plan_create")
+        self.names: List[str] = []
+
+    def __len__(self) -> int:
+        return int(_real_lib().bess_plan_length(self._h))
+
+    def _add(self, name: str, argtypes: Sequence[Any], args: Sequence[Any]) -> None:
+        n = len(args)
+        kinds = (ctypes.c_uint8 * max(1, n))()
+        values = (ctypes.c_uint64 * max(1, n))()
+        blobs = (_vp * max(1, n))()
+        sizes = (_i64 * max(1, n))()
+        keep = []  # the ctypes objects whose bytes are copied must outlive the call
+        for k, (tp, a) in enumerate(zip(argtypes, args)):
+            if k == n - 1:
+                kinds[k] = PLAN_ARG_STREAM
+            elif tp in _INT_TYPES:
+                kinds[k], values[k] = PLAN_ARG_INT, int(a) & 0xFFFFFFFFFFFFFFFF
+            elif tp is ctypes.c_float or tp is ctypes.c_double:
+                kinds[k] = PLAN_ARG_FLOAT
+                values[k] = ctypes.c_uint64.from_buffer_copy(ctypes.c_double(float(a))).value
+            elif tp is _vp:
+                kinds[k] = PLAN_ARG_PTR
+                values[k] = int(a.value or 0) if isinstance(a, ctypes.c_void_p) else int(a or 0)
+            else:  # POINTER(...): NULL, byref(struct), or a ctypes array - host bytes the call reads
+                obj = getattr(a, "_obj", a)
+                if a is None:
+                    kinds[k], values[k] = PLAN_ARG_PTR, 0
+                elif isinstance(obj, (ctypes.Structure, ctypes.Array, ctypes._SimpleCData)):
+                    kinds[k] = PLAN_ARG_BLOB
+                    blobs[k], sizes[k] = ctypes.addressof(obj), ctypes.sizeof(obj)
+                    keep.append(obj)
+                else:
+                    raise TypeError(f"record_plan: {name} argument {k}: cannot record a {type(a).__name__}")
+        _check(_real_lib().bess_plan_add_call(self._h, name.encode(), n, kinds, values, blobs, sizes), "bess_plan_add_call")
+        self.names.append(name)
+
+    def run(self) -> None:
+        with _on(self.device):
+            rc = _real_lib().bess_plan_run(self._h, _stream(self.device))
+        _check(rc, "bess_plan_run")
+
+    def run_on(self, stream: int) -> None:
+        """`bess_plan_run` on a raw hipStream_t (worker threads of a multi-device process: the device must be the
+        thread's current one)."""
+        _check(_real_lib().bess_plan_run(self._h, stream), "bess_plan_run")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            h, self._h = self._h, _vp()
+            _real_lib().bess_plan_destroy(h)
+
+    def __del__(self, _finalizing: Any = sys.is_finalizing) -> None:  # pragma: no cover
+        if not _finalizing():
+            try:
+                self.close()
+            except Exception:
+                pass
+
+
+class _RecordingLib:
+    """Stands in for the library while a plan is recorded: every call goes through to it; the ones that enqueue
+    work are noted in the plan with their argument values."""
+
+    def __init__(self, lib: ctypes.CDLL, plan: Plan) -> None:
+        self._lib, self._plan = lib, plan
+        self._wrapped: dict = {}
+
+    def __getattr__(self, name: str) -> Any:
+        fn = getattr(self._lib, name)
+        if not name.startswith("bess_") or not self._lib.bess_plan_knows(name.encode()):
+            return fn
+        w = self._wrapped.get(name)
+        if w is None:
+            plan, argtypes = self._plan, fn.argtypes
+
+            def w(*args: Any, _fn: Any = fn, _name: str = name) -> int:
+                rc = _fn(*args)
+                if rc == 0:
+                    plan._add(_name, argtypes, args)
+                return rc
+
+            self._wrapped[name] = w
+        return w
+
+
+def _real_lib() -> ctypes.CDLL:
+    lib = load()
+    return lib._lib if isinstance(lib, _RecordingLib) else lib
+
+
+@contextlib.contextmanager
+def record_plan(device: torch.device):
+    """Run a step inside this context: it executes as usual, and every library call that enqueues work is noted in
+    the `Plan` the context yields (`plan.run()` issues them again).  The step must be made of library calls only -
+    work enqueued by anything else (a torch operator) is not part of the plan - and must not allocate device
+    memory outside a pool the caller keeps (see `Runner._call_with_plans`)."""
+    global _lib
+    real = load()
+    if isinstance(real, _RecordingLib):
+        raise RuntimeError("record_plan: already recording")
+    plan = Plan(device)
+    _lib = _RecordingLib(real, plan)  # type: ignore[assignment]
+    try:
+        yield plan
+    finally:
+        _lib = real

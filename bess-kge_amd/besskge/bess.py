@@ -515,7 +515,8 @@ class BessKGE(torch.nn.Module, ABC):
             # Adam's bias correction lives on the device and the increment is part of the recorded step
             if "step_dev" not in state:
                 state["step_dev"] = torch.zeros((1,), dtype=torch.int32, device=table.device)
-            state["step_dev"].add_(1)
+            # (a call of the library, not a torch operator: the increment is then part of a recorded plan too)
+            nat.step_prologue([(state["step_dev"], state["step_dev"], 1)])
             o.step_ptr = state["step_dev"].data_ptr()
         o.momentum = float(getattr(opt, "momentum", 0.0))
         o.beta1, o.beta2 = float(getattr(opt, "beta1", 0.9)), float(getattr(opt, "beta2", 0.999))

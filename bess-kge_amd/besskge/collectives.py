@@ -180,6 +180,18 @@ class NativeGroup(ReplicaGroup):
     arguments, and torch.distributed is not needed at all).
     """
 
+    @classmethod
+    def from_communicator(cls, comm: Any, barrier: Optional[Any] = None) -> "NativeGroup":
+        """The group of one rank of an existing communicator (`Communicator.init_all`: one process, several GPUs);
+        `barrier`: a callable that synchronises the ranks' host threads (default: none)."""
+        g = cls.__new__(cls)
+        g.pg, g._has_dist = None, False
+        g.n_shard, g.rank, g.device = comm.world, comm.rank, comm.device
+        g.local_shards = [g.rank]
+        g.comm = comm
+        g._barrier = barrier
+        return g
+
     def __init__(self, device: torch.device, process_group: Optional[dist.ProcessGroup] = None,
                  unique_id: Optional[bytes] = None, world: Optional[int] = None,
                  rank: Optional[int] = None) -> None:
@@ -232,11 +244,11 @@ class NativeGroup(ReplicaGroup):
         return self.comm.pack_exchange(table, idx)[1]
 
     def barrier(self) -> None:
+        torch.cuda.current_stream(self.device).synchronize()
         if self._has_dist:
-            torch.cuda.current_stream(self.device).synchronize()
             dist.barrier(group=self.pg)
-        else:
-            torch.cuda.current_stream(self.device).synchronize()
+        elif getattr(self, "_barrier", None) is not None:
+            self._barrier()
 
     def close(self) -> None:
         """Destroy the recorded steps that use the communicator, then the communicator (in that order:
@@ -253,3 +265,32 @@ class NativeGroup(ReplicaGroup):
             self.close()
         except Exception:
             pass
+
+
+class MultiDeviceGroup:
+    """ONE host process driving n GPUs - the reference's own runtime contract (one process feeds `[bps * n, ...]`
+    tensors and reads stacked outputs: `/root/reference/tests/test_bess.py:122-150`, `besskge/pipeline.py:129-144`;
+    SURVEY section 7 "Process model").  `bess_comm_init_all` (= ncclCommInitAll) makes the n communicators of the
+    clique; rank r lives on `devices[r]` and is driven by its own host thread (`besskge.runtime.MultiDeviceRunner`),
+    whose library calls release the GIL - with `Options.use_plans` a step is one such call per device.
+
+    `ranks[r]` is the `NativeGroup` of rank r (collectives through the C ABI on the kernels' stream of that device).
+    """
+
+    def __init__(self, devices: Any) -> None:
+        import threading
+
+        from besskge import _native as nat
+
+        self.devices = [torch.device(d) if not isinstance(d, torch.device) else d for d in devices]
+        if len({(d.type, d.index) for d in self.devices}) != len(self.devices):
+            raise ValueError("MultiDeviceGroup: one rank per GPU (RCCL refuses a clique with a device twice)")
+        self.n_shard = len(self.devices)
+        self.local_shards = list(range(self.n_shard))
+        self._host_barrier = threading.Barrier(self.n_shard)
+        comms = nat.Communicator.init_all(self.devices)
+        self.ranks = [NativeGroup.from_communicator(c, barrier=self._host_barrier.wait) for c in comms]
+
+    def close(self) -> None:
+        for g in self.ranks:
+            g.close()

@@ -22,7 +22,7 @@ from typing import Any, Dict, List, Optional
 import torch
 
 from besskge.bess import BessKGE
-from besskge.collectives import DistributedGroup, NativeGroup, ReplicaGroup, SingleProcessGroup
+from besskge.collectives import DistributedGroup, MultiDeviceGroup, NativeGroup, ReplicaGroup, SingleProcessGroup
 
 _MULTI_PROCESS = (DistributedGroup, NativeGroup)
 
@@ -56,6 +56,15 @@ class Options:
     #: recorded by value).  One process per GPU: with `NativeGroup` (collectives on
     #: the kernels' stream, captured with them), not with c10d's `DistributedGroup`.
     use_graphs: bool = False
+    #: record one call of the runner as a STEP PLAN - the list of the library's own calls the step consists of
+    #: (`besskge._native.record_plan`, csrc/plan.hip) - and replay it from C: no Python between the launches (an
+    #: eager notebook-size step spends 0.24 ms of host time on 0.07 ms of kernels), collectives included
+    #: (`NativeGroup`: bess_pack_exchange / bess_alltoall / bess_allreduce_sum_f32 are calls like any other - no
+    #: RCCL inside a hipGraph), and runnable from one host thread per device (`MultiDeviceGroup`).  The first call
+    #: with an input signature records, then replays the plan from the same start and checks that it reproduces the
+    #: recorded step (a step that is not made of library calls only is refused: RuntimeError).  Inputs are copied
+    #: into static buffers, as with `use_graphs`.
+    use_plans: bool = False
     #: `use_graphs`: keep the recorded hipGraph_t next to its executable form, so that
     #: `Runner.graph_node_counts()` can say what a recorded step holds (kernel / memset / memcpy nodes)
     keep_graph: bool = False
@@ -337,6 +346,135 @@ class Runner:
             return {k: v.clone() for k, v in stacked.items()}
         return stacked.clone()
 
+    # ------------------------------------------------------------ step plans
+    def _call_with_plans(self, batch: Dict[str, torch.Tensor], iters: int) -> Dict[str, torch.Tensor]:
+        from besskge import _native as nat
+
+        if isinstance(self.group, DistributedGroup):
+            raise NotImplementedError(
+                "use_plans needs the collectives to be calls of the library: SingleProcessGroup with one shard, or "
+                "NativeGroup / MultiDeviceGroup (bess_comm_* / RCCL through the C ABI) - not c10d's DistributedGroup")
+        stateful = self.optimizer is not None and not getattr(self.optimizer, "is_plain_sgd", True)
+        if stateful:
+            self.model._device_step = True  # Adam's step count lives on the device (as under use_graphs)
+        sig = (iters,) + tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()))
+        cache = self.__dict__.setdefault("_plans", {})
+        generation = self.model.__dict__.get("_state_generation", 0)
+        if self.__dict__.get("_plans_generation", generation) != generation:
+            cache.clear()  # optimiser state tensors were replaced (checkpoint load): recorded addresses are stale
+        self.__dict__["_plans_generation"] = generation
+        if sig not in cache:
+            cache[sig] = self._record_plan(batch, iters)
+        plan, static, stacked, _pool = cache[sig]
+        for k, v in batch.items():
+            if v.data_ptr() != static[k].data_ptr():
+                static[k].copy_(v, non_blocking=True)
+        plan.run()
+        if isinstance(stacked, dict):
+            return {k: v.clone() for k, v in stacked.items()}
+        return stacked.clone()
+
+    def _record_plan(self, batch: Dict[str, torch.Tensor], iters: int) -> Any:
+        """Record one call (all its device iterations) as a plan and prove it: replayed from the same start it must
+        leave the tables and outputs the recorded call left."""
+        from besskge import _native as nat
+
+        static = {k: torch.empty(v.shape, dtype=v.dtype, device=self.device) for k, v in batch.items()}
+        for k, v in batch.items():
+            static[k].copy_(v)
+        training = self.optimizer is not None
+        snapshot = self._training_snapshot() if training else None
+        for _ in range(2):  # static index maps, allocator pools, per-stream counters: made outside the recording
+            self._iteration(static, 0)
+        if snapshot is not None:
+            self._restore_training_snapshot(snapshot)
+        torch.cuda.synchronize(self.device)
+        pool = torch.cuda.MemPool()
+        # Everything the step enqueues must be a call of the library.  A plan that lacks a producer - an index tensor
+        # made by a torch operator - would read whatever the recording left in that buffer's (recycled) memory: row
+        # ids that are not row ids.  So the recording runs under the profiler and is REFUSED, before anything is
+        # replayed, if the device saw work that is not the library's (or RCCL's).
+        acts = [torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA]
+        with torch.profiler.profile(activities=acts) as prof:
+            with torch.cuda.use_mem_pool(pool, device=self.device), nat.record_plan(self.device) as plan:
+                outs = [o for it in range(iters) for o in self._iteration(static, it)]
+                stacked = self._stack_outputs(outs)
+            torch.cuda.synchronize(self.device)
+        events = prof.events()
+        device_work = [e.name for e in events if e.device_type == torch.autograd.DeviceType.CUDA]
+        # work the device did for a torch operator: the operator's host-side event carries the kernels / copies it
+        # launched (the library's own calls - rocPRIM's scan inside bess_build_segment_index included - are no
+        # torch operators); and, as a second net, device kernels that are torch's by name
+        foreign = {e.name for e in events if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith("aten::")
+                   and len(getattr(e, "kernels", ())) > 0}
+        foreign |= {n for n in device_work if "at::native" in n or n.startswith("void at::") or "at_cuda_detail" in n}
+        foreign = sorted(foreign)
+        if snapshot is not None:
+            self._restore_training_snapshot(snapshot)
+        if foreign or not device_work:
+            del outs, stacked
+            raise RuntimeError(
+                "use_plans: the step is not made of library calls only - the device also ran "
+                f"{[n[:80] for n in foreign[:6]] if foreign else 'nothing the profiler saw'} (a torch operator between the "
+                "calls: an index tensor derived from the inputs, a concatenation, a dtype conversion of the outputs) - "
+                "run it eagerly or with use_graphs")
+        if len(plan) == 0:
+            raise RuntimeError("use_plans: the step made no library call")
+        fn = self.model.score_fn
+        # The proof runs on OTHER inputs than the recording saw (every input rotated by one position along its last
+        # axis: still a valid batch): whatever the step derived from its inputs with a torch operator - an index
+        # tensor made by `idx[sel]`, a concatenation - sits in the plan's buffers with the recording batch's values.
+        # The eager step on the rotated inputs is the reference.
+        rotated = {k: v.roll(1, dims=-1) if v.dim() > 1 else v.clone() for k, v in static.items()}
+        ref_outs = [o for it in range(iters) for o in self._iteration(rotated, it)]
+        ref_stacked = self._stack_outputs(ref_outs)
+        torch.cuda.synchronize(self.device)
+        want_out = {k: v.clone() for k, v in ref_stacked.items()} if isinstance(ref_stacked, dict) else ref_stacked.clone()
+        want_tables = (fn.entity_embedding.data.clone(), fn.relation_embedding.data.clone()) if training else None
+        del ref_outs, ref_stacked
+        if snapshot is not None:
+            self._restore_training_snapshot(snapshot)
+        for k, v in rotated.items():
+            static[k].copy_(v)
+        plan.run()
+        torch.cuda.synchronize(self.device)
+
+        def same(a: torch.Tensor, b: torch.Tensor, start: Optional[torch.Tensor] = None) -> bool:
+            """Do replay (a) and eager step (b) agree?  Judged on the elements the step moved (`start`: the table
+            before it): sums of fp32 atomics differ in their last bits from run to run, and where a gradient
+            cancels to ~0 Adam turns that into a +-lr step - a few per cent of the moved elements; a plan that is
+            missing work moves other rows, or the same rows somewhere else entirely."""
+            a, b = a.float(), b.float()
+            ok = torch.isclose(a, b, rtol=1e-3, atol=1e-3 * float(b.abs().max().clamp(min=1e-6)), equal_nan=True)
+            if start is None:
+                return float((~ok).float().mean()) <= 1e-3
+            moved = (a != start.float()) | (b != start.float())
+            n_moved = int(moved.sum())
+            return n_moved == 0 or float((~ok & moved).sum()) <= 0.25 * n_moved
+
+        got_out = stacked if isinstance(stacked, dict) else {"out": stacked}
+        ref_out = want_out if isinstance(want_out, dict) else {"out": want_out}
+        bad = [k for k in ref_out if not same(got_out[k], ref_out[k])]
+        if training and not bad:
+            if not same(fn.entity_embedding.data, want_tables[0], snapshot["entity"]):
+                bad.append("entity_embedding")
+            if not same(fn.relation_embedding.data, want_tables[1], snapshot["relation"]):
+                bad.append("relation_embedding")
+        if bad:
+            raise RuntimeError(
+                f"use_plans: replaying the recorded calls {plan.names} does not reproduce the step ({bad} differ): "
+                "something the step computes on the host changes from call to call and is not part of the plan - "
+                "run it eagerly or with use_graphs")
+        if snapshot is not None:
+            self._restore_training_snapshot(snapshot)  # the call that recorded takes its step by replaying, below
+        for k, v in batch.items():
+            static[k].copy_(v)
+        return plan, static, stacked, pool
+
+    def plan_calls(self) -> Dict[Any, List[str]]:
+        """`use_plans`: the entry points of every recorded step, in order, by input signature."""
+        return {sig: list(entry[0].names) for sig, entry in self.__dict__.get("_plans", {}).items()}
+
     def graph_node_counts(self) -> Dict[Any, Dict[str, int]]:
         """`Options(use_graphs=True, keep_graph=True)`: node types of every recorded step, by input signature
         (`bess_graph_node_counts`): {"kernel": n, "memset": n, "memcpy": n, ...}."""
@@ -449,6 +587,8 @@ class Runner:
             )
         if self.options.use_graphs:
             return self._call_with_graphs(batch, iters)
+        if self.options.use_plans:
+            return self._call_with_plans(batch, iters)
         collected: List[List[Dict[str, Any]]] = []
         n_streams = 1 if (self.optimizer is not None or iters == 1) else max(1, self.options.pipeline_streams)
         if isinstance(self.group, NativeGroup):
@@ -508,19 +648,145 @@ class Runner:
         return out["out"] if bare else out  # type: ignore[return-value]
 
 
+class MultiDeviceRunner:
+    """`Runner` for ONE process that drives n GPUs (`MultiDeviceGroup`): the call shape of the reference -
+    `runner(**{k: v.flatten(end_dim=1) for k, v in batch.items()})` with the full `[bps * n_shard, ...]` batch, stacked
+    outputs back (reference `tests/test_bess.py:146-150`, `pipeline.py:129-144`) - on n devices.
+
+    Shard r of `model.score_fn.entity_embedding` goes to `devices[r]` with a copy of the relation table and of the
+    scorer's dense parts; replica r is stepped by its own `Runner` over rank r's `NativeGroup`, from its own host
+    thread (the library calls release the GIL; with `Options.use_plans` a step is ONE call per device).  The
+    replicas' outputs come back concatenated in rank order on `devices[0]`.  `sync_to_model()` writes the trained
+    shards / relation table back into the module that was handed in."""
+
+    def __init__(self, model: BessKGE, options: Optional[Options], group: MultiDeviceGroup, optimizer: Optional[Any],
+                 dtype: Optional[torch.dtype] = None, default_reduction: str = "sum") -> None:
+        import copy
+        from concurrent.futures import ThreadPoolExecutor
+
+        n = group.n_shard
+        if model.sharding.n_shard != n:
+            raise ValueError(f"MultiDeviceGroup has {n} devices, the sharding {model.sharding.n_shard} shards")
+        emb = model.score_fn.entity_embedding.data
+        if emb.dim() != 3 or emb.shape[0] != n:
+            raise ValueError("entity_embedding must be [n_shard, max_entity_per_shard, W]")
+        self.model, self.group = model, group
+        self.options = options or Options()
+        self.optimizer = optimizer
+        self.replicas: List[BessKGE] = []
+        self.runners: List[Runner] = []
+        for r, rank_group in enumerate(group.ranks):
+            # a replica of the module that shares nothing mutable with the others: its own scorer (shallow copy with
+            # its own parameter / buffer / submodule tables; submodules - ConvE's network - copied), its own shard
+            rep = copy.copy(model)
+            rep.__dict__ = dict(model.__dict__)
+            rep._modules = dict(model._modules)
+            rep._parameters = dict(model._parameters)
+            rep._buffers = dict(model._buffers)
+            fn = copy.copy(model.score_fn)
+            fn.__dict__ = dict(model.score_fn.__dict__)
+            fn._parameters = dict(model.score_fn._parameters)
+            fn._buffers = dict(model.score_fn._buffers)
+            fn._modules = {k: copy.deepcopy(m) for k, m in model.score_fn._modules.items()}
+            fn.entity_embedding = torch.nn.Parameter(emb[r: r + 1], requires_grad=False)  # (placed by the Runner)
+            fn.relation_embedding = torch.nn.Parameter(model.score_fn.relation_embedding.data.clone(), requires_grad=False)
+            rep._modules["score_fn"] = fn
+            rep.entity_embedding = fn.entity_embedding
+            rep.replica_group = None
+            self.replicas.append(rep)
+            with torch.cuda.device(rank_group.device):
+                self.runners.append(Runner(rep, copy.copy(self.options), rank_group, rank_group.device, optimizer, dtype,
+                                           default_reduction=default_reduction))
+        self._pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix="bess-device")
+
+    @property
+    def device(self) -> torch.device:
+        return self.group.devices[0]
+
+    def _rows_of(self, batch: Dict[str, torch.Tensor], r: int) -> Dict[str, torch.Tensor]:
+        """Rank r's rows of a `[micro-batches * n, ...]` batch (micro-batch-major, as the reference flattens it)."""
+        n = self.group.n_shard
+        return {k: v[r::n] for k, v in batch.items()}
+
+    def __call__(self, **batch: torch.Tensor) -> Dict[str, torch.Tensor]:
+        n = self.group.n_shard
+        rows = batch["relation"].shape[0]
+        micro = self.options.device_iterations * (max(1, self.options.gradient_accumulation) if self.optimizer is not None else 1)
+        if rows != micro * n:
+            raise ValueError(f"inputs have {rows} rows; expected device_iterations * gradient_accumulation * n_shard = "
+                             f"{micro} * {n} (flatten [batches_per_step, n_shard, ...] with .flatten(end_dim=1))")
+
+        def one(r: int) -> Dict[str, torch.Tensor]:
+            dev = self.group.devices[r]
+            torch.cuda.set_device(dev)  # (the current device is per host thread)
+            mine = {k: v.to(dev, non_blocking=True) for k, v in self._rows_of(batch, r).items()}
+            out = self.runners[r](**mine)
+            torch.cuda.current_stream(dev).synchronize()
+            return out
+
+        outs = [f.result() for f in [self._pool.submit(one, r) for r in range(n)]]
+        if not isinstance(outs[0], dict):
+            outs = [{"out": o} for o in outs]
+            bare = True
+        else:
+            bare = False
+        dev0 = self.device
+        merged: Dict[str, torch.Tensor] = {}
+        for k in outs[0]:
+            # rank r returned its micro-batches in order: interleave to the reference's micro-batch-major stacking
+            per_rank = [o[k].to(dev0) for o in outs]
+            if per_rank[0].dim() == 0:
+                per_rank = [x.reshape(1) for x in per_rank]
+            m = per_rank[0].shape[0]
+            if m % max(1, self._outs_per_rank()) == 0 and self._outs_per_rank() > 1:
+                parts = [x.reshape(self._outs_per_rank(), -1, *x.shape[1:]) for x in per_rank]
+                merged[k] = torch.stack(parts, dim=1).flatten(end_dim=2)
+            else:
+                merged[k] = torch.cat(per_rank, dim=0)
+        return merged["out"] if bare else merged
+
+    def _outs_per_rank(self) -> int:
+        mode = self.options.output_mode or ("final" if self.optimizer is not None else "all")
+        return 1 if mode == "final" else self.options.device_iterations
+
+    def sync_to_model(self) -> None:
+        """Write the replicas' shards (and rank 0's replicated tables) back into the module handed to the constructor."""
+        with torch.no_grad():
+            emb = self.model.score_fn.entity_embedding.data
+            for r, rep in enumerate(self.replicas):
+                emb[r].copy_(rep.score_fn.entity_embedding.data[0].to(emb.device, emb.dtype))
+            self.model.score_fn.relation_embedding.data.copy_(
+                self.replicas[0].score_fn.relation_embedding.data.to(self.model.score_fn.relation_embedding.device,
+                                                                      self.model.score_fn.relation_embedding.dtype))
+
+    def close(self) -> None:
+        self._pool.shutdown(wait=True)
+        for r in self.runners:
+            r.reset_graphs()
+        self.group.close()
+
+
+def _runner(model: BessKGE, options: Optional[Options], group: Any, device: Optional[torch.device], optimizer: Optional[Any],
+            dtype: Optional[torch.dtype], default_reduction: str = "sum") -> Any:
+    if isinstance(group, MultiDeviceGroup):
+        return MultiDeviceRunner(model, options, group, optimizer, dtype, default_reduction)
+    return Runner(model, options, group, device, optimizer, dtype, default_reduction=default_reduction)
+
+
 def inference_model(model: BessKGE, options: Optional[Options] = None, group: Optional[ReplicaGroup] = None,
                     device: Optional[torch.device] = None, dtype: Optional[torch.dtype] = None) -> Runner:
-    """`poptorch.inferenceModel` analogue."""
+    """`poptorch.inferenceModel` analogue.  `group=MultiDeviceGroup(devices)`: one process, n GPUs."""
     model.eval()
-    return Runner(model, options, group, device, None, dtype)
+    return _runner(model, options, group, device, None, dtype)
 
 
 def training_model(model: BessKGE, options: Optional[Options] = None, optimizer: Optional[Any] = None,
                    group: Optional[ReplicaGroup] = None, device: Optional[torch.device] = None,
                    dtype: Optional[torch.dtype] = None) -> Runner:
-    """`poptorch.trainingModel` analogue (forward + backward + sparse update per call)."""
+    """`poptorch.trainingModel` analogue (forward + backward + sparse update per call).
+    `group=MultiDeviceGroup(devices)`: one process, n GPUs."""
     model.train()
-    return Runner(model, options, group, device, optimizer or SGD(), dtype)
+    return _runner(model, options, group, device, optimizer or SGD(), dtype)
 
 
 # PopTorch's spellings, so that `from besskge import runtime as poptorch` keeps a notebook's lines
@@ -534,7 +800,7 @@ def trainingModel(model: BessKGE, options: Optional[Options] = None, optimizer: 
     `accumulationAndReplicationReductionType` is Mean; the notebooks rely on it with `gradientAccumulation(6)` and
     four replicas) unless the options / the optimiser say otherwise."""
     model.train()
-    return Runner(model, options, group, device, optimizer or SGD(), dtype, default_reduction="mean")
+    return _runner(model, options, group, device, optimizer or SGD(), dtype, default_reduction="mean")
 
 
 inferenceModel = inference_model  # noqa: N816

@@ -832,6 +832,32 @@ int bess_direct_update(const bess_opt_desc* opt, int32_t dtype, int32_t width, v
                        const int32_t* const* id_lists, const int64_t* id_lens, float* acc, int32_t* claim,
                        const int32_t* generation, float* state1, float* state2, void* axpy_table,
                        const float* axpy_grad, int64_t axpy_n, float axpy_alpha, void* stream);
+/* ---- step plans -----------------------------------------------------------------
+ * A step as a recorded list of this library's calls, replayed from C (csrc/plan.hip).  The reference's step is
+ * compiled once by PopTorch and then runs without Python (bess.py:322-468 under poptorch.trainingModel,
+ * `device_iterations` micro-batches per host call); here the host program runs the step once while noting every call
+ * that enqueues work - bess_plan_add_call: the entry point's name and, per argument, its kind and value - and
+ * bess_plan_run issues the same calls again on the given stream: kernels and collectives (bess_pack_exchange,
+ * bess_alltoall, bess_allreduce_sum_f32 ...) alike, from any host thread (one per device for a process that drives
+ * several GPUs).  Argument kinds: INT (values[k] = the integer), FLOAT (values[k] = the bits of a double), PTR
+ * (values[k] = an address that stays valid: device buffers, communicators), BLOB (blobs[k] / blob_bytes[k]: host
+ * bytes the call reads - descriptors, arrays of pointers / sizes - copied into the plan), STREAM (the last argument
+ * of every recordable entry point: replaced by bess_plan_run's).  A plan owns nothing on the device: it is valid
+ * while the buffers it names are.  bess_plan_knows: 1 for the names of entry points that can be part of a plan. */
+#define BESS_PLAN_ARG_INT 0
+#define BESS_PLAN_ARG_FLOAT 1
+#define BESS_PLAN_ARG_PTR 2
+#define BESS_PLAN_ARG_BLOB 3
+#define BESS_PLAN_ARG_STREAM 4
+typedef struct bess_plan bess_plan;
+int bess_plan_create(bess_plan** plan);
+int bess_plan_destroy(bess_plan* plan);
+int bess_plan_knows(const char* name);
+int bess_plan_length(const bess_plan* plan);
+int bess_plan_add_call(bess_plan* plan, const char* name, int32_t n_args, const uint8_t* kinds,
+                       const uint64_t* values, const void* const* blobs, const int64_t* blob_bytes);
+int bess_plan_run(const bess_plan* plan, void* stream);
+
 /* ---- recorded steps -----------------------------------------------------------
  * A step of this library can be captured into a hipGraph as a whole (every call is asynchronous on the
  * caller's stream, every clear is a kernel).  bess_graph_node_counts tells what a captured graph holds:

@@ -263,8 +263,62 @@ def checkpoint(out_dir: str) -> None:
     np.savez(os.path.join(out_dir, f"checkpoint_{r}.npz"), files=np.array(sorted(os.listdir(d))))
 
 
+def multidevice(out_dir: str) -> None:
+    """ONE process, n GPUs (`MultiDeviceGroup`, `bess_comm_init_all`): the reference's call shape - the full
+    `[bps * n_shard, ...]` batch in, stacked outputs out (reference tests/test_bess.py:122-150) - on golden cases;
+    BESS_USE_PLANS=1: every replica's step is a recorded plan run from its own host thread."""
+    from besskge import runtime
+    from besskge.collectives import MultiDeviceGroup
+    from test_hip_parity import build_model
+    from test_oracle import load_bess_case
+
+    n = int(os.environ["BESS_N_DEVICES"])
+    devices = [torch.device("cuda", i) for i in range(n)]
+    plans = os.environ.get("BESS_USE_PLANS", "0") == "1"
+    out = {}
+    for case in [c for c in os.environ["BESS_CASES"].split(",") if c]:
+        c = load_bess_case(case)
+        assert c["meta"]["n_shard"] == n
+        bps = c["meta"]["bps"]
+        keys = ("head", "relation", "tail", "negative", "negative_mask")
+        batch = {k: c["batch"][k].flatten(end_dim=1) for k in keys if k in c["batch"]}
+        model = build_model(c, torch.device("cpu"))
+        group = MultiDeviceGroup(devices)
+        runner = runtime.inference_model(model, runtime.Options(device_iterations=bps), group=group)
+        if c["net"] is not None:
+            for rep in runner.replicas:
+                rep.train()
+        res = runner(**batch)
+        for k, v in res.items():
+            out[f"{case}_fwd_{k}"] = v.float().cpu().numpy()
+        runner.close()
+        if case.startswith("tr_"):
+            model = build_model(c, torch.device("cpu"))
+            group = MultiDeviceGroup(devices)
+            lr = 0.125
+            runner = runtime.training_model(model, runtime.Options(device_iterations=1, use_plans=plans), runtime.SGD(lr=lr),
+                                            group=group)
+            try:
+                res = runner(**{k: v[: n] for k, v in batch.items()})
+            except RuntimeError as e:
+                if not plans or "not made of library calls only" not in str(e):
+                    raise
+                out[f"{case}_refused"] = np.array(1)  # (a step with torch operators in it: eager is the answer)
+                runner.close()
+                continue
+            runner.sync_to_model()
+            out[f"{case}_train_loss"] = res["loss"].float().cpu().numpy()
+            out[f"{case}_train_entity"] = model.score_fn.entity_embedding.detach().float().cpu().numpy()
+            out[f"{case}_train_relation"] = model.score_fn.relation_embedding.detach().float().cpu().numpy()
+            runner.close()
+    np.savez(os.path.join(out_dir, "multidevice.npz"), **out)
+
+
 def main() -> None:
     mode, out_dir = sys.argv[1], sys.argv[2]
+    if mode == "multidevice":  # one process: no process group
+        multidevice(out_dir)
+        return
     # gloo: several ranks share the box's one GPU (host-staged collectives); nccl (= RCCL): one rank
     # per GPU - with a single GPU that is world_size 1, which still sends every collective through RCCL
     backend = os.environ.get("BESS_DIST_BACKEND", "gloo")

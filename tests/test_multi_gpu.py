@@ -13,6 +13,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 
 import numpy as np
 import pytest
@@ -126,3 +127,45 @@ def test_bench_c4_recorded_collectives(world):
     assert line["config"]["collectives"].startswith("native"), line["config"]["collectives"]
     (pt,) = line["c4"]["sweep"]
     assert pt["value"] > 0 and "graph_ms_per_step" in pt, pt
+
+
+@pytest.mark.parametrize("plans", [False, True], ids=["eager", "plans"])
+@pytest.mark.parametrize("world", WORLDS)
+def test_one_process_driving_n_devices(world, plans):
+    """`MultiDeviceGroup`: ONE host process, n GPUs (`bess_comm_init_all`), one host thread per device - the
+    reference's own runtime contract (`tests/test_bess.py:122-150`: every tensor `[bps * n_shard, ...]` in, stacked
+    outputs back).  Forward and one SGD step of the golden cases of this n_shard against the reference's outputs and
+    gradients; "plans": each replica's step is a recorded plan (`Options.use_plans`) replayed from its thread."""
+    from test_oracle import load_bess_case
+
+    cases = _cases(world)
+    assert cases
+    out_dir = tempfile.mkdtemp(prefix="bess_md_")
+    env = dict(os.environ, BESS_CASES=",".join(cases), BESS_N_DEVICES=str(world), BESS_USE_PLANS="1" if plans else "0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(HERE, "_dist_worker.py"), "multidevice", out_dir], env=env,
+                         capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    z = np.load(os.path.join(out_dir, "multidevice.npz"))
+    n_trained = 0
+    for case in cases:
+        c = load_bess_case(case)
+        bps = c["meta"]["bps"]
+        ssce = c["loss_name"] == "ssce"
+        S = c["outs"]["positive_score"].shape[-1]
+        # stacked over micro-batches and replicas, micro-batch-major: [bps, n, ...]
+        np.testing.assert_allclose(z[f"{case}_fwd_positive_score"].reshape(bps, world, S),
+                                   c["outs"]["positive_score"].numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(z[f"{case}_fwd_negative_score"].reshape(bps, world, S, -1),
+                                   c["outs"]["negative_score"].numpy(), rtol=1e-4, atol=2e-3 if ssce else 1e-5)
+        if c["loss"] is not None:
+            np.testing.assert_allclose(z[f"{case}_fwd_loss"].reshape(bps, world), c["outs"]["loss"].numpy(), rtol=1e-4, atol=1e-4)
+        if case.startswith("tr_") and f"{case}_refused" not in z.files:
+            n_trained += 1
+            lr = 0.125
+            np.testing.assert_allclose(z[f"{case}_train_loss"].reshape(world), c["outs"]["loss"][0].numpy(), rtol=1e-4, atol=1e-4)
+            np.testing.assert_allclose(z[f"{case}_train_entity"], (c["table"] - lr * c["grads"]["entity"]).numpy(),
+                                       rtol=1e-4, atol=2e-5)
+            np.testing.assert_allclose(z[f"{case}_train_relation"], (c["rel"] - lr * c["grads"]["relation"].sum(0)).numpy(),
+                                       rtol=1e-4, atol=2e-5)
+    assert n_trained > 0
