@@ -311,13 +311,14 @@ def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, c
     points = state.setdefault("points", {})
     for name in variants:
         graphs = name == "graph"
-        if graphs and isinstance(group, DistributedGroup):
+        plans = name == "plan"  # the step as a recorded list of library calls replayed from C (Options.use_plans)
+        if (graphs or plans) and isinstance(group, DistributedGroup):
             continue
         for S_, K_ in (sweep or C4_SWEEP):
             ppp = S_ // n
             if ppp * n != S_ or S_ > state.get("max_s", 1 << 30):
                 continue
-            if graphs and S_ > 4096:
+            if (graphs or plans) and S_ > 4096:
                 continue  # steps of 10+ ms: nothing for a replay to save
             rng = np.random.default_rng(100 + rank)
             M = int(sharding.shard_counts[rank])
@@ -335,11 +336,11 @@ def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, c
                 ns = RandomShardedNegativeSampler(K_, sharding, 0, "t", local_sampling=False, flat_negative_format=True)
                 model = EmbeddingMovingBessKGE(negative_sampler=ns, score_fn=fn, augment_negative=True,
                                                loss_fn=SampledSoftmaxCrossEntropyLoss(n_entity=C4_N_ENTITY))
-                opts = runtime.Options(device_iterations=iters, use_graphs=graphs, pipeline_streams=1)
+                opts = runtime.Options(device_iterations=iters, use_graphs=graphs, use_plans=plans, pipeline_streams=1)
                 runner = runtime.training_model(model, opts, runtime.SGD(lr=1e-3), group=group, device=dev)
-                if graphs:
+                if graphs or plans:
                     # inputs resident in HBM where the recorded step reads them (what a device-side sampler
-                    # writing into Runner.static_inputs() gives): a call is one graph launch, no input copies
+                    # writing into Runner.static_inputs() gives): a call is one graph launch / plan run, no input copies
                     static = runner.static_inputs(**batch)
                     for k_, v_ in batch.items():
                         static[k_].copy_(v_)
@@ -367,7 +368,7 @@ def c4_leg(world: int, rank: int, dev: torch.device, group, distributed: bool, c
             finally:
                 runner = model = fn = None
                 torch.cuda.empty_cache()
-            best = min((point[k] for k in ("eager_ms_per_step", "graph_ms_per_step") if k in point), default=None)
+            best = min((point[k] for k in ("eager_ms_per_step", "plan_ms_per_step", "graph_ms_per_step") if k in point), default=None)
             if best is not None:
                 point["ms_per_step"] = best
                 point["value"] = scored / (best * 1e-3)
@@ -746,7 +747,7 @@ def main() -> None:
     if extra_legs:
         c4_steps = max(16, min(args.steps, 48))
         state: dict = {"max_s": args.c4_max_s}
-        line["c4"] = c4_leg(world, rank, dev, group, distributed, comm_name, c4_steps, state, variants=("eager",))
+        line["c4"] = c4_leg(world, rank, dev, group, distributed, comm_name, c4_steps, state, variants=("eager", "plan"))
         if world > 1:
             try:
                 line["xgmi"] = xgmi_leg(group, world, rank, dev)
@@ -807,7 +808,7 @@ def main_c4(args, world: int, rank: int, dev, group, distributed: bool, comm_nam
         raise SystemExit(f"--c4-point: S = {S_} is not a multiple of n_shard = {world}")
     state: dict = {"max_s": 1 << 30}
     sweep = ((S_, K_),)
-    c4_leg(world, rank, dev, group, distributed, comm_name, args.steps, state, variants=("eager",), sweep=sweep,
+    c4_leg(world, rank, dev, group, distributed, comm_name, args.steps, state, variants=("eager", "plan"), sweep=sweep,
            warmup_calls=-(-args.warmup // 8))
     line: dict = {}
     if world == 1 or args.c4_graph:
@@ -815,7 +816,7 @@ def main_c4(args, world: int, rank: int, dev, group, distributed: bool, comm_nam
     point = state["points"][(S_, K_)]
     if "ms_per_step" not in point:
         raise SystemExit(f"c4 leg failed: {point}")
-    which = "graph" if point.get("graph_ms_per_step", 1e30) <= point.get("eager_ms_per_step", 1e30) else "eager"
+    which = min(("eager", "plan", "graph"), key=lambda v: point.get(f"{v}_ms_per_step", 1e30))
     n_neg = point["negatives_per_triple"]
     valu = dict(point["valu"])
     valu.update(kernel="k_l1_fwd_pk + k_neg_shared_bwd (both products), whole step", peak=VALU_PEAK_TLOPS,

@@ -509,11 +509,11 @@ class Runner:
         (recording it if need be).  A feed that fills them in place - `DeviceBatchSampler.sample(out=...)`, or
         any kernel of the host program - and then calls the runner with them pays no input copy: at the
         notebooks' micro-batch the four copies were 10 % of a replayed step."""
-        if not self.options.use_graphs:
-            raise RuntimeError("static_inputs() belongs to use_graphs=True")
-        self(**batch)  # records the graph for this signature (a training runner also takes this one step)
+        if not (self.options.use_graphs or self.options.use_plans):
+            raise RuntimeError("static_inputs() belongs to use_graphs=True / use_plans=True")
+        self(**batch)  # records the step for this signature (a training runner also takes this one step)
         sig = (self.options.device_iterations,) + tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()))
-        return dict(self._graphs[sig][1])
+        return dict((self._graphs if self.options.use_graphs else self._plans)[sig][1])
 
     def _training_snapshot(self) -> Dict[str, Any]:
         fn = self.model.score_fn
