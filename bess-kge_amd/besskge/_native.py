@@ -132,6 +132,8 @@ SIGNATURES = {
     "bess_query_triple_fwd": [_MD, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "bess_query_triple_bwd": [_MD, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "bess_sparse_sgd_lists": [_i32, _i32, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64), _f32, _vp],
+    "bess_sparse_sgd_lists_axpy": [_i32, _i32, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64), _f32,
+                                   _vp, _vp, _i64, _f32, _vp],
     "bess_neg_score_pertriple_fwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
     "bess_neg_score_pertriple_bwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
     "bess_neg_score_shared_fwd": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
@@ -1202,8 +1204,10 @@ def sparse_sgd(table: torch.Tensor, idx: torch.Tensor, grad: torch.Tensor, lr: f
     _check(rc, "bess_sparse_sgd")
 
 
-def sparse_sgd_lists(table: torch.Tensor, lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], lr: float) -> None:
-    """`sparse_sgd` for several (row ids, gradient rows) lists in one launch."""
+def sparse_sgd_lists(table: torch.Tensor, lists: Sequence[Tuple[torch.Tensor, torch.Tensor]], lr: float,
+                     axpy: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None) -> None:
+    """`sparse_sgd` for several (row ids, gradient rows) lists in one launch.  `axpy` = (table2, grad2, alpha):
+    `table2 += alpha * grad2` (dense, same dtype as `table`) by spare workgroups of the same launch."""
     if not 1 <= len(lists) <= MAX_ROW_LISTS:
         raise ValueError(f"sparse_sgd_lists: {len(lists)} lists (1 .. {MAX_ROW_LISTS})")
     dev = _same_device([("table", table)] + [(f"idx[{i}]", x) for i, (x, _) in enumerate(lists)]
@@ -1217,8 +1221,19 @@ def sparse_sgd_lists(table: torch.Tensor, lists: Sequence[Tuple[torch.Tensor, to
     ip = (_vp * len(lists))(*[x.data_ptr() for x, _ in lists])
     gp = (_vp * len(lists))(*[g.data_ptr() for _, g in lists])
     rows = (_i64 * len(lists))(*[int(g.shape[0]) for _, g in lists])
+    x_table = x_grad = None
+    x_n, x_alpha = 0, 0.0
+    if axpy is not None:
+        x_table, x_grad, x_alpha = axpy
+        _same_device([("table", table), ("axpy table", x_table), ("axpy grad", x_grad)])
+        _f32(x_grad, "axpy grad")
+        if x_table.dtype != table.dtype or not x_table.is_contiguous() or x_grad.numel() != x_table.numel():
+            raise ValueError("sparse_sgd_lists: the axpy table must be contiguous, of the table's dtype, and match its gradient")
+        x_n = int(x_table.numel())
     with _on(dev), _Timed("bess_sparse_sgd_lists", dev):
-        rc = load().bess_sparse_sgd_lists(_dtype_code(table), W, table.data_ptr(), len(lists), ip, gp, rows, lr, _stream(dev))
+        rc = load().bess_sparse_sgd_lists_axpy(_dtype_code(table), W, table.data_ptr(), len(lists), ip, gp, rows, lr,
+                                               x_table.data_ptr() if x_n else None, x_grad.data_ptr() if x_n else None,
+                                               x_n, float(x_alpha), _stream(dev))
     _check(rc, "bess_sparse_sgd_lists")
 
 

@@ -136,6 +136,7 @@ class _ReplicaStep:
         # rows into `direct.acc` at the rows' ids, `direct_lists` names the rows (no index, no dense row gradients)
         self.direct: Any = None
         self.direct_lists: List[torch.Tensor] = []
+        self.jobs_ride = False  # the step's copy / fill jobs go with the query / positive-score launch
 
 
 class _PendingUpdate:
@@ -711,12 +712,15 @@ class BessKGE(torch.nn.Module, ABC):
                 st.d_recv.view(st.n, -1, st.d_recv.shape[1])[:, : st.ppp].zero_()
             else:
                 jobs.append((st.d_recv, None, 0))
-        if st.direct is not None and st.fused_qt:
-            # nothing to index: the jobs ride in the query / positive-score launch (`fn.query_triple_fwd(jobs=...)`),
-            # none of whose inputs they write
-            st.jobs = jobs
-            return None
         plan = None if st.direct is not None else self._small_plan(st, optimizer)
+        if plan is not None and sum(int(x.numel()) for x in plan) > self.prologue_index_max:
+            plan = None
+        if plan is None and st.fused_qt and st.n == 1:
+            # nothing to index in a launch of its own: the jobs ride in the query / positive-score launch
+            # (`fn.query_triple_fwd(jobs=...)`), none of whose inputs they write
+            st.jobs = jobs
+            st.jobs_ride = True
+            return None
         # one workgroup indexes up to 4096 ids in ~12-15 us (notebook-size steps: cheaper than any fork / join);
         # longer lists are indexed by the device-wide pipeline on the side stream, under the forward kernels
         # (`_small_index_ahead`) - 12.5 k ids in the prologue's one workgroup were 58 us on the critical path
@@ -873,6 +877,10 @@ class BessKGE(torch.nn.Module, ABC):
         if plain and not plain_rows and rel_table.dtype == steps[-1].table.dtype \
                 and not any(item[0] is steps[-1].table for item in deferred):
             rel_axpy = (rel_table, d_rel, -lr)  # (with the last shard hosted here)
+        if plain_rows and rel_table.dtype == steps[-1].table.dtype and local_updates and local_updates[-1] \
+                and sum(int(i_.numel()) for i_, _ in local_updates[-1]) < self.coalesce_sgd_from \
+                and len(local_updates[-1]) <= nat.MAX_ROW_LISTS:
+            rel_axpy = (rel_table, d_rel, -lr)  # (in the launch of the last shard's atomic row updates)
         if plain_rows:
             # per-triple negatives of the own shard: segmented reduction.  A shard with a
             # single such group gets the SGD step fused into the reduction; with two
@@ -900,8 +908,10 @@ class BessKGE(torch.nn.Module, ABC):
                     self._apply_optimizer(_PlainSGD(lr), st.table, list(upd))
                     continue
                 lists = [(idx.contiguous(), g.contiguous()) for idx, g in upd]
+                ride = rel_axpy if (st is steps[-1] and len(lists) <= nat.MAX_ROW_LISTS) else None
                 for i in range(0, len(lists), nat.MAX_ROW_LISTS):
-                    nat.sparse_sgd_lists(st.table, lists[i: i + nat.MAX_ROW_LISTS], lr)
+                    nat.sparse_sgd_lists(st.table, lists[i: i + nat.MAX_ROW_LISTS], lr, axpy=ride)
+                rel_done = rel_done or ride is not None
         else:
             # non-linear optimisers need the *summed* gradient of every row first
             native = desc.scorer <= nat.COMPLEX
@@ -1096,8 +1106,8 @@ class EmbeddingMovingBessKGE(BessKGE):
             if st.fused_qt:
                 # K2 + K3 + K6: the query of the one negative-scoring problem and the positive scores, one launch
                 g0.query, st.positive_score = fn.query_triple_fwd(g0.side, RowSource(st.table, st.head_idx), st.tail,
-                                                                  st.rel_idx, jobs=st.jobs if st.direct is not None else None)
-                if st.direct is not None:
+                                                                  st.rel_idx, jobs=st.jobs if st.jobs_ride else None)
+                if st.jobs_ride:
                     st.jobs = None
             else:
                 st.positive_score, st.triple_ctx = fn.triple_fwd(

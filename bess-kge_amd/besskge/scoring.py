@@ -520,7 +520,6 @@ class _AffineScoreFunction(_TorchQueryHooks, DistanceBasedScoreFunction, ABC):
     """`-|| U * c1 + V * c2 + R ||_p` scorers; see the module docstring."""
 
     _scorer_id = nat.AFFINE
-    supported_norms = (1, 2)
     supports_fused_segments = True  # csrc/affine.hip: k_aff_grad_segments
     #: d-wide parts of an entity row (1 | 2)
     _n_part: int = 1
@@ -935,7 +934,6 @@ class BoxE(_TorchQueryHooks, DistanceBasedScoreFunction):
     bumped by the tail's bump and vice versa, and each bumped point is scored by a
     piecewise distance to its relation box."""
 
-    supported_norms = (1, 2)
 
     _scorer_id = nat.BOXE
 

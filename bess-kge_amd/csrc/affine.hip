@@ -291,6 +291,7 @@ struct AffArgs {
     int nch;              // chunks of VEC scalars per part
     int nb, items_per_query;
     int normalize;
+    float p;  // the norm of the P == 2 kernels: any p != 1 (2: multiply / sqrt; others through powf - common.h lp_*)
 };
 
 template <typename T, int VEC, int IT, int NPART>
@@ -369,10 +370,10 @@ __global__ __launch_bounds__(256) void k_aff_pertriple_fwd(AffArgs a, float* __r
             for (int v = 0; v < VEC; ++v) {
                 const float dlt = aff_delta<VEC, IT, NPART>(qv, ev, inv, it, v);
                 if (P == 1) acc += fabsf(dlt);
-                else acc = fmaf(dlt, dlt, acc);
+                else acc += lp_term(dlt, a.p);
             }
         acc = row16_allreduce_sum(acc);
-        if (P == 2) acc = sqrtf(acc);
+        if (P == 2) acc = lp_root(acc, a.p);
         if (g == 0 && valid) orow[k] = -acc;
     }
 }
@@ -414,10 +415,10 @@ __global__ __launch_bounds__(256) void k_aff_pertriple_bwd(AffArgs a, const floa
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     const float dlt = aff_delta<VEC, IT, NPART>(qv, ev, inv, it, v);
-                    ss = fmaf(dlt, dlt, ss);
+                    ss += lp_term(dlt, a.p);
                 }
             ss = row16_allreduce_sum(ss);
-            go = ss > 0.f ? go / sqrtf(ss) : 0.f;
+            go *= lp_inv(lp_root(ss, a.p), a.p);  // norm^(1 - p); 0 at the kink
         }
         float dc[NPART][IT][VEC];   // gradient wrt the normalised parts
         float dots[NPART];
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(256) void k_aff_pertriple_bwd(AffArgs a, const floa
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 const float dlt = aff_delta<VEC, IT, NPART>(qv, ev, inv, it, v);
-                const float s = (P == 1) ? go * sgnf(dlt) : go * dlt;
+                const float s = (P == 1) ? go * sgnf(dlt) : go * lp_dterm(dlt, a.p);
                 dq[NPART][it][v] += s;
 #pragma unroll
                 for (int p = 0; p < NPART; ++p) {
@@ -533,6 +534,7 @@ int affine_pertriple(const bess_model_desc* d, bool fwd, const float* query, int
     a.nb = nb;
     a.items_per_query = static_cast<int>(ceil_div(n_neg, nb));
     a.normalize = d->reserved[1] & 1;
+    a.p = static_cast<float>(d->norm_p);
     const int it = static_cast<int>(ceil_div(a.nch, 16));
     if (!fwd && a.items_per_query > 1) {
         hipError_t e = fill_words_async(dq, 0u, n_query * (n_part + 1) * dd, st);
@@ -568,6 +570,7 @@ struct AffSegArgs {
     int nch;
     int normalize;
     const int32_t* long_segs;    // optional: rows with more than BESS_SEGMENT_CAP references (segments.hip)
+    float p;                     // the norm of the P == 2 kernels (any p != 1)
 };
 
 // dc += contributions of references [r0, r1) of one destination row (ev, inv: the row and its part norms)
@@ -589,17 +592,17 @@ __device__ __forceinline__ void aff_seg_accumulate(const AffSegArgs& a, int g, c
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
                         const float dlt = aff_delta<VEC, IT, NPART>(qv, ev, inv, it, v);
-                        ss = fmaf(dlt, dlt, ss);
+                        ss += lp_term(dlt, a.p);
                     }
                 ss = row16_allreduce_sum(ss);
-                go = ss > 0.f ? go / sqrtf(ss) : 0.f;
+                go *= lp_inv(lp_root(ss, a.p), a.p);
             }
 #pragma unroll
             for (int it = 0; it < IT; ++it)
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     const float dlt = aff_delta<VEC, IT, NPART>(qv, ev, inv, it, v);
-                    const float sc = (P == 1) ? go * sgnf(dlt) : go * dlt;
+                    const float sc = (P == 1) ? go * sgnf(dlt) : go * lp_dterm(dlt, a.p);
 #pragma unroll
                     for (int p = 0; p < NPART; ++p) dc[p][it][v] = fmaf(sc, qv[p][it][v], dc[p][it][v]);
                 }
@@ -768,7 +771,7 @@ int affine_grad_segments(const bess_model_desc* d, const float* query, void* tab
     const int dd = d->width / n_part;
     const int vec = (dd % 4 == 0) ? 4 : 1;
     AffSegArgs a{query, table, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg, static_cast<int>(n_neg),
-                 dd, dd / vec, d->reserved[1] & 1, long_segs};
+                 dd, dd / vec, d->reserved[1] & 1, long_segs, static_cast<float>(d->norm_p)};
     const int it = static_cast<int>(ceil_div(a.nch, 16));
     const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(max_seg, 16), 256 * 16));
     int rc;
@@ -825,7 +828,7 @@ __device__ __forceinline__ void aff_stage_store(float (*tile)[AKT][ALDP], const 
 
 template <int NPART, int P>
 __global__ __launch_bounds__(256) void k_aff_shared_fwd(const float* __restrict__ Q, int64_t S, const float* __restrict__ C,
-                                                        int64_t N, int d, float* __restrict__ out, int64_t ld_out) {
+                                                        int64_t N, int d, float* __restrict__ out, int64_t ld_out, float pf) {
     __shared__ __attribute__((aligned(16))) float Qs[NPART + 1][AKT][ALDP];
     __shared__ __attribute__((aligned(16))) float Cs[NPART][AKT][ALDP];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -867,7 +870,7 @@ __global__ __launch_bounds__(256) void k_aff_shared_fwd(const float* __restrict_
 #pragma unroll
                     for (int p = NPART - 1; p >= 0; --p) dlt = fmaf(u[p][i], c[p][j], dlt);
                     if (P == 1) acc[i][j] += fabsf(dlt);
-                    else acc[i][j] = fmaf(dlt, dlt, acc[i][j]);
+                    else acc[i][j] += lp_term(dlt, pf);
                 }
         }
         __syncthreads();
@@ -879,7 +882,7 @@ __global__ __launch_bounds__(256) void k_aff_shared_fwd(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t jj = j0 + tx * 4 + j;
-            if (jj < N) out[q * ld_out + jj] = -(P == 2 ? sqrtf(acc[i][j]) : acc[i][j]);
+            if (jj < N) out[q * ld_out + jj] = -(P == 2 ? lp_root(acc[i][j], pf) : acc[i][j]);
         }
     }
 }
@@ -893,7 +896,7 @@ template <int NPART, int P, bool XQ>
 __global__ __launch_bounds__(256) void k_aff_shared_bwd(const float* __restrict__ X, int64_t nx, const float* __restrict__ Y,
                                                         int64_t ny, int d, const float* __restrict__ d_out, int64_t sa,
                                                         int64_t sb, const float* __restrict__ out, int64_t oa, int64_t ob,
-                                                        float* __restrict__ dX, int64_t b_chunk) {
+                                                        float* __restrict__ dX, int64_t b_chunk, float pf) {
     constexpr int NVX = XQ ? NPART + 1 : NPART;
     constexpr int NVY = XQ ? NPART : NPART + 1;
     __shared__ __attribute__((aligned(16))) float Ks[AKT][ALDP];        // coefficient [b][a]
@@ -933,7 +936,7 @@ __global__ __launch_bounds__(256) void k_aff_shared_bwd(const float* __restrict_
             float c;
             if (P == 2) {
                 const float o = out[ac * oa + bc * ob];
-                c = (o != 0.f) ? g / o : 0.f;     // -g * delta / ||delta||,  out = -||delta||
+                c = -g * lp_inv(-o, pf);          // -g * ||delta||^(1 - p),  out = -||delta||   (p = 2: g / out)
             } else {
                 c = -g;
             }
@@ -988,7 +991,7 @@ __global__ __launch_bounds__(256) void k_aff_shared_bwd(const float* __restrict_
 #pragma unroll
                         for (int p = NPART - 1; p >= 0; --p) dlt = fmaf(y[p][j], xv[p][i][j], dlt);
                     }
-                    const float tt = (P == 1) ? c[i] * sgn_prescaled(dlt * SGN_PRESCALE) : c[i] * dlt;
+                    const float tt = (P == 1) ? c[i] * sgn_prescaled(dlt * SGN_PRESCALE) : c[i] * lp_dterm(dlt, pf);
 #pragma unroll
                     for (int p = 0; p < NPART; ++p) acc[p][i][j] = fmaf(tt, y[p][j], acc[p][i][j]);
                     if (XQ) acc[NPART][i][j] += tt;
@@ -1016,7 +1019,7 @@ __global__ __launch_bounds__(256) void k_aff_shared_bwd(const float* __restrict_
 
 template <int NPART, int P, bool XQ>
 static int aff_bwd_launch(const float* X, int64_t nx, const float* Y, int64_t ny, int d, const float* d_out, int64_t sa,
-                          int64_t sb, const float* out, int64_t oa, int64_t ob, float* dX, hipStream_t st) {
+                          int64_t sb, const float* out, int64_t oa, int64_t ob, float* dX, hipStream_t st, float pf) {
     constexpr int NVX = XQ ? NPART + 1 : NPART;
     const int64_t tiles = ceil_div(d, 64) * ceil_div(nx, 64);
     int64_t split = 1;
@@ -1029,7 +1032,7 @@ static int aff_bwd_launch(const float* X, int64_t nx, const float* Y, int64_t ny
     }
     const dim3 grid(static_cast<unsigned>(ceil_div(d, 64)), static_cast<unsigned>(ceil_div(nx, 64)),
                     static_cast<unsigned>(split));
-    k_aff_shared_bwd<NPART, P, XQ><<<grid, 256, 0, st>>>(X, nx, Y, ny, d, d_out, sa, sb, out, oa, ob, dX, chunk);
+    k_aff_shared_bwd<NPART, P, XQ><<<grid, 256, 0, st>>>(X, nx, Y, ny, d, d_out, sa, sb, out, oa, ob, dX, chunk, pf);
     return BESS_OK;
 }
 
@@ -1037,13 +1040,14 @@ int affine_shared_fwd(const bess_model_desc* d, const float* query, int64_t S, c
                       int64_t ld, hipStream_t st) {
     const int n_part = d->reserved[0];
     const int dd = d->width / n_part;
+    const float pf = static_cast<float>(d->norm_p);
     const dim3 grid(static_cast<unsigned>(ceil_div(N, 64)), static_cast<unsigned>(ceil_div(S, 64)));
     if (n_part == 1) {
-        if (d->norm_p == 1) k_aff_shared_fwd<1, 1><<<grid, 256, 0, st>>>(query, S, cand, N, dd, out, ld);
-        else k_aff_shared_fwd<1, 2><<<grid, 256, 0, st>>>(query, S, cand, N, dd, out, ld);
+        if (d->norm_p == 1) k_aff_shared_fwd<1, 1><<<grid, 256, 0, st>>>(query, S, cand, N, dd, out, ld, pf);
+        else k_aff_shared_fwd<1, 2><<<grid, 256, 0, st>>>(query, S, cand, N, dd, out, ld, pf);
     } else {
-        if (d->norm_p == 1) k_aff_shared_fwd<2, 1><<<grid, 256, 0, st>>>(query, S, cand, N, dd, out, ld);
-        else k_aff_shared_fwd<2, 2><<<grid, 256, 0, st>>>(query, S, cand, N, dd, out, ld);
+        if (d->norm_p == 1) k_aff_shared_fwd<2, 1><<<grid, 256, 0, st>>>(query, S, cand, N, dd, out, ld, pf);
+        else k_aff_shared_fwd<2, 2><<<grid, 256, 0, st>>>(query, S, cand, N, dd, out, ld, pf);
     }
     return check_launch("neg_score_shared_fwd (affine)");
 }
@@ -1053,12 +1057,13 @@ int affine_shared_bwd(const bess_model_desc* d, const float* query, int64_t S, c
                       float* d_cand, hipStream_t st) {
     const int n_part = d->reserved[0];
     const int dd = d->width / n_part;
+    const float pf = static_cast<float>(d->norm_p);
     int rc;
 #define BESS_AFFB(NP, PP)                                                                                          \
     do {                                                                                                           \
-        rc = aff_bwd_launch<NP, PP, true>(query, S, cand, N, dd, d_out, ld_dout, 1, out, ld_out, 1, d_query, st);  \
+        rc = aff_bwd_launch<NP, PP, true>(query, S, cand, N, dd, d_out, ld_dout, 1, out, ld_out, 1, d_query, st, pf);  \
         if (!rc) rc = aff_bwd_launch<NP, PP, false>(cand, N, query, S, dd, d_out, 1, ld_dout, out, 1, ld_out,      \
-                                                    d_cand, st);                                                   \
+                                                    d_cand, st, pf);                                               \
     } while (0)
     if (n_part == 1) {
         if (d->norm_p == 1) BESS_AFFB(1, 1); else BESS_AFFB(1, 2);

@@ -37,6 +37,7 @@ struct BoxArgs {
     int d;
     int nch;
     int nb, items_per_query;
+    float p;  // the norm of the P == 2 kernels: any p != 1 (common.h lp_*)
 };
 
 template <int VEC, int IT>
@@ -133,10 +134,10 @@ __global__ __launch_bounds__(256) void k_box_fwd(BoxArgs a, float* __restrict__ 
                     if (!PERDIM) in = outside == 0.f;
                     const float f = box_final(dist, qv.h[p][it][v], in);
                     if (P == 1) acc += fabsf(f);
-                    else acc = fmaf(f, f, acc);
+                    else acc += lp_term(f, a.p);
                 }
             acc = row16_allreduce_sum(acc);
-            total += (P == 2) ? sqrtf(acc) : acc;
+            total += (P == 2) ? lp_root(acc, a.p) : acc;
         }
         if (g == 0 && valid) orow[k] = -total;
     }
@@ -199,11 +200,11 @@ __global__ __launch_bounds__(256) void k_box_bwd(BoxArgs a, const float* __restr
                         box_point<TANH>(ev[p][it][v], qv.s[p][it][v], qv.c[p][it][v], qv.h[p][it][v], xp, dist, in);
                         if (!PERDIM) in = outside == 0.f;
                         const float f = box_final(dist, qv.h[p][it][v], in);
-                        ss = fmaf(f, f, ss);
+                        ss += lp_term(f, a.p);
                     }
                 ss = row16_allreduce_sum(ss);
             }
-            const float gp = (P == 2) ? (ss > 0.f ? go / sqrtf(ss) : 0.f) : go;
+            const float gp = (P == 2) ? go * lp_inv(lp_root(ss, a.p), a.p) : go;
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 const int ch = g + 16 * it;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void k_box_bwd(BoxArgs a, const float* __restr
                     if (!PERDIM) in = outside == 0.f;
                     const float B = 1.f + 2.f * h, A = 1.f / B;
                     const float f = in ? dist * A : dist * B - h * (B - A);
-                    const float df = (P == 1) ? gp * sgnf(f) : gp * f;
+                    const float df = (P == 1) ? gp * sgnf(f) : gp * lp_dterm(f, a.p);
                     const float ddist = df * (in ? A : B);
                     const float dhh = df * (in ? -2.f * dist * A * A : 2.f * dist - (B - A) - h * (2.f + 2.f * A * A));
                     const float sg = sgnf(xp - c);
@@ -309,6 +310,7 @@ int boxe_negatives(const bess_model_desc* d, bool fwd, bool shared, const float*
     while (nb > 8 && n_query * ceil_div(n_neg, nb) < 256 * 16 * 2) nb >>= 1;
     a.nb = nb;
     a.items_per_query = static_cast<int>(ceil_div(n_neg, nb));
+    a.p = static_cast<float>(d->norm_p);
     const int it = static_cast<int>(ceil_div(a.nch, 16));
     if (!fwd) {
         hipError_t e = hipSuccess;
@@ -348,6 +350,7 @@ struct BoxSegArgs {
     int d;
     int nch;
     const int32_t* long_segs;
+    float p;
 };
 
 // acc += d score / d e over references [r0, r1) of one row (ev)
@@ -386,11 +389,11 @@ __device__ __forceinline__ void box_seg_accumulate(const BoxSegArgs& a, int g, c
                         box_point<TANH>(ev[p][it][v], qv.s[p][it][v], qv.c[p][it][v], qv.h[p][it][v], xp, dist, in);
                         if (!PERDIM) in = outside == 0.f;
                         const float f = box_final(dist, qv.h[p][it][v], in);
-                        ss = fmaf(f, f, ss);
+                        ss += lp_term(f, a.p);
                     }
                 ss = row16_allreduce_sum(ss);
             }
-            const float gp = (P == 2) ? (ss > 0.f ? go / sqrtf(ss) : 0.f) : go;
+            const float gp = (P == 2) ? go * lp_inv(lp_root(ss, a.p), a.p) : go;
 #pragma unroll
             for (int it = 0; it < IT; ++it)
 #pragma unroll
@@ -402,7 +405,7 @@ __device__ __forceinline__ void box_seg_accumulate(const BoxSegArgs& a, int g, c
                     if (!PERDIM) in = outside == 0.f;
                     const float B = 1.f + 2.f * h, A = 1.f / B;
                     const float f = in ? dist * A : dist * B - h * (B - A);
-                    const float df = (P == 1) ? gp * sgnf(f) : gp * f;
+                    const float df = (P == 1) ? gp * sgnf(f) : gp * lp_dterm(f, a.p);
                     float dx = df * (in ? A : B) * sgnf(xp - c);
                     if (TANH) dx *= (1.f - xp * xp);
                     acc[p][it][v] += dx;
@@ -561,7 +564,7 @@ int boxe_grad_segments(const bess_model_desc* d, const float* query, void* table
     const int dd = d->width / 2;
     const int vec = (dd % 4 == 0) ? 4 : 1;
     BoxSegArgs a{query, table, d_out, ld_dout, refs_sorted, seg_rows, seg_offsets, n_seg, static_cast<int>(n_neg),
-                 dd, dd / vec, long_segs};
+                 dd, dd / vec, long_segs, static_cast<float>(d->norm_p)};
     const int it = static_cast<int>(ceil_div(a.nch, 16));
     const int flags = d->reserved[0];
     const unsigned grid = static_cast<unsigned>(std::min<int64_t>(ceil_div(max_seg, 16), 256 * 16));

@@ -97,6 +97,7 @@ static const PlanFn PLAN_FNS[] = {
     BESS_PLAN_FN(bess_scatter_add_rows),
     BESS_PLAN_FN(bess_sparse_sgd),
     BESS_PLAN_FN(bess_sparse_sgd_lists),
+    BESS_PLAN_FN(bess_sparse_sgd_lists_axpy),
     BESS_PLAN_FN(bess_dense_sgd),
     BESS_PLAN_FN(bess_build_segment_index),
     BESS_PLAN_FN(bess_pad_segments),

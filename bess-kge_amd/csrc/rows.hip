@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace bess {
@@ -38,14 +40,14 @@ int check_desc(const bess_model_desc* d) {
         return fail(BESS_EINVAL, "unknown dtype %d", d->dtype);
     if (d->scorer == BESS_BOXE) {
         if (d->width <= 0 || d->width % 2) return fail(BESS_EINVAL, "BoxE: entity width %d is not 2 d", d->width);
-        if (d->norm_p != 1 && d->norm_p != 2) return fail(BESS_EINVAL, "scoring norm %d not in {1, 2}", d->norm_p);
+        if (d->norm_p < 1) return fail(BESS_EINVAL, "scoring norm %d is not a p >= 1", d->norm_p);
         return BESS_OK;
     }
     if (d->scorer == BESS_AFFINE) {
         const int n_part = d->reserved[0];
         if (n_part != 1 && n_part != 2) return fail(BESS_EINVAL, "affine scorer: n_part %d not in {1, 2}", n_part);
         if (d->width <= 0 || d->width % n_part) return fail(BESS_EINVAL, "affine scorer: width %d", d->width);
-        if (d->norm_p != 1 && d->norm_p != 2) return fail(BESS_EINVAL, "scoring norm %d not in {1, 2}", d->norm_p);
+        if (d->norm_p < 1) return fail(BESS_EINVAL, "scoring norm %d is not a p >= 1", d->norm_p);
         return BESS_OK;
     }
     if (d->width <= 0 || d->rel_width <= 0)
@@ -115,11 +117,34 @@ struct SgdLists {
     int64_t first[BESS_MAX_ROW_LISTS + 1];  // first[l] = rows in lists 0 .. l-1
     int n;
 };
+// (x: a dense `table2 += alpha * grad2` on a small replicated table - the relation table's plain SGD step - in the
+// last workgroups of the launch: one dispatch less per training step)
+struct DenseAxpy {
+    void* table;
+    const float* grad;
+    int64_t n;
+    float alpha;
+    int blocks;
+};
 template <bool F16>
-__global__ __launch_bounds__(256) void k_scatter_add_lists(void* __restrict__ dst, int width, SgdLists L, float scale) {
+__global__ __launch_bounds__(256) void k_scatter_add_lists(void* __restrict__ dst, int width, SgdLists L, float scale,
+                                                           DenseAxpy x) {
+    const int main_blocks = static_cast<int>(gridDim.x) - x.blocks;
+    if (static_cast<int>(blockIdx.x) >= main_blocks) {
+        for (int64_t t = (blockIdx.x - main_blocks) * 256ll + threadIdx.x; t < x.n; t += 256ll * x.blocks) {
+            if (F16) {
+                half_t* t2 = static_cast<half_t*>(x.table);
+                t2[t] = static_cast<half_t>(static_cast<float>(t2[t]) + x.alpha * x.grad[t]);
+            } else {
+                float* t2 = static_cast<float*>(x.table);
+                t2[t] += x.alpha * x.grad[t];
+            }
+        }
+        return;
+    }
     const int wv = F16 ? width / 2 : width;  // values a thread handles per row position: 1 float or 2 halves
     const int64_t total = L.first[L.n] * wv;
-    for (int64_t t = blockIdx.x * 256ll + threadIdx.x; t < total; t += 256ll * gridDim.x) {
+    for (int64_t t = blockIdx.x * 256ll + threadIdx.x; t < total; t += 256ll * main_blocks) {
         const int64_t i = t / wv;
         const int c = static_cast<int>(t - i * wv);
         int l = 0;
@@ -236,6 +261,15 @@ extern "C" int bess_dense_sgd(int32_t dtype, void* table, const float* grad, int
 extern "C" int bess_sparse_sgd_lists(int32_t dtype, int32_t width, void* table, int32_t n_lists,
                                      const int32_t* const* list_idx, const float* const* list_grad,
                                      const int64_t* list_rows, float lr, void* stream) {
+    return bess_sparse_sgd_lists_axpy(dtype, width, table, n_lists, list_idx, list_grad, list_rows, lr, nullptr, nullptr, 0,
+                                      0.f, stream);
+}
+
+extern "C" int bess_sparse_sgd_lists_axpy(int32_t dtype, int32_t width, void* table, int32_t n_lists,
+                                          const int32_t* const* list_idx, const float* const* list_grad,
+                                          const int64_t* list_rows, float lr, void* axpy_table, const float* axpy_grad,
+                                          int64_t axpy_n, float axpy_alpha, void* stream) {
+    BESS_REQUIRE(axpy_n >= 0 && (axpy_n == 0 || (axpy_table && axpy_grad)), "sparse_sgd_lists: axpy operands");
     BESS_REQUIRE(dtype == BESS_F32 || dtype == BESS_F16, "sparse_sgd_lists: unknown dtype %d", dtype);
     BESS_REQUIRE(width > 0 && n_lists >= 1 && n_lists <= BESS_MAX_ROW_LISTS, "sparse_sgd_lists: bad sizes");
     BESS_REQUIRE(table && list_idx && list_grad && list_rows, "sparse_sgd_lists: NULL pointer");
@@ -252,11 +286,13 @@ extern "C" int bess_sparse_sgd_lists(int32_t dtype, int32_t width, void* table, 
         total += list_rows[l];
     }
     for (int l = n_lists; l <= BESS_MAX_ROW_LISTS; ++l) L.first[l] = total;
-    if (total == 0) return BESS_OK;
+    if (total == 0 && axpy_n == 0) return BESS_OK;
     hipStream_t st = as_stream(stream);
+    const DenseAxpy x{axpy_table, axpy_grad, axpy_n, axpy_alpha,
+                      static_cast<int>(std::min<int64_t>(ceil_div(axpy_n, 256 * 4), 256))};
     if (dtype == BESS_F32)
-        k_scatter_add_lists<false><<<grid_for(total * width), 256, 0, st>>>(table, width, L, -lr);
+        k_scatter_add_lists<false><<<grid_for(total * width) + x.blocks, 256, 0, st>>>(table, width, L, -lr, x);
     else
-        k_scatter_add_lists<true><<<grid_for(total * (width / 2)), 256, 0, st>>>(table, width, L, -lr);
+        k_scatter_add_lists<true><<<grid_for(total * (width / 2)) + x.blocks, 256, 0, st>>>(table, width, L, -lr, x);
     return check_launch("sparse_sgd_lists");
 }

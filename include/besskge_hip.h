@@ -103,7 +103,8 @@ extern "C" {
 
 typedef struct bess_model_desc {
     int32_t scorer;    /* BESS_TRANSE ...                                  */
-    int32_t norm_p;    /* 1 or 2 (TransE / RotatE), ignored otherwise      */
+    int32_t norm_p;    /* p >= 1 of the distance scorers (scoring.py:174: any p; 1 and 2 have their own kernels,
+                          other p go through powf), ignored otherwise */
     int32_t dtype;     /* element type of entity and relation tables       */
     int32_t width;     /* W : scalars per entity row (2d for RotatE/ComplEx) */
     int32_t rel_width; /* Wr: scalars per relation row (d for RotatE)      */
@@ -452,6 +453,12 @@ int bess_sparse_sgd(int32_t dtype, int32_t width, void* table, const int32_t* id
 int bess_sparse_sgd_lists(int32_t dtype, int32_t width, void* table, int32_t n_lists,
                           const int32_t* const* list_idx, const float* const* list_grad,
                           const int64_t* list_rows, float lr, void* stream);
+/* The same with a dense `axpy_table[i] += axpy_alpha * axpy_grad[i]` (axpy_n elements, axpy_table of the table's dtype:
+ * the relation table's plain SGD step) done by spare workgroups of the same launch. */
+int bess_sparse_sgd_lists_axpy(int32_t dtype, int32_t width, void* table, int32_t n_lists,
+                               const int32_t* const* list_idx, const float* const* list_grad,
+                               const int64_t* list_rows, float lr, void* axpy_table, const float* axpy_grad,
+                               int64_t axpy_n, float axpy_alpha, void* stream);
 
 /* K9 without atomics (n_shard == 1, per-triple negatives read straight from
  * the shard): group the n_refs references idx[i] by destination row with a

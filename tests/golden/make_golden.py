@@ -581,7 +581,9 @@ def gen_scoring_affine() -> None:
 
 
 #: p-norms beyond 1 and 2 (the reference takes any p through torch.norm: scoring.py:174)
-LP_SCORERS = [("TransE", 3), ("RotatE", 3), ("TransE", 4)]
+LP_SCORERS = [("TransE", 3), ("RotatE", 3), ("TransE", 4),
+              # round 4: the affine family and BoxE take any p too (scoring.py:540-593, 1250-1340)
+              ("PairRE", 3), ("TripleREv2", 3), ("InterHT", 3), ("TranSnn", 4), ("BoxE", 3), ("BoxEnt", 3)]
 
 
 def gen_scoring_lp() -> None:
@@ -598,6 +600,14 @@ def gen_bess_lp() -> None:
         ("tr_EM_RotatE3_aug_t_flat_n2", EM, "RotatE", 3, 2, "t", "random_flat", "ssce", True, True),
         ("tr_SM_TransE4_t_pt_n2", SM, "TransE", 4, 2, "t", "random_pt", "logsigmoid", False, False),
         ("tr_SM_TransE3_ht_flat_n2", SM, "TransE", 3, 2, "ht", "random_flat", "margin", False, True),
+        # round 4: p = 3 / 4 for PairRE / TripleRE / InterHT / TranS / BoxE
+        ("tr_EM_PairRE3_t_flat_n1", EM, "PairRE", 3, 1, "t", "random_flat", "logsigmoid", False, True),
+        ("tr_EM_InterHT3_h_pt_n1", EM, "InterHT", 3, 1, "h", "random_pt", "logsigmoid", False, False),
+        ("tr_EM_TranSnn4_ht_pt_n2", EM, "TranSnn", 4, 2, "ht", "random_pt", "ssce", False, False),
+        ("tr_SM_TripleREv23_ht_flat_n2", SM, "TripleREv2", 3, 2, "ht", "random_flat", "margin", False, True),
+        ("tr_EM_BoxE3_t_flat_n1", EM, "BoxE", 3, 1, "t", "random_flat", "logsigmoid", False, True),
+        ("tr_EM_BoxEnt3_ht_pt_n2", EM, "BoxEnt", 3, 2, "ht", "random_pt", "ssce", False, False),
+        ("tr_SM_BoxE3_t_pt_n2", SM, "BoxE", 3, 2, "t", "random_pt", "logsigmoid", False, False),
     ]
     names = []
     for name, mcls, scorer, p, n, scheme, nk, loss, aug, sharing in cases:

@@ -92,9 +92,11 @@ def test_invalid_arguments_return_error_codes():
     d.scorer, d.norm_p = _native.TRANSE, 0  # (any p >= 1 is a norm: TransE / RotatE take it)
     assert lib.bess_score_triple_fwd(ctypes.byref(d), 0, 0, 0, 0, 0, 0, 0, 0, 0) == -1
     assert "norm" in last_error(lib)
-    d.scorer, d.norm_p, d.reserved[0] = _native.AFFINE, 3, 1  # the affine family: p in {1, 2}
-    assert lib.bess_score_triple_fwd(ctypes.byref(d), 0, 0, 0, 0, 0, 0, 0, 0, 0) == -1
+    d.scorer, d.norm_p, d.reserved[0] = _native.AFFINE, 0, 1  # the affine family and BoxE too (round 4: any p >= 1)
+    assert lib.bess_query_fwd(ctypes.byref(d), 0, 0, 0, 0, 0, 0, 0, 0) == -1
     assert "norm" in last_error(lib)
+    d.norm_p = 3
+    assert lib.bess_query_fwd(ctypes.byref(d), 0, 0, 0, 0, 0, 0, 0, 0) == 0  # (n_query = 0: nothing to do, p = 3 accepted)
     d.reserved[0] = 0
     d.scorer, d.norm_p, d.width, d.rel_width = _native.ROTATE, 1, 8, 8  # RotatE needs Wr = W/2
     assert lib.bess_query_fwd(ctypes.byref(d), 0, 0, 0, 0, 0, 0, 0, 0) == -1

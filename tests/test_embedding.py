@@ -119,8 +119,9 @@ def test_scorer_constructors_allocate_like_the_reference():
         TransE(True, 0, s, 5, 16)
     from besskge.scoring import PairRE
 
-    with pytest.raises(ValueError):  # the affine family's kernels: p in {1, 2}
-        PairRE(True, 3, s, 5, 16)
+    assert PairRE(True, 3, s, 5, 16).scoring_norm == 3  # (round 4: any p >= 1, as the reference - scoring.py:540-593)
+    with pytest.raises(ValueError):
+        PairRE(True, 0, s, 5, 16)
 
 
 def test_scorer_constructors_place_only_the_hosted_shards():

@@ -19,9 +19,10 @@ from oracle import kge  # noqa: E402
 
 from conftest import load_golden  # noqa: E402
 from test_oracle import (  # noqa: E402
-    AFFINE_SCORERS, BOXE_SCORERS, LOSSES, SCORERS, T, bess_cases, load_bess_case, scoring_fixture, step_batch)
+    AFFINE_LP, AFFINE_SCORERS, BOXE_LP, BOXE_SCORERS, LOSSES, SCORERS, T, bess_cases, load_bess_case, scoring_fixture,
+    step_batch)
 
-NATIVE_SCORERS = [s for s in SCORERS if s not in AFFINE_SCORERS + BOXE_SCORERS]
+NATIVE_SCORERS = [s for s in SCORERS if s not in AFFINE_SCORERS + BOXE_SCORERS + AFFINE_LP + BOXE_LP]
 
 RTOL, ATOL = 1e-4, 1e-5
 
@@ -627,7 +628,7 @@ def test_affine_grad_segments_match_scatter_of_row_gradients(dev, n_part, normal
         close(t2, table.float().cpu() - 0.5 * want.float(), rtol=tol, atol=tol, scale=4e-6)
 
 
-@pytest.mark.parametrize("name,p", AFFINE_SCORERS)
+@pytest.mark.parametrize("name,p", AFFINE_SCORERS + AFFINE_LP)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_affine_query_kernels_match_torch_formulas(dev, name, p, dtype):
     """k_aff_query_fwd / bwd (the [U | V | R] transform used by the fused step) against the torch
