@@ -255,7 +255,8 @@ def kernel_roofline(kernel_ms, world: int, k_pair: int, mode: str):
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if fwd else float("nan")
     return dict(
         kernel="k_neg_pertriple_fwd (bess_neg_score_pertriple_fwd)" if mode == "score" else
-               "k_neg_pertriple_fwd<FUSE> + k_combine_dq (bess_neg_score_pertriple_fwd_dq)",
+               "k_neg_pertriple_fwd<FUSE> (bess_neg_score_pertriple_fwd_dq; its partials are combined by "
+               "bess_pertriple_tail)",
         achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
         algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=avg_ms, launches_timed=len(fwd))
 

@@ -213,12 +213,16 @@ SIGNATURES = {
     "bess_neg_score_shared_bwd_parts": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
     "bess_query_triple_bwd_parts": [_MD, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _i64, _vp,
                                     _vp, _vp, _vp, _vp, _vp],
+    "bess_pertriple_tail_supported": [_MD, _i64],
+    "bess_pertriple_tail": [_MD, _LD, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp,
+                            _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "bess_query_triple_fwd_jobs": [_MD, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, ctypes.POINTER(_vp),
                                    ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(_i64), _vp],
     "bess_neg_score_shared_fwd_loss": [_MD, _vp, _i64, _vp, _vp, _i64, _vp, _i64, ctypes.POINTER(KillDesc), _LD, _vp, _vp, _i64,
                                        _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp],
 }
 COMM_ID_BYTES = 128
+TICKET_INTS = 544  # BESS_TICKET_INTS
 ECOMM_BASE = 10000
 
 _lib: Optional[ctypes.CDLL] = None
@@ -641,11 +645,13 @@ def neg_score_pertriple_fwd(d: ModelDesc, query: torch.Tensor, neg: RowSource, n
 
 
 def neg_score_pertriple_fwd_dq(d: ModelDesc, l: LossDesc, query: torch.Tensor, neg: RowSource, n_neg: int,
-                               pos: Optional[torch.Tensor], weight: torch.Tensor, mask: Optional[torch.Tensor] = None
-                               ) -> Tuple[torch.Tensor, torch.Tensor]:
+                               pos: Optional[torch.Tensor], weight: torch.Tensor, mask: Optional[torch.Tensor] = None,
+                               defer: bool = False) -> Tuple[torch.Tensor, Any]:
     """Fused training forward: (scores [nq, n_neg], d loss / d query [nq, W]) in one pass over
     the negative rows.  Only valid when the loss is taken over exactly these scores; `mask` (bool
-    [1 | nq, cols <= n_neg], False = masked out, over the last `cols` columns) is applied inside the pass."""
+    [1 | nq, cols <= n_neg], False = masked out, over the last `cols` columns) is applied inside the pass.
+    `defer`: the second item is (state_ml, state_acc) - the work items' partials, which `pertriple_tail`
+    turns into d loss / d query where it uses it."""
     nq = int(query.shape[0])
     dev = _neg_operands(d, query, neg, nq * n_neg)
     _same_device([("pos", pos), ("weight", weight), ("query", query)])
@@ -659,7 +665,7 @@ def neg_score_pertriple_fwd_dq(d: ModelDesc, l: LossDesc, query: torch.Tensor, n
     items = ctypes.c_int32(0)
     _check(load().bess_neg_pertriple_items(ctypes.byref(d), nq, n_neg, ctypes.byref(items)), "bess_neg_pertriple_items")
     out = torch.empty((nq, n_neg), dtype=torch.float32, device=dev)
-    dq = torch.empty((nq, d.width), dtype=torch.float32, device=dev)
+    dq = None if defer else torch.empty((nq, d.width), dtype=torch.float32, device=dev)
     st_ml = torch.empty((nq, items.value, 2), dtype=torch.float32, device=dev)
     st_acc = torch.empty((nq, items.value, d.width), dtype=torch.float32, device=dev)
     ip, keep = _neg_idx_ptr(neg, dev)
@@ -674,10 +680,54 @@ def neg_score_pertriple_fwd_dq(d: ModelDesc, l: LossDesc, query: torch.Tensor, n
             ctypes.byref(d), ctypes.byref(l), query.data_ptr(), nq, neg.base.data_ptr(), ip, n_neg,
             pos.data_ptr() if pos is not None else 0, weight.data_ptr(), weight.numel(),
             mask.data_ptr() if mask is not None else 0, mrows, mcols, out.data_ptr(), n_neg,
-            dq.data_ptr(), st_ml.data_ptr(), st_acc.data_ptr(), _stream(dev))
+            dq.data_ptr() if dq is not None else 0, st_ml.data_ptr(), st_acc.data_ptr(), _stream(dev))
     _check(rc, "bess_neg_score_pertriple_fwd_dq_masked")
     del keep
-    return out, dq
+    return out, ((st_ml, st_acc) if defer else dq)
+
+
+def pertriple_tail_supported(d: ModelDesc, n_neg: int) -> bool:
+    return bool(load().bess_pertriple_tail_supported(ctypes.byref(d), int(n_neg)))
+
+
+def pertriple_tail(d: ModelDesc, l: LossDesc, side: int, head: RowSource, tail: RowSource, rel_table: torch.Tensor,
+                   rel_idx: torch.Tensor, partials: Tuple[torch.Tensor, torch.Tensor], pos: torch.Tensor, neg: torch.Tensor,
+                   weight: torch.Tensor, d_rel_table: torch.Tensor, want_d_query: bool = False) -> Tuple[Any, ...]:
+    """The per-triple remainder of a training step whose negatives went through the fused forward with `defer=True`
+    (`bess_pertriple_tail`, one launch): returns (loss [], d_pos [n], d_neg [n, n_neg], d_head [n, W], d_tail [n, W])
+    - and d loss / d query [n, W] as a sixth item with `want_d_query`; relation gradients are added into
+    `d_rel_table`."""
+    dev, n = _triple_operands(d, head, tail, rel_table, rel_idx)
+    st_ml, st_acc = partials
+    _same_device([("partials", st_ml), ("partials", st_acc), ("positive_score", pos), ("negative_score", neg),
+                  ("triple_weight", weight), ("d_rel_table", d_rel_table), ("x", head.base)])
+    for t, nm in ((st_ml, "partials"), (st_acc, "partials"), (pos, "positive_score"), (neg, "negative_score"),
+                  (weight, "triple_weight"), (d_rel_table, "d_rel_table")):
+        _f32(t, nm)
+    N = int(neg.shape[1])
+    items = int(st_ml.shape[1])
+    if tuple(st_ml.shape) != (n, items, 2) or tuple(st_acc.shape) != (n, items, d.width) or pos.numel() != n \
+            or neg.shape[0] != n or weight.numel() not in (1, n) or tuple(d_rel_table.shape) != tuple(rel_table.shape):
+        raise ValueError("pertriple_tail: shapes do not match")
+    # ONE allocation for the small pieces (every piece starts on a 16-byte boundary)
+    n4 = (n + 3) // 4 * 4
+    small = torch.empty((2 * n4 + 4,), dtype=torch.float32, device=dev)
+    row_loss, dp, loss = small[:n], small[n4: n4 + n], small[2 * n4: 2 * n4 + 1]
+    dn = torch.empty((n, N), dtype=torch.float32, device=dev)
+    rows = torch.empty((3 if want_d_query else 2, n, d.width), dtype=torch.float32, device=dev)
+    with _on(dev):
+        stream = _stream(dev)
+        counter = _counters(dev, stream, 1)
+        rc = load().bess_pertriple_tail(
+            ctypes.byref(d), ctypes.byref(l), side, head.base.data_ptr(), _idx(head.idx, "head_idx"),
+            tail.base.data_ptr(), _idx(tail.idx, "tail_idx"), rel_table.data_ptr(), rel_idx.data_ptr(), n,
+            st_ml.data_ptr(), st_acc.data_ptr(), items, pos.data_ptr(), neg.data_ptr(), N, int(neg.stride(0)),
+            weight.data_ptr(), weight.numel(), row_loss.data_ptr(), loss.data_ptr(), dp.data_ptr(), dn.data_ptr(), N,
+            rows[2].data_ptr() if want_d_query else 0, rows[0].data_ptr(), rows[1].data_ptr(), d_rel_table.data_ptr(),
+            counter.data_ptr(), stream)
+    _check(rc, "bess_pertriple_tail")
+    res = (loss.reshape(()), dp, dn, rows[0], rows[1])
+    return res + (rows[2],) if want_d_query else res
 
 
 def row_fits_registers(d: ModelDesc) -> bool:
@@ -1066,7 +1116,7 @@ def mask_scores(neg: torch.Tensor, diag_step: int, ht: bool, ppp: int, mask: Opt
     _check(rc, "bess_mask_scores")
 
 
-_loss_counters: dict = {}  # (device, raw stream) -> int32 [1], zero between calls
+_loss_counters: dict = {}  # (device, raw stream) -> int32 [TICKET_INTS], zero between calls
 
 
 def loss_fwd_bwd(l: LossDesc, pos: torch.Tensor, neg: torch.Tensor, weight: torch.Tensor, want_grad: bool,
@@ -1091,11 +1141,11 @@ def loss_fwd_bwd(l: LossDesc, pos: torch.Tensor, neg: torch.Tensor, weight: torc
         key = (dev, "capture") if capturing else (dev, stream)
         counter = _loss_counters.get(key)
         if counter is None:
-            counter = _loss_counters[key] = torch.zeros((1,), dtype=torch.int32, device=dev)
+            counter = _loss_counters[key] = torch.zeros((TICKET_INTS,), dtype=torch.int32, device=dev)
             if not capturing and (dev, "capture") not in _loss_counters:
                 # the counter of recorded steps exists before any recording starts (a tensor made while a
                 # stream is capturing would be cleared by a fill node at every replay: one more dispatch)
-                _loss_counters[(dev, "capture")] = torch.zeros((1,), dtype=torch.int32, device=dev)
+                _loss_counters[(dev, "capture")] = torch.zeros((TICKET_INTS,), dtype=torch.int32, device=dev)
         rc = load().bess_loss_fwd_bwd_one_launch(ctypes.byref(l), pos.data_ptr(), neg.data_ptr(), S, N, N,
                                                  weight.data_ptr(), weight.numel(), row_loss.data_ptr(), loss.data_ptr(),
                                                  dp.data_ptr() if want_grad else 0, dn.data_ptr() if want_grad else 0, N,
@@ -1113,7 +1163,7 @@ def _counters(dev: torch.device, stream: int, slots: int) -> torch.Tensor:
     """Zeroed int32 counters that kernels of one stream leave zero again (one array per stream; recorded steps
     share one that exists before any recording starts - a tensor made while a stream is capturing would be
     cleared by a fill node at every replay)."""
-    slots = max(64, 1 << (slots - 1).bit_length())
+    slots = max(1024, 1 << (slots - 1).bit_length())  # (>= BESS_TICKET_INTS)
     capturing = torch.cuda.is_current_stream_capturing()
     key = (dev, "capture" if capturing else stream, slots)
     c = _tail_counters.get(key)

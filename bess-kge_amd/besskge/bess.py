@@ -125,6 +125,7 @@ class _ReplicaStep:
         self.loss_norm: Optional[torch.Tensor] = None  # [S, 2] (m, L / C) of each triple's softmax (ScoreMoving, fused)
         self.kill_applied = False  # the scoring call already applied K7 (mask / augment kill)
         self.fused_qt = False  # query + positive score came out of one launch (so will their backwards)
+        self.tail_pre: Optional[Tuple[torch.Tensor, torch.Tensor]] = None  # (d_head, d_tail) out of `pertriple_tail`
         # training: copy / fill jobs (dst, src | None, fill word) run by ONE launch in front of the step's kernels
         # (`nat.step_prologue`), together with the index of the step's small update lists
         self.jobs: Optional[List[Tuple[torch.Tensor, Optional[torch.Tensor], int]]] = None
@@ -653,6 +654,9 @@ class BessKGE(torch.nn.Module, ABC):
     #: shards whose fp32 image (+ 4 bytes per row) is at most this many bytes get a direct-addressed accumulator
     #: (`bess_direct_update`): their small update lists need no index.  0 switches it off.
     direct_update_max_bytes = 2 << 30
+    #: per-triple negatives through the fused forward: loss, score gradients and the positive / query backward in one
+    #: launch behind it (`bess_pertriple_tail`); False keeps the four separate launches (tests compare the two)
+    pertriple_tail = True
 
     def _direct_scratch(self, table: torch.Tensor) -> Any:
         held = self.__dict__.setdefault("_direct_acc", {})
@@ -675,6 +679,8 @@ class BessKGE(torch.nn.Module, ABC):
         plain = not hasattr(optimizer, "kind") or optimizer.is_plain_sgd
         if plain and st.table.dtype == torch.float32:
             return False
+        if getattr(optimizer, "dense", False):
+            return False  # (every row is stepped: `_apply_dense`)
         rows = getattr(optimizer, "state_rows", None)
         if rows is not None and int(rows) < st.table.shape[0]:
             return False
@@ -744,6 +750,32 @@ class BessKGE(torch.nn.Module, ABC):
                     and all((not g.shared) and g.neg.base is st.recv for g in st.groups)
                     and st.recv.shape[0] == st.n * (st.recv.shape[0] // st.n)
                     and sum(len(g.neg) for g in st.groups) == st.recv.shape[0] - st.n * st.ppp)
+
+    def _apply_dense(self, steps: List[_ReplicaStep], local_updates: List[List[Tuple[torch.Tensor, torch.Tensor]]],
+                     deferred: List[Tuple[torch.Tensor, _NegGroup, torch.Tensor]], seg_index: Dict[int, Any],
+                     optimizer: Any, desc: nat.ModelDesc) -> None:
+        """`optimizer.dense`: the step every dense optimiser of torch / PopTorch takes - EVERY row of the shard, with
+        the step's gradient rows summed into a dense [M, W] fp32 matrix first (the direct-update accumulator: zero
+        between steps), zero for the rows the micro-batch did not touch.  What the notebooks' `poptorch.optim.AdamW`
+        does (`notebooks/1_biokg_training_inference.ipynb:525-531`): reproducible step for step, at the price of a
+        pass over the whole shard and its state per update - for shards that fit, not for BASELINE configs[4]."""
+        if getattr(optimizer, "state_rows", None) is not None:
+            raise ValueError("a dense optimiser steps every row: it cannot have paged state (state_rows)")
+        for st, upd in zip(steps, local_updates):
+            acc = self._direct_scratch(st.table).acc
+            lists = [(idx.reshape(-1).contiguous(), g.contiguous()) for idx, g in upd]
+            for table, g, go in deferred:
+                if table is st.table:  # per-triple negatives of the own shard: summed per unique row on chip first
+                    seg = seg_index[id(g)]
+                    gseg = nat.neg_pertriple_grad_segments(desc, g.query, table, g.n_per_query, go, seg)
+                    lists.append(nat.pad_segments(seg, gseg))
+            for i in range(0, len(lists), nat.MAX_ROW_LISTS):
+                nat.sparse_sgd_lists(acc, lists[i: i + nat.MAX_ROW_LISTS], -1.0)  # acc += rows (fp32 atomics)
+            if hasattr(optimizer, "kind") and not optimizer.is_plain_sgd:
+                self._apply_optimizer_dense(optimizer, st.table, acc)
+            else:
+                nat.dense_sgd(st.table, acc, float(optimizer.lr) if hasattr(optimizer, "lr") else float(optimizer))
+            nat.step_prologue([(acc, None, 0)])  # back to zero for the next step
 
     def _apply_optimizer_dense(self, opt: Any, table: torch.Tensor, grad: torch.Tensor) -> None:
         """Optimiser step on every row of a small replicated table (relation table, dense parameters):
@@ -881,7 +913,14 @@ class BessKGE(torch.nn.Module, ABC):
                 and sum(int(i_.numel()) for i_, _ in local_updates[-1]) < self.coalesce_sgd_from \
                 and len(local_updates[-1]) <= nat.MAX_ROW_LISTS:
             rel_axpy = (rel_table, d_rel, -lr)  # (in the launch of the last shard's atomic row updates)
-        if plain_rows:
+        if getattr(optimizer, "dense", False):
+            self._apply_dense(steps, local_updates, deferred, seg_index, optimizer, desc)
+            if plain:
+                nat.dense_sgd(rel_table, d_rel, lr)
+            else:
+                self._apply_optimizer_dense(optimizer, rel_table, d_rel)
+            rel_done = True
+        elif plain_rows:
             # per-triple negatives of the own shard: segmented reduction.  A shard with a
             # single such group gets the SGD step fused into the reduction; with two
             # ("ht") all row gradients are formed before the first row is changed.
@@ -945,7 +984,7 @@ class BessKGE(torch.nn.Module, ABC):
                                       axpy=rel_axpy if last else None)
                 rel_done = rel_done or (last and rel_axpy is not None)
         if rel_done:
-            pass  # updated in the shard's launch
+            pass  # updated in the shard's launch (or by the dense branch above)
         elif plain:
             nat.dense_sgd(rel_table, d_rel, lr)
         else:
@@ -998,8 +1037,20 @@ class BessKGE(torch.nn.Module, ABC):
             if g.sel is not None:
                 pos = pos[g.sel].contiguous()
                 w = w if w.numel() == 1 else w[g.sel].contiguous()
-            g.out, g.dq = nat.neg_score_pertriple_fwd_dq(desc, fuse["loss"](g.n_per_query), g.query, g.neg,
-                                                         g.n_per_query, pos, w, mask=fuse.get("mask"))
+            # one group over all triples of the own shard, query + positive score out of one launch: everything
+            # per triple that follows - d loss / d query from the pass's partials, K8, K3' + K6' - is ONE more launch
+            d_rel = self.__dict__.get("_step_d_rel")
+            defer = (self.pertriple_tail and st.fused_qt and g.sel is None and g.neg.base is st.table and d_rel is not None
+                     and not self.evaluation and nat.pertriple_tail_supported(desc, g.n_per_query))
+            ldesc = fuse["loss"](g.n_per_query)
+            g.out, g.dq = nat.neg_score_pertriple_fwd_dq(desc, ldesc, g.query, g.neg, g.n_per_query, pos, w,
+                                                         mask=fuse.get("mask"), defer=defer)
+            if defer:
+                loss, d_pos, d_neg, dh, dt = nat.pertriple_tail(
+                    desc, ldesc, g.side, RowSource(st.table, st.head_idx), st.tail, self.score_fn.relation_embedding.data,
+                    st.rel_idx, g.dq, pos, g.out, w, d_rel)
+                st.loss_pre = (loss, d_pos, d_neg)
+                st.tail_pre = (dh, dt)
         elif partials_loss is not None:
             # ScoreMoving training: this shard holds a part of each query's negatives - scores plus the partials
             # from which its share of d loss / d query is formed once the owner has normalised over all shards
@@ -1403,8 +1454,11 @@ class EmbeddingMovingBessKGE(BessKGE):
                     if not in_place:
                         sink(g.neg, dn)
                 if st.fused_qt:
-                    dh, dt = fn.query_triple_bwd(g.side, RowSource(st.table, st.head_idx), st.tail, st.rel_idx, d_pos,
-                                                 dq, d_rel)
+                    if st.tail_pre is not None:  # `pertriple_tail` has done K3' + K6' behind the forward
+                        dh, dt = st.tail_pre
+                    else:
+                        dh, dt = fn.query_triple_bwd(g.side, RowSource(st.table, st.head_idx), st.tail, st.rel_idx,
+                                                     d_pos, dq, d_rel)
                     sink(RowSource(st.table, st.head_idx), dh)
                     sink(st.tail, dt)
                 else:

@@ -148,6 +148,11 @@ class SGD:
     #: paged state: keep at most this many rows of momentum per shard (rows get one when first stepped);
     #: None = a state table of the shard's own size
     state_rows: Optional[int] = None
+    #: exact DENSE semantics (torch.optim / poptorch.optim on a dense gradient): EVERY row of the shard is stepped in
+    #: every update - weight decay on all rows, momentum of untouched rows keeps decaying - for shards whose fp32
+    #: image fits next to them (the step's gradient rows are summed into a dense [M, W] accumulator).  The default
+    #: (False) is row-lazy: only touched rows and their state move - the only affordable form for a 128 GB shard.
+    dense: bool = False
     #: how replicated-parameter gradients are combined over replicas: "sum" (d of the summed replica losses),
     #: "mean", or None = as the runner's `Options.accumulation_reduction` resolves (PopTorch has ONE setting for
     #: both); a model stepped without a runner (`train_step_replicas`) sums
@@ -170,6 +175,8 @@ class Adagrad:
     replica_reduction: Optional[str] = None
     #: paged state (see :class:`SGD`)
     state_rows: Optional[int] = None
+    #: exact dense semantics (see :class:`SGD`)
+    dense: bool = False
     kind = 1  # BESS_OPT_ADAGRAD
     is_plain_sgd = False
 
@@ -190,6 +197,9 @@ class Adam:
     #: first time it is stepped (BASELINE configs[4]: Adam state of a 128 GB shard's own size would be
     #: 256 GB); `BessKGE.optimizer_state_rows_used()` tells when the pool is exhausted.  None = full tables
     state_rows: Optional[int] = None
+    #: exact dense semantics (see :class:`SGD`): torch.optim.AdamW / poptorch.optim.AdamW on a dense gradient - all
+    #: rows decayed, the moments of untouched rows keep decaying
+    dense: bool = False
     kind = 2  # BESS_OPT_ADAM
     is_plain_sgd = False
 

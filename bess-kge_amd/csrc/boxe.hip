@@ -286,7 +286,8 @@ static int box_by_it(int it, int p, int flags, bool fwd, const BoxArgs& a, float
     if (it <= 1) BESS_BOXP(1);
     else if (it <= 2) BESS_BOXP(2);
     else if (it <= 4) BESS_BOXP(4);
-    else return fail(BESS_EUNSUPPORTED, "BoxE: embedding size %d too wide for the kernels (max 256)", a.d);
+    else if (it <= 8) BESS_BOXP(8);
+    else return fail(BESS_EUNSUPPORTED, "BoxE: embedding size %d too wide for the kernels (max 512; 128 when not a multiple of 4)", a.d);
 #undef BESS_BOXP
     return BESS_OK;
 }
@@ -551,7 +552,8 @@ static int box_seg_by_it(int it, int p, int flags, const BoxSegArgs& a, float* g
     if (it <= 1) BESS_BOXSP(1);
     else if (it <= 2) BESS_BOXSP(2);
     else if (it <= 4) BESS_BOXSP(4);
-    else return fail(BESS_EUNSUPPORTED, "BoxE: embedding size %d too wide for the kernels (max 256)", a.d);
+    else if (it <= 8) BESS_BOXSP(8);
+    else return fail(BESS_EUNSUPPORTED, "BoxE: embedding size %d too wide for the kernels (max 512; 128 when not a multiple of 4)", a.d);
 #undef BESS_BOXSP
     return BESS_OK;
 }

@@ -183,6 +183,37 @@ __device__ __forceinline__ float sgnf(float x) {
     return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
 }
 
+// "Is this the last workgroup of the launch to get here?" - called by ONE thread of every workgroup, after the
+// workgroup's results are written and a release_to_agent() + __syncthreads().
+// No device-scope fence: on this chip (one L2 per XCD) a __threadfence() is a write-back of the XCD's whole L2
+// (buffer_wbl2) - with megabytes of freshly written score gradients in it, 256 workgroups fencing cost ~10 us of a
+// 40 us launch.  Instead, what the last workgroup reads from the others (a few floats per workgroup) is written
+// with agent-scope atomic stores (store_agent: write-through, complete once s_waitcnt has seen them) and read with
+// agent-scope loads (load_agent); everything else becomes visible at the kernel boundary as usual.
+// Tickets are taken in two levels: the workgroup's group (blockIdx.x % 16) has a counter of its own, the last arriver
+// of each group takes a ticket at the root - 16 + 16 same-address atomics in a row at most instead of gridDim.x.
+// counters: int32 [BESS_TICKET_INTS], zero on entry, left zero (every counter on a 128-byte line of its own).
+__device__ __forceinline__ void store_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float load_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every store_agent of this wave has completed: the wait of a release fence without its cache write-back (a
+// workgroup-scope fence emits no wait at all here - the waves of a workgroup share their CU's cache)
+__device__ __forceinline__ void release_to_agent() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ bool last_workgroup_ticket(int32_t* counters) {
+    const int grid = static_cast<int>(gridDim.x), sub = static_cast<int>(blockIdx.x) & 15;
+    const int members = (grid - sub + 15) >> 4;
+    int32_t* mine = counters + 32 * (1 + sub);
+    if (__hip_atomic_fetch_add(mine, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != members - 1) return false;
+    __hip_atomic_store(mine, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (nobody else comes here in this launch)
+    if (__hip_atomic_fetch_add(counters, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != min(grid, 16) - 1) return false;
+    __hip_atomic_store(counters, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
+
 // sgn(x - y) for operands pre-scaled by 2^100 (exact: power of two): the
 // difference d' = (x - y) * 2^100 is clamped to [-1, 1] by one v_med3.  Exact for
 // x == y and whenever |x - y| >= 2^-100; a smaller non-zero difference needs

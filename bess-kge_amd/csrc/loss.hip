@@ -63,26 +63,20 @@ __global__ __launch_bounds__(256) void k_loss_rows(bess_loss_desc l, const float
     // whatever the order the workgroups ran in), and leaves the counter at zero for the next call.
     __shared__ float part[256];
     __shared__ int last;
+    release_to_agent();
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        last = atomicAdd(counter, 1) == static_cast<int>(gridDim.x) - 1;
-    }
+    if (threadIdx.x == 0) last = last_workgroup_ticket(counter);
     __syncthreads();
     if (!last) return;
-    __threadfence();
     float acc = 0.f;
-    for (int64_t i = threadIdx.x; i < n_triple; i += 256) acc += __builtin_nontemporal_load(row_loss + i);
+    for (int64_t i = threadIdx.x; i < n_triple; i += 256) acc += load_agent(row_loss + i);
     part[threadIdx.x] = acc;
     __syncthreads();
     for (int h = 128; h > 0; h >>= 1) {
         if (threadIdx.x < h) part[threadIdx.x] += part[threadIdx.x + h];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        loss[0] = part[0];
-        *counter = 0;
-    }
+    if (threadIdx.x == 0) loss[0] = part[0];
 }
 
 // Prediction rank of the positive among its candidates (reference metric.py:129-182):
@@ -223,10 +217,9 @@ static int loss_impl(const bess_loss_desc* l, const float* pos, const float* neg
     if (grad) BESS_REQUIRE(d_pos && d_neg && ld_dneg >= n_neg, "loss: gradients need d_pos, d_neg and ld_dneg >= n_neg");
     hipStream_t st = as_stream(stream);
     const bool adv = l->adversarial != 0;
-    // the one-launch form costs one same-address atomic per workgroup (4 rows each): they serialise at ~30 ns a
-    // piece - 4 us for the 128 workgroups of a notebook-size micro-batch (what the second launch cost), 30 us for
-    // the 1024 of S = 4096.  Larger grids keep the second launch.
-    if (n_triple > 4 * 256) counter = nullptr;
+    // the one-launch form costs one atomic per workgroup (4 rows each), taken in two levels (last_workgroup_ticket:
+    // same-address atomics serialise at ~40 ns a piece).  Very large grids keep the second launch.
+    if (n_triple > 4 * 4096) counter = nullptr;
 #define BESS_LOSS(KIND, ADV) \
     launch_loss<KIND, ADV>(grad, *l, pos, neg, n_triple, n_neg, ld_neg, weight, weight_len, row_loss, d_pos, d_neg, ld_dneg, \
                            row_norm, counter, loss, st)

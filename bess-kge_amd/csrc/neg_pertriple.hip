@@ -21,6 +21,7 @@
 // to keep >= 8 x 16 B loads per lane in flight (the guide's recipe for ~5.7 TB/s
 // random-row gathers: "4 rows in flight per wave, 16 waves per CU").
 #include "common.h"
+#include "loss_rows.h"
 
 namespace bess {
 
@@ -196,65 +197,15 @@ __global__ __launch_bounds__(256) void k_neg_pertriple_fwd(NegPtArgs a, float* _
     }
 }
 
-// d_query[q, :] = C_q / L_q * sum_items exp(m_i - m) acc_i,  m = max_i m_i (and the positive for
-// ssce), L_q = sum_i exp(m_i - m) l_i (+ exp(pos - m) for ssce);  C_q = loss_scale * w_q (x 1/2
-// for the log-sigmoid loss).  One wave per query.
-// With `norm` ([n_query, 2] = (m, L / C_q) taken over ALL the negatives of the query, of which these items
-// hold a part - the other parts were scored on other shards, ScoreMoving) the items are only rescaled.
+// d loss / d query from the items' partials, one wave per query (loss_rows.h: combine_dq_row)
 __global__ __launch_bounds__(256) void k_combine_dq(const float* __restrict__ st_ml, const float* __restrict__ st_acc,
                                                     int64_t n_query, int items, int W, int kind, float loss_scale,
                                                     const float* __restrict__ pos, const float* __restrict__ weight,
                                                     int64_t weight_len, const float* __restrict__ norm,
                                                     float* __restrict__ d_query) {
-    const int lane = threadIdx.x & 63;
     const int64_t q = blockIdx.x * 4ll + (threadIdx.x >> 6);
     if (q >= n_query) return;
-    float m, scale;
-    if (norm) {
-        m = norm[2 * q];
-        const float l_over_c = norm[2 * q + 1];
-        scale = (l_over_c > 0.f && l_over_c < INFINITY) ? 1.f / l_over_c : 0.f;
-    } else {
-        // (m_i, l_i) of the items, strided over the lanes
-        m = -INFINITY;
-        for (int i = lane; i < items; i += 64) m = fmaxf(m, st_ml[(q * items + i) * 2]);
-        m = wave_allreduce_max(m);
-        if (kind == BESS_LOSS_SSCE) m = fmaxf(m, pos[q]);
-        float L = 0.f;
-        for (int i = lane; i < items; i += 64) {
-            const float mi = st_ml[(q * items + i) * 2];
-            if (mi != -INFINITY) L += st_ml[(q * items + i) * 2 + 1] * expf(mi - m);
-        }
-        L = wave_allreduce_sum(L);
-        if (kind == BESS_LOSS_SSCE) L += expf(pos[q] - m);
-        const float w = weight[weight_len == 1 ? 0 : q];
-        const float C = (kind == BESS_LOSS_LOGSIGMOID ? 0.5f : 1.f) * loss_scale * w;
-        scale = L > 0.f ? C / L : 0.f;
-    }
-    const float* ap = st_acc + q * items * W;
-    float* dq = d_query + q * W;
-    if ((W & 3) == 0) {
-        for (int c = lane * 4; c < W; c += 256) {
-            float x[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int i = 0; i < items; ++i) {
-                const float mi = st_ml[(q * items + i) * 2];  // wave-uniform, cached
-                if (mi == -INFINITY) continue;
-                const float f = expf(mi - m);
-                const float4 v = *reinterpret_cast<const float4*>(ap + static_cast<int64_t>(i) * W + c);
-                x[0] = fmaf(v.x, f, x[0]); x[1] = fmaf(v.y, f, x[1]); x[2] = fmaf(v.z, f, x[2]); x[3] = fmaf(v.w, f, x[3]);
-            }
-            *reinterpret_cast<float4*>(dq + c) = make_float4(scale * x[0], scale * x[1], scale * x[2], scale * x[3]);
-        }
-    } else {
-        for (int c = lane; c < W; c += 64) {
-            float x = 0.f;
-            for (int i = 0; i < items; ++i) {
-                const float mi = st_ml[(q * items + i) * 2];
-                if (mi != -INFINITY) x = fmaf(ap[static_cast<int64_t>(i) * W + c], expf(mi - m), x);
-            }
-            dq[c] = scale * x;
-        }
-    }
+    combine_dq_row(st_ml, st_acc, q, items, W, kind, loss_scale, pos, weight, weight_len, norm, d_query + q * W, nullptr);
 }
 
 // Backward: d_neg[(q, k), :] = g * df/de ; d_query[q, :] += sum_k g * df/dq  with
@@ -600,7 +551,8 @@ extern "C" int bess_neg_score_pertriple_fwd_dq_masked(const bess_model_desc* d, 
     BESS_REQUIRE(l->kind == BESS_LOSS_LOGSIGMOID || l->kind == BESS_LOSS_MARGIN || l->kind == BESS_LOSS_SSCE,
                  "neg_score_pertriple_fwd_dq: unknown loss %d", l->kind);
     if (n_query <= 0 || n_neg <= 0) return BESS_OK;
-    BESS_REQUIRE(out && d_query && state_ml && state_acc && weight && (weight_len == 1 || weight_len == n_query),
+    // (d_query may be NULL: the partials are then left for bess_pertriple_tail, which combines them where it uses them)
+    BESS_REQUIRE(out && state_ml && state_acc && weight && (weight_len == 1 || weight_len == n_query),
                  "neg_score_pertriple_fwd_dq: NULL pointer or bad weight length");
     BESS_REQUIRE(pos || l->kind == BESS_LOSS_LOGSIGMOID, "neg_score_pertriple_fwd_dq: this loss needs the positive scores");
     FuseArgs f;
@@ -624,6 +576,7 @@ extern "C" int bess_neg_score_pertriple_fwd_dq_masked(const bess_model_desc* d, 
                        &f);
     if (rc) return rc;
     const int items = static_cast<int>(ceil_div(n_neg, negatives_per_item(n_query, n_neg, row_bytes_of(d))));
+    if (!d_query) return BESS_OK;  // the partials stay as they are: bess_pertriple_tail combines them where it uses them
     k_combine_dq<<<static_cast<unsigned>(ceil_div(n_query, 4)), 256, 0, as_stream(stream)>>>(
         state_ml, state_acc, n_query, items, d->width, l->kind, l->loss_scale, pos, weight, weight_len, nullptr, d_query);
     return check_launch("neg_score_pertriple_fwd_dq");

@@ -76,6 +76,7 @@ static const PlanFn PLAN_FNS[] = {
     BESS_PLAN_FN(bess_neg_score_pertriple_fwd_dq_masked),
     BESS_PLAN_FN(bess_neg_score_pertriple_fwd_partials),
     BESS_PLAN_FN(bess_combine_dq_partials),
+    BESS_PLAN_FN(bess_pertriple_tail),
     BESS_PLAN_FN(bess_neg_score_shared_fwd),
     BESS_PLAN_FN(bess_neg_score_shared_fwd_ws),
     BESS_PLAN_FN(bess_neg_score_shared_fwd_masked),

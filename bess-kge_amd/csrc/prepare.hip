@@ -13,6 +13,7 @@
 // Entity rows of RotatE / ComplEx are stored [re(d) | im(d)]
 // (scoring.py:404-408, 881-885); RotatE relation rows are phases [d].
 #include "common.h"
+#include "loss_rows.h"
 
 namespace bess {
 
@@ -190,7 +191,7 @@ __device__ __forceinline__ void emit2(float* p, float v) {
 
 template <typename T, int SCORER, bool BYROW = false>
 __device__ __forceinline__ void triple_bwd_body(const TripleArgs& a, int64_t s, int lane,
-                                                const float* __restrict__ d_out, float* __restrict__ d_head,
+                                                const float g, float* __restrict__ d_head,
                                                 float* __restrict__ d_tail, float* __restrict__ d_rel) {
     const T* h = row_ptr(static_cast<const T*>(a.head_base), a.head_idx, s, a.W);
     const T* t = row_ptr(static_cast<const T*>(a.tail_base), a.tail_idx, s, a.W);
@@ -199,7 +200,6 @@ __device__ __forceinline__ void triple_bwd_body(const TripleArgs& a, int64_t s, 
     float* dh = d_head + (BYROW ? (a.head_idx ? static_cast<int64_t>(a.head_idx[s]) : s) : s) * a.W;
     float* dt = d_tail + (BYROW ? (a.tail_idx ? static_cast<int64_t>(a.tail_idx[s]) : s) : s) * a.W;
     float* dr = d_rel + rid * a.Wr;
-    const float g = d_out[s];
 
     if (SCORER == BESS_TRANSE) {
         float inv = 0.f;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_score_triple_bwd(TripleArgs a,
     const int lane = threadIdx.x & 63;
     const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
     if (s >= a.n) return;
-    triple_bwd_body<T, SCORER>(a, s, lane, d_out, d_head, d_tail, d_rel);
+    triple_bwd_body<T, SCORER>(a, s, lane, d_out[s], d_head, d_tail, d_rel);
 }
 
 // ACCUM: d_ent already holds this lane's contribution of the positive score (written by the same lane
@@ -335,6 +335,116 @@ __device__ __forceinline__ void query_bwd_body(const QueryArgs& a, int64_t q, in
     }
 }
 
+// K3' + K6' of ONE triple in one pass over its rows: the gradient of the positive score w.r.t. head / tail / relation
+// and of the query w.r.t. the entity it was built from (the head for tail corruption, else the tail), summed where
+// they meet - every gradient element is written once and the relation row takes ONE atomic per element (the two
+// bodies above, run one after the other, read the rows twice, read-modify-write the entity's gradient and send two
+// atomics per relation element: 4 M instead of 2 M at the C2 micro-batch).
+template <typename T, int SCORER, bool BYROW = false>
+__device__ __forceinline__ void query_triple_bwd_body(const TripleArgs& a, int side, int64_t s, int lane, const float g,
+                                                      const float* dq, float* __restrict__ d_head,
+                                                      float* __restrict__ d_tail, float* __restrict__ d_rel) {
+    const T* h = row_ptr(static_cast<const T*>(a.head_base), a.head_idx, s, a.W);
+    const T* t = row_ptr(static_cast<const T*>(a.tail_base), a.tail_idx, s, a.W);
+    const int64_t rid = a.rel_idx[s];
+    const T* r = static_cast<const T*>(a.rel_table) + rid * a.Wr;
+    float* dh = d_head + (BYROW ? (a.head_idx ? static_cast<int64_t>(a.head_idx[s]) : s) : s) * a.W;
+    float* dt = d_tail + (BYROW ? (a.tail_idx ? static_cast<int64_t>(a.tail_idx[s]) : s) : s) * a.W;
+    float* dr = d_rel + rid * a.Wr;
+    const bool tl = side == BESS_CORRUPT_TAIL;  // the query was built from the head
+    const float sg = tl ? 1.f : -1.f;
+    auto add_rel = [&](float* p, float v) {
+        if (v != 0.f) unsafeAtomicAdd(p, v);
+    };
+    if (SCORER == BESS_TRANSE) {
+        float inv = 0.f;
+        const float pf = static_cast<float>(a.norm_p);
+        if (a.norm_p != 1) {
+            float ss = 0.f;
+            for (int e = lane; e < a.W; e += 64) ss += lp_term(to_f32(h[e]) + to_f32(r[e]) - to_f32(t[e]), pf);
+            ss = wave_allreduce_sum(ss);
+            inv = lp_inv(lp_root(ss, pf), pf);
+        }
+        for (int e = lane; e < a.W; e += 64) {
+            const float x = to_f32(h[e]) + to_f32(r[e]) - to_f32(t[e]);
+            const float dx = -g * ((a.norm_p == 1) ? sgnf(x) : lp_dterm(x, pf) * inv);
+            const float gq = dq[e];
+            emit<BYROW>(dh + e, tl ? dx + gq : dx);
+            emit<BYROW>(dt + e, tl ? -dx : -dx + gq);
+            add_rel(dr + e, dx + sg * gq);
+        }
+    } else if (SCORER == BESS_DISTMULT) {
+        for (int e = lane; e < a.W; e += 64) {
+            const float hv = to_f32(h[e]), rv = to_f32(r[e]), tv = to_f32(t[e]);
+            const float gq = dq[e];
+            float vh = g * rv * tv, vt = g * hv * rv;
+            if (tl) vh = fmaf(gq, rv, vh);
+            else vt = fmaf(gq, rv, vt);
+            emit<BYROW>(dh + e, vh);
+            emit<BYROW>(dt + e, vt);
+            add_rel(dr + e, fmaf(gq, tl ? hv : tv, g * hv * tv));
+        }
+    } else {
+        const int d = a.W / 2;
+        float inv = 0.f;
+        const float pf = static_cast<float>(a.norm_p);
+        if (SCORER == BESS_ROTATE && a.norm_p != 1) {
+            float ss = 0.f;
+            for (int e = lane; e < d; e += 64) {
+                const float hr = to_f32(h[e]), hi = to_f32(h[d + e]);
+                const float ph = to_f32(r[e]);
+                const float c = cosf(ph), sn = sinf(ph);
+                ss += lp_term(hr * c - hi * sn - to_f32(t[e]), pf) + lp_term(hr * sn + hi * c - to_f32(t[d + e]), pf);
+            }
+            ss = wave_allreduce_sum(ss);
+            inv = lp_inv(lp_root(ss, pf), pf);
+        }
+        for (int e = lane; e < d; e += 64) {
+            const float hr = to_f32(h[e]), hi = to_f32(h[d + e]);
+            const float tr = to_f32(t[e]), ti = to_f32(t[d + e]);
+            const float gr = dq[e], gi = dq[d + e];
+            const float xr = tl ? hr : tr, xi = tl ? hi : ti;  // the entity the query was built from
+            float vhr, vhi, vtr, vti;
+            if (SCORER == BESS_ROTATE) {
+                const float ph = to_f32(r[e]);
+                const float c = cosf(ph), sn = sinf(ph);
+                const float yr = hr * c - hi * sn - tr;
+                const float yi = hr * sn + hi * c - ti;
+                const float dxr = -g * ((a.norm_p == 1) ? sgnf(yr) : lp_dterm(yr, pf) * inv);
+                const float dxi = -g * ((a.norm_p == 1) ? sgnf(yi) : lp_dterm(yi, pf) * inv);
+                vhr = dxr * c + dxi * sn;
+                vhi = -dxr * sn + dxi * c;
+                vtr = -dxr;
+                vti = -dxi;
+                // the query rotates by sg * phase: cos is even, sin odd
+                const float snq = sg * sn;
+                const float qr = gr * c + gi * snq, qi = -gr * snq + gi * c;
+                if (tl) vhr += qr, vhi += qi;
+                else vtr += qr, vti += qi;
+                const float dph = dxr * (-hr * sn - hi * c) + dxi * (hr * c - hi * sn);
+                const float dphq = gr * (-xr * snq - xi * c) + gi * (xr * c - xi * snq);
+                add_rel(dr + e, dph + sg * dphq);
+            } else {
+                const float rr = to_f32(r[e]), ri = to_f32(r[d + e]);
+                vhr = g * (rr * tr + ri * ti);
+                vhi = g * (-ri * tr + rr * ti);
+                vtr = g * (hr * rr - hi * ri);
+                vti = g * (hr * ri + hi * rr);
+                const float riq = sg * ri;  // conj r for heads
+                const float qr = gr * rr + gi * riq, qi = -gr * riq + gi * rr;
+                if (tl) vhr += qr, vhi += qi;
+                else vtr += qr, vti += qi;
+                unsafeAtomicAdd(dr + e, g * (hr * tr + hi * ti) + (gr * xr + gi * xi));
+                unsafeAtomicAdd(dr + d + e, g * (-hi * tr + hr * ti) + sg * (-gr * xi + gi * xr));
+            }
+            emit<BYROW>(dh + e, vhr);
+            emit<BYROW>(dh + d + e, vhi);
+            emit<BYROW>(dt + e, vtr);
+            emit<BYROW>(dt + d + e, vti);
+        }
+    }
+}
+
 template <typename T, int SCORER>
 __global__ __launch_bounds__(256) void k_query_bwd(QueryArgs a, const float* __restrict__ d_query,
                                                    float* __restrict__ d_ent,
@@ -356,8 +466,76 @@ __global__ __launch_bounds__(256) void k_query_triple_bwd(TripleArgs a, QueryArg
     const int lane = threadIdx.x & 63;
     const int64_t s = blockIdx.x * 4ll + (threadIdx.x >> 6);
     if (s >= a.n) return;
-    triple_bwd_body<T, SCORER>(a, s, lane, d_out, d_head, d_tail, d_rel);
-    query_bwd_body<T, SCORER, true>(qa, s, lane, d_query + s * qa.W, qa.side == BESS_CORRUPT_TAIL ? d_head : d_tail, d_rel);
+    query_triple_bwd_body<T, SCORER>(a, qa.side, s, lane, d_out[s], d_query + s * qa.W, d_head, d_tail, d_rel);
+}
+
+// The S-row tail of a training step with per-triple negatives scored by the fused forward, in ONE launch
+// (was k_combine_dq + k_loss_rows + k_sum_rows + k_query_triple_bwd: 47 us of launches for ~25 MB at the C2
+// micro-batch - latency, not bandwidth).  All four are per triple; a wave takes one triple through them:
+//   d loss / d query from the forward's partials -> a row in LDS (never written to memory unless asked for),
+//   K8: the triple's loss term, d loss / d positive score (kept in a register), the gradient row of its scores,
+//   K3' + K6': the gradients of head, tail and relation rows from the two.
+// The workgroup that finishes last sums the row terms in a fixed order (16 waves per workgroup at large
+// micro-batches; tickets in two levels, common.h: last_workgroup_ticket).
+struct TailArgs {
+    const float* st_ml;
+    const float* st_acc;
+    int items;
+    bess_loss_desc l;
+    const float* pos;
+    const float* neg;
+    int64_t n_neg, ld_neg;
+    const float* weight;
+    int64_t weight_len;
+    float* row_loss;
+    float* loss;
+    float* d_pos;
+    float* d_neg;
+    int64_t ld_dneg;
+    float* d_query;  // [n, W] or NULL
+    int32_t* counter;
+};
+
+template <typename T, int SCORER, int CH>
+__global__ __launch_bounds__(1024) void k_pertriple_tail(TripleArgs a, QueryArgs qa, TailArgs t, float* __restrict__ d_head,
+                                                         float* __restrict__ d_tail, float* __restrict__ d_rel) {
+    extern __shared__ float tail_lds[];  // [waves][W] rows of d loss / d query; then the partial sums of the loss
+    __shared__ int last;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int64_t s = static_cast<int64_t>(blockIdx.x) * nw + wv;
+    if (s < a.n) {  // (whole waves)
+        float* row = tail_lds + wv * a.W;
+        combine_dq_row(t.st_ml, t.st_acc, s, t.items, a.W, t.l.kind, t.l.loss_scale, t.pos, t.weight, t.weight_len, nullptr,
+                       row, t.d_query ? t.d_query + s * a.W : nullptr);
+        float g;
+#define BESS_TAIL_LOSS(KIND, ADV)                                                                                        \
+    g = loss_row_impl<KIND, ADV, true, CH>(t.l, t.pos, t.neg, s, t.n_neg, t.ld_neg, t.weight, t.weight_len, t.row_loss, \
+                                           t.d_pos, t.d_neg, t.ld_dneg, nullptr)
+        if (t.l.kind == BESS_LOSS_SSCE) BESS_TAIL_LOSS(BESS_LOSS_SSCE, false);
+        else if (t.l.kind == BESS_LOSS_LOGSIGMOID && t.l.adversarial) BESS_TAIL_LOSS(BESS_LOSS_LOGSIGMOID, true);
+        else if (t.l.kind == BESS_LOSS_LOGSIGMOID) BESS_TAIL_LOSS(BESS_LOSS_LOGSIGMOID, false);
+        else if (t.l.adversarial) BESS_TAIL_LOSS(BESS_LOSS_MARGIN, true);
+        else BESS_TAIL_LOSS(BESS_LOSS_MARGIN, false);
+#undef BESS_TAIL_LOSS
+        // (the row in LDS was written by lanes of this wave, whose LDS accesses execute in order)
+        query_triple_bwd_body<T, SCORER>(a, qa.side, s, lane, g, row, d_head, d_tail, d_rel);
+    }
+    // the sum of the row terms: as the one-launch form of k_loss_rows (loss.hip) - same order as k_sum_rows when the
+    // workgroup has 1024 threads
+    release_to_agent();
+    __syncthreads();
+    if (threadIdx.x == 0) last = last_workgroup_ticket(t.counter);
+    __syncthreads();
+    if (!last) return;
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < a.n; i += blockDim.x) acc += load_agent(t.row_loss + i);
+    tail_lds[threadIdx.x] = acc;
+    __syncthreads();
+    for (int h = blockDim.x >> 1; h > 0; h >>= 1) {
+        if (static_cast<int>(threadIdx.x) < h) tail_lds[threadIdx.x] += tail_lds[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) t.loss[0] = tail_lds[0];
 }
 
 // The same behind bess_neg_score_shared_bwd_parts, by row: d_query arrives as
@@ -426,8 +604,7 @@ __global__ __launch_bounds__(256) void k_query_triple_bwd_parts(TripleArgs a, Qu
             row[e] = sum;
         }
     }
-    triple_bwd_body<T, SCORER, true>(a, s, lane, d_out, acc_head, acc_tail, d_rel);
-    query_bwd_body<T, SCORER, true, true>(qa, s, lane, row, qa.side == BESS_CORRUPT_TAIL ? acc_head : acc_tail, d_rel);
+    query_triple_bwd_body<T, SCORER, true>(a, qa.side, s, lane, d_out[s], row, acc_head, acc_tail, d_rel);
 }
 
 template <template <typename, int> class Launcher, typename... Args>
@@ -500,6 +677,18 @@ struct LQueryTripleBwd {
     static void run(TripleArgs a, QueryArgs qa, const float* d_out, const float* dq, float* dh, float* dt, float* dr,
                     hipStream_t st) {
         k_query_triple_bwd<T, SC><<<ceil_div(a.n, 4), 256, 0, st>>>(a, qa, d_out, dq, dh, dt, dr);
+    }
+};
+
+template <typename T, int SC>
+struct LPertripleTail {
+    static void run(TripleArgs a, QueryArgs qa, TailArgs t, float* dh, float* dt, float* dr, int ch, hipStream_t st) {
+        // 16 waves (one triple each) per workgroup once that still fills the chip and the rows fit 64 KB of LDS
+        const int nw = (a.n > 1024 && a.W <= 1024) ? 16 : 4;
+        const unsigned grid = static_cast<unsigned>(ceil_div(a.n, nw));
+        const size_t lds = sizeof(float) * static_cast<size_t>(std::max(nw * a.W, 64 * nw));
+        if (ch == 4) k_pertriple_tail<T, SC, 4><<<grid, 64 * nw, lds, st>>>(a, qa, t, dh, dt, dr);
+        else k_pertriple_tail<T, SC, 12><<<grid, 64 * nw, lds, st>>>(a, qa, t, dh, dt, dr);
     }
 };
 
@@ -675,4 +864,42 @@ extern "C" int bess_query_triple_bwd(const bess_model_desc* d, int32_t side, con
     BESS_REQUIRE(d_out && d_query && d_head && d_tail && d_rel_table, "query_triple_bwd: NULL pointer");
     dispatch<LQueryTripleBwd>(d, a, qa, d_out, d_query, d_head, d_tail, d_rel_table, as_stream(stream));
     return check_launch("query_triple_bwd");
+}
+
+extern "C" int bess_pertriple_tail_supported(const bess_model_desc* d, int64_t n_neg) {
+    return d && d->scorer <= BESS_COMPLEX && d->width <= 4096 && n_neg > 0 && n_neg % 4 == 0 && n_neg <= 256 * 12;
+}
+
+extern "C" int bess_pertriple_tail(const bess_model_desc* d, const bess_loss_desc* l, int32_t side, const void* head_base,
+                                   const int32_t* head_idx, const void* tail_base, const int32_t* tail_idx,
+                                   const void* rel_table, const int32_t* rel_idx, int64_t n_triple,
+                                   const float* state_ml, const float* state_acc, int32_t items, const float* pos,
+                                   const float* neg, int64_t n_neg, int64_t ld_neg, const float* weight,
+                                   int64_t weight_len, float* row_loss, float* loss, float* d_pos, float* d_neg,
+                                   int64_t ld_dneg, float* d_query, float* d_head, float* d_tail, float* d_rel_table,
+                                   int32_t* counter, void* stream) {
+    TripleArgs a;
+    if (int e = triple_args(d, head_base, head_idx, tail_base, tail_idx, rel_table, rel_idx, n_triple, &a)) return e;
+    BESS_REQUIRE(d->scorer <= BESS_COMPLEX, "pertriple_tail: TransE / RotatE / DistMult / ComplEx only");
+    QueryArgs qa;
+    const bool tail = side == BESS_CORRUPT_TAIL;
+    if (int e = query_args(d, side, tail ? head_base : tail_base, tail ? head_idx : tail_idx, rel_table, rel_idx, n_triple,
+                           &qa))
+        return e;
+    BESS_REQUIRE(l, "pertriple_tail: NULL loss descriptor");
+    BESS_REQUIRE(l->kind >= BESS_LOSS_LOGSIGMOID && l->kind <= BESS_LOSS_SSCE, "pertriple_tail: unknown loss %d", l->kind);
+    BESS_REQUIRE(n_triple > 0 && items > 0, "pertriple_tail: bad sizes");
+    if (!bess_pertriple_tail_supported(d, n_neg))
+        return fail(BESS_EUNSUPPORTED, "pertriple_tail: rows of %lld scores (a multiple of 4, at most 3072) of %d scalars "
+                                       "(at most 4096)", (long long)n_neg, d->width);
+    BESS_REQUIRE(state_ml && state_acc && pos && neg && weight && row_loss && loss && d_pos && d_neg && d_head && d_tail &&
+                     d_rel_table && counter, "pertriple_tail: NULL pointer");
+    BESS_REQUIRE(weight_len == 1 || weight_len == n_triple, "pertriple_tail: weight_len must be 1 or n_triple");
+    BESS_REQUIRE(ld_neg >= n_neg && ld_dneg >= n_neg && ld_neg % 4 == 0 && ld_dneg % 4 == 0 &&
+                     reinterpret_cast<uintptr_t>(neg) % 16 == 0 && reinterpret_cast<uintptr_t>(d_neg) % 16 == 0,
+                 "pertriple_tail: score rows must be 16-byte aligned");
+    TailArgs t{state_ml, state_acc, items, *l, pos, neg, n_neg, ld_neg, weight, weight_len, row_loss, loss, d_pos, d_neg,
+               ld_dneg, d_query, counter};
+    dispatch<LPertripleTail>(d, a, qa, t, d_head, d_tail, d_rel_table, n_neg <= 1024 ? 4 : 12, as_stream(stream));
+    return check_launch("pertriple_tail");
 }

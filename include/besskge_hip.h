@@ -400,9 +400,10 @@ int bess_loss_fwd_bwd_norm(const bess_loss_desc* l, const float* pos, const floa
                            float* loss, float* d_pos, float* d_neg, int64_t ld_dneg,
                            float* row_norm, void* stream);
 
-/* The same in ONE launch for micro-batches of up to 1024 triples (two launches above that: the one-launch form
- * pays one same-address atomic per 4 rows): the workgroup that finishes last forms loss[0] from row_loss (fixed
- * order: bitwise reproducible).  counter: int32 [1] on the device, zero on entry, left zero (keep one per stream). */
+/* The same in ONE launch for micro-batches of up to 16,384 triples (two launches above that): the workgroup that finishes last forms loss[0] from row_loss (fixed
+ * order: bitwise reproducible).  counter: int32 [BESS_TICKET_INTS] on the device, zero on entry, left zero (keep one
+ * array per stream; the workgroups take their "am I last" tickets in two levels, each counter on its own line). */
+#define BESS_TICKET_INTS 544
 int bess_loss_fwd_bwd_one_launch(const bess_loss_desc* l, const float* pos, const float* neg,
                                  int64_t n_triple, int64_t n_neg, int64_t ld_neg,
                                  const float* weight, int64_t weight_len, float* row_loss,
@@ -651,6 +652,28 @@ int bess_neg_score_pertriple_fwd_dq_masked(const bess_model_desc* d, const bess_
                                            int64_t ld_out, float* d_query, float* state_ml,
                                            float* state_acc, void* stream);
 
+/* d_query == NULL (either form): the per-item partials are left in state_ml / state_acc for bess_pertriple_tail.
+ *
+ * bess_pertriple_tail: the per-triple remainder of such a training step in ONE launch - what the reference's
+ * autograd graph does between the negative scores and the embedding gradients for one micro-batch
+ * (reference besskge/bess.py:248-262 loss, 322-468 backward of K3 / K6; loss.py:28-251):
+ *   d loss / d query from the partials (never stored unless d_query != NULL),
+ *   K8 (as bess_loss_fwd_bwd: row_loss [n], loss [1], d_pos [n], d_neg [n, n_neg]),
+ *   K3' + K6' (as bess_query_triple_bwd: d_head / d_tail [n, W], relation gradients ADDED into d_rel_table).
+ * Results are those of bess_neg_score_pertriple_fwd_dq + bess_loss_fwd_bwd + bess_query_triple_bwd, to the bit
+ * (relation gradients: fp32 atomics, order-dependent in both).  n_neg % 4 == 0, n_neg <= 3072, 16-byte aligned
+ * score rows, TransE / RotatE / DistMult / ComplEx (bess_pertriple_tail_supported; else BESS_EUNSUPPORTED).
+ * counter: int32 [BESS_TICKET_INTS], zero on entry, left zero (the last workgroup sums the row terms in a fixed order). */
+int bess_pertriple_tail_supported(const bess_model_desc* d, int64_t n_neg);
+int bess_pertriple_tail(const bess_model_desc* d, const bess_loss_desc* l, int32_t side, const void* head_base,
+                        const int32_t* head_idx, const void* tail_base, const int32_t* tail_idx,
+                        const void* rel_table, const int32_t* rel_idx, int64_t n_triple,
+                        const float* state_ml, const float* state_acc, int32_t items, const float* pos,
+                        const float* neg, int64_t n_neg, int64_t ld_neg, const float* weight,
+                        int64_t weight_len, float* row_loss, float* loss, float* d_pos, float* d_neg,
+                        int64_t ld_dneg, float* d_query, float* d_head, float* d_tail, float* d_rel_table,
+                        int32_t* counter, void* stream);
+
 /* The same pass for queries whose negatives are spread over several shards (ScoreMoving: each shard
  * scores the gathered queries against its own rows).  bess_neg_score_pertriple_fwd_partials writes the
  * scores and leaves the per-item partials (m_i, l_i, acc_i) of the online softmax in state_ml / state_acc
@@ -781,7 +804,7 @@ int bess_pack_exchange(bess_comm* comm, int32_t dtype, int32_t width, const void
  * issued by one call (a step driven from C or from a recorded plan makes one call less; a variant that finished
  * the loss rows inside the packed L1 kernel - its last workgroup per block of rows - was built and measured in
  * round 4: 49 us against 12.7 + 9.4 at the notebook micro-batch, the rows of a block then run one after the other
- * on four waves).  counters: int32 [ceil(n_query / 16) + 1] on the device, zero on entry,
+ * on four waves).  counters: int32 [BESS_TICKET_INTS] on the device, zero on entry,
  * left zero (keep one array per stream). */
 int bess_neg_score_shared_fwd_loss(const bess_model_desc* desc, const float* query, int64_t n_query,
                                    const void* neg_base, const int32_t* neg_idx, int64_t n_neg, float* out,

@@ -8,7 +8,7 @@
 tensor: `FillFunctor<long>`); `show` lists the dispatches of the last marked step in start order with their
 duration and the idle gap in front of each (all streams), and the totals.  Workloads: c2score (the bench headline: gather + score + loss), c2 (the same as a
 training step), c2sm (that step in its multi-GPU form, ScoreMovingBessKGE, on one shard), c2adam, c4s (S=512, K=32: the notebook's micro-batch), c4 (S=4096, K=256), c4g (c4s replayed
-from a hipGraph), c2em2 (C2's scorer in the EmbeddingMoving form on two shards in lock-step: per-triple negatives through the all-to-all).
+from a hipGraph), c4p (c4s replayed from a C-side step plan: `Options.use_plans`), c4n2 / c4n2g (two shards stepped in lock-step on this GPU - the n > 1 code path - eager / replayed from a hipGraph), c2em2 (C2's scorer in the EmbeddingMoving form on two shards in lock-step: per-triple negatives through the all-to-all).
 """
 import csv
 import glob
@@ -75,8 +75,8 @@ def run(workload: str) -> None:
         from besskge.scoring import TransE
         from besskge.sharding import Sharding
 
-        S_, K_ = (512, 32) if workload in ("c4s", "c4g", "c4n2") else (4096, 256)
-        nsh = 2 if workload == "c4n2" else 1  # c4n2: two shards stepped in lock-step on this GPU (the n > 1 code path)
+        S_, K_ = (512, 32) if workload in ("c4s", "c4g", "c4p", "c4n2", "c4n2g") else (4096, 256)
+        nsh = 2 if workload in ("c4n2", "c4n2g") else 1  # c4n2: two shards stepped in lock-step on this GPU (the n > 1 code path)
         sharding = Sharding.create(bench.C4_ROWS_PER_SHARD * nsh, nsh, seed=0)
         fn = TransE(True, 1, sharding, bench.C4_N_REL, bench.C4_D, device=dev, shards=list(range(nsh)), dtype=torch.float16)
         ns = RandomShardedNegativeSampler(K_, sharding, 0, "t", local_sampling=False, flat_negative_format=True)
@@ -88,10 +88,11 @@ def run(workload: str) -> None:
         batch = dict(head=rng.integers(M, size=(nsh, nsh, pp)), relation=rng.integers(bench.C4_N_REL, size=(nsh, nsh, pp)),
                      tail=rng.integers(M, size=(nsh, nsh, pp)), negative=rng.integers(M, size=(nsh, nsh, 1, K_)))
         batch = {k: torch.from_numpy(v.astype(np.int32)).to(dev) for k, v in batch.items()}
-        runner = runtime.training_model(model, runtime.Options(device_iterations=1, use_graphs=workload == "c4g"),
+        runner = runtime.training_model(model, runtime.Options(device_iterations=1, use_graphs=workload in ("c4g", "c4n2g"),
+                                                        use_plans=workload == "c4p"),
                                         runtime.SGD(lr=1e-3), device=dev)
 
-        if workload == "c4g":  # inputs where the recorded step reads them: no copies in front of the replay
+        if workload in ("c4g", "c4n2g", "c4p"):  # inputs where the recorded step reads them: no copies in front of the replay
             static = runner.static_inputs(**batch)
             for k_, v_ in batch.items():
                 static[k_].copy_(v_)

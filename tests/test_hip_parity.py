@@ -236,6 +236,43 @@ def test_scoring_gradients_vs_oracle(dev, name, p, sharing):
         close(fn.relation_embedding.grad, ro.grad, rtol=1e-4, scale=2e-6)
 
 
+@pytest.mark.parametrize("name,p", [("BoxE", 1), ("BoxE", 2), ("BoxEnt", 3)])
+@pytest.mark.parametrize("dtype,d", [(torch.float32, 320), (torch.float32, 512), (torch.float16, 400)])
+def test_boxe_wide_embeddings_vs_oracle(dev, name, p, dtype, d):
+    """BoxE beyond 256 dimensions (the reference has no limit - scoring.py:690-797; the kernels keep a box row in a
+    16-lane group's registers: 512 dimensions since round 4, loud refusal above): scores and
+    gradients of both regimes against the oracle."""
+    gen = torch.Generator().manual_seed(d + p)
+    S, N, n_rel = 6, 9, 3
+    W, Wr = widths(name, d)
+    rel = (torch.randn(n_rel, Wr, generator=gen) * 0.5).to(dtype)
+    h = (torch.randn(S, W, generator=gen) * 0.5).to(dtype)
+    t = (torch.randn(S, W, generator=gen) * 0.5).to(dtype)
+    rid = torch.randint(n_rel, (S,), generator=gen)
+    neg = (torch.randn(S, N, W, generator=gen) * 0.5).to(dtype)
+    for sharing, cand in ((True, neg[:1]), (False, neg)):
+        fn = make_scorer(name, p, sharing, n_rel, d, torch.zeros(1, 4, W), rel.float(), dev, dtype)
+        hd, nd = (x.clone().to(dev).requires_grad_(True) for x in (h, cand))
+        ho, no, ro = (x.float().clone().requires_grad_(True) for x in (h, cand, rel))
+        fn.relation_embedding.grad = None
+        sc = fn.score_tails(hd, rid.to(dev), nd)
+        so = kge.score_candidates(name, p, sharing, "t", ho, ro, rid, no)
+        close(sc, so, scale=4e-6 if dtype == torch.float32 else 2e-3)
+        gn = torch.randn(so.shape, generator=gen)
+        (sc.float() * gn.to(dev)).sum().backward()
+        (so * gn).sum().backward()
+        tol = dict(scale=4e-6) if dtype == torch.float32 else dict(rtol=2e-2, scale=4e-3)
+        close(hd.grad, ho.grad, **tol)
+        close(nd.grad, no.grad, **tol)
+        close(fn.relation_embedding.grad, ro.grad, **(dict(rtol=1e-4, scale=4e-6) if dtype == torch.float32 else tol))
+    if dtype == torch.float32:
+        wide = make_scorer(name, p, True, n_rel, 520, torch.zeros(1, 4, kge.entity_width(name, 520)),
+                           torch.randn(n_rel, kge.relation_width(name, 520)), dev, dtype)
+        with pytest.raises(RuntimeError, match="too wide"):
+            wide.score_tails(torch.randn(2, kge.entity_width(name, 520), device=dev), rid[:2].to(dev),
+                             torch.randn(1, 3, kge.entity_width(name, 520), device=dev))
+
+
 # ---------------------------------------------------------------- losses ----
 @pytest.mark.parametrize("name", list(LOSSES))
 @pytest.mark.parametrize("wname", ["w", "one"])

@@ -354,3 +354,57 @@ def test_paged_optimizer_state(dev, case, graphs):
         (used, cap), = model.optimizer_state_rows_used().values()
         assert cap == 8 and used > 8  # exhausted: reported, rows beyond the pool were stepped from zero state
         assert bool(torch.isfinite(model.score_fn.entity_embedding.detach().float()).all())
+
+
+@pytest.mark.parametrize("opt_name", ["adamw", "sgdm_wd", "adagrad"])
+@pytest.mark.parametrize("case", ["tr_EM_ComplEx0_h_pt_n1", "tr_EM_TransE1_t_flat_n1", "tr_EM_RotatE2_ht_flat_n2"])
+def test_dense_optimizer_follows_torch_optim_step_for_step(dev, opt_name, case):
+    """`dense=True`: the optimisers of the notebooks as they are (`poptorch.optim.AdamW` on dense gradients, reference
+    `notebooks/1_biokg_training_inference.ipynb:525-531`): EVERY row is stepped in every update - decoupled weight
+    decay on all rows, moments of untouched rows decay.  Three steps (both micro-batches of the fixture, then the
+    first again) against oracle autograd + torch.optim on the dense tables: the trajectories agree row for row,
+    untouched rows included (the row-lazy default leaves those where they were)."""
+    from besskge import runtime
+    from test_hip_parity import build_model
+
+    c = load_bess_case(case)
+    keys = ("head", "relation", "tail", "negative", "negative_mask")
+    batches = [{k: c["batch"][k][it] for k in keys if k in c["batch"]} for it in (0, 1, 0)]
+    if opt_name == "adamw":
+        opt = runtime.Adam(lr=0.01, weight_decay=0.1, dense=True)
+        topt = lambda ps: torch.optim.AdamW(ps, lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)  # noqa: E731
+    elif opt_name == "sgdm_wd":
+        opt = runtime.SGD(lr=0.05, momentum=0.9, weight_decay=0.01, dense=True)
+        topt = lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, weight_decay=0.01)  # noqa: E731
+    else:
+        opt = runtime.Adagrad(lr=0.1, eps=1e-10, dense=True)
+        topt = lambda ps: torch.optim.Adagrad(ps, lr=0.1, eps=1e-10)  # noqa: E731
+    model = build_model(c, dev)
+    runner = runtime.training_model(model, runtime.Options(device_iterations=1), opt, device=dev)
+    t0 = c["table"].clone().requires_grad_(True)
+    r0 = c["rel"].clone().requires_grad_(True)
+    tor = topt([t0, r0])
+    solid_t = torch.ones_like(t0, dtype=torch.bool)
+    solid_r = torch.ones_like(r0, dtype=torch.bool)
+    for b in batches:
+        runner(**b)
+        tor.zero_grad()
+        want = kge.bess_step(c["spec"], c["model_cls"], t0, r0, b, c["loss"])
+        torch.stack(want["loss"]).sum().backward()
+        solid_t &= (t0.grad.abs() > 1e-4) | (t0.grad == 0)
+        solid_r &= (r0.grad.abs() > 1e-4) | (r0.grad == 0)
+        tor.step()
+    got_t = model.score_fn.entity_embedding.detach().float().cpu()
+    got_r = model.score_fn.relation_embedding.detach().float().cpu()
+    # (Adam / Adagrad divide by |g|: an entry whose gradient cancels to ~0 - exact 0 in dense autograd, 1e-9 from the
+    # kernels' sums - takes a +-lr step; compared where the gradient of EVERY step was solid, and on every untouched row)
+    moved = (t0.detach() - c["table"]).abs() > 0
+    assert bool(moved.reshape(-1, moved.shape[-1]).any(-1).all()) or opt_name == "adagrad"  # weight decay moves every row
+    for got, ref, solid in ((got_t, t0.detach(), solid_t), (got_r, r0.detach(), solid_r)):
+        if opt_name == "sgdm_wd":  # (linear in the gradient: every entry is compared)
+            solid = torch.ones_like(solid)
+        assert float(solid.float().mean()) > 0.5
+        torch.testing.assert_close(got[solid], ref[solid], rtol=2e-3, atol=1e-4)
+    # the accumulator is left zero
+    for scratch in model._direct_acc.values():
+        assert float(scratch.acc.abs().max()) == 0.0

@@ -310,3 +310,113 @@ def test_backward_as_partial_sums_equals_the_atomic_form(dev, scorer, dtype, S, 
     assert nat.shared_bwd_parts_plan(small, S, N) == (0, 0)
     assert nat.shared_bwd_parts_plan(d, 8, 16) == (0, 0)
     assert nat.shared_bwd_parts_plan(d, 4096, 4352) == (0, 0)  # (the slabs of d_query would be 570 MB: atomic form)
+
+
+@pytest.mark.parametrize("scorer,dtype,S,N,W,loss", [
+    ("ComplEx", torch.float32, 4096 + 3, 64, 128, "logsigmoid_adv"),  # 16 waves per workgroup, ragged last one
+    ("TransE", torch.float16, 300, 1028, 64, "ssce"),
+    ("RotatE", torch.float32, 257, 2048, 96, "margin_adv"),            # rows kept as 12 chunks per lane
+    ("DistMult", torch.float16, 512, 32, 50, "margin"),                # W % 4 != 0
+    ("ComplEx", torch.float32, 64, 256, 512, "logsigmoid"),
+])
+def test_pertriple_tail_equals_the_four_launches(dev, scorer, dtype, S, N, W, loss):
+    """`bess_pertriple_tail` (d loss / d query from the fused forward's partials + K8 + K3' + K6', one launch) against
+    `bess_neg_score_pertriple_fwd_dq` + `bess_loss_fwd_bwd` + `bess_query_triple_bwd`: every output to the bit, the
+    relation gradient (fp32 atomics in both) to rounding."""
+    from besskge import _native as nat
+    from besskge._native import RowSource
+
+    g = torch.Generator().manual_seed(S + N)
+    M, R = 5000, 11
+    sc = dict(TransE=nat.TRANSE, RotatE=nat.ROTATE, DistMult=nat.DISTMULT, ComplEx=nat.COMPLEX)[scorer]
+    Wr = W // 2 if scorer == "RotatE" else W
+    table = (torch.randn(M, W, generator=g) * 0.3).to(dtype).to(dev)
+    rel = (torch.randn(R, Wr, generator=g) * 0.3).to(dtype).to(dev)
+    desc = nat.make_desc(sc, 1 if scorer in ("TransE", "RotatE") else 0, table, Wr)
+    hi = torch.randint(M, (S,), generator=g, dtype=torch.int32).to(dev)
+    ti = torch.randint(M, (S,), generator=g, dtype=torch.int32).to(dev)
+    ri = torch.randint(R, (S,), generator=g, dtype=torch.int32).to(dev)
+    neg = RowSource(table, torch.randint(M, (S * N,), generator=g, dtype=torch.int32).to(dev))
+    w = (torch.rand(S, generator=g) + 0.5).to(dev) if S % 2 else torch.full((1,), 1.0 / S, device=dev)
+    ld = nat.LossDesc()
+    ld.kind = dict(logsigmoid=nat.LOSS_LOGSIGMOID, margin=nat.LOSS_MARGIN, ssce=nat.LOSS_SSCE)[loss.split("_")[0]]
+    ld.margin = 2.0
+    ld.adversarial = int(loss.endswith("_adv"))
+    ld.adversarial_scale = 0.7
+    ld.loss_scale = 3.0
+    ld.ssce_shift = float(np.log(M - 1) - np.log(N))
+    side = nat.CORRUPT_TAIL
+    head, tail = RowSource(table, hi), RowSource(table, ti)
+    q, pos = nat.query_triple_fwd(desc, side, head, tail, rel, ri)
+    assert nat.pertriple_tail_supported(desc, N)
+    # the four launches
+    out_a, dq_a = nat.neg_score_pertriple_fwd_dq(desc, ld, q, neg, N, pos, w)
+    loss_a, dp_a, dn_a = nat.loss_fwd_bwd(ld, pos, out_a, w, True)
+    drel_a = torch.zeros(rel.shape, dtype=torch.float32, device=dev)
+    dh_a, dt_a = nat.query_triple_bwd(desc, side, head, tail, rel, ri, dp_a, dq_a, drel_a)
+    # forward with the partials left + the tail
+    out_b, parts = nat.neg_score_pertriple_fwd_dq(desc, ld, q, neg, N, pos, w, defer=True)
+    drel_b = torch.zeros(rel.shape, dtype=torch.float32, device=dev)
+    loss_b, dp_b, dn_b, dh_b, dt_b, dq_b = nat.pertriple_tail(desc, ld, side, head, tail, rel, ri, parts, pos, out_b, w,
+                                                              drel_b, want_d_query=True)
+    torch.cuda.synchronize()
+    for a, b, nm in ((out_a, out_b, "scores"), (dq_a, dq_b, "d_query"), (dp_a, dp_b, "d_pos"), (dn_a, dn_b, "d_neg"),
+                     (dh_a, dh_b, "d_head"), (dt_a, dt_b, "d_tail")):
+        assert torch.equal(a, b), nm
+    assert float(loss_a) == float(loss_b) or abs(float(loss_a) - float(loss_b)) <= 1e-6 * abs(float(loss_a))
+    torch.testing.assert_close(drel_a, drel_b, rtol=1e-4, atol=1e-4)
+    # again: the ticket counter was left at zero, the sum is reproducible
+    drel_c = torch.zeros_like(drel_b)
+    loss_c = nat.pertriple_tail(desc, ld, side, head, tail, rel, ri, parts, pos, out_b, w, drel_c)[0]
+    assert float(loss_c) == float(loss_b)
+    with pytest.raises(RuntimeError, match="pertriple_tail"):
+        nat.pertriple_tail(desc, ld, side, head, tail, rel, ri, parts, pos, torch.zeros(S, 4100, device=dev), w, drel_c)
+
+
+@pytest.mark.parametrize("opt_name", ["sgd", "adam"])
+@pytest.mark.parametrize("scorer,dtype", [("ComplEx", torch.float32), ("TransE", torch.float16)])
+def test_training_step_through_the_pertriple_tail_equals_the_separate_launches(dev, scorer, dtype, opt_name):
+    """Per-triple negatives of the own shard (the C2 shape in small): three steps with `pertriple_tail` on and off -
+    same losses, same tables (plain SGD on fp32 rows adds with atomics: to rounding)."""
+    from besskge import _native as nat
+    from besskge import runtime
+    from besskge.bess import EmbeddingMovingBessKGE
+    from besskge.loss import LogSigmoidLoss
+    from besskge.negative_sampler import RandomShardedNegativeSampler
+    from besskge.scoring import ComplEx, TransE
+    from besskge.sharding import Sharding
+
+    S_, K_, M = 192, 64, 3000
+    sharding = Sharding.create(M, 1, seed=0)
+    rng = np.random.default_rng(0)
+    batches = []
+    for _ in range(3):
+        b = dict(head=rng.integers(M, size=(1, 1, S_)), relation=rng.integers(9, size=(1, 1, S_)),
+                 tail=rng.integers(M, size=(1, 1, S_)), negative=rng.integers(M, size=(1, 1, S_, K_)))
+        batches.append({k: torch.from_numpy(v.astype(np.int32)).to(dev) for k, v in b.items()})
+    out = []
+    for tail_on in (True, False):
+        torch.manual_seed(1)
+        fn = (ComplEx(False, sharding, 9, 32, device=dev, dtype=dtype) if scorer == "ComplEx"
+              else TransE(False, 1, sharding, 9, 64, device=dev, dtype=dtype))
+        ns = RandomShardedNegativeSampler(K_, sharding, 0, "t", local_sampling=False, flat_negative_format=False)
+        model = EmbeddingMovingBessKGE(negative_sampler=ns, score_fn=fn,
+                                       loss_fn=LogSigmoidLoss(margin=4.0, negative_adversarial_sampling=True))
+        model.pertriple_tail = tail_on
+        opt = dict(sgd=runtime.SGD(lr=0.05), adam=runtime.Adam(lr=0.01))[opt_name]
+        runner = runtime.training_model(model, runtime.Options(), opt, device=dev)
+        nat.start_kernel_timing(["bess_neg_score_pertriple_fwd_dq"])
+        losses = [float(runner(**b)["loss"]) for b in batches]
+        torch.cuda.synchronize()
+        calls = {k: len(v) for k, v in nat.stop_kernel_timing().items()}
+        assert calls.get("bess_neg_score_pertriple_fwd_dq", 0) == 3, calls  # the fused forward was taken
+        out.append((model.score_fn.entity_embedding.detach().float().clone(),
+                    model.score_fn.relation_embedding.detach().float().clone(), losses))
+    tol = dict(rtol=2e-3, atol=3e-3) if dtype == torch.float16 else dict(rtol=1e-4, atol=1e-5)
+    if opt_name == "adam":
+        off = (out[0][0] - out[1][0]).abs()
+        assert float((off > 3e-3).float().mean()) < 0.01
+    else:
+        torch.testing.assert_close(out[0][0], out[1][0], **tol)
+        torch.testing.assert_close(out[0][1], out[1][1], **tol)
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-5)
