@@ -21,6 +21,6 @@ $BENCH --entities-per-shard 4000000 > $OUT/score_hbm.json 2> $OUT/score_hbm.err 
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_hbm -- $BENCH --entities-per-shard 4000000 > $OUT/pmc_fetch_hbm.json 2> $OUT/pmc_fetch_hbm.err || exit 1
 find $OUT -name "*.csv" | head -50
 # 4. one traced training step per workload (kernel by kernel, in start order): C2 (SGD, AdamW), C4 (S=512 eager /
-#    hipGraph, S=4096), the headline scoring step and the ScoreMoving form of the C2 training step
-bash profiles/run_step_traces.sh $TAG "c2score c2 c2adam c2sm c2em2 c4s c4g c4n2 c4" || exit 1
+#    hipGraph / step plan, two shards in lock-step eager / hipGraph, S=4096), the headline scoring step and the ScoreMoving form of the C2 training step
+bash profiles/run_step_traces.sh $TAG "c2score c2 c2adam c2sm c2em2 c4s c4g c4p c4n2 c4n2g c4" || exit 1
 cp gpurun_out/step_${TAG}_*.txt $OUT/ 2>/dev/null

@@ -52,5 +52,6 @@ def time_parts(S, N, reps=20):
 
 for S, N in ((256, 288), (512, 544), (512, 768), (1024, 1088), (2048, 2176), (4096, 4352), (8192, 8448)):
     r = 5 if S > 1024 else 20
-    print(f"S={S:5d} N={N:5d}: atomic sums {time_graph(S, N, reps=r):8.1f} us   partial sums {time_parts(S, N, reps=r):8.1f} us "
+    parts_us = time_parts(S, N, reps=r) if nat.shared_bwd_parts_plan(dsc, S, N)[0] > 0 else float("nan")  # (capped at 24 MB of slabs)
+    print(f"S={S:5d} N={N:5d}: atomic sums {time_graph(S, N, reps=r):8.1f} us   partial sums {parts_us:8.1f} us "
           f"(parts {nat.shared_bwd_parts_plan(dsc, S, N)})", flush=True)
