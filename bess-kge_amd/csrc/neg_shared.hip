@@ -483,7 +483,7 @@ __global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, 
     }
 }
 
-// ---- the same two products as PARTIAL SUMS: no atomics, no LDS, no barrier ---------------------------------------
+// ---- the same two products as PARTIAL SUMS: no atomics, no barrier ------------------------------------------------
 // A wave = 64 columns x one group of 32 candidates x one slice of the queries, exactly as above - but it shares
 // nothing with other waves: the query's partial sum over the wave's 32 candidates is STORED, as row i of slab
 // `candidate group` of dq_parts [groups, S, W], the candidates' sums over the slice as rows of slab `slice` of
@@ -525,49 +525,64 @@ __global__ __launch_bounds__(256, 2) void k_l1_bwd_parts(RowSrc<float> Q, RowSrc
 #pragma unroll
         for (int jj = 0; jj < 32; ++jj) asm volatile("" : "+v"(e[jj]));  // (see k_l1_bwd_both)
     }
-    // running pointers (one add per query instead of 64-bit index products: the kernel lives at the SGPR limit -
-    // two sets of 32 coefficient registers)
-    const float* qptr = Q.base + static_cast<int64_t>(i_lo) * W + wc;        // the query value one query ahead
-    const float* __restrict__ cptr = d_out + static_cast<int64_t>(i_lo) * ld + jbase;  // wave-uniform: scalar loads
-    float* __restrict__ dq_out = dq_parts + (static_cast<int64_t>(jg) * Q.n + i_lo) * W + w0 + w;
-    float qnext = *qptr;
-    float cA[32], cB[32];
+    // Coefficients and query values arrive a BLOCK of FB_IS queries ahead, through vector loads: the block's 8 x 32
+    // coefficients as four coalesced loads per lane, staged in a wave-private piece of LDS and read back as broadcast
+    // b128 (a query's 32 coefficients: 8 reads, fetched one query ahead of their use), the lane's 8 query values
+    // straight into registers.  (Round 3 / early round 4 fetched them with scalar loads one query ahead: every
+    // s_load of the 128 B of a query is a miss of the scalar cache - ~0.7 us a query with two waves per SIMD where the
+    // 128 VALU instructions of a query need 0.2: 20 us for the kernel at the notebook micro-batch.)  The waves of a
+    // workgroup still share nothing: no barrier.
+    __shared__ __attribute__((aligned(16))) float cs[4][2][FB_IS][32];  // [wave][buffer][query][candidate]
+    __shared__ float qs[4][2][FB_IS][64];                               // [wave][buffer][query][column]
+    float(*mine)[FB_IS][32] = cs[threadIdx.x >> 6];
+    float(*myq)[FB_IS][64] = qs[threadIdx.x >> 6];
+    const int lq = w >> 5, lj = w & 31;
+    const int n_blk = n_i / FB_IS;  // (S % 8 == 0 and slices of multiples of 8 queries: whole blocks)
+    float rc[4], rq[FB_IS];
+    auto load_block = [&](int blk) {
+        const float* cp = d_out + static_cast<int64_t>(i_lo + blk * FB_IS + lq) * ld + jbase + lj;
 #pragma unroll
-    for (int jj = 0; jj < 32; ++jj) cA[jj] = cptr[jj];
-    auto one_query = [&](const float (&cur)[32], float (&nxt)[32], bool more) {
-        float qv = qnext;
-        if (more) {  // (wave-uniform)
-            qptr += W;
-            cptr += ld;
-        }
-        qnext = *qptr;
+        for (int k = 0; k < 4; ++k) rc[k] = cp[static_cast<int64_t>(2 * k) * ld];
+        const float* qp = Q.base + static_cast<int64_t>(i_lo + blk * FB_IS) * W + wc;
+#pragma unroll
+        for (int k = 0; k < FB_IS; ++k) rq[k] = qp[static_cast<int64_t>(k) * W];
+    };
+    float* __restrict__ dq_out = dq_parts + (static_cast<int64_t>(jg) * Q.n + i_lo) * W + w0 + w;
+    load_block(0);
+    float order = 0.f;  // (the previous query's sum: see the asm below)
+    auto one_query = [&](const float* crow, float qv) {
         if (ROUND16) qv = static_cast<float>(static_cast<_Float16>(qv));
         qv *= SGN_PRESCALE;
-        asm volatile("" : "+v"(qv));
+        // the scaled value is what the loop subtracts (k_l1_bwd_both), and it "depends" on the previous query's sum:
+        // left alone the compiler evaluates sgn(q - e) of several queries' pairs up front and spills them
+        asm volatile("" : "+v"(qv) : "v"(order));
         float pq4[4] = {0.f, 0.f, 0.f, 0.f};
-        {
-            const float sg = sgn_prescaled(qv - e[0]);
-            pq4[0] = fmaf(cur[0], sg, pq4[0]);
-            acc[0] = fmaf(cur[0], sg, acc[0]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int jj = 0; jj < 32; ++jj) nxt[jj] = cptr[jj];
-        __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < 8; ++k) {
+            const float4 c4 = *reinterpret_cast<const float4*>(crow + 4 * k);  // broadcast: the wave reads one address
+            const float c[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
-        for (int jj = 1; jj < 32; ++jj) {
-            const float c = cur[jj];
-            const float sg = sgn_prescaled(qv - e[jj]);
-            pq4[jj & 3] = fmaf(c, sg, pq4[jj & 3]);
-            acc[jj] = fmaf(c, sg, acc[jj]);
+            for (int u = 0; u < 4; ++u) {
+                const float sg = sgn_prescaled(qv - e[4 * k + u]);
+                pq4[u] = fmaf(c[u], sg, pq4[u]);
+                acc[4 * k + u] = fmaf(c[u], sg, acc[4 * k + u]);  // (d_neg is minus this sum: flipped at the store)
+            }
         }
-        if (w_ok) *dq_out = sign * ((pq4[0] + pq4[1]) + (pq4[2] + pq4[3]));
+        order = sign * ((pq4[0] + pq4[1]) + (pq4[2] + pq4[3]));
+        if (w_ok) *dq_out = order;
         dq_out += W;
     };
 #pragma unroll 1
-    for (int i = 0; i < n_i; i += 2) {
-        one_query(cA, cB, true);            // (n_i is even: query i + 1 exists)
-        one_query(cB, cA, i + 2 < n_i);
+    for (int blk = 0; blk < n_blk; ++blk) {
+        float(*buf)[32] = mine[blk & 1];
+        float(*qbuf)[64] = myq[blk & 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) buf[lq + 2 * k][lj] = rc[k];
+#pragma unroll
+        for (int k = 0; k < FB_IS; ++k) qbuf[k][w] = rq[k];
+        load_block(min(blk + 1, n_blk - 1));  // in flight while this block is worked on (after the last: a surplus copy)
+#pragma unroll 1
+        for (int ii = 0; ii < FB_IS; ++ii) one_query(buf[ii], qbuf[ii][w]);
     }
     if (w_ok) {
         float* __restrict__ de_out = de_parts + (static_cast<int64_t>(sl) * E.n + jbase) * W + w0 + w;
@@ -644,7 +659,10 @@ static L1PartsPlan plan_l1_bwd_parts(int64_t S, int64_t N, int W) {
         const int64_t waves = per_slice * actual;
         // rounds over the 4096 wave slots of the chip at 4 per SIMD; a SIMD's waves share its issue slots
         const double per_simd = static_cast<double>(ceil_div(waves, 1024));
-        // (measured, profiles/sweep_l1_bwd.py: 512 x 768 in 32 slices of 16 queries 20.7 us, 512 x 544 in 22 of 24 21.6)
+        // (measured, round 4 kernel - coefficients through LDS -, us for 4 / 8 / 11 / 16 / 22 / 32 / 64 slices:
+        //  512 x 544: 53.5 / 30.0 / 24.1 / 18.7 / 16.3 / 16.2 / 16.8; 256 x 288: 28.2 / 16.4 / 13.3 / 10.5 / - / 8.3 / -;
+        //  1024 x 544: 102.6 / 54.8 / 42.6 / 31.7 / 25.7 / 24.9 / 23.0 - a query costs a wave ~0.4 us alone on its
+        //  SIMD; beyond ~2 waves per SIMD the 27 MB of slabs the launch stores are what is left)
         const double cost = per_simd * (ch + 12.0) / std::min(per_simd, 2.5) + 0.1 * actual;
         if (cost < best) best = cost, p.i_chunk = ch, p.slices = actual;
     }
