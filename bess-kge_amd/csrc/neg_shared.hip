@@ -374,7 +374,11 @@ __global__ __launch_bounds__(64 * FB_NW, 4) void k_l1_bwd_both(RowSrc<float> Q, 
                                                         float* __restrict__ dq, float* __restrict__ de, int i_chunk) {
     // A wave = 64 columns x ONE group of 32 candidates: the coefficient of (query, candidate) is the same for all
     // its lanes - a wave-uniform address, i.e. scalar loads (s_load_dwordx8 into SGPRs that the v_fma reads
-    // directly): no LDS staging of the coefficients, no barrier for them.  Eight waves = 256 candidates; their
+    // directly): no LDS staging of the coefficients, no barrier for them.  (Round 4, on the counters of
+    // profiles/r04/pmc_l1_kernels.txt - 0.26 of a wave's life in s_waitcnt: a variant that fetches coefficients and
+    // query values a step ahead through vector loads + LDS, as k_l1_bwd_parts does, 108 VGPRs, still four waves per
+    // SIMD: 407.2 vs 409.2 us at 4096 x 4352, 1388 vs 1427 at 8192 x 8448, 26.4 vs 24.5 at 512 x 544 - with four waves
+    // per SIMD the waits were already covered; not kept.)  Eight waves = 256 candidates; their
     // partial sums of d_query meet in LDS every FB_IS queries.
     __shared__ float Rs[FB_NW][FB_IS][FB_TW];
     const int t = threadIdx.x;
