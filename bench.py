@@ -511,23 +511,26 @@ def train_leg(model, batches, steps: int):
     }
     # the notebooks train with AdamW: same step with the row-sparse AdamW of besskge.runtime
     out["adamw_ms_per_step"] = 1e3 * eager(_rt.Adam(lr=1e-3, weight_decay=1e-2), tsteps)
-    # hipGraph replay of the SGD step (one launch per step)
-    try:
-        iters = 8
-        stacked = {k: torch.cat([batches[i % len(batches)][k] for i in range(iters)], dim=0) for k in batches[0]}
-        runner = _rt.Runner(model, _rt.Options(device_iterations=iters, use_graphs=True), model.replica_group,
-                            stacked["head"].device, _rt.SGD(lr=1e-3))
-        for _ in range(2):
-            runner(**stacked)
-        torch.cuda.synchronize()
-        reps = max(1, tsteps // iters)
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            runner(**stacked)
-        torch.cuda.synchronize()
-        out["graph_ms_per_step"] = 1e3 * (time.perf_counter() - t1) / (reps * iters)
-    except Exception as e:  # noqa: BLE001
-        out["graph_error"] = f"{type(e).__name__}: {e}"[:300]
+    # hipGraph replay of the SGD step and of the AdamW step (one launch per 8 steps)
+    for key, opt in (("graph_ms_per_step", _rt.SGD(lr=1e-3)), ("adamw_graph_ms_per_step", _rt.Adam(lr=1e-3, weight_decay=1e-2))):
+        try:
+            iters = 8
+            stacked = {k: torch.cat([batches[i % len(batches)][k] for i in range(iters)], dim=0) for k in batches[0]}
+            runner = _rt.Runner(model, _rt.Options(device_iterations=iters, use_graphs=True), model.replica_group,
+                                stacked["head"].device, opt)
+            for _ in range(2):
+                runner(**stacked)
+            torch.cuda.synchronize()
+            reps = max(1, tsteps // iters)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                runner(**stacked)
+            torch.cuda.synchronize()
+            out[key] = 1e3 * (time.perf_counter() - t1) / (reps * iters)
+            runner.reset_graphs()
+            del runner
+        except Exception as e:  # noqa: BLE001
+            out[key.replace("ms_per_step", "error")] = f"{type(e).__name__}: {e}"[:300]
     return out
 
 
