@@ -683,8 +683,10 @@ struct LQueryTripleBwd {
 template <typename T, int SC>
 struct LPertripleTail {
     static void run(TripleArgs a, QueryArgs qa, TailArgs t, float* dh, float* dt, float* dr, int ch, hipStream_t st) {
-        // 16 waves (one triple each) per workgroup once that still fills the chip and the rows fit 64 KB of LDS
-        const int nw = (a.n > 1024 && a.W <= 1024) ? 16 : 4;
+        // 16 waves (one triple each) per workgroup once that still fills the chip, fewer when their rows would not fit
+        // 32 KB of LDS (W = 4096: two waves)
+        int nw = a.n > 1024 ? 16 : 4;
+        while (nw > 1 && static_cast<size_t>(nw) * a.W * sizeof(float) > (32u << 10)) nw >>= 1;
         const unsigned grid = static_cast<unsigned>(ceil_div(a.n, nw));
         const size_t lds = sizeof(float) * static_cast<size_t>(std::max(nw * a.W, 64 * nw));
         if (ch == 4) k_pertriple_tail<T, SC, 4><<<grid, 64 * nw, lds, st>>>(a, qa, t, dh, dt, dr);

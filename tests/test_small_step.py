@@ -318,6 +318,8 @@ def test_backward_as_partial_sums_equals_the_atomic_form(dev, scorer, dtype, S, 
     ("RotatE", torch.float32, 257, 2048, 96, "margin_adv"),            # rows kept as 12 chunks per lane
     ("DistMult", torch.float16, 512, 32, 50, "margin"),                # W % 4 != 0
     ("ComplEx", torch.float32, 64, 256, 512, "logsigmoid"),
+    ("TransE", torch.float32, 1100, 16, 1024, "ssce"),                 # widest rows of the fused forward: fewer waves
+    ("DistMult", torch.float16, 40, 8, 2048, "logsigmoid_adv"),        # per workgroup (their rows share 32 KB of LDS)
 ])
 def test_pertriple_tail_equals_the_four_launches(dev, scorer, dtype, S, N, W, loss):
     """`bess_pertriple_tail` (d loss / d query from the fused forward's partials + K8 + K3' + K6', one launch) against
