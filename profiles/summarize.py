@@ -63,6 +63,8 @@ if steps:
             "c2sm": "C2 training step in its multi-GPU form (ScoreMovingBessKGE, fused forward with partials), one shard",
             "c4s": "C4 TransE d=256 fp16, S=512, K=32, eager",
             "c4n2": "C4, two shards of S=512 stepped in lock-step on one GPU (the n > 1 code path: pack, exchange, C8), eager", "c4g": "C4 TransE d=256 fp16, S=512, K=32, hipGraph replay",
+            "c4p": "the same replayed from a C-side step plan (`Options.use_plans`, `bess_plan_run`)",
+            "c4n2g": "C4, two shards of S=512 in lock-step on one GPU, replayed from a hipGraph",
             "c4": "C4 TransE d=256 fp16, S=4096, K=256, eager",
             "c2em2": "C2's scorer and per-triple negatives in the EmbeddingMoving form on TWO shards stepped in lock-step on one GPU (S = 2048, 2 x 128 negatives per triple and shard; the n > 1 code path: pack, exchange - simulated by copies here -, fused forward over the received rows, in-place negative gradients, C8, coalesced update), SGD"}
     for f in steps:
@@ -82,8 +84,15 @@ INDEX = [
     ("microbench_final.log", "profiles/microbench.py", "every hot entry point on the BASELINE shapes (GB/s, TFLOP/s, T lane-ops/s)"),
     ("bench_gemm_split.log", "profiles/bench_gemm_split.py", "split-fp16 matrix-core products: accuracy vs float64 and rate, forward + backward"),
     ("bench_topk.log", "profiles/bench_topk.py", "top-k over all entities (YAGO3-10, wikikg2, biokg shapes) and full ranks of the same queries: counted in the scoring epilogue vs score matrix + `bess_ranks_from_scores`"),
-    ("sweep_l1_bwd.log", "profiles/sweep_l1_bwd.py", "`k_l1_bwd_both` alone (hipGraph of back-to-back launches) from 256 x 288 to 8192 x 8448"),
-    ("pmc_l1_kernels.txt", "profiles/pmc_l1_bwd.sh", "SQ counters of the shared-negative L1 kernels at 4096 x 4352"),
+    ("sweep_l1_bwd.log", "profiles/sweep_l1_bwd.py", "`k_l1_bwd_both` (atomic sums) and `k_l1_bwd_parts` (partial sums) alone (hipGraph of back-to-back launches) from 256 x 288 to 8192 x 8448"),
+    ("pmc_l1_kernels.txt", "profiles/pmc_l1_bwd.sh / pmc_l1_r04.sh", "SQ counters of the shared-negative L1 kernels (r04: 512 x 544, 2048 x 2176, 8192 x 8448)"),
+    ("pmc_gemm_split.txt", "profiles/pmc_gemm_split.sh", "SQ counters of the split-fp16 GEMM and its pre-pass; reading: `pmc_gemm_split.md`"),
+    ("gemm_kernel_trace.txt", "rocprofv3 --kernel-trace -- python3 profiles/bench_gemm_split.py", "un-profiled durations of `k_gemm_split_w8` and its pre-pass per shape"),
+    ("bench_tail.log", "profiles/bench_tail.py", "`bess_pertriple_tail` against the four launches it replaces, C2 and notebook shapes"),
+    ("timeline_r04_c2.txt", "profiles/step_timeline.py c2", "HIP-event timeline of a C2 training step, streams not serialised: the index build under the forward"),
+    ("timeline_r04_c2adam.txt", "profiles/step_timeline.py c2adam", "the same with AdamW"),
+    ("bench_index.log", "profiles/bench_index.py", "segment-index build: the library's kernel-only radix sort against rocPRIM's"),
+    ("graph_memset_probe.md", "profiles/graph_memset_probe.py", "what memset nodes of recorded steps do on replay (probe, DOT dump, fault tail)"),
     ("bench_c4.log", "profiles/bench_c4.py", "BASELINE configs[3] regime through runtime.Runner, hipGraph replay, SGD and AdamW"),
     ("bench_graphs.log", "profiles/bench_graphs.py", "hipGraph replay in the launch-bound regime (configs[0] shape)"),
     ("bench_optim.log", "profiles/bench_optim.py", "training step of the bench workload per optimiser"),
