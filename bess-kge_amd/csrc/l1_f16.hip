@@ -87,14 +87,19 @@ struct PruneArgs {
 };
 
 // out[q, j] = -sum_w |fp16(Q[q, w]) - E[idx[j], w]|        W % 32 == 0
-// MI: query rows per thread (4: 64 x 64 tile; 2: 32 x 64 tile for launches whose 64-row grid leaves CUs idle)
-template <int MI>
+// MI: query rows per thread (4: 64 x 64 tile; 2: 32 x 64 and 1: 16 x 64 tiles for launches whose grid of larger tiles
+// leaves CUs idle - at the notebook micro-batch, 512 x 544, a 32-row tile's wave runs ~2 k packed instructions alone
+// on its SIMD: the launch is issue-bound per wave while three quarters of the chip's issue slots are empty)
+// NS: 32-half slices of W per stage (per pair of barriers).  (NS = 2 for the 16-row tiles - half the stages, the same
+// order of sums - was measured at the notebook micro-batch: 10.7 against 10.6 us; the launch is not a chain of stage
+// latencies.  Every launch uses NS = 1.)
+template <int MI, int NS = 1>
 __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, int64_t nq,
                                                    const half_t* __restrict__ E, const int32_t* __restrict__ eidx,
                                                    int64_t ne, int W, float* __restrict__ out, int64_t ld,
                                                    KillArgs kill, PruneArgs prune) {
-    __shared__ __attribute__((aligned(16))) uint32_t Qs[FKH / 2][PLD];
-    __shared__ __attribute__((aligned(16))) uint32_t Es[FKH / 2][PLD];
+    __shared__ __attribute__((aligned(16))) uint32_t Qs[NS * FKH / 2][PLD];
+    __shared__ __attribute__((aligned(16))) uint32_t Es[NS * FKH / 2][PLD];
     __shared__ float rsq[PT], rse[PT];
     const int t = threadIdx.x;
     const int tx = t & 15, ty = t >> 4;
@@ -114,34 +119,45 @@ __global__ __launch_bounds__(256) void k_l1_fwd_pk(const float* __restrict__ Q, 
     const float* qp = Q + min(q0 + (stage_q ? m : 0), nq - 1) * W + kc * 8;
     const int64_t er = min(j0 + m, ne - 1);
     const half_t* ep = E + (eidx ? static_cast<int64_t>(eidx[er]) : er) * W + kc * 8;
-    float4 qa = *reinterpret_cast<const float4*>(qp), qb = *reinterpret_cast<const float4*>(qp + 4);
-    uint4 ev = *reinterpret_cast<const uint4*>(ep);
-    float sq = 0.f, se = 0.f;  // sums of the staged (rounded) values of row m
-    for (int k0 = 0; k0 < W; k0 += FKH) {
-        const uint32_t qd[4] = {pack_rn(qa.x, qa.y), pack_rn(qa.z, qa.w), pack_rn(qb.x, qb.y), pack_rn(qb.z, qb.w)};
-        const uint32_t ed[4] = {ev.x, ev.y, ev.z, ev.w};
+    float4 qa[NS], qb[NS];
+    uint4 ev[NS];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (stage_q) Qs[kc * 4 + i][m] = qd[i];
-            Es[kc * 4 + i][m] = ed[i];
-            sq = dot2_ones(qd[i], sq);
-            se = dot2_ones(ed[i], se);
+        for (int sl = 0; sl < NS; ++sl) {
+            qa[sl] = *reinterpret_cast<const float4*>(qp + k0 + sl * FKH);
+            qb[sl] = *reinterpret_cast<const float4*>(qp + k0 + sl * FKH + 4);
+            ev[sl] = *reinterpret_cast<const uint4*>(ep + k0 + sl * FKH);
+        }
+    };
+    fetch(0);
+    float sq = 0.f, se = 0.f;  // sums of the staged (rounded) values of row m
+    for (int k0 = 0; k0 < W; k0 += NS * FKH) {
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            const uint32_t qd[4] = {pack_rn(qa[sl].x, qa[sl].y), pack_rn(qa[sl].z, qa[sl].w), pack_rn(qb[sl].x, qb[sl].y),
+                                    pack_rn(qb[sl].z, qb[sl].w)};
+            const uint32_t ed[4] = {ev[sl].x, ev[sl].y, ev[sl].z, ev[sl].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (stage_q) Qs[sl * (FKH / 2) + kc * 4 + i][m] = qd[i];
+                Es[sl * (FKH / 2) + kc * 4 + i][m] = ed[i];
+                sq = dot2_ones(qd[i], sq);
+                se = dot2_ones(ed[i], se);
+            }
         }
         __syncthreads();
-        if (k0 + FKH < W) {
-            qa = *reinterpret_cast<const float4*>(qp + k0 + FKH);
-            qb = *reinterpret_cast<const float4*>(qp + k0 + FKH + 4);
-            ev = *reinterpret_cast<const uint4*>(ep + k0 + FKH);
-        }
+        if (k0 + NS * FKH < W) fetch(k0 + NS * FKH);
 #pragma unroll
-        for (int k = 0; k < FKH / 2; ++k) {
+        for (int k = 0; k < NS * FKH / 2; ++k) {
             uint32_t a[MI];
             if constexpr (MI == 4) {
                 const uint4 a4 = *reinterpret_cast<const uint4*>(&Qs[k][ty * 4]);
                 a[0] = a4.x, a[1] = a4.y, a[2] = a4.z, a[3] = a4.w;
-            } else {
+            } else if constexpr (MI == 2) {
                 const uint2 a2 = *reinterpret_cast<const uint2*>(&Qs[k][ty * 2]);
                 a[0] = a2.x, a[1] = a2.y;
+            } else {
+                a[0] = Qs[k][ty];
             }
             const uint4 b4 = *reinterpret_cast<const uint4*>(&Es[k][tx * 4]);
             const uint32_t b[4] = {b4.x, b4.y, b4.z, b4.w};
@@ -246,8 +262,14 @@ int l1_pk_fwd(const bess_model_desc* d, const float* query, int64_t n_query, con
     if (k) ka = KillArgs{k->diag_step, k->ht, k->ppp, k->mask, k->mask_rows, k->mask ? k->mask_cols : 0, n_neg};
     // 32-row tiles when the 64-row grid would leave most CUs without a workgroup
     const bool small = ceil_div(n_neg, PT) * ceil_div(n_query, PT) < 192;
-    const dim3 grid(static_cast<unsigned>(ceil_div(n_neg, PT)), static_cast<unsigned>(ceil_div(n_query, small ? PT / 2 : PT)));
-    if (small)
+    // (16-row tiles, kernel alone: 10.6 vs 12.1 us at 512 x 544, 9.5 vs 11.7 at 256 x 288, equal from 1024 x 544 on)
+    const bool tiny = ceil_div(n_neg, PT) * ceil_div(n_query, PT / 2) < 256;  // not even one 32-row tile per CU
+    const dim3 grid(static_cast<unsigned>(ceil_div(n_neg, PT)),
+                    static_cast<unsigned>(ceil_div(n_query, tiny ? PT / 4 : small ? PT / 2 : PT)));
+    if (tiny)
+        k_l1_fwd_pk<1><<<grid, 256, 0, st>>>(query, n_query, static_cast<const half_t*>(neg_base), neg_idx, n_neg,
+                                                    d->width, out, ld_out, ka, pr);
+    else if (small)
         k_l1_fwd_pk<2><<<grid, 256, 0, st>>>(query, n_query, static_cast<const half_t*>(neg_base), neg_idx, n_neg,
                                                     d->width, out, ld_out, ka, pr);
     else

@@ -511,24 +511,6 @@ __global__ __launch_bounds__(256, 2) void k_l1_bwd_parts(RowSrc<float> Q, RowSrc
     const int wc = min(w0 + w, W - 1);  // (columns past the end: clamped, dropped at the stores)
     const bool w_ok = w0 + w < W;
     const int64_t jbase = static_cast<int64_t>(jg) * 32;  // (n_neg % 32 == 0: all 32 candidates exist)
-    float e[32], acc[32];
-    {
-        int32_t rows[32];
-#pragma unroll
-        for (int jj = 0; jj < 32; ++jj) rows[jj] = static_cast<int32_t>(jbase + jj);
-        if (E.idx) {
-#pragma unroll
-            for (int jj = 0; jj < 32; ++jj) rows[jj] = E.idx[rows[jj]];
-        }
-        const TE* col = E.base + wc;
-#pragma unroll
-        for (int jj = 0; jj < 32; ++jj) {
-            e[jj] = to_f32(col[static_cast<int64_t>(rows[jj]) * W]) * SGN_PRESCALE;
-            acc[jj] = 0.f;
-        }
-#pragma unroll
-        for (int jj = 0; jj < 32; ++jj) asm volatile("" : "+v"(e[jj]));  // (see k_l1_bwd_both)
-    }
     // Coefficients and query values arrive a BLOCK of FB_IS queries ahead, through vector loads: the block's 8 x 32
     // coefficients as four coalesced loads per lane, staged in a wave-private piece of LDS and read back as broadcast
     // b128 (a query's 32 coefficients: 8 reads, fetched one query ahead of their use), the lane's 8 query values
@@ -552,7 +534,25 @@ __global__ __launch_bounds__(256, 2) void k_l1_bwd_parts(RowSrc<float> Q, RowSrc
         for (int k = 0; k < FB_IS; ++k) rq[k] = qp[static_cast<int64_t>(k) * W];
     };
     float* __restrict__ dq_out = dq_parts + (static_cast<int64_t>(jg) * Q.n + i_lo) * W + w0 + w;
-    load_block(0);
+    load_block(0);  // (requested before the candidates' values below: one wait for both)
+    float e[32], acc[32];
+    {
+        int32_t rows[32];
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) rows[jj] = static_cast<int32_t>(jbase + jj);
+        if (E.idx) {
+#pragma unroll
+            for (int jj = 0; jj < 32; ++jj) rows[jj] = E.idx[rows[jj]];
+        }
+        const TE* col = E.base + wc;
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) {
+            e[jj] = to_f32(col[static_cast<int64_t>(rows[jj]) * W]) * SGN_PRESCALE;
+            acc[jj] = 0.f;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) asm volatile("" : "+v"(e[jj]));  // (see k_l1_bwd_both)
+    }
     float order = 0.f;  // (the previous query's sum: see the asm below)
     auto one_query = [&](const float* crow, float qv) {
         if (ROUND16) qv = static_cast<float>(static_cast<_Float16>(qv));

@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void k_query_triple_bwd_parts(TripleArgs a, Qu
                     const float* src = de_parts + j * a.W + e;
                     const int64_t slab = n_neg * a.W;
                     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll 8
+#pragma unroll 16
                     for (int p = 0; p < n_de; ++p) {
                         const float4 v = *reinterpret_cast<const float4*>(src + p * slab);
                         s0 += v.x, s1 += v.y, s2 += v.z, s3 += v.w;
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void k_query_triple_bwd_parts(TripleArgs a, Qu
         for (int e = lane * 4; e < a.W; e += 256) {
             const float* src = dq_parts + s * a.W + e;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll 8
+#pragma unroll 16
             for (int p = 0; p < n_dq; ++p) {
                 const float4 v = *reinterpret_cast<const float4*>(src + p * slab);
                 s0 += v.x, s1 += v.y, s2 += v.z, s3 += v.w;
