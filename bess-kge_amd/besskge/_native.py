@@ -19,7 +19,7 @@ from typing import Any, List, Optional, Sequence, Tuple
 import torch
 
 LIB_NAME = "libbesskge_hip.so"
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 TRANSE, ROTATE, DISTMULT, COMPLEX, AFFINE, BOXE = 0, 1, 2, 3, 4, 5
 F32, F16 = 0, 1

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BESS_ABI_VERSION 2
+#define BESS_ABI_VERSION 3  /* 3 (round 4): the "last workgroup" counters are int32 [BESS_TICKET_INTS] (were [1]) */
 
 /* error codes (negative); positive return values are hipError_t, or
  * BESS_ECOMM_BASE + ncclResult_t for a failing RCCL call */

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert sorted(_native.SIGNATURES) == names, "ctypes binding and header disagree"
-    assert lib.bess_version() == _native.ABI_VERSION == 2
+    assert lib.bess_version() == _native.ABI_VERSION == 3
 
 
 def test_integration_doc_matches_the_library():
