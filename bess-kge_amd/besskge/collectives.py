@@ -58,6 +58,12 @@ class ReplicaGroup(ABC):
     def barrier(self) -> None:
         """Synchronise all replicas (no-op when they share a process)."""
 
+    def all_agree(self, ok: bool) -> bool:
+        """True iff `ok` on EVERY rank - for decisions that change which collectives a rank issues next (keep a
+        recorded plan or fall back): a rank deciding alone leaves its peers waiting in an exchange it never joins.
+        One process hosting every replica decides alone."""
+        return bool(ok)
+
     # ------------------------------------------------------------------ recorded steps
     # A hipGraph that recorded a collective keeps the communicator busy: `ncclCommDestroy` waits for it
     # (round 3: a process that ended with a `Runner(use_graphs=True)` over a `NativeGroup` alive hung in
@@ -242,6 +248,12 @@ class NativeGroup(ReplicaGroup):
     def pack_exchange(self, table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         """K1 + C1 in one native call: rows `table[idx]` (idx [n_shard, L]) -> received [n_shard, L, W]."""
         return self.comm.pack_exchange(table, idx)[1]
+
+    def all_agree(self, ok: bool) -> bool:
+        if self.n_shard == 1:
+            return bool(ok)
+        flag = torch.tensor([0.0 if ok else 1.0], dtype=torch.float32, device=self.device)
+        return float(self.comm.all_reduce_sum_(flag).item()) == 0.0
 
     def barrier(self) -> None:
         torch.cuda.current_stream(self.device).synchronize()

@@ -421,6 +421,12 @@ class Runner:
         foreign = sorted(foreign)
         if snapshot is not None:
             self._restore_training_snapshot(snapshot)
+        # (every decision below is taken by all ranks together: a rank that gave up alone would leave its peers in the
+        # collectives of the proof runs)
+        peers_ok = self.group.all_agree(not foreign and bool(device_work) and len(plan) > 0)
+        if not foreign and device_work and len(plan) > 0 and not peers_ok:
+            del outs, stacked
+            raise RuntimeError("use_plans: another rank could not record its step as a plan")
         if foreign or not device_work:
             del outs, stacked
             raise RuntimeError(
@@ -470,6 +476,8 @@ class Runner:
                 bad.append("entity_embedding")
             if not same(fn.relation_embedding.data, want_tables[1], snapshot["relation"]):
                 bad.append("relation_embedding")
+        if not self.group.all_agree(not bad) and not bad:
+            bad = ["(on another rank)"]
         if bad:
             raise RuntimeError(
                 f"use_plans: replaying the recorded calls {plan.names} does not reproduce the step ({bad} differ): "
