@@ -139,7 +139,12 @@ def test_one_process_driving_n_devices(world, plans):
     from test_oracle import load_bess_case
 
     cases = _cases(world)
-    assert cases
+    # (a spread of eight golden cases - training and inference, both schemes, several scorers: every case builds two
+    # cliques; all 45 single-shard cases took 52 s per variant of this test)
+    train = [c for c in cases if c.startswith("tr_")]
+    other = [c for c in cases if not c.startswith("tr_")]
+    cases = train[:: max(1, len(train) // 5)][:5] + other[:: max(1, len(other) // 3)][:3]
+    assert cases and any(c.startswith("tr_") for c in cases)
     out_dir = tempfile.mkdtemp(prefix="bess_md_")
     env = dict(os.environ, BESS_CASES=",".join(cases), BESS_N_DEVICES=str(world), BESS_USE_PLANS="1" if plans else "0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
